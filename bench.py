@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- k-mers/sec of the global counting hot path on MI355X.
+
+Workload (BASELINE.json configs[2], the one the metric is quoted on): R synthetic 150 bp
+reads generated on device (SURVEY.md 8d generator), k=31, canonical; inputs resident in HBM
+before the timed region.  A step = one full pass: clear the table, count every k-mer of the
+resident batch, (N>1: exchange owner segments over RCCL and merge), sync.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--k 31] [--L 150]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=3)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--reads", type=int, default=100_000_000)
+    p.add_argument("--L", type=int, default=150)
+    p.add_argument("--k", type=int, default=31)
+    p.add_argument("--glen", type=int, default=0, help="genome length (default: = reads)")
+    p.add_argument("--no-canonical", action="store_true")
+    p.add_argument("--cpu-reads", type=int, default=2_000_000,
+                   help="reads of the same generator timed on the host cores (0: skip)")
+    p.add_argument("--cpu-threads", type=int, default=0)
+    return p.parse_args()
+
+
+def cpu_baseline(args, glen):
+    """the oracle (a CPU restatement; the reference has no CPU path) on a bounded sample"""
+    from tests import oracle_lib as orc
+    R = min(args.cpu_reads, args.reads)
+    threads = args.cpu_threads or min(os.cpu_count() or 1, 32)
+    data, _, _ = orc.synth_reads(0, R, args.L, glen)
+    flags = 0 if args.no_canonical else orc.ORC_CANONICAL
+    t0 = time.perf_counter()
+    lo, hi, cnt = orc.global_count(data, args.k, flags, threads=threads)
+    dt = time.perf_counter() - t0
+    kmers = R * (args.L - args.k + 1)
+    return {"value": kmers / dt, "unit": "k-mers/s", "cores": threads, "kind": "port",
+            "sample": f"first {R} reads of the same generator ({kmers} k-mers, {dt:.2f} s, "
+                      f"{len(lo)} distinct), oracle/cfrk_oracle.c orc_global_count_mt"}, (lo, hi, cnt)
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import cfrk_amd
+    from cfrk_amd import sharded
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    R, L, k = args.reads, args.L, args.k
+    glen = args.glen or R
+    flags = 0 if args.no_canonical else cfrk_amd.CFRK_CANONICAL
+    r0, r1 = sharded.shard_range(R, rank, world)       # strong scaling: the R reads are split
+    Rl = r1 - r0
+    nN = Rl * (L + 1)
+
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = cfrk_amd.Context(local_rank, stream)
+    # struct-read buffers, resident in HBM (torch owns the memory; the library gets pointers)
+    d_data = torch.empty(nN + 64, dtype=torch.int8, device=dev)
+    d_start = torch.empty(Rl, dtype=torch.int64, device=dev)
+    d_length = torch.empty(Rl, dtype=torch.int32, device=dev)
+    ctx.synth_reads_device(r0, Rl, L, glen, d_data.data_ptr(), d_start.data_ptr(), d_length.data_ptr())
+    torch.cuda.synchronize()
+
+    hint = min(glen, R * (L - k + 1)) + 1024
+    owner_ctx = cfrk_amd.Context(local_rank, stream) if world > 1 else None
+
+    class Engine:
+        def __init__(self):
+            self.g = None
+            self.bufs = None
+
+        def export_parts(self, parts):
+            n = self.g.finish()
+            if self.bufs is None or self.bufs[0].numel() < n:
+                cap = int(n * 1.1) + 1024
+                self.bufs = (torch.empty(cap, dtype=torch.uint64, device=dev), None,
+                             torch.empty(cap, dtype=torch.uint32, device=dev))
+            lo, hi, cnt = self.bufs
+            pc = self.g.export_device(lo.data_ptr(), 0, cnt.data_ptr(), lo.numel(), parts)
+            return lo, hi, cnt, pc
+
+    eng = Engine()
+    kernel_ms = []
+
+    def step():
+        eng.g = cfrk_amd.GlobalCounter(ctx, k, flags, hint)
+        eng.g.add_device(d_data.data_ptr(), nN)
+        if world == 1:
+            ctx.sync()
+            return eng.g
+        rlo, rhi, rcnt = sharded.exchange_by_owner(eng, world, dev)
+        og = cfrk_amd.GlobalCounter(owner_ctx, k, flags, hint // world + 1024)
+        og.merge_device(rlo.data_ptr(), 0, rcnt.data_ptr(), rlo.numel())
+        owner_ctx.sync()
+        return og
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        final = step()
+        kernel_ms.append(eng.g.last_add_ms())
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    digest = final.digest()
+    if world > 1:
+        digest = sharded.merge_digests(digest, dev)
+
+    kmers_total = R * (L - k + 1)
+    D = digest[0]
+    ok = digest[1] == kmers_total
+    if rank == 0:
+        S = 12 if k <= 32 else 20
+        # SURVEY 8d algorithmic bytes per launch (per GPU): reads incl. terminators + the
+        # start/length tables + every occupied slot written once and read once
+        b_alg = Rl * (L + 1) + 12 * Rl + 2 * (D // world if world > 1 else D) * S
+        avg_ms = sum(kernel_ms) / len(kernel_ms)
+        achieved = b_alg / (avg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "k-mers/sec", "value": kmers_total * args.steps / dt, "unit": "k-mers/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"{R} synthetic {L} bp reads, k={k}, "
+                                   f"{'canonical' if flags else 'forward'}, genome {glen} "
+                                   f"(BASELINE.json configs[2]{'/[3]' if world > 1 else ''})",
+                       "reads": R, "read_len": L, "k": k, "parallelism": f"read-shard x{world}"
+                       + (" + owner all-to-all" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": None,
+                         "kernel": "counting kernels of cfrk_global_add_device (HIP events)",
+                         "kernel_ms": avg_ms, "algorithmic_bytes": b_alg},
+            "distinct": D, "sum_count_ok": ok,
+            "digest": [f"{x:016x}" for x in digest],
+        }
+        if world == 1 and args.cpu_reads > 0:
+            cb, _ = cpu_baseline(args, glen)
+            out["cpu_baseline"] = cb
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(f"sum(count) {digest[1]} != {kmers_total}")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,12 @@
+"""cfrk_amd -- MI355X-native k-mer counting behind the reference's kmer_main() boundary.
+
+The compute lives in libcfrk_hip.so (hand-written HIP for gfx950, C ABI in
+include/cfrk_abi.h); this package is the thin host-side mirror used by tests, bench.py and
+Python callers.  There is NO CPU fallback: if the HIP library is missing or no gfx950 device
+is present, every compute entry point raises.
+"""
+from .lib import (CFRK_CANONICAL, CFRK_COMPAT, CfrkError, Context, GlobalCounter, Read,
+                  abi_symbols, kmer_main, load_library, library_path)
+
+__all__ = ["CFRK_CANONICAL", "CFRK_COMPAT", "CfrkError", "Context", "GlobalCounter", "Read",
+           "abi_symbols", "kmer_main", "load_library", "library_path"]

@@ -1,0 +1,428 @@
+// abi.hip -- the C-ABI entry points of libcfrk_hip.so (include/cfrk_abi.h).
+// Replaces kmer_main() (/root/reference/src/kmer_main.cu:20-128): context + persistent device
+// pool instead of per-call cudaMalloc/cudaFree, error codes instead of printf/exit.
+#include "common.h"
+
+#include <stdarg.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <new>
+#include <numeric>
+#include <vector>
+
+#include "msp.h"
+
+int cfrk_fail(cfrk_ctx *ctx, int code, const char *fmt, ...) {
+  if (ctx) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(ctx->err, sizeof ctx->err, fmt, ap);
+    va_end(ap);
+  }
+  return code;
+}
+
+int cfrk_pool_get(cfrk_ctx *ctx, int slot, size_t bytes, void **out) {
+  cfrk_buf &b = ctx->pool[slot];
+  if (bytes == 0) bytes = 16;
+  if (b.cap < bytes) {
+    if (b.p) { HIP_TRY(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    size_t want = (bytes + 255) & ~(size_t)255;
+    HIP_TRY(ctx, hipMalloc(&b.p, want));
+    b.cap = want;
+  }
+  *out = b.p;
+  return CFRK_OK;
+}
+
+static int pool_release(cfrk_ctx *ctx, int slot) {
+  cfrk_buf &b = ctx->pool[slot];
+  if (b.p) { HIP_TRY(ctx, hipFree(b.p)); }
+  b.p = nullptr; b.cap = 0;
+  return CFRK_OK;
+}
+
+extern "C" {
+
+int cfrk_abi_version(void) { return CFRK_ABI_VERSION; }
+
+const char *cfrk_strerror(int code) {
+  switch (code) {
+    case CFRK_OK: return "ok";
+    case CFRK_ERR_ARG: return "invalid argument";
+    case CFRK_ERR_NOMEM: return "out of device or pinned memory";
+    case CFRK_ERR_HIP: return "HIP runtime error";
+    case CFRK_ERR_STATE: return "call sequence violated";
+    case CFRK_ERR_LAYOUT: return "data/start/length do not describe the struct-read layout";
+    case CFRK_ERR_TABLE_FULL: return "global table overflowed (raise capacity_hint)";
+    case CFRK_ERR_ALIGN: return "device pointer not 16-byte aligned";
+    case CFRK_ERR_NO_DEVICE: return "no usable gfx950 device";
+    case CFRK_ERR_SMALL_BUF: return "output buffer too small";
+    default: return "unknown error";
+  }
+}
+
+const char *cfrk_last_error(const cfrk_ctx *ctx) { return ctx ? ctx->err : ""; }
+
+int cfrk_device_count(int *count) {
+  if (!count) return CFRK_ERR_ARG;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { *count = 0; return CFRK_ERR_NO_DEVICE; }
+  *count = n;
+  return CFRK_OK;
+}
+
+int cfrk_ctx_create(int device, void *hip_stream, cfrk_ctx **out) {
+  if (!out) return CFRK_ERR_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return CFRK_ERR_NO_DEVICE;
+  if (device < 0 || device >= n) return CFRK_ERR_ARG;
+  if (hipSetDevice(device) != hipSuccess) return CFRK_ERR_NO_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return CFRK_ERR_NO_DEVICE;
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return CFRK_ERR_NO_DEVICE;  // gfx950 code objects only
+  cfrk_ctx *ctx = new (std::nothrow) cfrk_ctx();
+  if (!ctx) return CFRK_ERR_NOMEM;
+  memset(ctx, 0, sizeof *ctx);
+  ctx->device = device;
+  ctx->num_cus = prop.multiProcessorCount;
+  if (hip_stream) {
+    ctx->stream = (hipStream_t)hip_stream;
+  } else {
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return CFRK_ERR_HIP; }
+    ctx->own_stream = true;
+  }
+  if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
+      hipMalloc((void **)&ctx->g_stats, ST_NWORDS * sizeof(uint64_t)) != hipSuccess) {
+    cfrk_ctx_destroy(ctx);
+    return CFRK_ERR_HIP;
+  }
+  *out = ctx;
+  return CFRK_OK;
+}
+
+static void global_release(cfrk_ctx *ctx) {
+  if (ctx->g_keys_lo) hipFree(ctx->g_keys_lo);
+  if (ctx->g_keys_hi) hipFree(ctx->g_keys_hi);
+  if (ctx->g_counts) hipFree(ctx->g_counts);
+  ctx->g_keys_lo = ctx->g_keys_hi = nullptr;
+  ctx->g_counts = nullptr;
+  ctx->g_cap = 0;
+  ctx->g_active = false;
+}
+
+void cfrk_ctx_destroy(cfrk_ctx *ctx) {
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  cfrk_msp_destroy(ctx);
+  global_release(ctx);
+  for (int i = 0; i < BUF_NSLOTS; ++i)
+    if (ctx->pool[i].p) hipFree(ctx->pool[i].p);
+  if (ctx->pinned) hipHostFree(ctx->pinned);
+  if (ctx->g_stats) hipFree(ctx->g_stats);
+  if (ctx->ev0) hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) hipEventDestroy(ctx->ev1);
+  if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int cfrk_ctx_sync(cfrk_ctx *ctx) {
+  if (!ctx) return CFRK_ERR_ARG;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return CFRK_OK;
+}
+
+int cfrk_device_alloc(cfrk_ctx *ctx, size_t bytes, void **dptr) {
+  if (!ctx || !dptr) return CFRK_ERR_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipMalloc(dptr, bytes ? bytes : 16));
+  return CFRK_OK;
+}
+
+int cfrk_device_free(cfrk_ctx *ctx, void *dptr) {
+  if (!ctx) return CFRK_ERR_ARG;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (dptr) HIP_TRY(ctx, hipFree(dptr));
+  return CFRK_OK;
+}
+
+int cfrk_memcpy_h2d(cfrk_ctx *ctx, void *dst, const void *src, size_t bytes) {
+  if (!ctx || (bytes && (!dst || !src))) return CFRK_ERR_ARG;
+  HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return CFRK_OK;
+}
+
+int cfrk_memcpy_d2h(cfrk_ctx *ctx, void *dst, const void *src, size_t bytes) {
+  if (!ctx || (bytes && (!dst || !src))) return CFRK_ERR_ARG;
+  HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return CFRK_OK;
+}
+
+/* ------------------------------------------------------------------ per-read dense */
+
+static int dense_check(cfrk_ctx *ctx, int64_t nN, int64_t nS, int k) {
+  if (!ctx) return CFRK_ERR_ARG;
+  if (k < 1 || k > 15) return cfrk_fail(ctx, CFRK_ERR_ARG, "k=%d outside 1..15 (POW(k) is 1U<<2k in an int)", k);
+  if (nN < 0 || nS < 0) return cfrk_fail(ctx, CFRK_ERR_ARG, "negative size");
+  return CFRK_OK;
+}
+
+int cfrk_per_read_dense_device(cfrk_ctx *ctx, const int8_t *d_data, const int64_t *d_start,
+                               const int32_t *d_length, int64_t nN, int64_t nS, int k, int flags,
+                               int32_t *d_freq) {
+  int rc = dense_check(ctx, nN, nS, k);
+  if (rc) return rc;
+  if (nS == 0) return CFRK_OK;
+  if (!d_data || !d_start || !d_length || !d_freq) return cfrk_fail(ctx, CFRK_ERR_ARG, "NULL buffer");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  return cfrk_launch_dense(ctx, d_data, d_start, d_length, nN, nS, k, flags, d_freq);
+}
+
+int cfrk_per_read_dense(cfrk_ctx *ctx, const int8_t *data, const int64_t *start,
+                        const int32_t *length, int64_t nN, int64_t nS, int k, int flags,
+                        int32_t *freq_out) {
+  int rc = dense_check(ctx, nN, nS, k);
+  if (rc) return rc;
+  if (nS == 0) return CFRK_OK;
+  if (!data || !start || !length || !freq_out) return cfrk_fail(ctx, CFRK_ERR_ARG, "NULL buffer");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t fourk = (size_t)1 << (2 * k);
+  const size_t freq_bytes = (size_t)nS * fourk * sizeof(int32_t);
+  // the reference's up-front estimate (src/kmer_main.cu:44-56), against free memory
+  size_t free_b = 0, total_b = 0;
+  HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+  size_t need = (size_t)nN + (size_t)nS * 16 + freq_bytes;
+  size_t have = free_b + ctx->pool[BUF_DATA].cap + ctx->pool[BUF_START].cap +
+                ctx->pool[BUF_LENGTH].cap + ctx->pool[BUF_FREQ].cap + ctx->pool[BUF_SPILL].cap;
+  if (need > have)
+    return cfrk_fail(ctx, CFRK_ERR_NOMEM, "required %zu B, available %zu B", need, have);
+  void *d_data, *d_start, *d_length, *d_freq;
+  if ((rc = cfrk_pool_get(ctx, BUF_DATA, (size_t)nN + 64, &d_data))) return rc;
+  if ((rc = cfrk_pool_get(ctx, BUF_START, (size_t)nS * 8, &d_start))) return rc;
+  if ((rc = cfrk_pool_get(ctx, BUF_LENGTH, (size_t)nS * 4, &d_length))) return rc;
+  if ((rc = cfrk_pool_get(ctx, BUF_FREQ, freq_bytes, &d_freq))) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(d_data, data, (size_t)nN, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_start, start, (size_t)nS * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_length, length, (size_t)nS * 4, hipMemcpyHostToDevice, ctx->stream));
+  rc = cfrk_launch_dense(ctx, (const int8_t *)d_data, (const int64_t *)d_start,
+                         (const int32_t *)d_length, nN, nS, k, flags, (int32_t *)d_freq);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(freq_out, d_freq, freq_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return CFRK_OK;
+}
+
+/* ------------------------------------------------------------------ global counting */
+
+int cfrk_global_begin(cfrk_ctx *ctx, int k, int flags, uint64_t capacity_hint) {
+  if (!ctx) return CFRK_ERR_ARG;
+  if (k < 1 || k > 64) return cfrk_fail(ctx, CFRK_ERR_ARG, "k=%d outside 1..64", k);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  cfrk_msp_reset(ctx);
+  if (capacity_hint == 0) capacity_hint = 1ull << 24;
+  // distinct keys cannot exceed 4^k
+  if (k < 31) capacity_hint = std::min<uint64_t>(capacity_hint, 1ull << (2 * k));
+  int lg = 10;
+  while (lg < 40 && (1ull << lg) < capacity_hint * 2) ++lg;   // load factor <= 0.5 at the hint
+  const uint64_t cap = 1ull << lg;
+  const bool two = k > 32;
+  if (cap != ctx->g_cap || two != ctx->g_two || (two && !ctx->g_keys_hi)) {
+    global_release(ctx);
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->g_keys_lo, cap * 8));
+    if (two) HIP_TRY(ctx, hipMalloc((void **)&ctx->g_keys_hi, cap * 8));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->g_counts, cap * 4));
+    ctx->g_cap = cap;
+  }
+  ctx->g_log2cap = lg;
+  ctx->g_k = k;
+  ctx->g_flags = flags;
+  ctx->g_two = two;
+  // one-word: empty = all-ones key.  two-word: the COUNT word is the slot state (0 = empty).
+  if (!two) HIP_TRY(ctx, hipMemsetAsync(ctx->g_keys_lo, 0xFF, cap * 8, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->g_counts, 0, cap * 4, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats, 0, ST_NWORDS * 8, ctx->stream));
+  ctx->g_active = true;
+  ctx->ev_valid = false;
+  return CFRK_OK;
+}
+
+int cfrk_global_add_device(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
+  if (!ctx) return CFRK_ERR_ARG;
+  if (!ctx->g_active) return cfrk_fail(ctx, CFRK_ERR_STATE, "cfrk_global_add before cfrk_global_begin");
+  if (nN < 0) return cfrk_fail(ctx, CFRK_ERR_ARG, "negative size");
+  if (nN == 0) return CFRK_OK;
+  if (!d_data) return cfrk_fail(ctx, CFRK_ERR_ARG, "NULL buffer");
+  if (((uintptr_t)d_data & 15) != 0) return cfrk_fail(ctx, CFRK_ERR_ALIGN, "d_data %p", (const void *)d_data);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  int rc = cfrk_msp_usable(ctx) ? cfrk_msp_count(ctx, d_data, nN) : cfrk_hash_count(ctx, d_data, nN);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  ctx->ev_valid = true;
+  return CFRK_OK;
+}
+
+int cfrk_global_add(cfrk_ctx *ctx, const int8_t *data, const int64_t *start, const int32_t *length,
+                    int64_t nN, int64_t nS) {
+  if (!ctx) return CFRK_ERR_ARG;
+  if (!ctx->g_active) return cfrk_fail(ctx, CFRK_ERR_STATE, "cfrk_global_add before cfrk_global_begin");
+  if (nN < 0 || nS < 0) return cfrk_fail(ctx, CFRK_ERR_ARG, "negative size");
+  if (nN == 0) return CFRK_OK;
+  if (!data) return cfrk_fail(ctx, CFRK_ERR_ARG, "NULL buffer");
+  if (start && length) {
+    // struct-read layout (src/fastaIO.h:74-102, src/main.cu:195-200): read i occupies
+    // [start[i], start[i]+length[i]) and is followed by one terminator byte.
+    int64_t pos = 0;
+    for (int64_t i = 0; i < nS; ++i) {
+      if (start[i] != pos || length[i] < 0) return cfrk_fail(ctx, CFRK_ERR_LAYOUT, "read %lld: start %lld, expected %lld", (long long)i, (long long)start[i], (long long)pos);
+      pos += (int64_t)length[i] + 1;
+      if (pos > nN) return cfrk_fail(ctx, CFRK_ERR_LAYOUT, "read %lld runs past nN", (long long)i);
+      int8_t t = data[pos - 1];
+      if (t >= 0 && t <= 3) return cfrk_fail(ctx, CFRK_ERR_LAYOUT, "read %lld has no terminator", (long long)i);
+    }
+    if (pos != nN) return cfrk_fail(ctx, CFRK_ERR_LAYOUT, "sum(length)+nS = %lld but nN = %lld", (long long)pos, (long long)nN);
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  void *d_data;
+  int rc;
+  // the previous add may still be reading BUF_DATA
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if ((rc = cfrk_pool_get(ctx, BUF_DATA, (size_t)nN + 64, &d_data))) return rc;
+  // staged H2D through a pinned bounce buffer (pageable caller memory -> pinned -> device)
+  const size_t chunk = 64u << 20;
+  if (ctx->pinned_cap < 2 * chunk) {
+    if (ctx->pinned) { HIP_TRY(ctx, hipHostFree(ctx->pinned)); ctx->pinned = nullptr; ctx->pinned_cap = 0; }
+    HIP_TRY(ctx, hipHostMalloc(&ctx->pinned, 2 * chunk, hipHostMallocDefault));
+    ctx->pinned_cap = 2 * chunk;
+  }
+  hipEvent_t done[2];
+  HIP_TRY(ctx, hipEventCreateWithFlags(&done[0], hipEventDisableTiming));
+  HIP_TRY(ctx, hipEventCreateWithFlags(&done[1], hipEventDisableTiming));
+  bool used[2] = {false, false};
+  int which = 0;
+  for (size_t off = 0; off < (size_t)nN; off += chunk, which ^= 1) {
+    size_t n = std::min(chunk, (size_t)nN - off);
+    char *stage = (char *)ctx->pinned + (size_t)which * chunk;
+    if (used[which]) HIP_TRY(ctx, hipEventSynchronize(done[which]));
+    memcpy(stage, data + off, n);
+    HIP_TRY(ctx, hipMemcpyAsync((char *)d_data + off, stage, n, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(done[which], ctx->stream));
+    used[which] = true;
+  }
+  rc = cfrk_global_add_device(ctx, (const int8_t *)d_data, nN);
+  hipEventDestroy(done[0]);
+  hipEventDestroy(done[1]);
+  return rc;
+}
+
+int cfrk_global_merge_device(cfrk_ctx *ctx, const uint64_t *d_lo, const uint64_t *d_hi,
+                             const uint32_t *d_cnt, int64_t n) {
+  if (!ctx) return CFRK_ERR_ARG;
+  if (!ctx->g_active) return cfrk_fail(ctx, CFRK_ERR_STATE, "merge before begin");
+  if (n < 0) return cfrk_fail(ctx, CFRK_ERR_ARG, "negative size");
+  if (n == 0) return CFRK_OK;
+  if (!d_lo || !d_cnt || (ctx->g_two && !d_hi)) return cfrk_fail(ctx, CFRK_ERR_ARG, "NULL buffer");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = cfrk_msp_flush_to_table(ctx);
+  if (rc) return rc;
+  return cfrk_hash_merge(ctx, d_lo, d_hi, d_cnt, n);
+}
+
+int cfrk_global_finish(cfrk_ctx *ctx, uint64_t *n_distinct) {
+  uint64_t d[4];
+  int rc = cfrk_global_digest(ctx, d);
+  if (rc) return rc;
+  if (n_distinct) *n_distinct = d[0];
+  return CFRK_OK;
+}
+
+int cfrk_global_digest(cfrk_ctx *ctx, uint64_t out[4]) {
+  if (!ctx || !out) return CFRK_ERR_ARG;
+  if (!ctx->g_active) return cfrk_fail(ctx, CFRK_ERR_STATE, "digest before begin");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = cfrk_msp_flush_to_table(ctx);
+  if (rc) return rc;
+  uint64_t st[ST_NWORDS];
+  if ((rc = cfrk_hash_scan(ctx, st))) return rc;
+  if (st[ST_OVERFLOW]) return cfrk_fail(ctx, CFRK_ERR_TABLE_FULL, "table of %llu slots overflowed", (unsigned long long)ctx->g_cap);
+  out[0] = st[ST_DIG0]; out[1] = st[ST_DIG1]; out[2] = st[ST_DIG2]; out[3] = st[ST_DIG3];
+  return CFRK_OK;
+}
+
+int cfrk_global_export_device(cfrk_ctx *ctx, uint64_t *d_lo, uint64_t *d_hi, uint32_t *d_cnt,
+                              uint64_t cap, int parts, uint64_t *part_counts) {
+  if (!ctx || !part_counts || parts < 1 || parts > 1024) return CFRK_ERR_ARG;
+  if (!ctx->g_active) return cfrk_fail(ctx, CFRK_ERR_STATE, "export before begin");
+  if (cap && (!d_lo || !d_cnt || (ctx->g_two && !d_hi))) return cfrk_fail(ctx, CFRK_ERR_ARG, "NULL buffer");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = cfrk_msp_flush_to_table(ctx);
+  if (rc) return rc;
+  return cfrk_hash_export(ctx, d_lo, d_hi, d_cnt, cap, parts, part_counts);
+}
+
+int cfrk_global_export(cfrk_ctx *ctx, uint64_t *keys_lo, uint64_t *keys_hi, uint32_t *counts,
+                       uint64_t cap, uint64_t *n_out) {
+  if (!ctx || !n_out) return CFRK_ERR_ARG;
+  uint64_t n = 0;
+  int rc = cfrk_global_finish(ctx, &n);
+  if (rc) return rc;
+  *n_out = n;
+  if (n > cap) return cfrk_fail(ctx, CFRK_ERR_SMALL_BUF, "%llu entries, room for %llu", (unsigned long long)n, (unsigned long long)cap);
+  if (n == 0) return CFRK_OK;
+  if (!keys_lo || !counts) return cfrk_fail(ctx, CFRK_ERR_ARG, "NULL buffer");
+  void *d_lo, *d_hi = nullptr, *d_cnt;
+  if ((rc = cfrk_pool_get(ctx, BUF_EXPORT_LO, n * 8, &d_lo))) return rc;
+  if (ctx->g_two && (rc = cfrk_pool_get(ctx, BUF_EXPORT_HI, n * 8, &d_hi))) return rc;
+  if ((rc = cfrk_pool_get(ctx, BUF_EXPORT_CNT, n * 4, &d_cnt))) return rc;
+  uint64_t pc = 0;
+  rc = cfrk_hash_export(ctx, (uint64_t *)d_lo, (uint64_t *)d_hi, (uint32_t *)d_cnt, n, 1, &pc);
+  if (rc) return rc;
+  std::vector<uint64_t> lo(n), hi(ctx->g_two ? n : 0);
+  std::vector<uint32_t> cnt(n);
+  HIP_TRY(ctx, hipMemcpyAsync(lo.data(), d_lo, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (ctx->g_two) HIP_TRY(ctx, hipMemcpyAsync(hi.data(), d_hi, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(cnt.data(), d_cnt, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  std::vector<uint64_t> order(n);
+  std::iota(order.begin(), order.end(), 0);
+  const bool two = ctx->g_two;
+  std::sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) {
+    if (two && hi[a] != hi[b]) return hi[a] < hi[b];
+    return lo[a] < lo[b];
+  });
+  for (uint64_t i = 0; i < n; ++i) {
+    keys_lo[i] = lo[order[i]];
+    if (keys_hi) keys_hi[i] = two ? hi[order[i]] : 0;
+    counts[i] = cnt[order[i]];
+  }
+  return CFRK_OK;
+}
+
+int cfrk_global_last_add_ms(cfrk_ctx *ctx, float *ms) {
+  if (!ctx || !ms) return CFRK_ERR_ARG;
+  if (!ctx->ev_valid) return cfrk_fail(ctx, CFRK_ERR_STATE, "no add recorded");
+  HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+  HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+  return CFRK_OK;
+}
+
+/* ------------------------------------------------------------------ synthetic reads */
+
+int cfrk_synth_reads_device(cfrk_ctx *ctx, int64_t r0, int64_t R, int L, int64_t Glen,
+                            uint64_t seedG, uint64_t seedR, uint64_t seedS, int uniform,
+                            int8_t *d_data, int64_t *d_start, int32_t *d_length) {
+  if (!ctx) return CFRK_ERR_ARG;
+  if (r0 < 0 || R < 0 || L < 1 || (!uniform && Glen < L)) return cfrk_fail(ctx, CFRK_ERR_ARG, "bad generator parameters");
+  if (R == 0) return CFRK_OK;
+  if (!d_data) return cfrk_fail(ctx, CFRK_ERR_ARG, "NULL buffer");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  return cfrk_launch_synth(ctx, r0, R, L, Glen, seedG, seedR, seedS, uniform, d_data, d_start, d_length);
+}
+
+}  // extern "C"

@@ -1,0 +1,144 @@
+// common.h -- context, error plumbing and device helpers shared by the gfx950 kernels.
+// Product code: must never include or link anything under oracle/.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/cfrk_abi.h"
+
+#define CFRK_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
+#define CFRK_MAX_PROBE (1u << 22)
+
+enum {  // pool slots
+  BUF_DATA = 0, BUF_START, BUF_LENGTH, BUF_FREQ, BUF_SPILL, BUF_EXPORT_LO, BUF_EXPORT_HI,
+  BUF_EXPORT_CNT, BUF_SCRATCH, BUF_MSP_L1, BUF_MSP_L2, BUF_MSP_OUTK, BUF_MSP_OUTC, BUF_MSP_AUX,
+  BUF_NSLOTS
+};
+
+enum {  // device stats words (uint64 each)
+  ST_OVERFLOW = 0, ST_ONES, ST_CURSOR, ST_DIG0, ST_DIG1, ST_DIG2, ST_DIG3, ST_SPILLED, ST_AUX0,
+  ST_AUX1, ST_NWORDS = 16
+};
+
+struct cfrk_buf { void *p; size_t cap; };
+
+struct cfrk_ctx {
+  int device;
+  hipStream_t stream;
+  bool own_stream;
+  char err[512];
+  cfrk_buf pool[BUF_NSLOTS];
+  void *pinned; size_t pinned_cap;
+  int num_cus;
+  // global-count state
+  bool g_active;
+  int g_k, g_flags;
+  bool g_two;            // two-word keys (k > 32)
+  int g_log2cap;
+  uint64_t g_cap;
+  uint64_t *g_keys_lo, *g_keys_hi;
+  uint32_t *g_counts;
+  uint64_t *g_stats;     // device, ST_NWORDS
+  hipEvent_t ev0, ev1;
+  bool ev_valid;
+  // minimizer-partitioned fast path (msp.hip)
+  struct cfrk_msp *msp;
+};
+
+int cfrk_fail(cfrk_ctx *ctx, int code, const char *fmt, ...);
+int cfrk_pool_get(cfrk_ctx *ctx, int slot, size_t bytes, void **out);
+
+#define HIP_TRY(ctx, expr)                                                                   \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return cfrk_fail((ctx), (e_ == hipErrorOutOfMemory) ? CFRK_ERR_NOMEM : CFRK_ERR_HIP,   \
+                       "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);  \
+  } while (0)
+
+// ---- kernels' host-side launchers (one per .hip file) ------------------------------------
+int cfrk_launch_dense(cfrk_ctx *ctx, const int8_t *d_data, const int64_t *d_start,
+                      const int32_t *d_length, int64_t nN, int64_t nS, int k, int flags,
+                      int32_t *d_freq);
+int cfrk_launch_synth(cfrk_ctx *ctx, int64_t r0, int64_t R, int L, int64_t Glen, uint64_t seedG,
+                      uint64_t seedR, uint64_t seedS, int uniform, int8_t *d_data, int64_t *d_start,
+                      int32_t *d_length);
+int cfrk_hash_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN);
+int cfrk_hash_merge(cfrk_ctx *ctx, const uint64_t *lo, const uint64_t *hi, const uint32_t *cnt,
+                    int64_t n);
+int cfrk_hash_scan(cfrk_ctx *ctx, uint64_t stats_host[ST_NWORDS]);   // digest + distinct
+int cfrk_hash_export(cfrk_ctx *ctx, uint64_t *d_lo, uint64_t *d_hi, uint32_t *d_cnt, uint64_t cap,
+                     int parts, uint64_t *part_counts);
+
+// ---- device helpers -----------------------------------------------------------------------
+#ifdef __HIPCC__
+
+__device__ __forceinline__ uint64_t dev_splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+// slot / owner hash of a key
+__device__ __forceinline__ uint64_t dev_mix64(uint64_t x) {
+  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
+  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
+  x ^= x >> 32;
+  return x;
+}
+
+// 4 code bytes (first base in the lowest byte) -> 8 bits, first base most significant
+__device__ __forceinline__ uint32_t dev_pack4(uint32_t w) {
+  return ((w & 0x03030303u) * 0x40100401u) >> 24;
+}
+// 4 code bytes -> 4 bits, bit 3 = first base; set where the byte is not in 0..3
+__device__ __forceinline__ uint32_t dev_bad4(uint32_t w) {
+  uint32_t b = w & 0xFCFCFCFCu;
+  uint32_t t = b | (b >> 4);
+  t |= t >> 2;
+  t |= t >> 1;
+  return ((t & 0x01010101u) * 0x08040201u) >> 24;
+}
+__device__ __forceinline__ void dev_pack16(uint4 v, uint32_t &bases, uint32_t &bad) {
+  bases = (dev_pack4(v.x) << 24) | (dev_pack4(v.y) << 16) | (dev_pack4(v.z) << 8) | dev_pack4(v.w);
+  bad = (dev_bad4(v.x) << 12) | (dev_bad4(v.y) << 8) | (dev_bad4(v.z) << 4) | dev_bad4(v.w);
+}
+
+// One lane's 32-byte chunk at byte offset off (multiple of 32) of the flat code buffer:
+// b0,b1 = bases 0..15 / 16..31 packed 2 bits each, first base most significant;
+// bad bit (31-j) set when base j is invalid or lies at/after nN.
+__device__ __forceinline__ void dev_load_chunk32(const int8_t *__restrict__ data, int64_t off,
+                                                 int64_t nN, uint32_t &b0, uint32_t &b1,
+                                                 uint32_t &bad) {
+  if (off + 32 <= nN) {
+    const uint4 *p = reinterpret_cast<const uint4 *>(data + off);
+    uint4 v0 = p[0], v1 = p[1];
+    uint32_t m0, m1;
+    dev_pack16(v0, b0, m0);
+    dev_pack16(v1, b1, m1);
+    bad = (m0 << 16) | m1;
+  } else {
+    b0 = 0; b1 = 0; bad = 0;
+    for (int j = 0; j < 32; ++j) {
+      int c = (off + j < nN) ? (int)data[off + j] : -1;
+      bool inv = (c < 0 || c > 3);
+      uint32_t v = inv ? 0u : (uint32_t)c;
+      if (j < 16) b0 |= v << (30 - 2 * j); else b1 |= v << (30 - 2 * (j - 16));
+      if (inv) bad |= 1u << (31 - j);
+    }
+  }
+}
+
+// reverse complement of a k-mer held in the low 2k bits (first base most significant)
+__device__ __forceinline__ uint64_t dev_revcomp64(uint64_t x, int k) {
+  uint64_t r = __brevll(x);
+  r = ((r >> 1) & 0x5555555555555555ull) | ((r & 0x5555555555555555ull) << 1);
+  r = ~r;
+  return r >> (64 - 2 * k);
+}
+
+#endif  // __HIPCC__

@@ -1,0 +1,247 @@
+"""ctypes binding of libcfrk_hip.so and the host-side mirror of the reference interface.
+
+Reference interface mirrored here (paths under /root/reference/):
+  struct read { char *data; int *length; lint *start; int *Freq; }      src/tipos.h:23-30
+  void kmer_main(struct read *rd, lint nN, lint nS, int k, ushort device) src/kmer_main.cu:20
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+CFRK_COMPAT = 0x1
+CFRK_CANONICAL = 0x2
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libcfrk_hip.so")
+_HEADER = os.path.join(os.path.dirname(_HERE), "include", "cfrk_abi.h")
+
+_lib = None
+
+
+class CfrkError(RuntimeError):
+    def __init__(self, code, what, detail=""):
+        self.code = code
+        super().__init__(f"{what}: {detail}" if detail else what)
+
+
+def library_path():
+    return _SO
+
+
+def abi_symbols():
+    """every function include/cfrk_abi.h declares"""
+    text = open(_HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cfrk_[a-z0-9_]+)\s*\(", text)))
+
+
+def load_library():
+    """dlopen libcfrk_hip.so; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise CfrkError(-100, "libcfrk_hip.so is missing",
+                        "build it with `make -C cfrk_amd/csrc` or __graft_entry__.build(); "
+                        "there is no CPU fallback")
+    L = C.CDLL(_SO)
+    vp, i64, i32, u64 = C.c_void_p, C.c_int64, C.c_int, C.c_uint64
+    sig = {
+        "cfrk_abi_version": ([], C.c_int),
+        "cfrk_strerror": ([C.c_int], C.c_char_p),
+        "cfrk_last_error": ([vp], C.c_char_p),
+        "cfrk_device_count": ([C.POINTER(C.c_int)], C.c_int),
+        "cfrk_ctx_create": ([C.c_int, vp, C.POINTER(vp)], C.c_int),
+        "cfrk_ctx_destroy": ([vp], None),
+        "cfrk_ctx_sync": ([vp], C.c_int),
+        "cfrk_device_alloc": ([vp, C.c_size_t, C.POINTER(vp)], C.c_int),
+        "cfrk_device_free": ([vp, vp], C.c_int),
+        "cfrk_memcpy_h2d": ([vp, vp, vp, C.c_size_t], C.c_int),
+        "cfrk_memcpy_d2h": ([vp, vp, vp, C.c_size_t], C.c_int),
+        "cfrk_per_read_dense": ([vp, vp, vp, vp, i64, i64, i32, i32, vp], C.c_int),
+        "cfrk_per_read_dense_device": ([vp, vp, vp, vp, i64, i64, i32, i32, vp], C.c_int),
+        "cfrk_global_begin": ([vp, i32, i32, u64], C.c_int),
+        "cfrk_global_add": ([vp, vp, vp, vp, i64, i64], C.c_int),
+        "cfrk_global_add_device": ([vp, vp, i64], C.c_int),
+        "cfrk_global_merge_device": ([vp, vp, vp, vp, i64], C.c_int),
+        "cfrk_global_finish": ([vp, C.POINTER(u64)], C.c_int),
+        "cfrk_global_export": ([vp, vp, vp, vp, u64, C.POINTER(u64)], C.c_int),
+        "cfrk_global_export_device": ([vp, vp, vp, vp, u64, C.c_int, C.POINTER(u64)], C.c_int),
+        "cfrk_global_digest": ([vp, C.POINTER(u64)], C.c_int),
+        "cfrk_global_last_add_ms": ([vp, C.POINTER(C.c_float)], C.c_int),
+        "cfrk_synth_reads_device": ([vp, i64, i64, i32, i64, u64, u64, u64, i32, vp, vp, vp], C.c_int),
+    }
+    for name, (args, res) in sig.items():
+        f = getattr(L, name)
+        f.argtypes = args
+        f.restype = res
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One HIP stream + persistent device pool on one GPU (cfrk_ctx)."""
+
+    def __init__(self, device=0, stream=None):
+        self._L = load_library()
+        h = C.c_void_p()
+        rc = self._L.cfrk_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h))
+        if rc != 0:
+            raise CfrkError(rc, "cfrk_ctx_create", self._L.cfrk_strerror(rc).decode())
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.cfrk_ctx_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def check(self, rc, what):
+        if rc != 0:
+            raise CfrkError(rc, f"{what}: {self._L.cfrk_strerror(rc).decode()}",
+                            self._L.cfrk_last_error(self._h).decode())
+
+    def sync(self):
+        self.check(self._L.cfrk_ctx_sync(self._h), "cfrk_ctx_sync")
+
+    # -- raw device buffers --------------------------------------------------------------
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        self.check(self._L.cfrk_device_alloc(self._h, nbytes, C.byref(p)), "cfrk_device_alloc")
+        return p.value
+
+    def free(self, dptr):
+        self.check(self._L.cfrk_device_free(self._h, C.c_void_p(dptr)), "cfrk_device_free")
+
+    def h2d(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        self.check(self._L.cfrk_memcpy_h2d(self._h, C.c_void_p(dptr), _ptr(arr), arr.nbytes), "cfrk_memcpy_h2d")
+
+    def d2h(self, arr, dptr):
+        self.check(self._L.cfrk_memcpy_d2h(self._h, _ptr(arr), C.c_void_p(dptr), arr.nbytes), "cfrk_memcpy_d2h")
+
+    # -- per-read dense (kmer_main) --------------------------------------------------------
+    def per_read_dense(self, data, start, length, k, flags=CFRK_COMPAT):
+        data = np.ascontiguousarray(data, np.int8)
+        start = np.ascontiguousarray(start, np.int64)
+        length = np.ascontiguousarray(length, np.int32)
+        nS = len(length)
+        if len(start) != nS:
+            raise ValueError("start and length differ in size")
+        freq = np.empty(nS * 4 ** k if 1 <= k <= 15 else 0, np.int32)
+        self.check(self._L.cfrk_per_read_dense(self._h, _ptr(data), _ptr(start), _ptr(length),
+                                               len(data), nS, k, flags, _ptr(freq)),
+                   "cfrk_per_read_dense")
+        return freq.reshape(nS, -1) if nS else freq.reshape(0, 4 ** k)
+
+    def synth_reads_device(self, r0, R, L, Glen, d_data, d_start=None, d_length=None,
+                           seedG=1, seedR=2, seedS=3, uniform=False):
+        self.check(self._L.cfrk_synth_reads_device(self._h, r0, R, L, Glen, seedG, seedR, seedS,
+                                                   int(uniform), C.c_void_p(d_data),
+                                                   C.c_void_p(d_start) if d_start else None,
+                                                   C.c_void_p(d_length) if d_length else None),
+                   "cfrk_synth_reads_device")
+
+
+class GlobalCounter:
+    """Global (all-reads) k-mer counts: begin / add* / finish / export."""
+
+    def __init__(self, ctx, k, flags=0, capacity_hint=0):
+        self.ctx, self.k, self.flags = ctx, k, flags
+        self._L = ctx._L
+        ctx.check(self._L.cfrk_global_begin(ctx._h, k, flags, capacity_hint), "cfrk_global_begin")
+
+    def add(self, data, start=None, length=None):
+        data = np.ascontiguousarray(data, np.int8)
+        if start is not None:
+            start = np.ascontiguousarray(start, np.int64)
+            length = np.ascontiguousarray(length, np.int32)
+        nS = 0 if length is None else len(length)
+        self.ctx.check(self._L.cfrk_global_add(self.ctx._h, _ptr(data), _ptr(start), _ptr(length),
+                                               len(data), nS), "cfrk_global_add")
+
+    def add_device(self, d_data, nN):
+        self.ctx.check(self._L.cfrk_global_add_device(self.ctx._h, C.c_void_p(d_data), nN),
+                       "cfrk_global_add_device")
+
+    def merge_device(self, d_lo, d_hi, d_cnt, n):
+        self.ctx.check(self._L.cfrk_global_merge_device(self.ctx._h, C.c_void_p(d_lo),
+                                                        C.c_void_p(d_hi) if d_hi else None,
+                                                        C.c_void_p(d_cnt), n),
+                       "cfrk_global_merge_device")
+
+    def finish(self):
+        n = C.c_uint64()
+        self.ctx.check(self._L.cfrk_global_finish(self.ctx._h, C.byref(n)), "cfrk_global_finish")
+        return n.value
+
+    def digest(self):
+        out = (C.c_uint64 * 4)()
+        self.ctx.check(self._L.cfrk_global_digest(self.ctx._h, out), "cfrk_global_digest")
+        return tuple(int(x) for x in out)
+
+    def last_add_ms(self):
+        ms = C.c_float()
+        self.ctx.check(self._L.cfrk_global_last_add_ms(self.ctx._h, C.byref(ms)), "cfrk_global_last_add_ms")
+        return ms.value
+
+    def export(self):
+        """-> (keys_lo, keys_hi, counts) sorted by (hi, lo)"""
+        n = self.finish()
+        lo = np.empty(n, np.uint64)
+        hi = np.empty(n, np.uint64)
+        cnt = np.empty(n, np.uint32)
+        got = C.c_uint64()
+        self.ctx.check(self._L.cfrk_global_export(self.ctx._h, _ptr(lo), _ptr(hi), _ptr(cnt), n,
+                                                  C.byref(got)), "cfrk_global_export")
+        assert got.value == n
+        return lo, hi, cnt
+
+    def export_device(self, d_lo, d_hi, d_cnt, cap, parts=1):
+        pc = (C.c_uint64 * parts)()
+        self.ctx.check(self._L.cfrk_global_export_device(self.ctx._h, C.c_void_p(d_lo),
+                                                         C.c_void_p(d_hi) if d_hi else None,
+                                                         C.c_void_p(d_cnt), cap, parts, pc),
+                       "cfrk_global_export_device")
+        return [int(x) for x in pc]
+
+
+class Read:
+    """Mirror of `struct read` (src/tipos.h:23-30): data / length / start in, Freq out."""
+
+    def __init__(self, data, length, start):
+        self.data = np.ascontiguousarray(data, np.int8)
+        self.length = np.ascontiguousarray(length, np.int32)
+        self.start = np.ascontiguousarray(start, np.int64)
+        self.Freq = None
+
+
+_default_ctx = {}
+
+
+def kmer_main(rd, nN, nS, k, device=0, flags=CFRK_COMPAT):
+    """Drop-in mirror of kmer_main (src/kmer_main.cu:20): fills rd.Freq (nS x 4^k int32).
+
+    Same argument meaning as the reference; errors raise CfrkError instead of printing and
+    continuing (src/kmer_main.cu:59-63) or exit(1) (src/kmer_main.cu:51-56)."""
+    if nN != len(rd.data) or nS != len(rd.length):
+        raise ValueError("nN / nS do not match the buffers")
+    ctx = _default_ctx.get(device)
+    if ctx is None:
+        ctx = _default_ctx[device] = Context(device)
+    rd.Freq = ctx.per_read_dense(rd.data, rd.start, rd.length, k, flags).reshape(-1)
+    return rd

@@ -1,0 +1,64 @@
+"""Read-sharded global counting over N GPUs with one key-owner exchange.
+
+The reference's "multi GPU" fan-out (/root/reference/src/main.cu:208-230,277-284) runs every
+pthread on the same device and has no merge step; this replaces it.  Reads are range-partitioned
+(rank r counts reads [r*R/N, (r+1)*R/N)); each rank then splits its table into N segments by
+owner(key) = mix(key) % N, one all-to-all (RCCL over xGMI; gloo in the CPU tests) moves
+segment j to rank j, and the owner adds the received (key, count) pairs.  Afterwards rank j
+holds the final counts of exactly the keys it owns: a reduce-scatter by key.  An element-wise
+ncclReduce of the raw tables would be wrong because slot positions depend on insertion order.
+
+The counting engine is passed in (duck-typed):
+    engine.export_parts(parts) -> (lo, hi_or_None, cnt, part_counts)   torch tensors + list
+    engine.merge(lo, hi_or_None, cnt)                                  add pairs into the owner table
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total, rank, world):
+    """contiguous range of units for `rank` (GPU g gets reads [g*R/G, (g+1)*R/G))"""
+    return (total * rank) // world, (total * (rank + 1)) // world
+
+
+def exchange_by_owner(engine, world, device):
+    """all-to-all of the owner segments; returns (lo, hi, cnt) received by this rank"""
+    lo, hi, cnt, part_counts = engine.export_parts(world)
+    send = torch.tensor(part_counts, dtype=torch.int64, device=device)
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send)
+    send_l = [int(x) for x in part_counts]
+    recv_l = [int(x) for x in recv.cpu().tolist()]
+    n_recv = sum(recv_l)
+
+    def a2a(t):
+        out = torch.empty(n_recv, dtype=t.dtype, device=device)
+        dist.all_to_all_single(out, t[:sum(send_l)].contiguous(), recv_l, send_l)
+        return out
+
+    # torch has no uint64 collectives everywhere: move keys as int64 bit patterns
+    rlo = a2a(lo.view(torch.int64))
+    rhi = a2a(hi.view(torch.int64)) if hi is not None else None
+    rcnt = a2a(cnt.view(torch.int32))
+    return rlo, rhi, rcnt
+
+
+def merge_digests(local, device):
+    """combine per-rank digests (owners hold disjoint key sets): sums mod 2^64 and xor"""
+    world = dist.get_world_size()
+    mine = torch.tensor([_to_i64(x) for x in local], dtype=torch.int64, device=device)
+    allv = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(allv, mine)
+    d = s = w = x = 0
+    for v in allv:
+        a = [int(t) & 0xFFFFFFFFFFFFFFFF for t in v.cpu().tolist()]
+        d = (d + a[0]) & 0xFFFFFFFFFFFFFFFF
+        s = (s + a[1]) & 0xFFFFFFFFFFFFFFFF
+        w = (w + a[2]) & 0xFFFFFFFFFFFFFFFF
+        x ^= a[3]
+    return (d, s, w, x)
+
+
+def _to_i64(u):
+    u &= 0xFFFFFFFFFFFFFFFF
+    return u - (1 << 64) if u >= (1 << 63) else u

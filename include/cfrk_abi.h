@@ -1,0 +1,155 @@
+/*
+ * cfrk_abi.h -- C ABI of libcfrk_hip.so, the MI355X (gfx950) replacement for the
+ * reference's device hot path.
+ *
+ * What it replaces (paths under /root/reference/):
+ *   void kmer_main(struct read *rd, lint nN, lint nS, int k, ushort device);
+ *        declared src/kmer.cuh:6, defined src/kmer_main.cu:20-128, called from
+ *        src/main.cu:222,294,300; launches SetMatrix / ComputeIndex / ComputeFreqNew
+ *        (src/kmer_kernel.cu:6-90).
+ *   struct read { char *data; int *length; lint *start; int *Freq; ... }   src/tipos.h:23-30
+ *
+ * Data contract (identical to struct read):
+ *   data    int8 codes, A=0 C=1 G=2 T=3 (src/fastaIO.h:121-140); any other value (the
+ *           reference uses -1) is an invalid base AND the per-read terminator
+ *           (src/fastaIO.h:96).
+ *   length  bases per read, terminator excluded (src/fastaIO.h:98).
+ *   start   byte offset of read i in data; start[0]=0,
+ *           start[i]=start[i-1]+length[i-1]+1 (src/main.cu:195-200).
+ *   nN      bytes in data = sum(length)+nS (src/fastaIO.h:145).
+ *   k-mer index = sum_i code[i] * 4^(k-1-i), first base most significant
+ *           (src/kmer_kernel.cu:38).
+ *
+ * Conventions: every function returns CFRK_OK (0) or a negative CFRK_ERR_* code; the
+ * library never prints and never calls exit() (the reference does both:
+ * src/kmer_main.cu:51-63).  A cfrk_ctx owns one HIP stream and a device memory pool that
+ * persists across calls (the reference mallocs/frees per call, src/kmer_main.cu:59-63,
+ * 120-124).  Different contexts may be used concurrently from different threads; one
+ * context may not.  Plain pointers and sizes only: no torch / C++ types cross this boundary.
+ */
+#ifndef CFRK_ABI_H
+#define CFRK_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CFRK_ABI_VERSION 1
+
+/* error codes */
+#define CFRK_OK              0
+#define CFRK_ERR_ARG        -1   /* bad argument (k out of range, NULL pointer, negative size) */
+#define CFRK_ERR_NOMEM      -2   /* device (or pinned host) allocation failed / would not fit   */
+#define CFRK_ERR_HIP        -3   /* a HIP runtime call failed; see cfrk_last_error              */
+#define CFRK_ERR_STATE      -4   /* call sequence violated (e.g. add before begin)              */
+#define CFRK_ERR_LAYOUT     -5   /* data/start/length inconsistent with the struct-read layout  */
+#define CFRK_ERR_TABLE_FULL -6   /* global table overflowed; re-run with a larger capacity_hint */
+#define CFRK_ERR_ALIGN      -7   /* device data pointer not 16-byte aligned                      */
+#define CFRK_ERR_NO_DEVICE  -8   /* no usable gfx950 device                                      */
+#define CFRK_ERR_SMALL_BUF  -9   /* output buffer smaller than the result                        */
+
+/* flags */
+#define CFRK_COMPAT     0x1  /* per-read dense only: reproduce ComputeFreqNew exactly (no -1 guard ->
+                                spill into the previous row's last bin, bound length-1, 1024-window
+                                cap; src/kmer_kernel.cu:73-90, src/kmer_main.cu:82-83).  Without it:
+                                the guarded ComputeFreq semantics (src/kmer_kernel.cu:52-70).        */
+#define CFRK_CANONICAL  0x2  /* global only: key = min(kmer, reverse complement)                     */
+
+typedef struct cfrk_ctx cfrk_ctx;
+
+/* ---- context ------------------------------------------------------------------------- */
+
+/* Replaces cudaSetDevice + GetDeviceProp + per-call cudaMalloc (src/kmer_main.cu:40-63).
+ * hip_stream == NULL: the context creates its own non-blocking stream; otherwise it
+ * launches on the caller's hipStream_t (e.g. torch.cuda.current_stream().cuda_stream). */
+int  cfrk_ctx_create(int device, void *hip_stream, cfrk_ctx **out);
+void cfrk_ctx_destroy(cfrk_ctx *ctx);
+int  cfrk_abi_version(void);
+const char *cfrk_strerror(int code);
+const char *cfrk_last_error(const cfrk_ctx *ctx);   /* detail of the last failure on ctx */
+int  cfrk_device_count(int *count);
+int  cfrk_ctx_sync(cfrk_ctx *ctx);                  /* cudaStreamSynchronize(0) at src/main.cu:223 */
+
+/* plain device buffers on the context's device (for callers without another allocator) */
+int  cfrk_device_alloc(cfrk_ctx *ctx, size_t bytes, void **dptr);
+int  cfrk_device_free(cfrk_ctx *ctx, void *dptr);
+int  cfrk_memcpy_h2d(cfrk_ctx *ctx, void *dst_device, const void *src_host, size_t bytes);
+int  cfrk_memcpy_d2h(cfrk_ctx *ctx, void *dst_host, const void *src_device, size_t bytes);
+
+/* ---- per-read dense counting: the drop-in for kmer_main ------------------------------- */
+
+/* Host buffers in, host buffer out; synchronous like kmer_main (blocking D2H at
+ * src/kmer_main.cu:116).  freq_out is CALLER-allocated, nS * 4^k int32 (the reference
+ * allocates rd->Freq itself and never frees it, src/kmer_main.cu:115).  1 <= k <= 15
+ * (src/tipos.h:5).  Index arithmetic is exact integer for every k (the reference's float
+ * accumulation, src/kmer_kernel.cu:38, is exact only for k <= 12). */
+int cfrk_per_read_dense(cfrk_ctx *ctx, const int8_t *data, const int64_t *start,
+                        const int32_t *length, int64_t nN, int64_t nS, int k, int flags,
+                        int32_t *freq_out);
+
+/* Same with every buffer already resident on the context's device; asynchronous on the
+ * context stream. */
+int cfrk_per_read_dense_device(cfrk_ctx *ctx, const int8_t *d_data, const int64_t *d_start,
+                               const int32_t *d_length, int64_t nN, int64_t nS, int k, int flags,
+                               int32_t *d_freq_out);
+
+/* ---- global counting: sum over reads of the per-read rows, any 1 <= k <= 64 ------------ */
+
+/* Semantics: the guarded ComputeFreq (src/kmer_kernel.cu:52-70) summed over all reads of all
+ * cfrk_global_add calls since begin; a window counts iff its k codes are all valid, so no
+ * window crosses a terminator.  Result = set of (key, count), count < 2^32.
+ * capacity_hint = expected number of DISTINCT keys (0: library default). */
+int cfrk_global_begin(cfrk_ctx *ctx, int k, int flags, uint64_t capacity_hint);
+
+/* Host buffers (struct read fields).  start/length may be NULL; when given they are checked
+ * against the terminators in data (CFRK_ERR_LAYOUT).  Stages through pinned memory, H2D on the
+ * context stream, then counts; returns after the counting kernels are enqueued. */
+int cfrk_global_add(cfrk_ctx *ctx, const int8_t *data, const int64_t *start,
+                    const int32_t *length, int64_t nN, int64_t nS);
+
+/* Device-resident data (16-byte aligned); asynchronous on the context stream. */
+int cfrk_global_add_device(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN);
+
+/* Add pre-counted (key, count) pairs, e.g. another GPU's export received over RCCL.
+ * d_keys_hi may be NULL for k <= 32. */
+int cfrk_global_merge_device(cfrk_ctx *ctx, const uint64_t *d_keys_lo, const uint64_t *d_keys_hi,
+                             const uint32_t *d_counts, int64_t n);
+
+/* Wait for all adds; report the number of distinct keys.  CFRK_ERR_TABLE_FULL if the table
+ * overflowed. */
+int cfrk_global_finish(cfrk_ctx *ctx, uint64_t *n_distinct);
+
+/* Sorted ascending by (hi, lo).  keys_hi may be NULL for k <= 32.  cap = entries available. */
+int cfrk_global_export(cfrk_ctx *ctx, uint64_t *keys_lo, uint64_t *keys_hi, uint32_t *counts,
+                       uint64_t cap, uint64_t *n_out);
+
+/* Unsorted export into device buffers, grouped into `parts` contiguous segments by
+ * owner(key) = (mix(key) >> 32) % parts (key-owner partition for the multi-GPU
+ * merge).  part_counts (host, `parts` entries) receives the segment sizes.  Synchronises. */
+int cfrk_global_export_device(cfrk_ctx *ctx, uint64_t *d_keys_lo, uint64_t *d_keys_hi,
+                              uint32_t *d_counts, uint64_t cap, int parts, uint64_t *part_counts);
+
+/* Order-independent digest: out[0]=distinct, out[1]=sum count,
+ * out[2]=sum count*splitmix64(kh) mod 2^64, out[3]=xor splitmix64(kh ^ count);
+ * kh = lo (k<=32) or lo + splitmix64(hi). Synchronises. */
+int cfrk_global_digest(cfrk_ctx *ctx, uint64_t out[4]);
+
+/* Device time (ms, HIP events on the context stream) of the counting kernels of the most
+ * recent cfrk_global_add / cfrk_global_add_device; synchronises. */
+int cfrk_global_last_add_ms(cfrk_ctx *ctx, float *ms);
+
+/* ---- synthetic reads, generated on device ----------------------------------- */
+
+/* Reads [r0, r0+R) of the deterministic generator, struct-read layout: d_data R*(L+1) bytes,
+ * d_start R int64 (may be NULL), d_length R int32 (may be NULL). */
+int cfrk_synth_reads_device(cfrk_ctx *ctx, int64_t r0, int64_t R, int L, int64_t Glen,
+                            uint64_t seedG, uint64_t seedR, uint64_t seedS, int uniform,
+                            int8_t *d_data, int64_t *d_start, int32_t *d_length);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,259 @@
+"""GPU parity: the HIP path (through the C ABI) against the oracle and the reference goldens.
+
+Bit-exact everywhere: this is integer work.  Run with `pytest -m gpu` on an MI355X.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from . import oracle_lib as orc
+from . import refsem
+from .conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import cfrk_amd
+    c = cfrk_amd.Context(0)
+    yield c
+    c.close()
+
+
+def _random_reads(rng, n, lo, hi, p_invalid=0.02):
+    reads = []
+    for L in rng.integers(lo, hi, n):
+        r = rng.integers(0, 4, int(L)).astype(np.int8)
+        if p_invalid:
+            r[rng.random(int(L)) < p_invalid] = -1
+        reads.append(r)
+    return reads
+
+
+# ------------------------------------------------------------------ per-read dense (kmer_main)
+
+@pytest.mark.parametrize("name", ["seq1", "seq2"])
+def test_golden_k2_byte_exact(ctx, derived_fasta, name):
+    """reference test/test.sh:13-19 against the reference's own goldens"""
+    import cfrk_amd
+    raw = open(derived_fasta[name], "rb").read()
+    reads = refsem.remainder_chunk(refsem.read_fasta_compat(raw), 8192)
+    data, start, length = refsem.flatten(reads)
+    rd = cfrk_amd.Read(data, length, start)
+    cfrk_amd.kmer_main(rd, len(data), len(length), 2, 0)
+    got = orc.format_cfrk(rd.Freq, 2)           # checker-side formatter (src/main.cu:26-62)
+    want = open(os.path.join(GOLDEN, f"out-{name}.cfrk"), "rb").read()
+    assert got == want
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 6, 7, 8, 10])
+@pytest.mark.parametrize("compat", [True, False])
+def test_dense_vs_oracle(ctx, k, compat):
+    import cfrk_amd
+    rng = np.random.default_rng(100 + k)
+    n = 300 if k <= 8 else 20
+    reads = _random_reads(rng, n, 1, 400)
+    reads[3] = np.zeros(0, np.int8)                       # empty read
+    reads[4] = np.array([2], np.int8)                     # single base
+    reads[5] = rng.integers(0, 4, 3000).astype(np.int8)   # > 1025: compat truncates at 1024 windows
+    reads[6] = np.full(50, -1, np.int8)                   # all invalid
+    reads[0][:k] = -1                                     # read 0 spills to Freq[-1] in compat: dropped
+    data, start, length = refsem.flatten(reads)
+    flags = cfrk_amd.CFRK_COMPAT if compat else 0
+    got = ctx.per_read_dense(data, start, length, k, flags)
+    want = orc.per_read_dense(data, start, length, k, orc.ORC_COMPAT if compat else 0)
+    assert (got == want).all()
+
+
+def test_dense_single_read_and_empty_batch(ctx):
+    import cfrk_amd
+    data, start, length = refsem.flatten([np.array([0, 1, 2, 3, 0, 1], np.int8)])
+    got = ctx.per_read_dense(data, start, length, 2, cfrk_amd.CFRK_COMPAT)
+    assert (got == orc.per_read_dense(data, start, length, 2, orc.ORC_COMPAT)).all()
+    e = ctx.per_read_dense(np.zeros(0, np.int8), np.zeros(0, np.int64), np.zeros(0, np.int32), 3)
+    assert e.shape == (0, 64)
+
+
+def test_dense_chunk_of_8192_reads_k4(ctx):
+    """the reference's default chunk (src/main.cu:235) at k=4"""
+    import cfrk_amd
+    rng = np.random.default_rng(7)
+    reads = _random_reads(rng, 8192, 140, 160, 0.005)
+    data, start, length = refsem.flatten(reads)
+    got = ctx.per_read_dense(data, start, length, 4, cfrk_amd.CFRK_COMPAT)
+    want = orc.per_read_dense(data, start, length, 4, orc.ORC_COMPAT)
+    assert (got == want).all()
+
+
+def test_dense_errors(ctx):
+    import cfrk_amd
+    data, start, length = refsem.flatten([np.array([0, 1, 2, 3], np.int8)])
+    for k in (0, 16, -1):
+        with pytest.raises(cfrk_amd.CfrkError) as e:
+            ctx.per_read_dense(data, start, length, k)
+        assert e.value.code == -1
+
+
+# ------------------------------------------------------------------ global counting
+
+def _cmp_global(ctx, data, k, canonical, hint=0, start=None, length=None):
+    import cfrk_amd
+    g = cfrk_amd.GlobalCounter(ctx, k, cfrk_amd.CFRK_CANONICAL if canonical else 0, hint)
+    g.add(data, start, length)
+    lo, hi, cnt = g.export()
+    wlo, whi, wcnt = orc.global_count(data, k, orc.ORC_CANONICAL if canonical else 0)
+    assert len(lo) == len(wlo)
+    assert (lo == wlo).all() and (hi == whi).all() and (cnt.astype(np.uint64) == wcnt).all()
+    assert g.digest() == orc.digest(wlo, whi, wcnt, two_word=k > 32)
+    return g
+
+
+@pytest.mark.parametrize("k", [1, 2, 5, 15, 16, 21, 31, 32, 33, 47, 63, 64])
+@pytest.mark.parametrize("canonical", [False, True])
+def test_global_vs_oracle(ctx, k, canonical):
+    rng = np.random.default_rng(200 + k)
+    reads = _random_reads(rng, 400, 1, 300)
+    reads.append(np.full(200, 3, np.int8))      # poly-T: the all-ones key at k=32
+    reads.append(np.full(200, 0, np.int8))      # poly-A
+    reads.append(np.zeros(0, np.int8))
+    data, start, length = refsem.flatten(reads)
+    _cmp_global(ctx, data, k, canonical, start=start, length=length)
+
+
+def test_global_ragged_tail_sizes(ctx):
+    """buffer lengths around the 32-byte chunk / 2 KiB tile edges of the packed front end"""
+    rng = np.random.default_rng(5)
+    for n in (1, 15, 31, 32, 33, 63, 64, 65, 2047, 2048, 2049, 2079, 2080, 4096 + 31, 70000):
+        data = rng.integers(0, 4, n).astype(np.int8)
+        data[rng.random(n) < 0.01] = -1
+        data[-1] = -1
+        for k in (1, 7, 31, 32):
+            _cmp_global(ctx, data, k, True)
+
+
+def test_global_multiple_adds_accumulate(ctx):
+    import cfrk_amd
+    d1, _, _ = orc.synth_reads(0, 3000, 150, 20000)
+    d2, _, _ = orc.synth_reads(3000, 2000, 150, 20000)
+    g = cfrk_amd.GlobalCounter(ctx, 31, cfrk_amd.CFRK_CANONICAL, 50000)
+    g.add(d1)
+    g.add(d2)
+    lo, hi, cnt = g.export()
+    wlo, whi, wcnt = orc.global_count(np.concatenate([d1, d2]), 31, orc.ORC_CANONICAL)
+    assert (lo == wlo).all() and (cnt.astype(np.uint64) == wcnt).all()
+    assert int(cnt.sum()) == 5000 * 120
+
+
+def test_synth_device_matches_oracle_generator(ctx):
+    R, L, G = 1000, 150, 5000
+    want, wstart, wlen = orc.synth_reads(17, R, L, G)
+    d = ctx.alloc(R * (L + 1)); s = ctx.alloc(R * 8); l = ctx.alloc(R * 4)
+    ctx.synth_reads_device(17, R, L, G, d, s, l)
+    got = np.empty(R * (L + 1), np.int8); gs = np.empty(R, np.int64); gl = np.empty(R, np.int32)
+    ctx.d2h(got, d); ctx.d2h(gs, s); ctx.d2h(gl, l)
+    assert (got == want).all() and (gs == wstart).all() and (gl == wlen).all()
+    want_u, _, _ = orc.synth_reads(0, 200, 100, 0, uniform=True)
+    ctx.synth_reads_device(0, 200, 100, 0, d, uniform=True)
+    got_u = np.empty(200 * 101, np.int8); ctx.d2h(got_u, d)
+    assert (got_u == want_u).all()
+    for p in (d, s, l):
+        ctx.free(p)
+
+
+def test_c2_shape_1m_reads_k15_full_equality(ctx):
+    """BASELINE config 2 shape (150 bp, k=15, canonical) at 1 M reads: full (key,count) equality"""
+    import cfrk_amd
+    R, L, G = 1_000_000, 150, 1_000_000
+    d = ctx.alloc(R * (L + 1))
+    ctx.synth_reads_device(0, R, L, G, d)
+    g = cfrk_amd.GlobalCounter(ctx, 15, cfrk_amd.CFRK_CANONICAL, 2_000_000)
+    g.add_device(d, R * (L + 1))
+    lo, hi, cnt = g.export()
+    host = np.empty(R * (L + 1), np.int8)
+    ctx.d2h(host, d)
+    wlo, _, wcnt = orc.global_count(host, 15, orc.ORC_CANONICAL, threads=8)
+    assert len(lo) == len(wlo) and (lo == wlo).all() and (cnt.astype(np.uint64) == wcnt).all()
+    ctx.free(d)
+
+
+def test_c3_shape_properties_k31(ctx):
+    """config-3 shape (k=31, 150 bp, canonical) at 4 M reads: size-independent properties --
+    sum(count) == R*(L-k+1) exactly (no invalid bases), counting reads twice doubles every
+    count (linearity), distinct <= 2*Glen windows of the genome."""
+    import cfrk_amd
+    R, L, G, k = 4_000_000, 150, 4_000_000, 31
+    nN = R * (L + 1)
+    d = ctx.alloc(nN)
+    ctx.synth_reads_device(0, R, L, G, d)
+    g = cfrk_amd.GlobalCounter(ctx, k, cfrk_amd.CFRK_CANONICAL, 2 * G)
+    g.add_device(d, nN)
+    d1 = g.digest()
+    assert d1[1] == R * (L - k + 1)
+    assert d1[0] <= G - k + 1
+    g.add_device(d, nN)
+    d2 = g.digest()
+    assert d2[0] == d1[0] and d2[1] == 2 * d1[1]
+    assert d2[2] == (2 * d1[2]) % (1 << 64)
+    # prefix equality against the oracle on the first 100k reads
+    g2 = cfrk_amd.GlobalCounter(ctx, k, cfrk_amd.CFRK_CANONICAL, 2 * G)
+    n1 = 100_000 * (L + 1)
+    g2.add_device(d, n1)
+    host = np.empty(n1, np.int8)
+    ctx.d2h(host, d)
+    wlo, whi, wcnt = orc.global_count(host, k, orc.ORC_CANONICAL, threads=8)
+    assert g2.digest() == orc.digest(wlo, whi, wcnt)
+    ctx.free(d)
+
+
+def test_export_partition_and_merge_roundtrip(ctx):
+    """key-owner partitioned export, then count-add merge into another table"""
+    import cfrk_amd
+    data, _, _ = orc.synth_reads(0, 5000, 150, 30000)
+    for k in (31, 47):
+        g = cfrk_amd.GlobalCounter(ctx, k, cfrk_amd.CFRK_CANONICAL, 100000)
+        g.add(data)
+        want = g.digest()
+        n = want[0]
+        lo, hi, cn = ctx.alloc(n * 8), ctx.alloc(n * 8), ctx.alloc(n * 4)
+        parts = g.export_device(lo, hi, cn, n, parts=3)
+        assert sum(parts) == n and min(parts) > 0
+        klo = np.empty(n, np.uint64); ctx.d2h(klo, lo)
+        ctx2 = cfrk_amd.Context(0)
+        g2 = cfrk_amd.GlobalCounter(ctx2, k, cfrk_amd.CFRK_CANONICAL, 100000)
+        off = 0
+        for p in parts:                      # merge segment by segment, twice the first one
+            g2.merge_device(lo + off * 8, hi + off * 8, cn + off * 4, p)
+            off += p
+        assert g2.digest() == want
+        g2.merge_device(lo, hi, cn, n)
+        d2 = g2.digest()
+        assert d2[0] == n and d2[1] == 2 * want[1]
+        ctx2.close()
+        for p in (lo, hi, cn):
+            ctx.free(p)
+
+
+def test_global_errors(ctx):
+    import cfrk_amd
+    with pytest.raises(cfrk_amd.CfrkError) as e:
+        cfrk_amd.GlobalCounter(ctx, 65)
+    assert e.value.code == -1
+    data, start, length = refsem.flatten([np.array([0, 1, 2, 3], np.int8), np.array([1, 1], np.int8)])
+    g = cfrk_amd.GlobalCounter(ctx, 3)
+    bad = start.copy(); bad[1] += 1
+    with pytest.raises(cfrk_amd.CfrkError) as e:
+        g.add(data, bad, length)
+    assert e.value.code == -5
+    noterm = data.copy(); noterm[4] = 0
+    with pytest.raises(cfrk_amd.CfrkError) as e:
+        g.add(noterm, start, length)
+    assert e.value.code == -5
+    # table overflow is reported, not silently wrong
+    rnd = np.random.default_rng(0).integers(0, 4, 200000).astype(np.int8)
+    g = cfrk_amd.GlobalCounter(ctx, 31, 0, 64)
+    g.add(rnd)
+    with pytest.raises(cfrk_amd.CfrkError) as e:
+        g.finish()
+    assert e.value.code == -6
