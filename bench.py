@@ -38,7 +38,7 @@ def cpu_baseline(args, glen):
     """the oracle (a CPU restatement; the reference has no CPU path) on a bounded sample"""
     from tests import oracle_lib as orc
     R = min(args.cpu_reads, args.reads)
-    threads = args.cpu_threads or min(os.cpu_count() or 1, 32)
+    threads = args.cpu_threads or min(os.cpu_count() or 1, 16)
     data, _, _ = orc.synth_reads(0, R, args.L, glen)
     flags = 0 if args.no_canonical else orc.ORC_CANONICAL
     t0 = time.perf_counter()

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "msp.h"
+#include "table.h"
 
 int cfrk_fail(cfrk_ctx *ctx, int code, const char *fmt, ...) {
   if (ctx) {
@@ -261,7 +262,13 @@ int cfrk_global_add_device(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   if (((uintptr_t)d_data & 15) != 0) return cfrk_fail(ctx, CFRK_ERR_ALIGN, "d_data %p", (const void *)d_data);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  int rc = cfrk_msp_usable(ctx) ? cfrk_msp_count(ctx, d_data, nN) : cfrk_hash_count(ctx, d_data, nN);
+  int rc;
+  if (cfrk_msp_usable(ctx)) {
+    rc = cfrk_msp_count(ctx, d_data, nN);
+  } else {
+    cfrk_msp_note_table_write(ctx);
+    rc = cfrk_hash_count(ctx, d_data, nN);
+  }
   if (rc) return rc;
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   ctx->ev_valid = true;
@@ -331,6 +338,7 @@ int cfrk_global_merge_device(cfrk_ctx *ctx, const uint64_t *d_lo, const uint64_t
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   int rc = cfrk_msp_flush_to_table(ctx);
   if (rc) return rc;
+  cfrk_msp_note_table_write(ctx);
   return cfrk_hash_merge(ctx, d_lo, d_hi, d_cnt, n);
 }
 
@@ -346,10 +354,12 @@ int cfrk_global_digest(cfrk_ctx *ctx, uint64_t out[4]) {
   if (!ctx || !out) return CFRK_ERR_ARG;
   if (!ctx->g_active) return cfrk_fail(ctx, CFRK_ERR_STATE, "digest before begin");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  int rc = cfrk_msp_flush_to_table(ctx);
+  ResultSrc src;
+  bool use_list = false;
+  int rc = cfrk_msp_resolve(ctx, &src, &use_list);
   if (rc) return rc;
   uint64_t st[ST_NWORDS];
-  if ((rc = cfrk_hash_scan(ctx, st))) return rc;
+  if ((rc = cfrk_result_scan(ctx, use_list ? &src : nullptr, st))) return rc;
   if (st[ST_OVERFLOW]) return cfrk_fail(ctx, CFRK_ERR_TABLE_FULL, "table of %llu slots overflowed", (unsigned long long)ctx->g_cap);
   out[0] = st[ST_DIG0]; out[1] = st[ST_DIG1]; out[2] = st[ST_DIG2]; out[3] = st[ST_DIG3];
   return CFRK_OK;
@@ -361,9 +371,11 @@ int cfrk_global_export_device(cfrk_ctx *ctx, uint64_t *d_lo, uint64_t *d_hi, uin
   if (!ctx->g_active) return cfrk_fail(ctx, CFRK_ERR_STATE, "export before begin");
   if (cap && (!d_lo || !d_cnt || (ctx->g_two && !d_hi))) return cfrk_fail(ctx, CFRK_ERR_ARG, "NULL buffer");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  int rc = cfrk_msp_flush_to_table(ctx);
+  ResultSrc src;
+  bool use_list = false;
+  int rc = cfrk_msp_resolve(ctx, &src, &use_list);
   if (rc) return rc;
-  return cfrk_hash_export(ctx, d_lo, d_hi, d_cnt, cap, parts, part_counts);
+  return cfrk_result_export(ctx, use_list ? &src : nullptr, d_lo, d_hi, d_cnt, cap, parts, part_counts);
 }
 
 int cfrk_global_export(cfrk_ctx *ctx, uint64_t *keys_lo, uint64_t *keys_hi, uint32_t *counts,
@@ -381,7 +393,7 @@ int cfrk_global_export(cfrk_ctx *ctx, uint64_t *keys_lo, uint64_t *keys_hi, uint
   if (ctx->g_two && (rc = cfrk_pool_get(ctx, BUF_EXPORT_HI, n * 8, &d_hi))) return rc;
   if ((rc = cfrk_pool_get(ctx, BUF_EXPORT_CNT, n * 4, &d_cnt))) return rc;
   uint64_t pc = 0;
-  rc = cfrk_hash_export(ctx, (uint64_t *)d_lo, (uint64_t *)d_hi, (uint32_t *)d_cnt, n, 1, &pc);
+  rc = cfrk_global_export_device(ctx, (uint64_t *)d_lo, (uint64_t *)d_hi, (uint32_t *)d_cnt, n, 1, &pc);
   if (rc) return rc;
   std::vector<uint64_t> lo(n), hi(ctx->g_two ? n : 0);
   std::vector<uint32_t> cnt(n);

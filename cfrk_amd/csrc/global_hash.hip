@@ -15,79 +15,12 @@
 //   k  > 32: keys_lo[], keys_hi[] u64, counts[] u32 doubles as the slot state
 //            (0 empty, 0xFFFFFFFF locked, else count): CAS 0->locked, store both key words,
 //            release, publish count.  No 128-bit atomics needed.
-#include "common.h"
+#include "table.h"
 
 #include <algorithm>
 #include <vector>
 
 namespace {
-
-constexpr uint32_t LOCKED = 0xFFFFFFFFu;
-
-template <typename T>
-__device__ __forceinline__ T ld_agent(const T *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-struct TableView {
-  uint64_t *lo, *hi;
-  uint32_t *cnt;
-  uint64_t *stats;
-  uint64_t mask;
-  int shift;  // 64 - log2(cap)
-};
-
-__device__ __forceinline__ void table_add1(const TableView &t, uint64_t key, uint32_t add) {
-  if (key == CFRK_EMPTY_KEY) {
-    atomicAdd((unsigned long long *)&t.stats[ST_ONES], (unsigned long long)add);
-    return;
-  }
-  uint64_t h = dev_mix64(key) >> t.shift;
-  for (uint32_t probe = 0; probe < CFRK_MAX_PROBE; ++probe) {
-    uint64_t cur = ld_agent(&t.lo[h]);   // a stale read can only show EMPTY; the CAS decides
-    if (cur == CFRK_EMPTY_KEY) {
-      cur = atomicCAS((unsigned long long *)&t.lo[h], (unsigned long long)CFRK_EMPTY_KEY,
-                      (unsigned long long)key);
-      if (cur == CFRK_EMPTY_KEY) cur = key;
-    }
-    if (cur == key) {
-      atomicAdd(&t.cnt[h], add);
-      return;
-    }
-    h = (h + 1) & t.mask;
-  }
-  t.stats[ST_OVERFLOW] = 1;
-}
-
-__device__ __forceinline__ void table_add2(const TableView &t, uint64_t lo, uint64_t hi, uint32_t add) {
-  uint64_t h = dev_mix64(lo ^ dev_mix64(hi)) >> t.shift;
-  uint32_t probe = 0, spins = 0;
-  while (probe < CFRK_MAX_PROBE && spins < (1u << 24)) {
-    uint32_t c = ld_agent(&t.cnt[h]);
-    if (c == 0) {
-      uint32_t old = atomicCAS(&t.cnt[h], 0u, LOCKED);
-      if (old == 0) {
-        __hip_atomic_store(&t.lo[h], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&t.hi[h], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __hip_atomic_store(&t.cnt[h], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-      }
-      ++spins;
-      continue;  // somebody else took the slot: look at it again
-    }
-    if (c == LOCKED) { ++spins; continue; }
-    const uint64_t klo = ld_agent(&t.lo[h]);
-    const uint64_t khi = ld_agent(&t.hi[h]);
-    if (klo == lo && khi == hi) {
-      atomicAdd(&t.cnt[h], add);
-      return;
-    }
-    h = (h + 1) & t.mask;
-    ++probe;
-  }
-  t.stats[ST_OVERFLOW] = 1;
-}
 
 // ---- k <= 32: packed front end ---------------------------------------------------------------
 // A wave takes 2 KiB tiles of the flat code buffer; lane l owns the 32 window starts at
@@ -168,15 +101,17 @@ __global__ __launch_bounds__(256) void hash_merge_kernel(const uint64_t *__restr
   }
 }
 
-__device__ __forceinline__ bool slot_read(const TableView &t, int two, uint64_t s, uint64_t &lo,
-                                          uint64_t &hi, uint32_t &c) {
-  c = t.cnt[s];
-  if (two) {
+__device__ __forceinline__ bool src_read(const ResultSrc &r, uint64_t s, uint64_t &lo, uint64_t &hi,
+                                         uint32_t &c) {
+  c = r.cnt[s];
+  hi = 0;
+  if (r.kind == 1) {
     if (c == 0) return false;
-    lo = t.lo[s]; hi = t.hi[s];
+    lo = r.lo[s]; hi = r.hi[s];
     return true;
   }
-  lo = t.lo[s]; hi = 0;
+  lo = r.lo[s];
+  if (r.kind == 2) return c != 0;
   return lo != CFRK_EMPTY_KEY && c != 0;
 }
 
@@ -189,21 +124,22 @@ __device__ __forceinline__ uint64_t wave_xor64(uint64_t v) {
   return v;
 }
 
-// distinct / sum / weighted sum / xor digest over occupied slots
-__global__ __launch_bounds__(256) void hash_scan_kernel(TableView t, uint64_t cap, int two) {
+// distinct / sum / weighted sum / xor digest over the result
+__global__ __launch_bounds__(256) void result_scan_kernel(ResultSrc r) {
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+  const bool two = r.kind == 1;
   uint64_t d = 0, s = 0, w = 0, x = 0;
-  for (uint64_t i = tid; i < cap; i += nthreads) {
+  for (uint64_t i = tid; i < r.n; i += nthreads) {
     uint64_t lo, hi; uint32_t c;
-    if (!slot_read(t, two, i, lo, hi, c)) continue;
+    if (!src_read(r, i, lo, hi, c)) continue;
     const uint64_t kh = two ? lo + dev_splitmix64(hi) : lo;
     d += 1; s += c;
     w += (uint64_t)c * dev_splitmix64(kh);
     x ^= dev_splitmix64(kh ^ (uint64_t)c);
   }
   if (tid == 0 && !two) {
-    const uint64_t ones = t.stats[ST_ONES];
+    const uint64_t ones = r.stats[ST_ONES];
     if (ones) {
       d += 1; s += ones;
       w += ones * dev_splitmix64(CFRK_EMPTY_KEY);
@@ -212,50 +148,54 @@ __global__ __launch_bounds__(256) void hash_scan_kernel(TableView t, uint64_t ca
   }
   d = wave_sum64(d); s = wave_sum64(s); w = wave_sum64(w); x = wave_xor64(x);
   if ((threadIdx.x & 63) == 0) {
-    if (d) atomicAdd((unsigned long long *)&t.stats[ST_DIG0], (unsigned long long)d);
-    if (s) atomicAdd((unsigned long long *)&t.stats[ST_DIG1], (unsigned long long)s);
-    if (w) atomicAdd((unsigned long long *)&t.stats[ST_DIG2], (unsigned long long)w);
-    if (x) atomicXor((unsigned long long *)&t.stats[ST_DIG3], (unsigned long long)x);
+    if (d) atomicAdd((unsigned long long *)&r.stats[ST_DIG0], (unsigned long long)d);
+    if (s) atomicAdd((unsigned long long *)&r.stats[ST_DIG1], (unsigned long long)s);
+    if (w) atomicAdd((unsigned long long *)&r.stats[ST_DIG2], (unsigned long long)w);
+    if (x) atomicXor((unsigned long long *)&r.stats[ST_DIG3], (unsigned long long)x);
   }
 }
 
-__device__ __forceinline__ uint32_t owner_of(uint64_t lo, uint64_t hi, int two, int parts) {
+__device__ __forceinline__ uint32_t owner_of(uint64_t lo, uint64_t hi, bool two, int parts) {
   const uint64_t m = two ? dev_mix64(lo ^ dev_mix64(hi)) : dev_mix64(lo);
   return (uint32_t)((m & 0xFFFFFFFFull) % (uint32_t)parts);
 }
 
 // pass 1: entries per owner part
-__global__ __launch_bounds__(256) void hash_export_count_kernel(TableView t, uint64_t cap, int two,
-                                                                int parts, unsigned long long *part_n) {
-  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
-  for (uint64_t base = (uint64_t)tid - (threadIdx.x & 63); base < cap; base += nthreads) {
-    const uint64_t i = base + (threadIdx.x & 63);
-    uint64_t lo = 0, hi = 0; uint32_t c = 0;
-    const bool occ = (i < cap) && slot_read(t, two, i, lo, hi, c);
-    const uint32_t own = occ ? owner_of(lo, hi, two, parts) : 0xFFFFFFFFu;
-    if (parts == 1) {
-      const unsigned long long m = __ballot(occ);
-      if ((threadIdx.x & 63) == 0 && m) atomicAdd(&part_n[0], (unsigned long long)__popcll(m));
-    } else if (occ) {
-      atomicAdd(&part_n[own], 1ull);
-    }
-  }
-}
-
-// pass 2: scatter into the owner segments (part_cursor starts at the exclusive prefix)
-__global__ __launch_bounds__(256) void hash_export_scatter_kernel(TableView t, uint64_t cap, int two,
-                                                                  int parts, unsigned long long *part_cursor,
-                                                                  uint64_t *__restrict__ out_lo,
-                                                                  uint64_t *__restrict__ out_hi,
-                                                                  uint32_t *__restrict__ out_cnt) {
+__global__ __launch_bounds__(256) void result_export_count_kernel(ResultSrc r, int parts,
+                                                                  unsigned long long *part_n) {
   const int lane = threadIdx.x & 63;
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
-  for (uint64_t base = (uint64_t)tid - lane; base < cap; base += nthreads) {
+  const bool two = r.kind == 1;
+  for (uint64_t base = (uint64_t)tid - lane; base < r.n; base += nthreads) {
     const uint64_t i = base + lane;
     uint64_t lo = 0, hi = 0; uint32_t c = 0;
-    const bool occ = (i < cap) && slot_read(t, two, i, lo, hi, c);
+    const bool occ = (i < r.n) && src_read(r, i, lo, hi, c);
+    if (parts == 1) {
+      const unsigned long long m = __ballot(occ);
+      if (lane == 0 && m) atomicAdd(&part_n[0], (unsigned long long)__popcll(m));
+    } else if (occ) {
+      atomicAdd(&part_n[owner_of(lo, hi, two, parts)], 1ull);
+    }
+  }
+  if (tid == 0 && !two && r.stats[ST_ONES])
+    atomicAdd(&part_n[owner_of(CFRK_EMPTY_KEY, 0, false, parts)], 1ull);
+}
+
+// pass 2: scatter into the owner segments (part_cursor starts at the exclusive prefix)
+__global__ __launch_bounds__(256) void result_export_scatter_kernel(ResultSrc r, int parts,
+                                                                    unsigned long long *part_cursor,
+                                                                    uint64_t *__restrict__ out_lo,
+                                                                    uint64_t *__restrict__ out_hi,
+                                                                    uint32_t *__restrict__ out_cnt) {
+  const int lane = threadIdx.x & 63;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+  const bool two = r.kind == 1;
+  for (uint64_t base = (uint64_t)tid - lane; base < r.n; base += nthreads) {
+    const uint64_t i = base + lane;
+    uint64_t lo = 0, hi = 0; uint32_t c = 0;
+    const bool occ = (i < r.n) && src_read(r, i, lo, hi, c);
     unsigned long long dst;
     if (parts == 1) {
       const unsigned long long m = __ballot(occ);
@@ -273,26 +213,13 @@ __global__ __launch_bounds__(256) void hash_export_scatter_kernel(TableView t, u
     }
   }
   if (tid == 0 && !two) {
-    const uint64_t ones = t.stats[ST_ONES];
+    const uint64_t ones = r.stats[ST_ONES];
     if (ones) {
-      const unsigned long long dst = atomicAdd(&part_cursor[owner_of(CFRK_EMPTY_KEY, 0, 0, parts)], 1ull);
+      const unsigned long long dst = atomicAdd(&part_cursor[owner_of(CFRK_EMPTY_KEY, 0, false, parts)], 1ull);
       out_lo[dst] = CFRK_EMPTY_KEY;
       out_cnt[dst] = (uint32_t)ones;
     }
   }
-}
-
-__global__ void hash_export_ones_count_kernel(TableView t, int parts, unsigned long long *part_n) {
-  if (threadIdx.x == 0 && blockIdx.x == 0 && t.stats[ST_ONES])
-    atomicAdd(&part_n[owner_of(CFRK_EMPTY_KEY, 0, 0, parts)], 1ull);
-}
-
-TableView view_of(const cfrk_ctx *ctx) {
-  TableView t;
-  t.lo = ctx->g_keys_lo; t.hi = ctx->g_keys_hi; t.cnt = ctx->g_counts; t.stats = ctx->g_stats;
-  t.mask = ctx->g_cap - 1;
-  t.shift = 64 - ctx->g_log2cap;
-  return t;
 }
 
 int grid_for(const cfrk_ctx *ctx, int64_t items_per_block_hint, int64_t items) {
@@ -302,9 +229,25 @@ int grid_for(const cfrk_ctx *ctx, int64_t items_per_block_hint, int64_t items) {
 
 }  // namespace
 
+TableView cfrk_table_view(const cfrk_ctx *ctx) {
+  TableView t;
+  t.lo = ctx->g_keys_lo; t.hi = ctx->g_keys_hi; t.cnt = ctx->g_counts; t.stats = ctx->g_stats;
+  t.mask = ctx->g_cap - 1;
+  t.shift = 64 - ctx->g_log2cap;
+  return t;
+}
+
+static ResultSrc table_src(const cfrk_ctx *ctx) {
+  ResultSrc r;
+  r.lo = ctx->g_keys_lo; r.hi = ctx->g_keys_hi; r.cnt = ctx->g_counts; r.n = ctx->g_cap;
+  r.kind = ctx->g_two ? 1 : 0;
+  r.stats = ctx->g_stats;
+  return r;
+}
+
 int cfrk_hash_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   const bool canon = (ctx->g_flags & CFRK_CANONICAL) != 0;
-  TableView t = view_of(ctx);
+  TableView t = cfrk_table_view(ctx);
   if (!ctx->g_two) {
     const int grid = grid_for(ctx, 4 * 2048, nN);
     if (canon) hipLaunchKernelGGL((hash_count1_kernel<true>), dim3(grid), dim3(256), 0, ctx->stream, d_data, nN, ctx->g_k, t);
@@ -320,7 +263,7 @@ int cfrk_hash_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
 
 int cfrk_hash_merge(cfrk_ctx *ctx, const uint64_t *lo, const uint64_t *hi, const uint32_t *cnt,
                     int64_t n) {
-  TableView t = view_of(ctx);
+  TableView t = cfrk_table_view(ctx);
   const int grid = grid_for(ctx, 256, n);
   hipLaunchKernelGGL(hash_merge_kernel, dim3(grid), dim3(256), 0, ctx->stream, lo, hi, cnt, n,
                      ctx->g_two ? 1 : 0, t);
@@ -328,30 +271,27 @@ int cfrk_hash_merge(cfrk_ctx *ctx, const uint64_t *lo, const uint64_t *hi, const
   return CFRK_OK;
 }
 
-int cfrk_hash_scan(cfrk_ctx *ctx, uint64_t st[ST_NWORDS]) {
-  TableView t = view_of(ctx);
+int cfrk_result_scan(cfrk_ctx *ctx, const ResultSrc *src, uint64_t st[ST_NWORDS]) {
+  ResultSrc r = src ? *src : table_src(ctx);
   HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_DIG0, 0, 4 * sizeof(uint64_t), ctx->stream));
-  const int grid = grid_for(ctx, 256 * 16, (int64_t)ctx->g_cap);
-  hipLaunchKernelGGL(hash_scan_kernel, dim3(grid), dim3(256), 0, ctx->stream, t, ctx->g_cap,
-                     ctx->g_two ? 1 : 0);
+  const int grid = grid_for(ctx, 256 * 16, (int64_t)r.n);
+  hipLaunchKernelGGL(result_scan_kernel, dim3(grid), dim3(256), 0, ctx->stream, r);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(st, ctx->g_stats, ST_NWORDS * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return CFRK_OK;
 }
 
-int cfrk_hash_export(cfrk_ctx *ctx, uint64_t *d_lo, uint64_t *d_hi, uint32_t *d_cnt, uint64_t cap,
-                     int parts, uint64_t *part_counts) {
-  TableView t = view_of(ctx);
+int cfrk_result_export(cfrk_ctx *ctx, const ResultSrc *src, uint64_t *d_lo, uint64_t *d_hi,
+                       uint32_t *d_cnt, uint64_t cap, int parts, uint64_t *part_counts) {
+  ResultSrc r = src ? *src : table_src(ctx);
   void *scratch;
   int rc = cfrk_pool_get(ctx, BUF_SCRATCH, (size_t)parts * 8, &scratch);
   if (rc) return rc;
   unsigned long long *d_part = (unsigned long long *)scratch;
-  const int two = ctx->g_two ? 1 : 0;
-  const int grid = grid_for(ctx, 256 * 16, (int64_t)ctx->g_cap);
+  const int grid = grid_for(ctx, 256 * 16, (int64_t)r.n);
   HIP_TRY(ctx, hipMemsetAsync(d_part, 0, (size_t)parts * 8, ctx->stream));
-  hipLaunchKernelGGL(hash_export_count_kernel, dim3(grid), dim3(256), 0, ctx->stream, t, ctx->g_cap, two, parts, d_part);
-  if (!two) hipLaunchKernelGGL(hash_export_ones_count_kernel, dim3(1), dim3(64), 0, ctx->stream, t, parts, d_part);
+  hipLaunchKernelGGL(result_export_count_kernel, dim3(grid), dim3(256), 0, ctx->stream, r, parts, d_part);
   HIP_TRY(ctx, hipGetLastError());
   std::vector<uint64_t> n(parts), cur(parts);
   HIP_TRY(ctx, hipMemcpyAsync(n.data(), d_part, (size_t)parts * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -361,7 +301,7 @@ int cfrk_hash_export(cfrk_ctx *ctx, uint64_t *d_lo, uint64_t *d_hi, uint32_t *d_
   if (total > cap) return cfrk_fail(ctx, CFRK_ERR_SMALL_BUF, "%llu entries, room for %llu", (unsigned long long)total, (unsigned long long)cap);
   if (total == 0) return CFRK_OK;
   HIP_TRY(ctx, hipMemcpyAsync(d_part, cur.data(), (size_t)parts * 8, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(hash_export_scatter_kernel, dim3(grid), dim3(256), 0, ctx->stream, t, ctx->g_cap, two, parts, d_part, d_lo, d_hi, d_cnt);
+  hipLaunchKernelGGL(result_export_scatter_kernel, dim3(grid), dim3(256), 0, ctx->stream, r, parts, d_part, d_lo, d_hi, d_cnt);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return CFRK_OK;

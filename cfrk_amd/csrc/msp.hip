@@ -1,8 +1,484 @@
-// msp.hip -- minimizer-partitioned counting (placeholder until the fast path lands).
+// msp.hip -- minimizer-partitioned global k-mer counting for gfx950 (16 <= k <= 32).
+//
+// Why: one HBM atomic per k-mer occurrence (global_hash.hip) runs at the chip's scattered-atomic
+// rate (~2e10/s), two orders of magnitude under what HBM bandwidth allows.  Here HBM only sees
+// streams, and every occurrence is counted with LDS atomics:
+//
+//   P1  partition_l1   read the flat code buffer once (2 x dwordx4 per lane, 2-bit packing in
+//                      registers), compute for every k-mer the minimum hash over its W = k-m+1
+//                      canonical m-mers (its minimizer), cut each lane's 32 window starts into
+//                      runs of equal minimizer ("super-k-mers"), and append each run as one 16-B
+//                      record {48 bases, leaf id, n} to L1 bin = leaf >> 8.  A workgroup stages
+//                      its records in LDS, reserves space with ONE global atomic per non-empty
+//                      bin per 32 KiB tile, then copies out.
+//   P2  partition_l2   stream every L1 bin, split it 256 ways on the leaf's low byte
+//                      (LDS histogram, one global atomic per bin per 4096 records).
+//   P3  count_leaf     one workgroup per leaf (65536 leaves): an open-addressing table of 4096
+//                      {u64 key, u32 count} slots in LDS; expand records to (canonical) k-mers,
+//                      ds_cmpst_b64 to claim, ds_add_u32 to count; then compact the occupied
+//                      slots to the output list with one wave-aggregated cursor atomic.
+//
+// All occurrences of a k-mer share its minimizer, hence its leaf, so leaves are disjoint in key
+// space and the output list is the final result.  Anything that does not fit (bin capacity, LDS
+// table) is counted with table_add1() into the global HBM table instead ("64-bit HBM atomics
+// only on spill") and ST_SPILLED is raised; the host then folds the list into the table.
+//
+// Semantics are those of global_hash.hip (the guarded ComputeFreq of
+// /root/reference/src/kmer_kernel.cu:52-70 summed over reads).
 #include "msp.h"
+#include "table.h"
 
-bool cfrk_msp_usable(const cfrk_ctx *) { return false; }
-int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *, int64_t) { return cfrk_fail(ctx, CFRK_ERR_STATE, "msp path not built"); }
-int cfrk_msp_flush_to_table(cfrk_ctx *) { return CFRK_OK; }
-void cfrk_msp_reset(cfrk_ctx *) {}
-void cfrk_msp_destroy(cfrk_ctx *) {}
+#include <algorithm>
+#include <new>
+
+namespace {
+
+constexpr int B1_LOG = 8, B2_LOG = 8;
+constexpr int B1 = 1 << B1_LOG, B2 = 1 << B2_LOG;
+constexpr int NLEAF = B1 * B2;
+
+constexpr int P1_THREADS = 1024;
+constexpr int P1_TILE = P1_THREADS * 32;   // bytes of input per workgroup tile
+constexpr int P1_RCAP = 6144;              // records staged in LDS per tile (expected ~4200)
+
+constexpr int P2_THREADS = 256, P2_PER = 16, P2_TILE = P2_THREADS * P2_PER;
+
+constexpr int P3_THREADS = 256;
+constexpr int TS_LOG = 12, TS = 1 << TS_LOG;   // LDS table slots per leaf
+constexpr int P3_PROBE_LIMIT = 96;
+
+struct MspView {
+  uint4 *rec1; uint32_t *cnt1; uint64_t cap1;
+  uint4 *rec2; uint32_t *cnt2; uint64_t cap2;
+  uint64_t *out_keys; uint32_t *out_cnt; uint64_t out_cap;
+  uint64_t *stats;
+};
+
+// ordering hash of a canonical m-mer (bijective: odd multiplier, xorshift)
+__device__ __forceinline__ uint32_t hash_mmer(uint32_t c) {
+  uint32_t h = c * 0x9E3779B1u;
+  return h ^ (h >> 16);
+}
+// minimizer hash -> leaf id (16 bits); re-mixed because the minimum of W hashes is skewed low
+__device__ __forceinline__ uint32_t leaf_of(uint32_t wmin) {
+  uint32_t x = wmin * 0x85EBCA77u;
+  x ^= x >> 15;
+  x *= 0xC2B2AE3Du;
+  return x >> 16;
+}
+
+// count every k-mer of a record straight into the global HBM table
+__device__ __noinline__ void spill_record(uint4 rec, int k, bool canon, const TableView &t) {
+  t.stats[ST_SPILLED] = 1;
+  const int nk = (int)(rec.w & 63u) + 1;
+  const uint64_t hi = ((uint64_t)rec.x << 32) | rec.y;
+  const uint64_t lo = (uint64_t)rec.z << 32;
+  for (int j = 0; j < nk; ++j) {
+    const uint64_t x = j ? ((hi << (2 * j)) | (lo >> (64 - 2 * j))) : hi;
+    uint64_t key = x >> (64 - 2 * k);
+    if (canon) {
+      const uint64_t rc = dev_revcomp64(key, k);
+      key = rc < key ? rc : key;
+    }
+    table_add1(t, key, 1u);
+  }
+}
+
+// w[a] for a lane-varying a in 0..31, as a 5-level select tree on VALUES (31 v_cndmask);
+// selecting between array elements directly makes clang select pointers and park the
+// arrays in scratch/LDS.
+template <int N>
+__device__ __forceinline__ uint32_t pick32(const uint32_t (&w)[N], int a) {
+  const bool c16 = (a & 16) != 0, c8 = (a & 8) != 0, c4 = (a & 4) != 0, c2 = (a & 2) != 0, c1 = (a & 1) != 0;
+#define CFRK_SEL(c, hi_, lo_) ({ const uint32_t x_ = (lo_), y_ = (hi_); (c) ? y_ : x_; })
+  const uint32_t s0 = CFRK_SEL(c16, w[16], w[0]), s1 = CFRK_SEL(c16, w[17], w[1]);
+  const uint32_t s2 = CFRK_SEL(c16, w[18], w[2]), s3 = CFRK_SEL(c16, w[19], w[3]);
+  const uint32_t s4 = CFRK_SEL(c16, w[20], w[4]), s5 = CFRK_SEL(c16, w[21], w[5]);
+  const uint32_t s6 = CFRK_SEL(c16, w[22], w[6]), s7 = CFRK_SEL(c16, w[23], w[7]);
+  const uint32_t s8 = CFRK_SEL(c16, w[24], w[8]), s9 = CFRK_SEL(c16, w[25], w[9]);
+  const uint32_t s10 = CFRK_SEL(c16, w[26], w[10]), s11 = CFRK_SEL(c16, w[27], w[11]);
+  const uint32_t s12 = CFRK_SEL(c16, w[28], w[12]), s13 = CFRK_SEL(c16, w[29], w[13]);
+  const uint32_t s14 = CFRK_SEL(c16, w[30], w[14]), s15 = CFRK_SEL(c16, w[31], w[15]);
+  const uint32_t e0 = CFRK_SEL(c8, s8, s0), e1 = CFRK_SEL(c8, s9, s1), e2 = CFRK_SEL(c8, s10, s2);
+  const uint32_t e3 = CFRK_SEL(c8, s11, s3), e4 = CFRK_SEL(c8, s12, s4), e5 = CFRK_SEL(c8, s13, s5);
+  const uint32_t e6 = CFRK_SEL(c8, s14, s6), e7 = CFRK_SEL(c8, s15, s7);
+  const uint32_t f0 = CFRK_SEL(c4, e4, e0), f1 = CFRK_SEL(c4, e5, e1), f2 = CFRK_SEL(c4, e6, e2);
+  const uint32_t f3 = CFRK_SEL(c4, e7, e3);
+  const uint32_t g0 = CFRK_SEL(c2, f2, f0), g1 = CFRK_SEL(c2, f3, f1);
+#undef CFRK_SEL
+  return c1 ? g1 : g0;
+}
+
+// ---------------------------------------------------------------------------------------- P1
+template <int W>
+__global__ __launch_bounds__(P1_THREADS) void msp_p1_kernel(const int8_t *__restrict__ data,
+                                                            int64_t nN, int k, int m, int canon,
+                                                            MspView v, TableView t) {
+  constexpr int NH = 32 + W - 1;                 // m-mer hashes a lane needs
+  constexpr int P = (W >= 16) ? 16 : (W >= 8) ? 8 : 4;
+  __shared__ uint4 rec_tmp[P1_RCAP];
+  __shared__ uint8_t bin_tmp[P1_RCAP];
+  __shared__ uint32_t hist[B1], gbase[B1], fill[B1];
+  __shared__ uint32_t nrec_s;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int nkmax = min(48 - k + 1, 32);
+  const int64_t tile = blockIdx.x;
+
+  if (tid < B1) { hist[tid] = 0; fill[tid] = 0; }
+  if (tid == 0) nrec_s = 0;
+  __syncthreads();
+
+  // ---- A: load 32 own bases + 32 look-ahead bases, packed 2 bits each ----
+  const int64_t off = tile * P1_TILE + (int64_t)tid * 32;
+  uint32_t b0, b1, bad;
+  dev_load_chunk32(data, off, nN, b0, b1, bad);
+  uint32_t n0 = __shfl_down(b0, 1), n1 = __shfl_down(b1, 1), nbad = __shfl_down(bad, 1);
+  if (lane == 63) dev_load_chunk32(data, off + 32, nN, n0, n1, nbad);
+  const uint64_t hi = ((uint64_t)b0 << 32) | b1;
+  const uint64_t lo = ((uint64_t)n0 << 32) | n1;
+  const uint64_t M = ((uint64_t)bad << 32) | nbad;
+
+  // V bit(31-i): the k-mer starting at own position i has k valid bases
+  uint64_t Y = M;
+  Y |= Y << 1; Y |= Y << 2; Y |= Y << 4; Y |= Y << 8;   // OR over the 16 following bases
+  Y |= Y << (k - 16);                                    // ... over k (16 <= k <= 32)
+  const uint32_t V = ~(uint32_t)(Y >> 32);
+
+  uint32_t S = 0, E = 0;
+  uint32_t H[NH];   // m-mer hashes; after the sliding minimum H[0..31] are the k-mers' minimizers
+  if (V == 0) {
+#pragma unroll
+    for (int j = 0; j < NH; ++j) H[j] = 0;
+  } else {
+    // canonical m-mer hashes H[j], j = 0..NH-1, rolled one base at a time
+    {
+      const uint64_t Shi = (hi << (2 * m)) | (lo >> (64 - 2 * m));
+      const uint64_t Slo = lo << (2 * m);
+      uint32_t fm = (uint32_t)(hi >> (64 - 2 * m));
+      uint32_t rm = (uint32_t)dev_revcomp64((uint64_t)fm, m);
+      const uint32_t mmask = (m == 16) ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1u);
+      const int rsh = 2 * m - 2;
+#pragma unroll
+      for (int j = 0; j < NH; ++j) {
+        H[j] = hash_mmer(min(fm, rm));
+        if (j + 1 < NH) {
+          const uint32_t nb = (j < 32) ? ((uint32_t)(Shi >> (62 - 2 * j)) & 3u)
+                                       : ((uint32_t)(Slo >> (62 - 2 * (j - 32))) & 3u);
+          fm = ((fm << 2) | nb) & mmask;
+          rm = (rm >> 2) | ((3u - nb) << rsh);
+        }
+      }
+    }
+    // sliding-window minimum over W by doubling: H[j] <- min H[j .. j+P), then one combine
+#pragma unroll
+    for (int s = 1; s < P; s <<= 1) {
+#pragma unroll
+      for (int j = 0; j + s < NH; ++j) H[j] = min(H[j], H[j + s]);
+    }
+    if (W > P) {
+#pragma unroll
+      for (int i = 0; i < 32; ++i) H[i] = min(H[i], H[i + W - P]);
+    }
+
+    uint32_t C = 0x80000000u;
+#pragma unroll
+    for (int i = 1; i < 32; ++i) C |= (H[i] != H[i - 1]) ? (0x80000000u >> i) : 0u;
+    S = V & (C | ~(V >> 1));   // run starts: valid and (first | previous invalid | minimizer changed)
+    E = S | ~V;                // positions that end the run before them
+  }
+
+  // ---- B: one 16-byte record per run, staged in LDS ----
+  while (S) {
+    const int a = __clz(S);
+    S &= ~(0x80000000u >> a);
+    const uint32_t rest = (a == 31) ? 0u : (E << (a + 1));
+    int n = rest ? (__clz(rest) + 1) : (32 - a);
+    if (n > nkmax) { n = nkmax; S |= 0x80000000u >> (a + nkmax); }
+    const uint32_t leaf = leaf_of(pick32(H, a));
+    const uint32_t bin1 = leaf >> B2_LOG;
+    uint4 rec;
+    const uint64_t r01 = a ? ((hi << (2 * a)) | (lo >> (64 - 2 * a))) : hi;
+    rec.x = (uint32_t)(r01 >> 32);
+    rec.y = (uint32_t)r01;
+    rec.z = (uint32_t)((lo << (2 * a)) >> 32);
+    rec.w = (leaf << 8) | (uint32_t)(n - 1);
+
+    const unsigned long long act = __ballot(1);
+    const int leader = __ffsll(act) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&nrec_s, (uint32_t)__popcll(act));
+    base = __shfl(base, leader);
+    const uint32_t slot = base + (uint32_t)__popcll(act & ((1ull << lane) - 1ull));
+    if (slot < (uint32_t)P1_RCAP) {
+      rec_tmp[slot] = rec;
+      bin_tmp[slot] = (uint8_t)bin1;
+      atomicAdd(&hist[bin1], 1u);
+    } else {
+      // LDS staging full (pathological tile): append directly
+      const uint32_t dst = atomicAdd(&v.cnt1[bin1], 1u);
+      if (dst < v.cap1) v.rec1[(uint64_t)bin1 * v.cap1 + dst] = rec;
+      else spill_record(rec, k, canon != 0, t);
+    }
+  }
+  __syncthreads();
+
+  // ---- C: one global reservation per non-empty bin ----
+  if (tid < B1) {
+    const uint32_t c = hist[tid];
+    gbase[tid] = c ? atomicAdd(&v.cnt1[tid], c) : 0u;
+  }
+  __syncthreads();
+
+  // ---- D: copy out ----
+  const uint32_t nrec = min(nrec_s, (uint32_t)P1_RCAP);
+  for (uint32_t s = tid; s < nrec; s += P1_THREADS) {
+    const uint32_t b = bin_tmp[s];
+    const uint32_t dst = gbase[b] + atomicAdd(&fill[b], 1u);
+    const uint4 rec = rec_tmp[s];
+    if (dst < v.cap1) v.rec1[(uint64_t)b * v.cap1 + dst] = rec;
+    else spill_record(rec, k, canon != 0, t);
+  }
+}
+
+// ---------------------------------------------------------------------------------------- P2
+__global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int tiles_per_bin, int k, int canon,
+                                                            MspView v, TableView t) {
+  __shared__ uint32_t hist[B2], gbase[B2], fill[B2];
+  const int tid = threadIdx.x;
+  const uint32_t b1 = blockIdx.x / (uint32_t)tiles_per_bin;
+  const uint32_t tile = blockIdx.x % (uint32_t)tiles_per_bin;
+  const uint64_t n = min((uint64_t)v.cnt1[b1], v.cap1);
+  const uint64_t r0 = (uint64_t)tile * P2_TILE;
+  if (r0 >= n) return;
+  if (tid < B2) { hist[tid] = 0; fill[tid] = 0; }
+  __syncthreads();
+  const uint4 *src = v.rec1 + (uint64_t)b1 * v.cap1;
+  uint4 r[P2_PER];
+#pragma unroll
+  for (int i = 0; i < P2_PER; ++i) {
+    const uint64_t idx = r0 + (uint64_t)i * P2_THREADS + tid;
+    if (idx < n) {
+      r[i] = src[idx];
+      atomicAdd(&hist[(r[i].w >> 8) & (B2 - 1)], 1u);
+    }
+  }
+  __syncthreads();
+  if (tid < B2) {
+    const uint32_t c = hist[tid];
+    gbase[tid] = c ? atomicAdd(&v.cnt2[b1 * B2 + tid], c) : 0u;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < P2_PER; ++i) {
+    const uint64_t idx = r0 + (uint64_t)i * P2_THREADS + tid;
+    if (idx < n) {
+      const uint32_t b2 = (r[i].w >> 8) & (B2 - 1);
+      const uint32_t dst = gbase[b2] + atomicAdd(&fill[b2], 1u);
+      const uint64_t leaf = (uint64_t)b1 * B2 + b2;
+      if (dst < v.cap2) v.rec2[leaf * v.cap2 + dst] = r[i];
+      else spill_record(r[i], k, canon != 0, t);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------- P3
+template <bool CANON>
+__global__ __launch_bounds__(P3_THREADS) void msp_p3_kernel(int k, MspView v, TableView t) {
+  __shared__ unsigned long long keys[TS];
+  __shared__ uint32_t cnts[TS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const uint32_t leaf = blockIdx.x;
+  const uint64_t n = min((uint64_t)v.cnt2[leaf], v.cap2);
+  if (n == 0) return;
+  for (int s = tid; s < TS; s += P3_THREADS) { keys[s] = CFRK_EMPTY_KEY; cnts[s] = 0; }
+  __syncthreads();
+
+  const uint4 *src = v.rec2 + (uint64_t)leaf * v.cap2;
+  for (uint64_t r = tid; r < n; r += P3_THREADS) {
+    const uint4 rec = src[r];
+    const int nk = (int)(rec.w & 63u) + 1;
+    const uint64_t hi = ((uint64_t)rec.x << 32) | rec.y;
+    const uint64_t lo = (uint64_t)rec.z << 32;
+    for (int j = 0; j < nk; ++j) {
+      const uint64_t x = j ? ((hi << (2 * j)) | (lo >> (64 - 2 * j))) : hi;
+      uint64_t key = x >> (64 - 2 * k);
+      if (CANON) {
+        const uint64_t rc = dev_revcomp64(key, k);
+        key = rc < key ? rc : key;
+      }
+      if (key == CFRK_EMPTY_KEY) {   // k = 32, all T, forward strand
+        atomicAdd((unsigned long long *)&t.stats[ST_ONES], 1ull);
+        continue;
+      }
+      uint32_t hx = ((uint32_t)key ^ (uint32_t)(key >> 32)) * 0x9E3779B1u;
+      uint32_t h = hx >> (32 - TS_LOG);
+      bool done = false;
+      for (int p = 0; p < P3_PROBE_LIMIT; ++p) {
+        unsigned long long cur = keys[h];
+        if (cur == CFRK_EMPTY_KEY) {
+          cur = atomicCAS(&keys[h], (unsigned long long)CFRK_EMPTY_KEY, (unsigned long long)key);
+          if (cur == CFRK_EMPTY_KEY) cur = key;
+        }
+        if (cur == key) { atomicAdd(&cnts[h], 1u); done = true; break; }
+        h = (h + 1) & (TS - 1);
+      }
+      if (!done) {          // leaf table full around this key: count it in HBM
+        t.stats[ST_SPILLED] = 1;
+        table_add1(t, key, 1u);
+      }
+    }
+  }
+  __syncthreads();
+
+  // compact occupied slots to the output list
+  for (int s0 = 0; s0 < TS; s0 += P3_THREADS) {
+    const int s = s0 + tid;
+    const unsigned long long key = keys[s];
+    const bool occ = key != CFRK_EMPTY_KEY;
+    const unsigned long long m = __ballot(occ);
+    if (m == 0) continue;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd((unsigned long long *)&v.stats[ST_CURSOR], (unsigned long long)__popcll(m));
+    base = __shfl(base, 0);
+    if (occ) {
+      const unsigned long long dst = base + __popcll(m & ((1ull << lane) - 1ull));
+      if (dst < v.out_cap) { v.out_keys[dst] = key; v.out_cnt[dst] = cnts[s]; }
+      else v.stats[ST_OVERFLOW] = 1;
+    }
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------ host
+struct cfrk_msp {
+  bool pending;        // a leaf-output list exists that has not been folded into the table
+  bool table_dirty;    // the table holds counts of its own since begin()
+  uint64_t list_n;     // entries in the list (valid after resolve)
+  bool list_n_valid;
+  MspView view;
+};
+
+static cfrk_msp *msp_get(cfrk_ctx *ctx) {
+  if (!ctx->msp) {
+    ctx->msp = new (std::nothrow) cfrk_msp();
+    if (ctx->msp) memset(ctx->msp, 0, sizeof(cfrk_msp));
+  }
+  return ctx->msp;
+}
+
+bool cfrk_msp_usable(const cfrk_ctx *ctx) {
+  return !ctx->g_two && ctx->g_k >= 16 && ctx->g_k <= 32 && !(ctx->g_flags & CFRK_FORCE_HASH);
+}
+
+void cfrk_msp_reset(cfrk_ctx *ctx) {
+  if (ctx->msp) { ctx->msp->pending = false; ctx->msp->table_dirty = false; ctx->msp->list_n_valid = false; }
+}
+
+void cfrk_msp_note_table_write(cfrk_ctx *ctx) {
+  cfrk_msp *m = msp_get(ctx);
+  if (m) m->table_dirty = true;
+}
+
+void cfrk_msp_destroy(cfrk_ctx *ctx) {
+  delete ctx->msp;
+  ctx->msp = nullptr;
+}
+
+static void msp_params(int k, int *W, int *m) {
+  if (k >= 30) *W = 20; else if (k >= 26) *W = 16; else if (k >= 20) *W = 10; else *W = 6;
+  *m = k - *W + 1;
+}
+
+int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
+  cfrk_msp *ms = msp_get(ctx);
+  if (!ms) return cfrk_fail(ctx, CFRK_ERR_NOMEM, "host allocation failed");
+  int rc;
+  if (ms->pending && (rc = cfrk_msp_flush_to_table(ctx))) return rc;
+  const int k = ctx->g_k;
+  int W, m;
+  msp_params(k, &W, &m);
+  const int canon = (ctx->g_flags & CFRK_CANONICAL) ? 1 : 0;
+
+  // expected records: one per minimizer change (2/(W+1) per position) + one per 32-position lane
+  const double dens = 2.0 / (W + 1) + 1.0 / 32.0;
+  const double expect = (double)nN * dens;
+  const uint64_t cap1 = (uint64_t)(expect / B1 * 1.3) + 4096;
+  const uint64_t cap2 = (uint64_t)(expect / NLEAF * 1.6) + 96;
+  const int64_t tiles_per_bin = (int64_t)((cap1 + P2_TILE - 1) / P2_TILE);
+  if (tiles_per_bin * B1 > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
+
+  void *p;
+  MspView &v = ms->view;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L1, (size_t)B1 * cap1 * sizeof(uint4), &p))) return rc;
+  v.rec1 = (uint4 *)p; v.cap1 = cap1;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)NLEAF * cap2 * sizeof(uint4), &p))) return rc;
+  v.rec2 = (uint4 *)p; v.cap2 = cap2;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_AUX, (size_t)(B1 + NLEAF) * sizeof(uint32_t), &p))) return rc;
+  v.cnt1 = (uint32_t *)p; v.cnt2 = v.cnt1 + B1;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTK, (size_t)ctx->g_cap * 8, &p))) return rc;
+  v.out_keys = (uint64_t *)p;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTC, (size_t)ctx->g_cap * 4, &p))) return rc;
+  v.out_cnt = (uint32_t *)p; v.out_cap = ctx->g_cap;
+  v.stats = ctx->g_stats;
+  TableView t = cfrk_table_view(ctx);
+
+  HIP_TRY(ctx, hipMemsetAsync(v.cnt1, 0, (size_t)(B1 + NLEAF) * sizeof(uint32_t), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_CURSOR, 0, sizeof(uint64_t), ctx->stream));
+
+  const int64_t ntiles = (nN + P1_TILE - 1) / P1_TILE;
+  if (ntiles > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
+  const dim3 g1((unsigned)ntiles), b1(P1_THREADS);
+  switch (W) {
+    case 20: hipLaunchKernelGGL((msp_p1_kernel<20>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, v, t); break;
+    case 16: hipLaunchKernelGGL((msp_p1_kernel<16>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, v, t); break;
+    case 10: hipLaunchKernelGGL((msp_p1_kernel<10>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, v, t); break;
+    default: hipLaunchKernelGGL((msp_p1_kernel<6>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, v, t); break;
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  hipLaunchKernelGGL(msp_p2_kernel, dim3((unsigned)(tiles_per_bin * B1)), dim3(P2_THREADS), 0, ctx->stream,
+                     (int)tiles_per_bin, k, canon, v, t);
+  HIP_TRY(ctx, hipGetLastError());
+  if (canon) hipLaunchKernelGGL((msp_p3_kernel<true>), dim3(NLEAF), dim3(P3_THREADS), 0, ctx->stream, k, v, t);
+  else hipLaunchKernelGGL((msp_p3_kernel<false>), dim3(NLEAF), dim3(P3_THREADS), 0, ctx->stream, k, v, t);
+  HIP_TRY(ctx, hipGetLastError());
+  ms->pending = true;
+  ms->list_n_valid = false;
+  return CFRK_OK;
+}
+
+static int msp_sync_stats(cfrk_ctx *ctx, uint64_t st[ST_NWORDS]) {
+  HIP_TRY(ctx, hipMemcpyAsync(st, ctx->g_stats, ST_NWORDS * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return CFRK_OK;
+}
+
+int cfrk_msp_flush_to_table(cfrk_ctx *ctx) {
+  cfrk_msp *ms = ctx->msp;
+  if (!ms || !ms->pending) return CFRK_OK;
+  uint64_t st[ST_NWORDS];
+  int rc = msp_sync_stats(ctx, st);
+  if (rc) return rc;
+  if (st[ST_OVERFLOW]) return cfrk_fail(ctx, CFRK_ERR_TABLE_FULL, "result list of %llu entries overflowed", (unsigned long long)ms->view.out_cap);
+  const uint64_t n = st[ST_CURSOR];
+  ms->pending = false;
+  ms->table_dirty = true;
+  if (n == 0) return CFRK_OK;
+  return cfrk_hash_merge(ctx, ms->view.out_keys, nullptr, ms->view.out_cnt, (int64_t)n);
+}
+
+int cfrk_msp_resolve(cfrk_ctx *ctx, ResultSrc *src, bool *use_list) {
+  *use_list = false;
+  cfrk_msp *ms = ctx->msp;
+  if (!ms || !ms->pending) return CFRK_OK;
+  uint64_t st[ST_NWORDS];
+  int rc = msp_sync_stats(ctx, st);
+  if (rc) return rc;
+  if (st[ST_OVERFLOW]) return cfrk_fail(ctx, CFRK_ERR_TABLE_FULL, "result list of %llu entries overflowed", (unsigned long long)ms->view.out_cap);
+  if (st[ST_SPILLED] || ms->table_dirty) return cfrk_msp_flush_to_table(ctx);
+  src->lo = ms->view.out_keys; src->hi = nullptr; src->cnt = ms->view.out_cnt;
+  src->n = st[ST_CURSOR]; src->kind = 2; src->stats = ctx->g_stats;
+  *use_list = true;
+  return CFRK_OK;
+}

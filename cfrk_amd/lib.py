@@ -12,6 +12,7 @@ import numpy as np
 
 CFRK_COMPAT = 0x1
 CFRK_CANONICAL = 0x2
+CFRK_FORCE_HASH = 0x4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libcfrk_hip.so")

@@ -57,6 +57,8 @@ extern "C" {
                                 cap; src/kmer_kernel.cu:73-90, src/kmer_main.cu:82-83).  Without it:
                                 the guarded ComputeFreq semantics (src/kmer_kernel.cu:52-70).        */
 #define CFRK_CANONICAL  0x2  /* global only: key = min(kmer, reverse complement)                     */
+#define CFRK_FORCE_HASH 0x4  /* global only: count with one HBM atomic per occurrence (the general
+                                path) even where the minimizer-partitioned LDS path applies          */
 
 typedef struct cfrk_ctx cfrk_ctx;
 

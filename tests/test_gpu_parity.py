@@ -98,9 +98,10 @@ def test_dense_errors(ctx):
 
 # ------------------------------------------------------------------ global counting
 
-def _cmp_global(ctx, data, k, canonical, hint=0, start=None, length=None):
+def _cmp_global(ctx, data, k, canonical, hint=0, start=None, length=None, force_hash=False):
     import cfrk_amd
-    g = cfrk_amd.GlobalCounter(ctx, k, cfrk_amd.CFRK_CANONICAL if canonical else 0, hint)
+    flags = (cfrk_amd.CFRK_CANONICAL if canonical else 0) | (cfrk_amd.CFRK_FORCE_HASH if force_hash else 0)
+    g = cfrk_amd.GlobalCounter(ctx, k, flags, hint)
     g.add(data, start, length)
     lo, hi, cnt = g.export()
     wlo, whi, wcnt = orc.global_count(data, k, orc.ORC_CANONICAL if canonical else 0)
@@ -110,16 +111,19 @@ def _cmp_global(ctx, data, k, canonical, hint=0, start=None, length=None):
     return g
 
 
-@pytest.mark.parametrize("k", [1, 2, 5, 15, 16, 21, 31, 32, 33, 47, 63, 64])
+@pytest.mark.parametrize("k", [1, 2, 5, 15, 16, 17, 19, 20, 21, 25, 26, 29, 30, 31, 32, 33, 47, 63, 64])
 @pytest.mark.parametrize("canonical", [False, True])
-def test_global_vs_oracle(ctx, k, canonical):
+@pytest.mark.parametrize("force_hash", [False, True])
+def test_global_vs_oracle(ctx, k, canonical, force_hash):
+    if force_hash and not 16 <= k <= 32:
+        pytest.skip("the HBM hash path is the only path for this k")
     rng = np.random.default_rng(200 + k)
     reads = _random_reads(rng, 400, 1, 300)
     reads.append(np.full(200, 3, np.int8))      # poly-T: the all-ones key at k=32
     reads.append(np.full(200, 0, np.int8))      # poly-A
     reads.append(np.zeros(0, np.int8))
     data, start, length = refsem.flatten(reads)
-    _cmp_global(ctx, data, k, canonical, start=start, length=length)
+    _cmp_global(ctx, data, k, canonical, start=start, length=length, force_hash=force_hash)
 
 
 def test_global_ragged_tail_sizes(ctx):
@@ -129,8 +133,10 @@ def test_global_ragged_tail_sizes(ctx):
         data = rng.integers(0, 4, n).astype(np.int8)
         data[rng.random(n) < 0.01] = -1
         data[-1] = -1
-        for k in (1, 7, 31, 32):
+        for k in (1, 7, 16, 31, 32):
             _cmp_global(ctx, data, k, True)
+            if k >= 16:
+                _cmp_global(ctx, data, k, False, force_hash=True)
 
 
 def test_global_multiple_adds_accumulate(ctx):
@@ -252,8 +258,53 @@ def test_global_errors(ctx):
     assert e.value.code == -5
     # table overflow is reported, not silently wrong
     rnd = np.random.default_rng(0).integers(0, 4, 200000).astype(np.int8)
-    g = cfrk_amd.GlobalCounter(ctx, 31, 0, 64)
+    g = cfrk_amd.GlobalCounter(ctx, 31, cfrk_amd.CFRK_FORCE_HASH, 64)
     g.add(rnd)
     with pytest.raises(cfrk_amd.CfrkError) as e:
         g.finish()
     assert e.value.code == -6
+
+
+# ------------------------------------------------------------------ minimizer-partitioned path
+
+def test_msp_low_complexity_and_many_invalid(ctx):
+    """homopolymers / short tandem repeats (runs longer than one record, one minimizer for
+    thousands of k-mers) and reads riddled with N"""
+    rng = np.random.default_rng(11)
+    reads = [np.zeros(5000, np.int8), np.full(5000, 3, np.int8),
+             np.tile(np.array([0, 1], np.int8), 3000), np.tile(np.array([0, 1, 2, 3, 3, 2], np.int8), 1500)]
+    reads += _random_reads(rng, 200, 20, 400, 0.05)
+    data, _, _ = refsem.flatten(reads)
+    for k in (16, 21, 31, 32):
+        for canonical in (False, True):
+            _cmp_global(ctx, data, k, canonical)
+
+
+def test_msp_leaf_table_overflow_spills_to_hbm_table(ctx):
+    """all-distinct input with far more distinct k-mers per leaf than an LDS table holds: the
+    excess is counted in the HBM table and the result is still exact"""
+    import cfrk_amd
+    data, _, _ = orc.synth_reads(0, 3_000_000, 150, 0, uniform=True)   # 3.6e8 k-mers, ~all distinct
+    g = cfrk_amd.GlobalCounter(ctx, 31, cfrk_amd.CFRK_CANONICAL, 400_000_000)
+    g.add(data)
+    d = g.digest()
+    assert d[1] == 3_000_000 * 120
+    g2 = cfrk_amd.GlobalCounter(ctx, 31, cfrk_amd.CFRK_CANONICAL | cfrk_amd.CFRK_FORCE_HASH, 400_000_000)
+    g2.add(data)
+    assert g2.digest() == d
+
+
+def test_msp_then_merge_and_second_add(ctx):
+    """the leaf-output list is folded into the table when a later add / merge needs it"""
+    import cfrk_amd
+    d1, _, _ = orc.synth_reads(0, 4000, 150, 30000)
+    d2, _, _ = orc.synth_reads(4000, 4000, 150, 30000)
+    g = cfrk_amd.GlobalCounter(ctx, 25, cfrk_amd.CFRK_CANONICAL, 100000)
+    g.add(d1)
+    a = g.digest()
+    g.add(d2)
+    lo, hi, cnt = g.export()
+    wlo, whi, wcnt = orc.global_count(np.concatenate([d1, d2]), 25, orc.ORC_CANONICAL)
+    assert (lo == wlo).all() and (cnt.astype(np.uint64) == wcnt).all()
+    w1 = orc.global_count(d1, 25, orc.ORC_CANONICAL)
+    assert a == orc.digest(*w1)
