@@ -136,6 +136,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    info = eng.g.msp_info() if os.environ.get("CFRK_BENCH_INFO") else None
     digest = final.digest()
     if world > 1:
         digest = sharded.merge_digests(digest, dev)
@@ -167,6 +168,8 @@ def main():
             "distinct": D, "sum_count_ok": ok,
             "digest": [f"{x:016x}" for x in digest],
         }
+        if info:
+            out["msp_info"] = info
         if world == 1 and args.cpu_reads > 0:
             cb, _ = cpu_baseline(args, glen)
             out["cpu_baseline"] = cb

@@ -10,7 +10,7 @@
 //                      runs of equal minimizer ("super-k-mers"), and append each run as one 16-B
 //                      record {48 bases, leaf id, n} to L1 bin = leaf >> 8.  A workgroup stages
 //                      its records in LDS, reserves space with ONE global atomic per non-empty
-//                      bin per 32 KiB tile, then copies out.
+//                      bin per 16 KiB tile, then copies out in bin order (coalesced).
 //   P2  partition_l2   stream every L1 bin, split it 256 ways on the leaf's low byte
 //                      (LDS histogram, one global atomic per bin per 4096 records).
 //   P3  count_leaf     one workgroup per leaf (65536 leaves): an open-addressing table of 4096
@@ -37,13 +37,13 @@ constexpr int B1_LOG = 8, B2_LOG = 8;
 constexpr int B1 = 1 << B1_LOG, B2 = 1 << B2_LOG;
 constexpr int NLEAF = B1 * B2;
 
-constexpr int P1_THREADS = 1024;
+constexpr int P1_THREADS = 512;
 constexpr int P1_TILE = P1_THREADS * 32;   // bytes of input per workgroup tile
-constexpr int P1_RCAP = 6144;              // records staged in LDS per tile (expected ~4200)
+constexpr int P1_RCAP = 3072;              // records staged in LDS per tile (expected ~2250)
 
-constexpr int P2_THREADS = 256, P2_PER = 16, P2_TILE = P2_THREADS * P2_PER;
+constexpr int P2_THREADS = 512, P2_PER = 8, P2_TILE = P2_THREADS * P2_PER;
 
-constexpr int P3_THREADS = 256;
+constexpr int P3_THREADS = 1024;
 constexpr int TS_LOG = 12, TS = 1 << TS_LOG;   // LDS table slots per leaf
 constexpr int P3_PROBE_LIMIT = 96;
 
@@ -70,6 +70,7 @@ __device__ __forceinline__ uint32_t leaf_of(uint32_t wmin) {
 // count every k-mer of a record straight into the global HBM table
 __device__ __noinline__ void spill_record(uint4 rec, int k, bool canon, const TableView &t) {
   t.stats[ST_SPILLED] = 1;
+  atomicAdd((unsigned long long *)&t.stats[ST_AUX0], 1ull);
   const int nk = (int)(rec.w & 63u) + 1;
   const uint64_t hi = ((uint64_t)rec.x << 32) | rec.y;
   const uint64_t lo = (uint64_t)rec.z << 32;
@@ -109,6 +110,30 @@ __device__ __forceinline__ uint32_t pick32(const uint32_t (&w)[N], int a) {
   return c1 ? g1 : g0;
 }
 
+// exclusive prefix sum of cnt[0..255] into off[0..255]; every thread of the block must call it
+// (blockDim >= 256); wtot is 4 words of LDS scratch
+__device__ __forceinline__ void block_scan256(const uint32_t *cnt, uint32_t *off, uint32_t *wtot) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t x = 0, incl = 0;
+  if (tid < 256) {
+    x = cnt[tid];
+    incl = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t y = __shfl_up(incl, d);
+      if (lane >= d) incl += y;
+    }
+    if (lane == 63) wtot[wave] = incl;
+  }
+  __syncthreads();
+  if (tid < 256) {
+    uint32_t base = 0;
+    for (int w = 0; w < wave; ++w) base += wtot[w];
+    off[tid] = base + incl - x;
+  }
+  __syncthreads();
+}
+
 // ---------------------------------------------------------------------------------------- P1
 template <int W>
 __global__ __launch_bounds__(P1_THREADS) void msp_p1_kernel(const int8_t *__restrict__ data,
@@ -117,8 +142,10 @@ __global__ __launch_bounds__(P1_THREADS) void msp_p1_kernel(const int8_t *__rest
   constexpr int NH = 32 + W - 1;                 // m-mer hashes a lane needs
   constexpr int P = (W >= 16) ? 16 : (W >= 8) ? 8 : 4;
   __shared__ uint4 rec_tmp[P1_RCAP];
+  __shared__ uint16_t perm[P1_RCAP];
   __shared__ uint8_t bin_tmp[P1_RCAP];
-  __shared__ uint32_t hist[B1], gbase[B1], fill[B1];
+  __shared__ uint32_t hist[B1], loff[B1], gbase[B1], fill[B1];
+  __shared__ uint32_t wtot[4];
   __shared__ uint32_t nrec_s;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -223,18 +250,24 @@ __global__ __launch_bounds__(P1_THREADS) void msp_p1_kernel(const int8_t *__rest
   }
   __syncthreads();
 
-  // ---- C: one global reservation per non-empty bin ----
+  // ---- C: one global reservation per non-empty bin; LDS offsets for a bin-sorted order ----
   if (tid < B1) {
     const uint32_t c = hist[tid];
     gbase[tid] = c ? atomicAdd(&v.cnt1[tid], c) : 0u;
   }
-  __syncthreads();
-
-  // ---- D: copy out ----
+  block_scan256(hist, loff, wtot);
   const uint32_t nrec = min(nrec_s, (uint32_t)P1_RCAP);
   for (uint32_t s = tid; s < nrec; s += P1_THREADS) {
     const uint32_t b = bin_tmp[s];
-    const uint32_t dst = gbase[b] + atomicAdd(&fill[b], 1u);
+    perm[loff[b] + atomicAdd(&fill[b], 1u)] = (uint16_t)s;
+  }
+  __syncthreads();
+
+  // ---- D: copy out in bin order: consecutive lanes write consecutive 16-byte records ----
+  for (uint32_t p = tid; p < nrec; p += P1_THREADS) {
+    const uint32_t s = perm[p];
+    const uint32_t b = bin_tmp[s];
+    const uint32_t dst = gbase[b] + (p - loff[b]);
     const uint4 rec = rec_tmp[s];
     if (dst < v.cap1) v.rec1[(uint64_t)b * v.cap1 + dst] = rec;
     else spill_record(rec, k, canon != 0, t);
@@ -244,45 +277,76 @@ __global__ __launch_bounds__(P1_THREADS) void msp_p1_kernel(const int8_t *__rest
 // ---------------------------------------------------------------------------------------- P2
 __global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int tiles_per_bin, int k, int canon,
                                                             MspView v, TableView t) {
-  __shared__ uint32_t hist[B2], gbase[B2], fill[B2];
+  __shared__ uint4 sorted[P2_TILE];
+  __shared__ uint32_t hist[B2], loff[B2], gbase[B2], fill[B2];
+  __shared__ uint32_t wtot[4];
   const int tid = threadIdx.x;
   const uint32_t b1 = blockIdx.x / (uint32_t)tiles_per_bin;
   const uint32_t tile = blockIdx.x % (uint32_t)tiles_per_bin;
   const uint64_t n = min((uint64_t)v.cnt1[b1], v.cap1);
   const uint64_t r0 = (uint64_t)tile * P2_TILE;
   if (r0 >= n) return;
+  const uint32_t nt = (uint32_t)min((uint64_t)P2_TILE, n - r0);
   if (tid < B2) { hist[tid] = 0; fill[tid] = 0; }
   __syncthreads();
-  const uint4 *src = v.rec1 + (uint64_t)b1 * v.cap1;
+  const uint4 *src = v.rec1 + (uint64_t)b1 * v.cap1 + r0;
   uint4 r[P2_PER];
 #pragma unroll
   for (int i = 0; i < P2_PER; ++i) {
-    const uint64_t idx = r0 + (uint64_t)i * P2_THREADS + tid;
-    if (idx < n) {
-      r[i] = src[idx];
-      atomicAdd(&hist[(r[i].w >> 8) & (B2 - 1)], 1u);
-    }
+    const uint32_t idx = (uint32_t)i * P2_THREADS + tid;
+    uint4 x = make_uint4(0u, 0u, 0u, 0u);
+    if (idx < nt) x = src[idx];
+    r[i] = x;
+    if (idx < nt) atomicAdd(&hist[(x.w >> 8) & (B2 - 1)], 1u);
   }
   __syncthreads();
   if (tid < B2) {
     const uint32_t c = hist[tid];
     gbase[tid] = c ? atomicAdd(&v.cnt2[b1 * B2 + tid], c) : 0u;
   }
-  __syncthreads();
+  block_scan256(hist, loff, wtot);
+  // counting sort of the tile by leaf byte, in LDS
 #pragma unroll
   for (int i = 0; i < P2_PER; ++i) {
-    const uint64_t idx = r0 + (uint64_t)i * P2_THREADS + tid;
-    if (idx < n) {
+    const uint32_t idx = (uint32_t)i * P2_THREADS + tid;
+    if (idx < nt) {
       const uint32_t b2 = (r[i].w >> 8) & (B2 - 1);
-      const uint32_t dst = gbase[b2] + atomicAdd(&fill[b2], 1u);
-      const uint64_t leaf = (uint64_t)b1 * B2 + b2;
-      if (dst < v.cap2) v.rec2[leaf * v.cap2 + dst] = r[i];
-      else spill_record(r[i], k, canon != 0, t);
+      sorted[loff[b2] + atomicAdd(&fill[b2], 1u)] = r[i];
     }
+  }
+  __syncthreads();
+  // copy out: consecutive lanes -> consecutive records of the same leaf segment
+  for (uint32_t p = tid; p < nt; p += P2_THREADS) {
+    const uint4 rec = sorted[p];
+    const uint32_t b2 = (rec.w >> 8) & (B2 - 1);
+    const uint32_t dst = gbase[b2] + (p - loff[b2]);
+    const uint64_t leaf = (uint64_t)b1 * B2 + b2;
+    if (dst < v.cap2) v.rec2[leaf * v.cap2 + dst] = rec;
+    else spill_record(rec, k, canon != 0, t);
   }
 }
 
 // ---------------------------------------------------------------------------------------- P3
+// one LDS table update; returns false when the probe window is full (caller spills to HBM)
+__device__ __forceinline__ bool lds_count(unsigned long long *keys, uint32_t *cnts, uint64_t key,
+                                          uint32_t h, unsigned long long cur) {
+  // cur = keys[h] was read by the caller (so two reads can be in flight before either is used)
+  for (int p = 0; p < P3_PROBE_LIMIT; ++p) {
+    if (cur == CFRK_EMPTY_KEY) {
+      cur = atomicCAS(&keys[h], (unsigned long long)CFRK_EMPTY_KEY, (unsigned long long)key);
+      if (cur == CFRK_EMPTY_KEY) cur = key;
+    }
+    if (cur == key) { atomicAdd(&cnts[h], 1u); return true; }
+    h = (h + 1) & (TS - 1);
+    cur = keys[h];
+  }
+  return false;
+}
+
+__device__ __forceinline__ uint32_t lds_slot(uint64_t key) {
+  return (((uint32_t)key ^ (uint32_t)(key >> 32)) * 0x9E3779B1u) >> (32 - TS_LOG);
+}
+
 template <bool CANON>
 __global__ __launch_bounds__(P3_THREADS) void msp_p3_kernel(int k, MspView v, TableView t) {
   __shared__ unsigned long long keys[TS];
@@ -294,38 +358,50 @@ __global__ __launch_bounds__(P3_THREADS) void msp_p3_kernel(int k, MspView v, Ta
   for (int s = tid; s < TS; s += P3_THREADS) { keys[s] = CFRK_EMPTY_KEY; cnts[s] = 0; }
   __syncthreads();
 
+  const uint64_t kmask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1ull);
+  const int rcsh = 2 * k - 2;
   const uint4 *src = v.rec2 + (uint64_t)leaf * v.cap2;
   for (uint64_t r = tid; r < n; r += P3_THREADS) {
     const uint4 rec = src[r];
     const int nk = (int)(rec.w & 63u) + 1;
     const uint64_t hi = ((uint64_t)rec.x << 32) | rec.y;
     const uint64_t lo = (uint64_t)rec.z << 32;
-    for (int j = 0; j < nk; ++j) {
-      const uint64_t x = j ? ((hi << (2 * j)) | (lo >> (64 - 2 * j))) : hi;
-      uint64_t key = x >> (64 - 2 * k);
-      if (CANON) {
-        const uint64_t rc = dev_revcomp64(key, k);
-        key = rc < key ? rc : key;
-      }
-      if (key == CFRK_EMPTY_KEY) {   // k = 32, all T, forward strand
+    // rolling forward / reverse-complement k-mers; T feeds base k+j from its top 2 bits
+    uint64_t fwd = hi >> (64 - 2 * k);
+    uint64_t rc = CANON ? dev_revcomp64(fwd, k) : 0;
+    uint64_t T = (k == 32) ? lo : ((hi << (2 * k)) | (lo >> (64 - 2 * k)));
+    for (int j = 0; j < nk; j += 2) {
+      // two k-mers per trip so that two LDS reads are in flight before either is consumed
+      uint64_t key0 = (CANON && rc < fwd) ? rc : fwd;
+      uint32_t nb = (uint32_t)(T >> 62);
+      T <<= 2;
+      fwd = ((fwd << 2) | nb) & kmask;
+      if (CANON) rc = (rc >> 2) | ((uint64_t)(3u - nb) << rcsh);
+      const bool two = j + 1 < nk;
+      uint64_t key1 = (CANON && rc < fwd) ? rc : fwd;
+      nb = (uint32_t)(T >> 62);
+      T <<= 2;
+      fwd = ((fwd << 2) | nb) & kmask;
+      if (CANON) rc = (rc >> 2) | ((uint64_t)(3u - nb) << rcsh);
+
+      const uint32_t h0 = lds_slot(key0), h1 = lds_slot(key1);
+      const unsigned long long c0 = keys[h0];
+      const unsigned long long c1 = keys[h1];
+      if (key0 == CFRK_EMPTY_KEY) {   // k = 32, all T, forward strand
         atomicAdd((unsigned long long *)&t.stats[ST_ONES], 1ull);
-        continue;
-      }
-      uint32_t hx = ((uint32_t)key ^ (uint32_t)(key >> 32)) * 0x9E3779B1u;
-      uint32_t h = hx >> (32 - TS_LOG);
-      bool done = false;
-      for (int p = 0; p < P3_PROBE_LIMIT; ++p) {
-        unsigned long long cur = keys[h];
-        if (cur == CFRK_EMPTY_KEY) {
-          cur = atomicCAS(&keys[h], (unsigned long long)CFRK_EMPTY_KEY, (unsigned long long)key);
-          if (cur == CFRK_EMPTY_KEY) cur = key;
-        }
-        if (cur == key) { atomicAdd(&cnts[h], 1u); done = true; break; }
-        h = (h + 1) & (TS - 1);
-      }
-      if (!done) {          // leaf table full around this key: count it in HBM
+      } else if (!lds_count(keys, cnts, key0, h0, c0)) {
         t.stats[ST_SPILLED] = 1;
-        table_add1(t, key, 1u);
+        atomicAdd((unsigned long long *)&t.stats[ST_AUX1], 1ull);
+        table_add1(t, key0, 1u);
+      }
+      if (two) {
+        if (key1 == CFRK_EMPTY_KEY) {
+          atomicAdd((unsigned long long *)&t.stats[ST_ONES], 1ull);
+        } else if (!lds_count(keys, cnts, key1, h1, (key1 == key0) ? keys[h1] : c1)) {
+          t.stats[ST_SPILLED] = 1;
+          atomicAdd((unsigned long long *)&t.stats[ST_AUX1], 1ull);
+          table_add1(t, key1, 1u);
+        }
       }
     }
   }
@@ -346,6 +422,25 @@ __global__ __launch_bounds__(P3_THREADS) void msp_p3_kernel(int k, MspView v, Ta
       if (dst < v.out_cap) { v.out_keys[dst] = key; v.out_cnt[dst] = cnts[s]; }
       else v.stats[ST_OVERFLOW] = 1;
     }
+  }
+}
+
+__global__ void msp_info_kernel(MspView v, uint64_t *out) {
+  // diagnostics: record totals / maxima per level (single block)
+  __shared__ unsigned long long tot1, max1, tot2, max2;
+  if (threadIdx.x == 0) { tot1 = max1 = tot2 = max2 = 0; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < B1; i += blockDim.x) {
+    atomicAdd(&tot1, (unsigned long long)v.cnt1[i]);
+    atomicMax(&max1, (unsigned long long)v.cnt1[i]);
+  }
+  for (int i = threadIdx.x; i < NLEAF; i += blockDim.x) {
+    atomicAdd(&tot2, (unsigned long long)v.cnt2[i]);
+    atomicMax(&max2, (unsigned long long)v.cnt2[i]);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[0] = tot1; out[1] = max1; out[2] = v.cap1; out[3] = tot2; out[4] = max2; out[5] = v.cap2;
   }
 }
 
@@ -387,7 +482,9 @@ void cfrk_msp_destroy(cfrk_ctx *ctx) {
 }
 
 static void msp_params(int k, int *W, int *m) {
-  if (k >= 30) *W = 20; else if (k >= 26) *W = 16; else if (k >= 20) *W = 10; else *W = 6;
+  // m = k - W + 1 stays in 11..16 (32-bit m-mers) and >= 13 wherever k allows: with too few
+  // distinct minimizers the leaves get lumpy (several genome loci share one minimizer value)
+  if (k >= 30) *W = 18; else if (k >= 26) *W = 14; else if (k >= 22) *W = 10; else *W = 6;
   *m = k - *W + 1;
 }
 
@@ -405,7 +502,7 @@ int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   const double dens = 2.0 / (W + 1) + 1.0 / 32.0;
   const double expect = (double)nN * dens;
   const uint64_t cap1 = (uint64_t)(expect / B1 * 1.3) + 4096;
-  const uint64_t cap2 = (uint64_t)(expect / NLEAF * 1.6) + 96;
+  const uint64_t cap2 = (uint64_t)(expect / NLEAF * 2.0) + 96;
   const int64_t tiles_per_bin = (int64_t)((cap1 + P2_TILE - 1) / P2_TILE);
   if (tiles_per_bin * B1 > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
 
@@ -431,8 +528,8 @@ int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   if (ntiles > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
   const dim3 g1((unsigned)ntiles), b1(P1_THREADS);
   switch (W) {
-    case 20: hipLaunchKernelGGL((msp_p1_kernel<20>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, v, t); break;
-    case 16: hipLaunchKernelGGL((msp_p1_kernel<16>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, v, t); break;
+    case 18: hipLaunchKernelGGL((msp_p1_kernel<18>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, v, t); break;
+    case 14: hipLaunchKernelGGL((msp_p1_kernel<14>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, v, t); break;
     case 10: hipLaunchKernelGGL((msp_p1_kernel<10>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, v, t); break;
     default: hipLaunchKernelGGL((msp_p1_kernel<6>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, v, t); break;
   }
@@ -480,5 +577,26 @@ int cfrk_msp_resolve(cfrk_ctx *ctx, ResultSrc *src, bool *use_list) {
   src->lo = ms->view.out_keys; src->hi = nullptr; src->cnt = ms->view.out_cnt;
   src->n = st[ST_CURSOR]; src->kind = 2; src->stats = ctx->g_stats;
   *use_list = true;
+  return CFRK_OK;
+}
+
+// diagnostics (not part of the counting path): out[0..5] = L1 records total / max bin / bin
+// capacity, L2 records total / max leaf / leaf capacity; out[6] = records spilled to the HBM
+// table, out[7] = k-mers spilled by full leaf tables, out[8] = entries in the result list
+extern "C" int cfrk_debug_msp_info(cfrk_ctx *ctx, uint64_t out[9]) {
+  if (!ctx || !out) return CFRK_ERR_ARG;
+  cfrk_msp *ms = ctx->msp;
+  for (int i = 0; i < 9; ++i) out[i] = 0;
+  if (!ms || !ms->view.cnt1) return CFRK_OK;
+  void *p;
+  int rc = cfrk_pool_get(ctx, BUF_SCRATCH, 64 * sizeof(uint64_t), &p);
+  if (rc) return rc;
+  hipLaunchKernelGGL(msp_info_kernel, dim3(1), dim3(1024), 0, ctx->stream, ms->view, (uint64_t *)p);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(out, p, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  uint64_t st[ST_NWORDS];
+  rc = msp_sync_stats(ctx, st);
+  if (rc) return rc;
+  out[6] = st[ST_AUX0]; out[7] = st[ST_AUX1]; out[8] = st[ST_CURSOR];
   return CFRK_OK;
 }

@@ -72,6 +72,7 @@ def load_library():
         "cfrk_global_export_device": ([vp, vp, vp, vp, u64, C.c_int, C.POINTER(u64)], C.c_int),
         "cfrk_global_digest": ([vp, C.POINTER(u64)], C.c_int),
         "cfrk_global_last_add_ms": ([vp, C.POINTER(C.c_float)], C.c_int),
+        "cfrk_debug_msp_info": ([vp, C.POINTER(u64)], C.c_int),
         "cfrk_synth_reads_device": ([vp, i64, i64, i32, i64, u64, u64, u64, i32, vp, vp, vp], C.c_int),
     }
     for name, (args, res) in sig.items():
@@ -194,6 +195,13 @@ class GlobalCounter:
         out = (C.c_uint64 * 4)()
         self.ctx.check(self._L.cfrk_global_digest(self.ctx._h, out), "cfrk_global_digest")
         return tuple(int(x) for x in out)
+
+    def msp_info(self):
+        out = (C.c_uint64 * 9)()
+        self.ctx.check(self._L.cfrk_debug_msp_info(self.ctx._h, out), "cfrk_debug_msp_info")
+        names = ("l1_records", "l1_max_bin", "l1_cap", "l2_records", "l2_max_leaf", "l2_cap",
+                 "spilled_records", "spilled_kmers", "list_entries")
+        return dict(zip(names, (int(x) for x in out)))
 
     def last_add_ms(self):
         ms = C.c_float()

@@ -143,6 +143,12 @@ int cfrk_global_digest(cfrk_ctx *ctx, uint64_t out[4]);
  * recent cfrk_global_add / cfrk_global_add_device; synchronises. */
 int cfrk_global_last_add_ms(cfrk_ctx *ctx, float *ms);
 
+/* Diagnostics of the minimizer-partitioned path after the most recent add (synchronises):
+ * out[0..2] = level-1 records: total, largest bin, bin capacity; out[3..5] = level-2 records:
+ * total, largest leaf, leaf capacity; out[6] = records and out[7] = k-mers that were counted in
+ * the HBM table instead (spill); out[8] = entries in the leaf-output list. */
+int cfrk_debug_msp_info(cfrk_ctx *ctx, uint64_t out[9]);
+
 /* ---- synthetic reads, generated on device ----------------------------------- */
 
 /* Reads [r0, r0+R) of the deterministic generator, struct-read layout: d_data R*(L+1) bytes,
