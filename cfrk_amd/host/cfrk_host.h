@@ -1,0 +1,56 @@
+// cfrk_host.h -- host side of the cfrk drop-in: FASTA ingest, chunking, .cfrk output.
+//
+// Mirrors the reference's host code around kmer_main() (paths under /root/reference/):
+//   ReadFasta / ReadFASTASequences / ProcessData   src/fastaIO.h:24-148
+//   SelectChunk / SelectChunkRemain                src/main.cu:110-206
+//   PrintFreq                                      src/main.cu:26-62
+// Plain C ABI so that the CPU tests (ctypes) and the CLI share one implementation.
+// Pure host code: no HIP, no oracle.
+#ifndef CFRK_HOST_H
+#define CFRK_HOST_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CFRK_INGEST_COMPAT 0x1   /* reproduce ReadFasta's quirks (see cfrk_host_read_fasta) */
+
+typedef struct cfrk_batch {      /* struct read (src/tipos.h:23-30) with owned storage */
+  int8_t  *data;                 /* nN codes, -1 = invalid base / terminator */
+  int64_t *start;                /* nS */
+  int32_t *length;               /* nS */
+  int64_t nN, nS;
+} cfrk_batch;
+
+/* Parse a FASTA file (or memory image) into the struct-read layout.
+ * CFRK_INGEST_COMPAT (what the reference does, src/fastaIO.h:24-71,105-148):
+ *   - a record starts at a line BEGINNING with '>' (fastaIO.h:40);
+ *   - every other line, newline included, is appended to the record (fastaIO.h:49-66), so the
+ *     newlines inside a multi-line record and trailing blank lines become -1 codes;
+ *   - length = strlen - 1 (fastaIO.h:53,65): the last char is dropped, which is the final
+ *     newline, or the last BASE when the file has no final newline.
+ * Without the flag: sequence lines are joined without their line ends ('\n', '\r'), nothing
+ * is dropped.  Both: aA cC gG tT -> 0 1 2 3, anything else -1 (fastaIO.h:121-140).
+ * Returns 0, -1 (cannot open), -2 (sequence before the first header), -3 (header without
+ * sequence: undefined behaviour in the reference, rejected here), -4 (out of memory). */
+int  cfrk_host_read_fasta(const char *path, int flags, cfrk_batch *out);
+int  cfrk_host_parse_fasta(const char *buf, size_t len, int flags, cfrk_batch *out);
+void cfrk_host_free_batch(cfrk_batch *b);
+
+/* Chunk [first, first+count) of a batch with chunk-relative start[] (SelectChunk,
+ * src/main.cu:160-206): views into the batch, nothing is copied; start_out needs count slots. */
+int cfrk_host_chunk(const cfrk_batch *b, int64_t first, int64_t count, const int8_t **data,
+                    int64_t *start_out, const int32_t **length, int64_t *nN);
+
+/* PrintFreq (src/main.cu:26-62): "<idx>:<count> " for every bin, '\n' between rows, none at the
+ * end.  Returns bytes needed/written (buf may be NULL to size). */
+size_t cfrk_host_format_dense(const int32_t *freq, int64_t nS, int k, char *buf, size_t cap);
+/* Sparse global form: "<key>:<count>\n" per distinct key, ascending (keys < 2^64, k <= 32). */
+size_t cfrk_host_format_sparse(const uint64_t *keys, const uint32_t *counts, uint64_t n, char *buf,
+                               size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -308,3 +308,56 @@ def test_msp_then_merge_and_second_add(ctx):
     assert (lo == wlo).all() and (cnt.astype(np.uint64) == wcnt).all()
     w1 = orc.global_count(d1, 25, orc.ORC_CANONICAL)
     assert a == orc.digest(*w1)
+
+
+# ------------------------------------------------------------------ the cfrk command
+
+def _cli():
+    import subprocess
+    from .conftest import ROOT
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "cfrk_amd", "host")], stdout=subprocess.DEVNULL)
+    return os.path.join(ROOT, "cfrk_amd", "cfrk")
+
+
+@pytest.mark.parametrize("name", ["seq1", "seq2"])
+def test_cli_reproduces_reference_test(derived_fasta, tmp_path, name):
+    """reference test/test.sh:13-19: `cfrk seqN.fasta out.cfrk 2 12 8192`, diff against the golden"""
+    import subprocess
+    out = tmp_path / "out.cfrk"
+    subprocess.check_call([_cli(), derived_fasta[name], str(out), "2", "12", "8192"])
+    assert out.read_bytes() == open(os.path.join(GOLDEN, f"out-{name}.cfrk"), "rb").read()
+
+
+def test_cli_chunking_quirks_and_modes(tmp_path):
+    import subprocess
+    cli = _cli()
+    fa = tmp_path / "r.fasta"
+    raw = b"".join(b">r%d\n%s\n" % (i, s) for i, s in enumerate([b"ACGTACGT", b"TTTTGGGG", b"ACNNAC", b"GGGGGGGG", b"CATCATCAT"]))
+    fa.write_bytes(raw)
+    out = tmp_path / "o.cfrk"
+    # only the remainder chunk reaches the file (src/main.cu:303-305)
+    subprocess.check_call([cli, str(fa), str(out), "3", "12", "2"])
+    assert out.read_bytes() == refsem.reference_cfrk_bytes(raw, 3, 2)
+    # reads % chunkSize == 0 -> empty file
+    subprocess.check_call([cli, str(fa), str(out), "3", "12", "5"])
+    assert out.read_bytes() == b""
+    # argc == 5: the 4th positional is nt, chunk stays 8192
+    subprocess.check_call([cli, str(fa), str(out), "3", "2"])
+    assert out.read_bytes() == refsem.reference_cfrk_bytes(raw, 3, 8192)
+    # --all-chunks: every chunk, each counted on its own (spill stays inside a chunk)
+    subprocess.check_call([cli, str(fa), str(out), "2", "12", "2", "--all-chunks"])
+    reads = refsem.read_fasta_compat(raw)
+    rows = []
+    for c in range(0, 5, 2):
+        d, s, l = refsem.flatten(reads[c:c + 2])
+        rows.append(orc.format_cfrk(orc.per_read_dense(d, s, l, 2, orc.ORC_COMPAT), 2))
+    assert out.read_bytes() == b"\n".join(rows)
+    # --global --canonical: sparse "key:count" lines
+    subprocess.check_call([cli, str(fa), str(out), "5", "--global", "--canonical"])
+    data, _, _ = refsem.flatten([refsem._CODE[np.frombuffer(s, np.uint8)] for s in
+                                 [b"ACGTACGT", b"TTTTGGGG", b"ACNNAC", b"GGGGGGGG", b"CATCATCAT"]])
+    lo, _, cnt = orc.global_count(data, 5, orc.ORC_CANONICAL)
+    assert out.read_bytes() == b"".join(b"%d:%d\n" % (int(a), int(b)) for a, b in zip(lo, cnt))
+    # usage
+    r = subprocess.run([cli, str(fa)], capture_output=True)
+    assert r.returncode == 1 and r.stdout.startswith(b"Usage: ./cfrk")

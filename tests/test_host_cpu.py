@@ -1,0 +1,122 @@
+"""Host-side C++ (ingest, chunk views, .cfrk text) against the Python restatement of the
+reference's host semantics and the oracle's formatter.  CPU only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from . import oracle_lib as orc
+from . import refsem
+from .conftest import GOLDEN, ROOT
+
+
+class Batch(C.Structure):
+    _fields_ = [("data", C.POINTER(C.c_int8)), ("start", C.POINTER(C.c_int64)),
+                ("length", C.POINTER(C.c_int32)), ("nN", C.c_int64), ("nS", C.c_int64)]
+
+
+@pytest.fixture(scope="module")
+def host():
+    so = os.path.join(ROOT, "cfrk_amd", "libcfrk_host.so")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "cfrk_amd", "host"), "../libcfrk_host.so"],
+                          stdout=subprocess.DEVNULL)
+    L = C.CDLL(so)
+    L.cfrk_host_parse_fasta.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(Batch)]
+    L.cfrk_host_read_fasta.argtypes = [C.c_char_p, C.c_int, C.POINTER(Batch)]
+    L.cfrk_host_free_batch.argtypes = [C.POINTER(Batch)]
+    L.cfrk_host_format_dense.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_char_p, C.c_size_t]
+    L.cfrk_host_format_dense.restype = C.c_size_t
+    L.cfrk_host_format_sparse.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_char_p, C.c_size_t]
+    L.cfrk_host_format_sparse.restype = C.c_size_t
+    L.cfrk_host_chunk.argtypes = [C.POINTER(Batch), C.c_int64, C.c_int64, C.POINTER(C.POINTER(C.c_int8)),
+                                  C.POINTER(C.c_int64), C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_int64)]
+    return L
+
+
+def _parse(L, raw, flags):
+    b = Batch()
+    rc = L.cfrk_host_parse_fasta(raw, len(raw), flags, C.byref(b))
+    if rc:
+        return rc, None
+    data = np.ctypeslib.as_array(b.data, (max(b.nN, 1),))[:b.nN].copy()
+    start = np.ctypeslib.as_array(b.start, (max(b.nS, 1),))[:b.nS].copy()
+    length = np.ctypeslib.as_array(b.length, (max(b.nS, 1),))[:b.nS].copy()
+    L.cfrk_host_free_batch(C.byref(b))
+    return 0, (data, start, length)
+
+
+CASES = [
+    b">a\nACGTACGTAC\n>b\nAAAANAAAA\n>c\nTTTTT\n>d\nACGT\nACGT\n",
+    b">a\nacgtn\n>b\nRYKM\n\n\n\n",
+    b">only\nACGT",                       # no final newline: compat drops the last base
+    b">x\nAC\r\nGT\r\n",
+    b">h1 some text > more\nAAAA\n>h2\nC\n",
+]
+
+
+@pytest.mark.parametrize("raw", CASES)
+def test_compat_ingest_matches_reference_semantics(host, raw):
+    rc, got = _parse(host, raw, 1)
+    assert rc == 0
+    want = refsem.flatten(refsem.read_fasta_compat(raw))
+    for g, w in zip(got, want):
+        assert g.shape == w.shape and (g == w).all()
+
+
+def test_native_ingest_joins_lines_and_keeps_last_base(host):
+    rc, (data, start, length) = _parse(host, b">a\nAC\r\nGT\n>b\nTTTT", 0)
+    assert rc == 0
+    assert list(length) == [4, 4] and list(start) == [0, 5]
+    assert list(data) == [0, 1, 2, 3, -1, 3, 3, 3, 3, -1]
+
+
+def test_ingest_errors(host):
+    assert _parse(host, b"ACGT\n>a\nAC\n", 1)[0] == -2
+    assert _parse(host, b">a\n>b\nAC\n", 1)[0] == -3          # UB in the reference: rejected
+    b = Batch()
+    assert host.cfrk_host_read_fasta(b"/nonexistent/file.fasta", 1, C.byref(b)) == -1
+    rc, (data, start, length) = _parse(host, b"", 1)
+    assert rc == 0 and len(data) == 0 and len(length) == 0
+
+
+@pytest.mark.parametrize("name", ["seq1", "seq2"])
+def test_golden_through_host_ingest_and_writer(host, derived_fasta, name):
+    """reference goldens: C++ ingest -> oracle counts -> C++ writer == golden bytes"""
+    raw = open(derived_fasta[name], "rb").read()
+    rc, (data, start, length) = _parse(host, raw, 1)
+    assert rc == 0
+    freq = orc.per_read_dense(data, start, length, 2, orc.ORC_COMPAT)
+    n = host.cfrk_host_format_dense(freq.ctypes.data, len(length), 2, None, 0)
+    buf = C.create_string_buffer(n)
+    assert host.cfrk_host_format_dense(freq.ctypes.data, len(length), 2, buf, n) == n
+    assert buf.raw[:n] == open(os.path.join(GOLDEN, f"out-{name}.cfrk"), "rb").read()
+
+
+def test_writer_matches_oracle_formatter(host):
+    rng = np.random.default_rng(0)
+    f = rng.integers(0, 100000, 5 * 64).astype(np.int32)
+    n = host.cfrk_host_format_dense(f.ctypes.data, 5, 3, None, 0)
+    buf = C.create_string_buffer(n)
+    host.cfrk_host_format_dense(f.ctypes.data, 5, 3, buf, n)
+    assert buf.raw[:n] == orc.format_cfrk(f, 3)
+    keys = np.array([0, 7, 2 ** 63 + 5], np.uint64)
+    cnt = np.array([1, 4000000000, 9], np.uint32)
+    n = host.cfrk_host_format_sparse(keys.ctypes.data, cnt.ctypes.data, 3, None, 0)
+    buf = C.create_string_buffer(n)
+    host.cfrk_host_format_sparse(keys.ctypes.data, cnt.ctypes.data, 3, buf, n)
+    assert buf.raw[:n] == b"0:1\n7:4000000000\n9223372036854775813:9\n"
+
+
+def test_chunk_views_are_chunk_relative(host):
+    raw = b"".join(b">r%d\n%s\n" % (i, b"ACGT" * (i + 1)) for i in range(5))
+    b = Batch()
+    assert host.cfrk_host_parse_fasta(raw, len(raw), 1, C.byref(b)) == 0
+    data = C.POINTER(C.c_int8)(); length = C.POINTER(C.c_int32)(); nN = C.c_int64()
+    start = (C.c_int64 * 2)()
+    assert host.cfrk_host_chunk(C.byref(b), 2, 2, C.byref(data), start, C.byref(length), C.byref(nN)) == 0
+    assert list(start) == [0, 13] and nN.value == 13 + 17 and length[0] == 12 and length[1] == 16
+    assert data[0] == 0 and data[12] == -1
+    assert host.cfrk_host_chunk(C.byref(b), 4, 2, C.byref(data), start, C.byref(length), C.byref(nN)) == -1
+    host.cfrk_host_free_batch(C.byref(b))
