@@ -28,6 +28,8 @@
 #include "msp.h"
 #include "table.h"
 
+#include <stdlib.h>
+
 #include <algorithm>
 #include <new>
 
@@ -110,12 +112,13 @@ __device__ __forceinline__ uint32_t pick32(const uint32_t (&w)[N], int a) {
   return c1 ? g1 : g0;
 }
 
-// exclusive prefix sum of cnt[0..255] into off[0..255]; every thread of the block must call it
-// (blockDim >= 256); wtot is 4 words of LDS scratch
-__device__ __forceinline__ void block_scan256(const uint32_t *cnt, uint32_t *off, uint32_t *wtot) {
+// exclusive prefix sum of cnt[0..NB) into off[0..NB); every thread of the block must call it
+// (blockDim >= NB, NB a multiple of 64, NB <= 512); wtot is NB/64 words of LDS scratch
+template <int NB>
+__device__ __forceinline__ void block_scan(const uint32_t *cnt, uint32_t *off, uint32_t *wtot) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   uint32_t x = 0, incl = 0;
-  if (tid < 256) {
+  if (tid < NB) {
     x = cnt[tid];
     incl = x;
 #pragma unroll
@@ -126,7 +129,7 @@ __device__ __forceinline__ void block_scan256(const uint32_t *cnt, uint32_t *off
     if (lane == 63) wtot[wave] = incl;
   }
   __syncthreads();
-  if (tid < 256) {
+  if (tid < NB) {
     uint32_t base = 0;
     for (int w = 0; w < wave; ++w) base += wtot[w];
     off[tid] = base + incl - x;
@@ -221,15 +224,26 @@ __global__ __launch_bounds__(P1_THREADS) void msp_p1_kernel(const int8_t *__rest
     S &= ~(0x80000000u >> a);
     const uint32_t rest = (a == 31) ? 0u : (E << (a + 1));
     int n = rest ? (__clz(rest) + 1) : (32 - a);
+    // "complete": both ends of the run are minimizer changes between valid k-mers (not a lane
+    // edge, a read end or the record-size cap), so every read covering this locus emits the
+    // same record
+    uint32_t complete = 0;
+    if (a >= 1 && rest != 0u && n <= nkmax)
+      complete = ((V >> (32 - a)) & (V >> (31 - (a + n))) & 1u) << 6;
     if (n > nkmax) { n = nkmax; S |= 0x80000000u >> (a + nkmax); }
     const uint32_t leaf = leaf_of(pick32(H, a));
     const uint32_t bin1 = leaf >> B2_LOG;
     uint4 rec;
     const uint64_t r01 = a ? ((hi << (2 * a)) | (lo >> (64 - 2 * a))) : hi;
     rec.x = (uint32_t)(r01 >> 32);
-    rec.y = (uint32_t)r01;
-    rec.z = (uint32_t)((lo << (2 * a)) >> 32);
-    rec.w = (leaf << 8) | (uint32_t)(n - 1);
+    // bases after the run's last k-mer are cleared: equal runs -> byte-identical records (P3
+    // counts identical records once)
+    const int z = 2 * (48 - (n + k - 1));
+    uint64_t r12 = ((uint64_t)(uint32_t)r01 << 32) | (uint32_t)((lo << (2 * a)) >> 32);
+    r12 = (z >= 64) ? 0ull : ((r12 >> z) << z);
+    rec.y = (uint32_t)(r12 >> 32);
+    rec.z = (uint32_t)r12;
+    rec.w = (leaf << 8) | complete | (uint32_t)(n - 1);
 
     const unsigned long long act = __ballot(1);
     const int leader = __ffsll(act) - 1;
@@ -255,7 +269,7 @@ __global__ __launch_bounds__(P1_THREADS) void msp_p1_kernel(const int8_t *__rest
     const uint32_t c = hist[tid];
     gbase[tid] = c ? atomicAdd(&v.cnt1[tid], c) : 0u;
   }
-  block_scan256(hist, loff, wtot);
+  block_scan<B1>(hist, loff, wtot);
   const uint32_t nrec = min(nrec_s, (uint32_t)P1_RCAP);
   for (uint32_t s = tid; s < nrec; s += P1_THREADS) {
     const uint32_t b = bin_tmp[s];
@@ -275,11 +289,17 @@ __global__ __launch_bounds__(P1_THREADS) void msp_p1_kernel(const int8_t *__rest
 }
 
 // ---------------------------------------------------------------------------------------- P2
+// sub-bin of a record inside its level-1 bin: leaf low byte x {truncated run, complete run}.
+// Complete runs get a stream of their own so that P3 can count them per RECORD with every lane
+// busy, instead of k-mer by k-mer.
+constexpr int NSUB = 2 * B2;
+__device__ __forceinline__ uint32_t sub_of(uint32_t w) { return (((w >> 8) & (B2 - 1)) << 1) | ((w >> 6) & 1u); }
+
 __global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int tiles_per_bin, int k, int canon,
                                                             MspView v, TableView t) {
   __shared__ uint4 sorted[P2_TILE];
-  __shared__ uint32_t hist[B2], loff[B2], gbase[B2], fill[B2];
-  __shared__ uint32_t wtot[4];
+  __shared__ uint32_t hist[NSUB], loff[NSUB], gbase[NSUB], fill[NSUB];
+  __shared__ uint32_t wtot[NSUB / 64];
   const int tid = threadIdx.x;
   const uint32_t b1 = blockIdx.x / (uint32_t)tiles_per_bin;
   const uint32_t tile = blockIdx.x % (uint32_t)tiles_per_bin;
@@ -287,7 +307,7 @@ __global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int tiles_per_bin, i
   const uint64_t r0 = (uint64_t)tile * P2_TILE;
   if (r0 >= n) return;
   const uint32_t nt = (uint32_t)min((uint64_t)P2_TILE, n - r0);
-  if (tid < B2) { hist[tid] = 0; fill[tid] = 0; }
+  if (tid < NSUB) { hist[tid] = 0; fill[tid] = 0; }
   __syncthreads();
   const uint4 *src = v.rec1 + (uint64_t)b1 * v.cap1 + r0;
   uint4 r[P2_PER];
@@ -297,46 +317,46 @@ __global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int tiles_per_bin, i
     uint4 x = make_uint4(0u, 0u, 0u, 0u);
     if (idx < nt) x = src[idx];
     r[i] = x;
-    if (idx < nt) atomicAdd(&hist[(x.w >> 8) & (B2 - 1)], 1u);
+    if (idx < nt) atomicAdd(&hist[sub_of(x.w)], 1u);
   }
   __syncthreads();
-  if (tid < B2) {
+  if (tid < NSUB) {
     const uint32_t c = hist[tid];
-    gbase[tid] = c ? atomicAdd(&v.cnt2[b1 * B2 + tid], c) : 0u;
+    gbase[tid] = c ? atomicAdd(&v.cnt2[b1 * NSUB + tid], c) : 0u;
   }
-  block_scan256(hist, loff, wtot);
-  // counting sort of the tile by leaf byte, in LDS
+  block_scan<NSUB>(hist, loff, wtot);
+  // counting sort of the tile by sub-bin, in LDS
 #pragma unroll
   for (int i = 0; i < P2_PER; ++i) {
     const uint32_t idx = (uint32_t)i * P2_THREADS + tid;
     if (idx < nt) {
-      const uint32_t b2 = (r[i].w >> 8) & (B2 - 1);
-      sorted[loff[b2] + atomicAdd(&fill[b2], 1u)] = r[i];
+      const uint32_t sb = sub_of(r[i].w);
+      sorted[loff[sb] + atomicAdd(&fill[sb], 1u)] = r[i];
     }
   }
   __syncthreads();
-  // copy out: consecutive lanes -> consecutive records of the same leaf segment
+  // copy out: consecutive lanes -> consecutive records of the same stream
   for (uint32_t p = tid; p < nt; p += P2_THREADS) {
     const uint4 rec = sorted[p];
-    const uint32_t b2 = (rec.w >> 8) & (B2 - 1);
-    const uint32_t dst = gbase[b2] + (p - loff[b2]);
-    const uint64_t leaf = (uint64_t)b1 * B2 + b2;
-    if (dst < v.cap2) v.rec2[leaf * v.cap2 + dst] = rec;
+    const uint32_t sb = sub_of(rec.w);
+    const uint32_t dst = gbase[sb] + (p - loff[sb]);
+    const uint64_t stream = (uint64_t)b1 * NSUB + sb;
+    if (dst < v.cap2) v.rec2[stream * v.cap2 + dst] = rec;
     else spill_record(rec, k, canon != 0, t);
   }
 }
 
 // ---------------------------------------------------------------------------------------- P3
-// one LDS table update; returns false when the probe window is full (caller spills to HBM)
+// one LDS k-mer table update (+add); returns false when the probe window is full (caller spills)
 __device__ __forceinline__ bool lds_count(unsigned long long *keys, uint32_t *cnts, uint64_t key,
-                                          uint32_t h, unsigned long long cur) {
+                                          uint32_t h, unsigned long long cur, uint32_t add) {
   // cur = keys[h] was read by the caller (so two reads can be in flight before either is used)
   for (int p = 0; p < P3_PROBE_LIMIT; ++p) {
     if (cur == CFRK_EMPTY_KEY) {
       cur = atomicCAS(&keys[h], (unsigned long long)CFRK_EMPTY_KEY, (unsigned long long)key);
       if (cur == CFRK_EMPTY_KEY) cur = key;
     }
-    if (cur == key) { atomicAdd(&cnts[h], 1u); return true; }
+    if (cur == key) { atomicAdd(&cnts[h], add); return true; }
     h = (h + 1) & (TS - 1);
     cur = keys[h];
   }
@@ -348,77 +368,158 @@ __device__ __forceinline__ uint32_t lds_slot(uint64_t key) {
 }
 
 template <bool CANON>
-__global__ __launch_bounds__(P3_THREADS) void msp_p3_kernel(int k, MspView v, TableView t) {
+__device__ __forceinline__ void count_kmer(unsigned long long *keys, uint32_t *cnts, uint64_t key,
+                                           uint32_t h, unsigned long long cur, uint32_t add,
+                                           const TableView &t) {
+  if (key == CFRK_EMPTY_KEY) {   // k = 32, all T, forward strand
+    atomicAdd((unsigned long long *)&t.stats[ST_ONES], (unsigned long long)add);
+  } else if (!lds_count(keys, cnts, key, h, cur, add)) {
+    t.stats[ST_SPILLED] = 1;
+    atomicAdd((unsigned long long *)&t.stats[ST_AUX1], (unsigned long long)add);
+    table_add1(t, key, add);
+  }
+}
+
+// expand one record into its k-mers (rolling), each counted `add` times
+template <bool CANON>
+__device__ __forceinline__ void count_record(unsigned long long *keys, uint32_t *cnts, uint4 rec,
+                                             uint32_t add, int k, uint64_t kmask, int rcsh,
+                                             const TableView &t) {
+  const int nk = (int)(rec.w & 63u) + 1;
+  const uint64_t hi = ((uint64_t)rec.x << 32) | rec.y;
+  const uint64_t lo = (uint64_t)rec.z << 32;
+  uint64_t fwd = hi >> (64 - 2 * k);
+  uint64_t rc = CANON ? dev_revcomp64(fwd, k) : 0;
+  uint64_t T = (k == 32) ? lo : ((hi << (2 * k)) | (lo >> (64 - 2 * k)));
+  for (int j = 0; j < nk; j += 2) {
+    // two k-mers per trip so that two LDS reads are in flight before either is consumed
+    const uint64_t key0 = (CANON && rc < fwd) ? rc : fwd;
+    uint32_t nb = (uint32_t)(T >> 62);
+    T <<= 2;
+    fwd = ((fwd << 2) | nb) & kmask;
+    if (CANON) rc = (rc >> 2) | ((uint64_t)(3u - nb) << rcsh);
+    const bool two = j + 1 < nk;
+    const uint64_t key1 = (CANON && rc < fwd) ? rc : fwd;
+    nb = (uint32_t)(T >> 62);
+    T <<= 2;
+    fwd = ((fwd << 2) | nb) & kmask;
+    if (CANON) rc = (rc >> 2) | ((uint64_t)(3u - nb) << rcsh);
+    const uint32_t h0 = lds_slot(key0), h1 = lds_slot(key1);
+    const unsigned long long c0 = keys[h0];
+    const unsigned long long c1 = keys[h1];
+    count_kmer<CANON>(keys, cnts, key0, h0, c0, add, t);
+    if (two) count_kmer<CANON>(keys, cnts, key1, h1, c1, add, t);   // a stale c1 can only read EMPTY: the CAS decides
+  }
+}
+
+// Record table: at high coverage most complete super-k-mer records of a leaf are byte-identical
+// (the same genome locus seen by many reads).  Entries are {R0,R1,R2,meta},
+// meta = count << 6 | (n-1); meta == 0 empty, RT_LOCK while the claiming lane writes the bases.
+constexpr int RT_LOG = 10, RT = 1 << RT_LOG;
+constexpr uint32_t RT_LOCK = 0xFFFFFFFFu;
+constexpr int RT_PROBES = 8;
+
+// true when the record was counted in the record table
+__device__ __forceinline__ bool rtab_insert(uint4 *rtab, uint4 rec) {
+  uint32_t *rmeta = reinterpret_cast<uint32_t *>(rtab);
+  const uint32_t nm1 = rec.w & 63u;
+  uint32_t h = (rec.x * 0x9E3779B1u) ^ (rec.y * 0x85EBCA77u) ^ (rec.z * 0xC2B2AE3Du) ^ (nm1 * 0x27D4EB2Fu);
+  h = (h ^ (h >> 15)) * 0x2C1B3C6Du;
+  h >>= (32 - RT_LOG);
+  int probes = 0, spins = 0;
+  while (probes < RT_PROBES && spins < 4096) {
+    const uint4 e = rtab[h];
+    if (e.w == 0u) {
+      const uint32_t old = atomicCAS(&rmeta[4 * h + 3], 0u, RT_LOCK);
+      if (old == 0u) {
+        rmeta[4 * h + 0] = rec.x; rmeta[4 * h + 1] = rec.y; rmeta[4 * h + 2] = rec.z;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        atomicExch(&rmeta[4 * h + 3], (1u << 6) | nm1);
+        return true;
+      }
+      ++spins;             // somebody else is claiming it: look again
+    } else if (e.w == RT_LOCK) {
+      ++spins;
+    } else if ((e.w & 63u) == nm1 && e.x == rec.x && e.y == rec.y && e.z == rec.z) {
+      atomicAdd(&rmeta[4 * h + 3], 1u << 6);
+      return true;
+    } else {
+      h = (h + 1) & (RT - 1);
+      ++probes;
+    }
+  }
+  return false;
+}
+
+template <bool CANON>
+__global__ __launch_bounds__(P3_THREADS) void msp_p3_kernel(int k, MspView v, TableView t, int dbg) {
   __shared__ unsigned long long keys[TS];
   __shared__ uint32_t cnts[TS];
+  __shared__ uint4 rtab[RT];
+  __shared__ uint32_t wg_total;
+  __shared__ unsigned long long wg_base;
   const int tid = threadIdx.x, lane = tid & 63;
   const uint32_t leaf = blockIdx.x;
-  const uint64_t n = min((uint64_t)v.cnt2[leaf], v.cap2);
-  if (n == 0) return;
+  const uint64_t n0 = min((uint64_t)v.cnt2[2 * leaf], v.cap2);        // truncated runs
+  const uint64_t n1 = min((uint64_t)v.cnt2[2 * leaf + 1], v.cap2);    // complete runs
+  if (n0 + n1 == 0) return;
   for (int s = tid; s < TS; s += P3_THREADS) { keys[s] = CFRK_EMPTY_KEY; cnts[s] = 0; }
+  for (int s = tid; s < RT; s += P3_THREADS) rtab[s] = make_uint4(0u, 0u, 0u, 0u);
+  if (tid == 0) wg_total = 0;
   __syncthreads();
 
   const uint64_t kmask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1ull);
   const int rcsh = 2 * k - 2;
-  const uint4 *src = v.rec2 + (uint64_t)leaf * v.cap2;
-  for (uint64_t r = tid; r < n; r += P3_THREADS) {
-    const uint4 rec = src[r];
-    const int nk = (int)(rec.w & 63u) + 1;
-    const uint64_t hi = ((uint64_t)rec.x << 32) | rec.y;
-    const uint64_t lo = (uint64_t)rec.z << 32;
-    // rolling forward / reverse-complement k-mers; T feeds base k+j from its top 2 bits
-    uint64_t fwd = hi >> (64 - 2 * k);
-    uint64_t rc = CANON ? dev_revcomp64(fwd, k) : 0;
-    uint64_t T = (k == 32) ? lo : ((hi << (2 * k)) | (lo >> (64 - 2 * k)));
-    for (int j = 0; j < nk; j += 2) {
-      // two k-mers per trip so that two LDS reads are in flight before either is consumed
-      uint64_t key0 = (CANON && rc < fwd) ? rc : fwd;
-      uint32_t nb = (uint32_t)(T >> 62);
-      T <<= 2;
-      fwd = ((fwd << 2) | nb) & kmask;
-      if (CANON) rc = (rc >> 2) | ((uint64_t)(3u - nb) << rcsh);
-      const bool two = j + 1 < nk;
-      uint64_t key1 = (CANON && rc < fwd) ? rc : fwd;
-      nb = (uint32_t)(T >> 62);
-      T <<= 2;
-      fwd = ((fwd << 2) | nb) & kmask;
-      if (CANON) rc = (rc >> 2) | ((uint64_t)(3u - nb) << rcsh);
 
-      const uint32_t h0 = lds_slot(key0), h1 = lds_slot(key1);
-      const unsigned long long c0 = keys[h0];
-      const unsigned long long c1 = keys[h1];
-      if (key0 == CFRK_EMPTY_KEY) {   // k = 32, all T, forward strand
-        atomicAdd((unsigned long long *)&t.stats[ST_ONES], 1ull);
-      } else if (!lds_count(keys, cnts, key0, h0, c0)) {
-        t.stats[ST_SPILLED] = 1;
-        atomicAdd((unsigned long long *)&t.stats[ST_AUX1], 1ull);
-        table_add1(t, key0, 1u);
-      }
-      if (two) {
-        if (key1 == CFRK_EMPTY_KEY) {
-          atomicAdd((unsigned long long *)&t.stats[ST_ONES], 1ull);
-        } else if (!lds_count(keys, cnts, key1, h1, (key1 == key0) ? keys[h1] : c1)) {
-          t.stats[ST_SPILLED] = 1;
-          atomicAdd((unsigned long long *)&t.stats[ST_AUX1], 1ull);
-          table_add1(t, key1, 1u);
-        }
-      }
+  // ---- phase 1a: complete runs, one record-table update per record (every lane busy);
+  //      a record that finds no room is expanded on the spot
+  if (!(dbg & 1)) {
+    const uint4 *src = v.rec2 + (uint64_t)(2 * leaf + 1) * v.cap2;
+    for (uint64_t r = tid; r < n1; r += P3_THREADS) {
+      const uint4 rec = src[r];
+      if (!rtab_insert(rtab, rec)) count_record<CANON>(keys, cnts, rec, 1u, k, kmask, rcsh, t);
     }
+  }
+  // ---- phase 1b: truncated runs, k-mer by k-mer
+  if (!(dbg & 2)) {
+    const uint4 *src = v.rec2 + (uint64_t)(2 * leaf) * v.cap2;
+    for (uint64_t r = tid; r < n0; r += P3_THREADS)
+      count_record<CANON>(keys, cnts, src[r], 1u, k, kmask, rcsh, t);
   }
   __syncthreads();
 
-  // compact occupied slots to the output list
-  for (int s0 = 0; s0 < TS; s0 += P3_THREADS) {
-    const int s = s0 + tid;
+  // ---- phase 2: expand every distinct complete record once, weighted by its multiplicity
+  if (!(dbg & 4))
+  for (int s = tid; s < RT; s += P3_THREADS) {
+    const uint4 e = rtab[s];
+    if (e.w != 0u) count_record<CANON>(keys, cnts, e, e.w >> 6, k, kmask, rcsh, t);
+  }
+  __syncthreads();
+
+  // ---- compact occupied slots to the output list: ONE cursor atomic per workgroup (a global
+  //      atomic per wave on the single cursor word serialises the whole grid)
+  if (dbg & 8) return;
+  constexpr int NIT = TS / P3_THREADS;
+  uint32_t wbase[NIT];
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const unsigned long long m = __ballot(keys[i * P3_THREADS + tid] != CFRK_EMPTY_KEY);
+    uint32_t b = 0;
+    if (lane == 0 && m) b = atomicAdd(&wg_total, (uint32_t)__popcll(m));
+    wbase[i] = __shfl(b, 0);
+  }
+  __syncthreads();
+  if (tid == 0) wg_base = atomicAdd((unsigned long long *)&v.stats[ST_CURSOR], (unsigned long long)wg_total);
+  __syncthreads();
+  const unsigned long long gb = wg_base;
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int s = i * P3_THREADS + tid;
     const unsigned long long key = keys[s];
     const bool occ = key != CFRK_EMPTY_KEY;
     const unsigned long long m = __ballot(occ);
-    if (m == 0) continue;
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd((unsigned long long *)&v.stats[ST_CURSOR], (unsigned long long)__popcll(m));
-    base = __shfl(base, 0);
     if (occ) {
-      const unsigned long long dst = base + __popcll(m & ((1ull << lane) - 1ull));
+      const unsigned long long dst = gb + wbase[i] + __popcll(m & ((1ull << lane) - 1ull));
       if (dst < v.out_cap) { v.out_keys[dst] = key; v.out_cnt[dst] = cnts[s]; }
       else v.stats[ST_OVERFLOW] = 1;
     }
@@ -434,7 +535,7 @@ __global__ void msp_info_kernel(MspView v, uint64_t *out) {
     atomicAdd(&tot1, (unsigned long long)v.cnt1[i]);
     atomicMax(&max1, (unsigned long long)v.cnt1[i]);
   }
-  for (int i = threadIdx.x; i < NLEAF; i += blockDim.x) {
+  for (int i = threadIdx.x; i < 2 * NLEAF; i += blockDim.x) {
     atomicAdd(&tot2, (unsigned long long)v.cnt2[i]);
     atomicMax(&max2, (unsigned long long)v.cnt2[i]);
   }
@@ -502,7 +603,7 @@ int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   const double dens = 2.0 / (W + 1) + 1.0 / 32.0;
   const double expect = (double)nN * dens;
   const uint64_t cap1 = (uint64_t)(expect / B1 * 1.3) + 4096;
-  const uint64_t cap2 = (uint64_t)(expect / NLEAF * 2.0) + 96;
+  const uint64_t cap2 = (uint64_t)(expect / NLEAF * 1.2) + 96;   // per stream (2 per leaf)
   const int64_t tiles_per_bin = (int64_t)((cap1 + P2_TILE - 1) / P2_TILE);
   if (tiles_per_bin * B1 > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
 
@@ -510,9 +611,9 @@ int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   MspView &v = ms->view;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_L1, (size_t)B1 * cap1 * sizeof(uint4), &p))) return rc;
   v.rec1 = (uint4 *)p; v.cap1 = cap1;
-  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)NLEAF * cap2 * sizeof(uint4), &p))) return rc;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)2 * NLEAF * cap2 * sizeof(uint4), &p))) return rc;
   v.rec2 = (uint4 *)p; v.cap2 = cap2;
-  if ((rc = cfrk_pool_get(ctx, BUF_MSP_AUX, (size_t)(B1 + NLEAF) * sizeof(uint32_t), &p))) return rc;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_AUX, (size_t)(B1 + 2 * NLEAF) * sizeof(uint32_t), &p))) return rc;
   v.cnt1 = (uint32_t *)p; v.cnt2 = v.cnt1 + B1;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTK, (size_t)ctx->g_cap * 8, &p))) return rc;
   v.out_keys = (uint64_t *)p;
@@ -521,7 +622,7 @@ int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   v.stats = ctx->g_stats;
   TableView t = cfrk_table_view(ctx);
 
-  HIP_TRY(ctx, hipMemsetAsync(v.cnt1, 0, (size_t)(B1 + NLEAF) * sizeof(uint32_t), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(v.cnt1, 0, (size_t)(B1 + 2 * NLEAF) * sizeof(uint32_t), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_CURSOR, 0, sizeof(uint64_t), ctx->stream));
 
   const int64_t ntiles = (nN + P1_TILE - 1) / P1_TILE;
@@ -537,8 +638,10 @@ int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   hipLaunchKernelGGL(msp_p2_kernel, dim3((unsigned)(tiles_per_bin * B1)), dim3(P2_THREADS), 0, ctx->stream,
                      (int)tiles_per_bin, k, canon, v, t);
   HIP_TRY(ctx, hipGetLastError());
-  if (canon) hipLaunchKernelGGL((msp_p3_kernel<true>), dim3(NLEAF), dim3(P3_THREADS), 0, ctx->stream, k, v, t);
-  else hipLaunchKernelGGL((msp_p3_kernel<false>), dim3(NLEAF), dim3(P3_THREADS), 0, ctx->stream, k, v, t);
+  const char *dbg_env = getenv("CFRK_DEBUG_P3");     // timing ablations only (results are wrong)
+  const int dbg = dbg_env ? atoi(dbg_env) : 0;
+  if (canon) hipLaunchKernelGGL((msp_p3_kernel<true>), dim3(NLEAF), dim3(P3_THREADS), 0, ctx->stream, k, v, t, dbg);
+  else hipLaunchKernelGGL((msp_p3_kernel<false>), dim3(NLEAF), dim3(P3_THREADS), 0, ctx->stream, k, v, t, dbg);
   HIP_TRY(ctx, hipGetLastError());
   ms->pending = true;
   ms->list_n_valid = false;
