@@ -40,8 +40,7 @@ constexpr int B1 = 1 << B1_LOG, B2 = 1 << B2_LOG;
 constexpr int NLEAF = B1 * B2;
 
 constexpr int P1_THREADS = 512;
-constexpr int P1_TILE = P1_THREADS * 32;   // bytes of input per workgroup tile
-constexpr int P1_RCAP = 3072;              // records staged in LDS per tile (expected ~2250)
+constexpr int P1_RCAP = 2816;              // records staged in LDS per workgroup (expected ~1800 at W=18)
 
 constexpr int P2_THREADS = 512, P2_PER = 8, P2_TILE = P2_THREADS * P2_PER;
 
@@ -138,11 +137,19 @@ __device__ __forceinline__ void block_scan(const uint32_t *cnt, uint32_t *off, u
 }
 
 // ---------------------------------------------------------------------------------------- P1
+// Wave layout: 64 lanes load 64 consecutive 32-byte chunks; lane 0 and lanes 62, 63 are halo
+// lanes (they compute, never emit), lanes 1..61 own their chunk's 32 window starts.  A run is
+// emitted by the lane that owns its FIRST k-mer and may extend up to W-1 positions into the next
+// lane's chunk, so run boundaries depend on the sequence only -- not on where a read happens to
+// sit in the buffer -- and every read covering a locus emits the same record.
+constexpr int P1_OWN = 61;                       // owner lanes per wave
+constexpr int P1_WAVES = P1_THREADS / 64;
+
 template <int W>
 __global__ __launch_bounds__(P1_THREADS) void msp_p1_kernel(const int8_t *__restrict__ data,
                                                             int64_t nN, int k, int m, int canon,
                                                             MspView v, TableView t) {
-  constexpr int NH = 32 + W - 1;                 // m-mer hashes a lane needs
+  constexpr int NH = 32 + W - 1;                 // positions a lane looks at: its own 32 + W-1 ahead
   constexpr int P = (W >= 16) ? 16 : (W >= 8) ? 8 : 4;
   __shared__ uint4 rec_tmp[P1_RCAP];
   __shared__ uint16_t perm[P1_RCAP];
@@ -152,94 +159,107 @@ __global__ __launch_bounds__(P1_THREADS) void msp_p1_kernel(const int8_t *__rest
   __shared__ uint32_t nrec_s;
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int nkmax = min(48 - k + 1, 32);
-  const int64_t tile = blockIdx.x;
+  const int nkmax = min(48 - k + 1, 32);         // >= W for every (k, W) class
 
   if (tid < B1) { hist[tid] = 0; fill[tid] = 0; }
   if (tid == 0) nrec_s = 0;
   __syncthreads();
 
-  // ---- A: load 32 own bases + 32 look-ahead bases, packed 2 bits each ----
-  const int64_t off = tile * P1_TILE + (int64_t)tid * 32;
-  uint32_t b0, b1, bad;
-  dev_load_chunk32(data, off, nN, b0, b1, bad);
-  uint32_t n0 = __shfl_down(b0, 1), n1 = __shfl_down(b1, 1), nbad = __shfl_down(bad, 1);
-  if (lane == 63) dev_load_chunk32(data, off + 32, nN, n0, n1, nbad);
-  const uint64_t hi = ((uint64_t)b0 << 32) | b1;
-  const uint64_t lo = ((uint64_t)n0 << 32) | n1;
-  const uint64_t M = ((uint64_t)bad << 32) | nbad;
+  // ---- A: this lane's chunk, packed 2 bits per base; neighbours' chunks by shuffle ----
+  const int64_t wave_g = (int64_t)blockIdx.x * P1_WAVES + (tid >> 6);
+  const int64_t chunk = wave_g * P1_OWN + lane - 1;          // lane 0 of wave 0: chunk -1
+  const int64_t off = chunk * 32;
+  uint32_t b0 = 0, b1 = 0, bad = 0xFFFFFFFFu;
+  if (chunk >= 0) dev_load_chunk32(data, off, nN, b0, b1, bad);
+  const uint32_t n0 = __shfl_down(b0, 1), n1 = __shfl_down(b1, 1), nn0 = __shfl_down(b0, 2);
+  const uint32_t nbad = __shfl_down(bad, 1), nnbad = __shfl_down(bad, 2);
+  const uint64_t hi = ((uint64_t)b0 << 32) | b1;              // bases 0..31
+  const uint64_t mid = ((uint64_t)n0 << 32) | n1;             // bases 32..63
+  const uint64_t lo = (uint64_t)nn0 << 32;                    // bases 64..79
 
-  // V bit(31-i): the k-mer starting at own position i has k valid bases
-  uint64_t Y = M;
-  Y |= Y << 1; Y |= Y << 2; Y |= Y << 4; Y |= Y << 8;   // OR over the 16 following bases
-  Y |= Y << (k - 16);                                    // ... over k (16 <= k <= 32)
-  const uint32_t V = ~(uint32_t)(Y >> 32);
+  // Vx bit(63-p): the k-mer starting at position p (0..63 relative to this chunk) has k valid
+  // bases; only p <= 31 + W - 1 is used
+  uint64_t Yh = ((uint64_t)bad << 32) | nbad, Yl = (uint64_t)nnbad << 32;
+#pragma unroll
+  for (int sft = 1; sft <= 8; sft <<= 1) {                    // OR over the 16 following bases
+    Yh |= (Yh << sft) | (Yl >> (64 - sft));
+    Yl |= Yl << sft;
+  }
+  if (k > 16) { Yh |= (Yh << (k - 16)) | (Yl >> (64 - (k - 16))); }
+  const uint64_t Vx = ~Yh;
+  const uint32_t V = (uint32_t)(Vx >> 32);
+  const uint32_t prevV = __shfl_up(V, 1) & 1u;                // validity of position -1
 
-  uint32_t S = 0, E = 0;
-  uint32_t H[NH];   // m-mer hashes; after the sliding minimum H[0..31] are the k-mers' minimizers
-  if (V == 0) {
+  // canonical m-mer hashes of the own 32 positions, rolled one base at a time; the low 7 bits
+  // carry the absolute position (mod 128) so that equal packed values mean the SAME m-mer
+  // occurrence: a run then never exceeds W k-mers
+  uint32_t H[NH];
+  {
+    const uint64_t Shi = (hi << (2 * m)) | (mid >> (64 - 2 * m));   // bases m.. of the string
+    uint32_t fm = (uint32_t)(hi >> (64 - 2 * m));
+    uint32_t rm = (uint32_t)dev_revcomp64((uint64_t)fm, m);
+    const uint32_t mmask = (m == 16) ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1u);
+    const int rsh = 2 * m - 2;
+    const uint32_t pos0 = ((uint32_t)chunk & 3u) << 5;
 #pragma unroll
-    for (int j = 0; j < NH; ++j) H[j] = 0;
-  } else {
-    // canonical m-mer hashes H[j], j = 0..NH-1, rolled one base at a time
-    {
-      const uint64_t Shi = (hi << (2 * m)) | (lo >> (64 - 2 * m));
-      const uint64_t Slo = lo << (2 * m);
-      uint32_t fm = (uint32_t)(hi >> (64 - 2 * m));
-      uint32_t rm = (uint32_t)dev_revcomp64((uint64_t)fm, m);
-      const uint32_t mmask = (m == 16) ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1u);
-      const int rsh = 2 * m - 2;
-#pragma unroll
-      for (int j = 0; j < NH; ++j) {
-        H[j] = hash_mmer(min(fm, rm));
-        if (j + 1 < NH) {
-          const uint32_t nb = (j < 32) ? ((uint32_t)(Shi >> (62 - 2 * j)) & 3u)
-                                       : ((uint32_t)(Slo >> (62 - 2 * (j - 32))) & 3u);
-          fm = ((fm << 2) | nb) & mmask;
-          rm = (rm >> 2) | ((3u - nb) << rsh);
-        }
+    for (int j = 0; j < 32; ++j) {
+      H[j] = (hash_mmer(min(fm, rm)) & ~127u) | (pos0 + j);
+      if (j + 1 < 32) {
+        const uint32_t nb = (uint32_t)(Shi >> (62 - 2 * j)) & 3u;
+        fm = ((fm << 2) | nb) & mmask;
+        rm = (rm >> 2) | ((3u - nb) << rsh);
       }
     }
-    // sliding-window minimum over W by doubling: H[j] <- min H[j .. j+P), then one combine
-#pragma unroll
-    for (int s = 1; s < P; s <<= 1) {
-#pragma unroll
-      for (int j = 0; j + s < NH; ++j) H[j] = min(H[j], H[j + s]);
-    }
-    if (W > P) {
-#pragma unroll
-      for (int i = 0; i < 32; ++i) H[i] = min(H[i], H[i + W - P]);
-    }
-
-    uint32_t C = 0x80000000u;
-#pragma unroll
-    for (int i = 1; i < 32; ++i) C |= (H[i] != H[i - 1]) ? (0x80000000u >> i) : 0u;
-    S = V & (C | ~(V >> 1));   // run starts: valid and (first | previous invalid | minimizer changed)
-    E = S | ~V;                // positions that end the run before them
   }
+#pragma unroll
+  for (int j = 0; j < W - 1; ++j) H[32 + j] = __shfl_down(H[j], 1);   // next lane's first W-1 hashes
+  // sliding-window minimum over W by doubling: H[j] <- min H[j .. j+P), then one combine
+#pragma unroll
+  for (int s = 1; s < P; s <<= 1) {
+#pragma unroll
+    for (int j = 0; j + s < NH; ++j) H[j] = min(H[j], H[j + s]);
+  }
+  if (W > P) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) H[i] = min(H[i], H[i + W - P]);
+  }
+  // H[0..31] = minimizers of the own k-mers; fetch the next lane's first W-1 and the previous
+  // lane's last one
+  const uint32_t prevW = __shfl_up(H[31], 1);
+#pragma unroll
+  for (int j = 0; j < W - 1; ++j) H[32 + j] = __shfl_down(H[j], 1);
+
+  // Cx bit(63-p): minimizer occurrence changes between positions p-1 and p (p = 0..NH-1)
+  uint64_t Cx = (H[0] != prevW) ? (1ull << 63) : 0ull;
+#pragma unroll
+  for (int p = 1; p < NH; ++p) Cx |= (H[p] != H[p - 1]) ? (1ull << (63 - p)) : 0ull;
+  // terminators: change, invalid, or the end of what this lane can see (never reached: runs <= W)
+  const uint64_t E = Cx | ~Vx | (1ull << (63 - NH));
+  const uint32_t Vprev = (V >> 1) | (prevV << 31);
+  uint32_t S = V & ((uint32_t)(Cx >> 32) | ~Vprev);             // run starts among own positions
+  const bool owner = lane >= 1 && lane <= P1_OWN && off < nN;
+  if (!owner) S = 0;
 
   // ---- B: one 16-byte record per run, staged in LDS ----
   while (S) {
     const int a = __clz(S);
     S &= ~(0x80000000u >> a);
-    const uint32_t rest = (a == 31) ? 0u : (E << (a + 1));
-    int n = rest ? (__clz(rest) + 1) : (32 - a);
-    // "complete": both ends of the run are minimizer changes between valid k-mers (not a lane
-    // edge, a read end or the record-size cap), so every read covering this locus emits the
-    // same record
-    uint32_t complete = 0;
-    if (a >= 1 && rest != 0u && n <= nkmax)
-      complete = ((V >> (32 - a)) & (V >> (31 - (a + n))) & 1u) << 6;
-    if (n > nkmax) { n = nkmax; S |= 0x80000000u >> (a + nkmax); }
-    const uint32_t leaf = leaf_of(pick32(H, a));
+    const uint64_t rest = E << (a + 1);
+    int n = __clzll(rest) + 1;
+    if (n > nkmax) n = nkmax;                                   // cannot happen (W <= nkmax)
+    // "complete": both ends are minimizer changes between valid k-mers, so every read covering
+    // this locus emits the same record
+    const uint32_t pv = a ? ((V >> (32 - a)) & 1u) : prevV;
+    const uint32_t complete = (pv & (uint32_t)(Vx >> (63 - (a + n))) & 1u) << 6;
+    const uint32_t leaf = leaf_of(pick32(H, a) & ~127u);
     const uint32_t bin1 = leaf >> B2_LOG;
     uint4 rec;
-    const uint64_t r01 = a ? ((hi << (2 * a)) | (lo >> (64 - 2 * a))) : hi;
+    const uint64_t r01 = a ? ((hi << (2 * a)) | (mid >> (64 - 2 * a))) : hi;
+    const uint64_t r23 = a ? ((mid << (2 * a)) | (lo >> (64 - 2 * a))) : mid;
     rec.x = (uint32_t)(r01 >> 32);
-    // bases after the run's last k-mer are cleared: equal runs -> byte-identical records (P3
-    // counts identical records once)
+    // bases after the run's last k-mer are cleared: equal runs -> byte-identical records
     const int z = 2 * (48 - (n + k - 1));
-    uint64_t r12 = ((uint64_t)(uint32_t)r01 << 32) | (uint32_t)((lo << (2 * a)) >> 32);
+    uint64_t r12 = ((uint64_t)(uint32_t)r01 << 32) | (uint32_t)(r23 >> 32);
     r12 = (z >= 64) ? 0ull : ((r12 >> z) << z);
     rec.y = (uint32_t)(r12 >> 32);
     rec.z = (uint32_t)r12;
@@ -585,7 +605,8 @@ void cfrk_msp_destroy(cfrk_ctx *ctx) {
 static void msp_params(int k, int *W, int *m) {
   // m = k - W + 1 stays in 11..16 (32-bit m-mers) and >= 13 wherever k allows: with too few
   // distinct minimizers the leaves get lumpy (several genome loci share one minimizer value)
-  if (k >= 30) *W = 18; else if (k >= 26) *W = 14; else if (k >= 22) *W = 10; else *W = 6;
+  // W never exceeds what a 48-base record holds (48 - k + 1 k-mers): k = 32 -> W = 17
+  if (k == 32) *W = 17; else if (k >= 30) *W = 18; else if (k >= 26) *W = 14; else if (k >= 22) *W = 10; else *W = 6;
   *m = k - *W + 1;
 }
 
@@ -599,8 +620,8 @@ int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   msp_params(k, &W, &m);
   const int canon = (ctx->g_flags & CFRK_CANONICAL) ? 1 : 0;
 
-  // expected records: one per minimizer change (2/(W+1) per position) + one per 32-position lane
-  const double dens = 2.0 / (W + 1) + 1.0 / 32.0;
+  // expected records: one per minimizer change (2/(W+1) per position) plus read ends
+  const double dens = 2.0 / (W + 1) + 1.0 / 64.0;
   const double expect = (double)nN * dens;
   const uint64_t cap1 = (uint64_t)(expect / B1 * 1.3) + 4096;
   const uint64_t cap2 = (uint64_t)(expect / NLEAF * 1.2) + 96;   // per stream (2 per leaf)
@@ -625,11 +646,14 @@ int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   HIP_TRY(ctx, hipMemsetAsync(v.cnt1, 0, (size_t)(B1 + 2 * NLEAF) * sizeof(uint32_t), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_CURSOR, 0, sizeof(uint64_t), ctx->stream));
 
-  const int64_t ntiles = (nN + P1_TILE - 1) / P1_TILE;
+  const int64_t nchunks = (nN + 31) / 32;
+  const int64_t nwaves = (nchunks + P1_OWN - 1) / P1_OWN;
+  const int64_t ntiles = (nwaves + P1_WAVES - 1) / P1_WAVES;
   if (ntiles > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
   const dim3 g1((unsigned)ntiles), b1(P1_THREADS);
   switch (W) {
     case 18: hipLaunchKernelGGL((msp_p1_kernel<18>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, v, t); break;
+    case 17: hipLaunchKernelGGL((msp_p1_kernel<17>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, v, t); break;
     case 14: hipLaunchKernelGGL((msp_p1_kernel<14>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, v, t); break;
     case 10: hipLaunchKernelGGL((msp_p1_kernel<10>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, v, t); break;
     default: hipLaunchKernelGGL((msp_p1_kernel<6>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, v, t); break;
