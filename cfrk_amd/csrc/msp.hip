@@ -50,7 +50,7 @@ constexpr int P3_PROBE_LIMIT = 96;
 
 struct MspView {
   uint4 *rec1; uint32_t *cnt1; uint64_t cap1;
-  uint4 *rec2; uint32_t *cnt2; uint64_t cap2;
+  uint4 *rec2; uint32_t *cnt2; uint64_t cap2c, cap2t;   // per leaf: complete stream, then truncated stream
   uint64_t *out_keys; uint32_t *out_cnt; uint64_t out_cap;
   uint64_t *stats;
 };
@@ -360,8 +360,10 @@ __global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int tiles_per_bin, i
     const uint4 rec = sorted[p];
     const uint32_t sb = sub_of(rec.w);
     const uint32_t dst = gbase[sb] + (p - loff[sb]);
-    const uint64_t stream = (uint64_t)b1 * NSUB + sb;
-    if (dst < v.cap2) v.rec2[stream * v.cap2 + dst] = rec;
+    const uint64_t leaf = ((uint64_t)b1 * NSUB + sb) >> 1;
+    const uint64_t cap = (sb & 1u) ? v.cap2c : v.cap2t;
+    const uint64_t at = leaf * (v.cap2c + v.cap2t) + ((sb & 1u) ? 0 : v.cap2c);
+    if (dst < cap) v.rec2[at + dst] = rec;
     else spill_record(rec, k, canon != 0, t);
   }
 }
@@ -387,17 +389,22 @@ __device__ __forceinline__ uint32_t lds_slot(uint64_t key) {
   return (((uint32_t)key ^ (uint32_t)(key >> 32)) * 0x9E3779B1u) >> (32 - TS_LOG);
 }
 
+// rare paths, kept out of line so that the hot loops stay small in the instruction cache
+__device__ __noinline__ void spill_kmer(const TableView &t, uint64_t key, uint32_t add) {
+  if (key == CFRK_EMPTY_KEY) {   // k = 32, all T, forward strand
+    atomicAdd((unsigned long long *)&t.stats[ST_ONES], (unsigned long long)add);
+    return;
+  }
+  t.stats[ST_SPILLED] = 1;
+  atomicAdd((unsigned long long *)&t.stats[ST_AUX1], (unsigned long long)add);
+  table_add1(t, key, add);
+}
+
 template <bool CANON>
 __device__ __forceinline__ void count_kmer(unsigned long long *keys, uint32_t *cnts, uint64_t key,
                                            uint32_t h, unsigned long long cur, uint32_t add,
                                            const TableView &t) {
-  if (key == CFRK_EMPTY_KEY) {   // k = 32, all T, forward strand
-    atomicAdd((unsigned long long *)&t.stats[ST_ONES], (unsigned long long)add);
-  } else if (!lds_count(keys, cnts, key, h, cur, add)) {
-    t.stats[ST_SPILLED] = 1;
-    atomicAdd((unsigned long long *)&t.stats[ST_AUX1], (unsigned long long)add);
-    table_add1(t, key, add);
-  }
+  if (key == CFRK_EMPTY_KEY || !lds_count(keys, cnts, key, h, cur, add)) spill_kmer(t, key, add);
 }
 
 // expand one record into its k-mers (rolling), each counted `add` times
@@ -432,6 +439,13 @@ __device__ __forceinline__ void count_record(unsigned long long *keys, uint32_t 
   }
 }
 
+template <bool CANON>
+__device__ __noinline__ void count_record_slow(unsigned long long *keys, uint32_t *cnts, uint4 rec,
+                                               uint32_t add, int k, const TableView &t) {
+  const uint64_t kmask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1ull);
+  count_record<CANON>(keys, cnts, rec, add, k, kmask, 2 * k - 2, t);
+}
+
 // Record table: at high coverage most complete super-k-mer records of a leaf are byte-identical
 // (the same genome locus seen by many reads).  Entries are {R0,R1,R2,meta},
 // meta = count << 6 | (n-1); meta == 0 empty, RT_LOCK while the claiming lane writes the bases.
@@ -439,16 +453,19 @@ constexpr int RT_LOG = 10, RT = 1 << RT_LOG;
 constexpr uint32_t RT_LOCK = 0xFFFFFFFFu;
 constexpr int RT_PROBES = 8;
 
-// true when the record was counted in the record table
-__device__ __forceinline__ bool rtab_insert(uint4 *rtab, uint4 rec) {
+__device__ __forceinline__ uint32_t rtab_slot(uint4 rec) {
+  uint32_t h = (rec.x * 0x9E3779B1u) ^ (rec.y * 0x85EBCA77u) ^ (rec.z * 0xC2B2AE3Du) ^ ((rec.w & 63u) * 0x27D4EB2Fu);
+  h = (h ^ (h >> 15)) * 0x2C1B3C6Du;
+  return h >> (32 - RT_LOG);
+}
+
+// true when the record was counted in the record table; e = rtab[h] as read by the caller
+// (several reads can then be in flight before the first is used; a stale e only costs a retry)
+__device__ __forceinline__ bool rtab_insert(uint4 *rtab, uint4 rec, uint32_t h, uint4 e, int dbg) {
   uint32_t *rmeta = reinterpret_cast<uint32_t *>(rtab);
   const uint32_t nm1 = rec.w & 63u;
-  uint32_t h = (rec.x * 0x9E3779B1u) ^ (rec.y * 0x85EBCA77u) ^ (rec.z * 0xC2B2AE3Du) ^ (nm1 * 0x27D4EB2Fu);
-  h = (h ^ (h >> 15)) * 0x2C1B3C6Du;
-  h >>= (32 - RT_LOG);
   int probes = 0, spins = 0;
   while (probes < RT_PROBES && spins < 4096) {
-    const uint4 e = rtab[h];
     if (e.w == 0u) {
       const uint32_t old = atomicCAS(&rmeta[4 * h + 3], 0u, RT_LOCK);
       if (old == 0u) {
@@ -461,12 +478,13 @@ __device__ __forceinline__ bool rtab_insert(uint4 *rtab, uint4 rec) {
     } else if (e.w == RT_LOCK) {
       ++spins;
     } else if ((e.w & 63u) == nm1 && e.x == rec.x && e.y == rec.y && e.z == rec.z) {
-      atomicAdd(&rmeta[4 * h + 3], 1u << 6);
+      if (!(dbg & 64)) atomicAdd(&rmeta[4 * h + 3], 1u << 6);
       return true;
     } else {
       h = (h + 1) & (RT - 1);
       ++probes;
     }
+    e = rtab[h];
   }
   return false;
 }
@@ -480,8 +498,9 @@ __global__ __launch_bounds__(P3_THREADS) void msp_p3_kernel(int k, MspView v, Ta
   __shared__ unsigned long long wg_base;
   const int tid = threadIdx.x, lane = tid & 63;
   const uint32_t leaf = blockIdx.x;
-  const uint64_t n0 = min((uint64_t)v.cnt2[2 * leaf], v.cap2);        // truncated runs
-  const uint64_t n1 = min((uint64_t)v.cnt2[2 * leaf + 1], v.cap2);    // complete runs
+  const uint64_t n0 = min((uint64_t)v.cnt2[2 * leaf], v.cap2t);       // truncated runs
+  const uint64_t n1 = min((uint64_t)v.cnt2[2 * leaf + 1], v.cap2c);   // complete runs
+  const uint4 *leaf_rec = v.rec2 + (uint64_t)leaf * (v.cap2c + v.cap2t);
   if (n0 + n1 == 0) return;
   for (int s = tid; s < TS; s += P3_THREADS) { keys[s] = CFRK_EMPTY_KEY; cnts[s] = 0; }
   for (int s = tid; s < RT; s += P3_THREADS) rtab[s] = make_uint4(0u, 0u, 0u, 0u);
@@ -494,25 +513,60 @@ __global__ __launch_bounds__(P3_THREADS) void msp_p3_kernel(int k, MspView v, Ta
   // ---- phase 1a: complete runs, one record-table update per record (every lane busy);
   //      a record that finds no room is expanded on the spot
   if (!(dbg & 1)) {
-    const uint4 *src = v.rec2 + (uint64_t)(2 * leaf + 1) * v.cap2;
-    for (uint64_t r = tid; r < n1; r += P3_THREADS) {
-      const uint4 rec = src[r];
-      if (!rtab_insert(rtab, rec)) count_record<CANON>(keys, cnts, rec, 1u, k, kmask, rcsh, t);
+    // four records per trip: four global loads, then four LDS reads, in flight together
+    const uint4 *src = leaf_rec;
+    constexpr int U = 4;
+    for (uint64_t r = tid; r < n1; r += (uint64_t)U * P3_THREADS) {
+      uint4 rec[U], e[U];
+      uint32_t h[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint64_t ru = r + (uint64_t)u * P3_THREADS;
+        rec[u] = make_uint4(0u, 0u, 0u, 0u);
+        if (ru < n1) rec[u] = src[ru];
+      }
+      if (dbg & 16) {      // timing ablation: loads only
+        uint32_t acc = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += rec[u].x ^ rec[u].y ^ rec[u].z ^ rec[u].w;
+        if (acc == 0x12345678u) cnts[tid] = acc;
+        continue;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) { h[u] = rtab_slot(rec[u]); e[u] = rtab[h[u]]; }
+      if (dbg & 32) {      // timing ablation: loads + table reads, no updates
+        uint32_t acc = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += e[u].x ^ e[u].w ^ h[u];
+        if (acc == 0x12345678u) cnts[tid] = acc;
+        continue;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint64_t ru = r + (uint64_t)u * P3_THREADS;
+        if (ru < n1 && !rtab_insert(rtab, rec[u], h[u], e[u], dbg))
+          count_record_slow<CANON>(keys, cnts, rec[u], 1u, k, t);
+      }
     }
   }
-  // ---- phase 1b: truncated runs, k-mer by k-mer
-  if (!(dbg & 2)) {
-    const uint4 *src = v.rec2 + (uint64_t)(2 * leaf) * v.cap2;
-    for (uint64_t r = tid; r < n0; r += P3_THREADS)
-      count_record<CANON>(keys, cnts, src[r], 1u, k, kmask, rcsh, t);
-  }
   __syncthreads();
-
-  // ---- phase 2: expand every distinct complete record once, weighted by its multiplicity
-  if (!(dbg & 4))
-  for (int s = tid; s < RT; s += P3_THREADS) {
-    const uint4 e = rtab[s];
-    if (e.w != 0u) count_record<CANON>(keys, cnts, e, e.w >> 6, k, kmask, rcsh, t);
+  // ---- phase 2: k-mer by k-mer -- the truncated runs (weight 1) and every distinct complete
+  //      record of the record table (weight = its multiplicity), in ONE loop (one copy of the
+  //      expansion code)
+  if (!(dbg & 2)) {
+    const uint4 *src = leaf_rec + v.cap2c;
+    for (uint64_t i = tid; i < n0 + RT; i += P3_THREADS) {
+      uint4 rec;
+      uint32_t wgt = 1u;
+      if (i < n0) {
+        rec = src[i];
+      } else {
+        rec = rtab[i - n0];
+        wgt = rec.w >> 6;
+        if (rec.w == 0u) continue;
+      }
+      count_record<CANON>(keys, cnts, rec, wgt, k, kmask, rcsh, t);
+    }
   }
   __syncthreads();
 
@@ -561,7 +615,7 @@ __global__ void msp_info_kernel(MspView v, uint64_t *out) {
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    out[0] = tot1; out[1] = max1; out[2] = v.cap1; out[3] = tot2; out[4] = max2; out[5] = v.cap2;
+    out[0] = tot1; out[1] = max1; out[2] = v.cap1; out[3] = tot2; out[4] = max2; out[5] = v.cap2c;
   }
 }
 
@@ -624,7 +678,9 @@ int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   const double dens = 2.0 / (W + 1) + 1.0 / 64.0;
   const double expect = (double)nN * dens;
   const uint64_t cap1 = (uint64_t)(expect / B1 * 1.3) + 4096;
-  const uint64_t cap2 = (uint64_t)(expect / NLEAF * 1.2) + 96;   // per stream (2 per leaf)
+  // per leaf: complete runs dominate at depth; truncated ones are ~2 per read plus invalid bases
+  const uint64_t cap2c = (uint64_t)(expect / NLEAF * 1.8) + 96;
+  const uint64_t cap2t = (uint64_t)(expect / NLEAF * 0.7) + 96;
   const int64_t tiles_per_bin = (int64_t)((cap1 + P2_TILE - 1) / P2_TILE);
   if (tiles_per_bin * B1 > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
 
@@ -632,8 +688,8 @@ int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   MspView &v = ms->view;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_L1, (size_t)B1 * cap1 * sizeof(uint4), &p))) return rc;
   v.rec1 = (uint4 *)p; v.cap1 = cap1;
-  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)2 * NLEAF * cap2 * sizeof(uint4), &p))) return rc;
-  v.rec2 = (uint4 *)p; v.cap2 = cap2;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)NLEAF * (cap2c + cap2t) * sizeof(uint4), &p))) return rc;
+  v.rec2 = (uint4 *)p; v.cap2c = cap2c; v.cap2t = cap2t;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_AUX, (size_t)(B1 + 2 * NLEAF) * sizeof(uint32_t), &p))) return rc;
   v.cnt1 = (uint32_t *)p; v.cnt2 = v.cnt1 + B1;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTK, (size_t)ctx->g_cap * 8, &p))) return rc;
