@@ -46,7 +46,7 @@ constexpr int P2_THREADS = 512, P2_PER = 8, P2_TILE = P2_THREADS * P2_PER;
 
 constexpr int P3_THREADS = 1024;
 constexpr int TS_LOG = 12, TS = 1 << TS_LOG;   // LDS table slots per leaf
-constexpr int P3_PROBE_LIMIT = 96;
+constexpr int P3_PROBE_LIMIT = 48;      // buckets probed before a key is counted in HBM instead
 
 struct MspView {
   uint4 *rec1; uint32_t *cnt1; uint64_t cap1;
@@ -369,27 +369,7 @@ __global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int tiles_per_bin, i
 }
 
 // ---------------------------------------------------------------------------------------- P3
-// one LDS k-mer table update (+add); returns false when the probe window is full (caller spills)
-__device__ __forceinline__ bool lds_count(unsigned long long *keys, uint32_t *cnts, uint64_t key,
-                                          uint32_t h, unsigned long long cur, uint32_t add) {
-  // cur = keys[h] was read by the caller (so two reads can be in flight before either is used)
-  for (int p = 0; p < P3_PROBE_LIMIT; ++p) {
-    if (cur == CFRK_EMPTY_KEY) {
-      cur = atomicCAS(&keys[h], (unsigned long long)CFRK_EMPTY_KEY, (unsigned long long)key);
-      if (cur == CFRK_EMPTY_KEY) cur = key;
-    }
-    if (cur == key) { atomicAdd(&cnts[h], add); return true; }
-    h = (h + 1) & (TS - 1);
-    cur = keys[h];
-  }
-  return false;
-}
-
-__device__ __forceinline__ uint32_t lds_slot(uint64_t key) {
-  return (((uint32_t)key ^ (uint32_t)(key >> 32)) * 0x9E3779B1u) >> (32 - TS_LOG);
-}
-
-// rare paths, kept out of line so that the hot loops stay small in the instruction cache
+// rare path, kept out of line so that the hot loop stays small
 __device__ __noinline__ void spill_kmer(const TableView &t, uint64_t key, uint32_t add) {
   if (key == CFRK_EMPTY_KEY) {   // k = 32, all T, forward strand
     atomicAdd((unsigned long long *)&t.stats[ST_ONES], (unsigned long long)add);
@@ -400,11 +380,51 @@ __device__ __noinline__ void spill_kmer(const TableView &t, uint64_t key, uint32
   table_add1(t, key, add);
 }
 
-template <bool CANON>
-__device__ __forceinline__ void count_kmer(unsigned long long *keys, uint32_t *cnts, uint64_t key,
-                                           uint32_t h, unsigned long long cur, uint32_t add,
-                                           const TableView &t) {
-  if (key == CFRK_EMPTY_KEY || !lds_count(keys, cnts, key, h, cur, add)) spill_kmer(t, key, add);
+// The leaf's k-mer table is TS/2 buckets of two keys (one ds_read_b128 fetches a bucket), linear
+// probing over buckets.  Control flow is kept flat on purpose: this kernel is bound by the CU's
+// scalar unit (exec-mask bookkeeping of divergent branches), not by LDS or VALU.
+constexpr int NBUCKET = TS / 2;
+__device__ __forceinline__ uint32_t lds_bucket(uint64_t key) {
+  return (((uint32_t)key ^ (uint32_t)(key >> 32)) * 0x9E3779B1u) >> (32 - (TS_LOG - 1));
+}
+
+// one probe step for one pending key; q = the bucket as read by the caller (may be stale: a stale
+// view can only show EMPTY where a key now sits, and the CAS settles that)
+__device__ __forceinline__ void lds_step(unsigned long long *keys, uint32_t *cnts, uint64_t key,
+                                         uint32_t &b, ulonglong2 q, bool &pend, int &probes,
+                                         uint32_t add, const TableView &t) {
+  if (pend) {
+    const bool m0 = q.x == key, m1 = q.y == key;
+    const bool e0 = q.x == CFRK_EMPTY_KEY, e1 = q.y == CFRK_EMPTY_KEY;
+    if (m0 | m1) {
+      atomicAdd(&cnts[2 * b + (m0 ? 0u : 1u)], add);
+      pend = false;
+    } else if (e0 | e1) {
+      const uint32_t s = 2 * b + (e0 ? 0u : 1u);
+      const unsigned long long old = atomicCAS(&keys[s], (unsigned long long)CFRK_EMPTY_KEY, (unsigned long long)key);
+      if (old == CFRK_EMPTY_KEY || old == key) { atomicAdd(&cnts[s], add); pend = false; }
+      // else another key took that slot: look at the same bucket again
+    } else {
+      b = (b + 1) & (NBUCKET - 1);
+      if (++probes >= P3_PROBE_LIMIT) { spill_kmer(t, key, add); pend = false; }
+    }
+  }
+}
+
+// count key0 (and key1 when has1) `add` times each; one wave-uniform loop serves both keys
+__device__ __forceinline__ void lds_count_pair(unsigned long long *keys, uint32_t *cnts, uint64_t key0,
+                                               uint64_t key1, bool has1, uint32_t add,
+                                               const TableView &t) {
+  uint32_t b0 = lds_bucket(key0), b1 = lds_bucket(key1);
+  bool p0 = true, p1 = has1;
+  int pr0 = 0, pr1 = 0;
+  const ulonglong2 *buckets = reinterpret_cast<const ulonglong2 *>(keys);
+  do {
+    const ulonglong2 q0 = buckets[b0];
+    const ulonglong2 q1 = buckets[b1];
+    lds_step(keys, cnts, key0, b0, q0, p0, pr0, add, t);
+    lds_step(keys, cnts, key1, b1, q1, p1, pr1, add, t);
+  } while (__ballot(p0 | p1));
 }
 
 // expand one record into its k-mers (rolling), each counted `add` times
@@ -419,7 +439,6 @@ __device__ __forceinline__ void count_record(unsigned long long *keys, uint32_t 
   uint64_t rc = CANON ? dev_revcomp64(fwd, k) : 0;
   uint64_t T = (k == 32) ? lo : ((hi << (2 * k)) | (lo >> (64 - 2 * k)));
   for (int j = 0; j < nk; j += 2) {
-    // two k-mers per trip so that two LDS reads are in flight before either is consumed
     const uint64_t key0 = (CANON && rc < fwd) ? rc : fwd;
     uint32_t nb = (uint32_t)(T >> 62);
     T <<= 2;
@@ -431,11 +450,17 @@ __device__ __forceinline__ void count_record(unsigned long long *keys, uint32_t 
     T <<= 2;
     fwd = ((fwd << 2) | nb) & kmask;
     if (CANON) rc = (rc >> 2) | ((uint64_t)(3u - nb) << rcsh);
-    const uint32_t h0 = lds_slot(key0), h1 = lds_slot(key1);
-    const unsigned long long c0 = keys[h0];
-    const unsigned long long c1 = keys[h1];
-    count_kmer<CANON>(keys, cnts, key0, h0, c0, add, t);
-    if (two) count_kmer<CANON>(keys, cnts, key1, h1, c1, add, t);   // a stale c1 can only read EMPTY: the CAS decides
+    if (!CANON && k == 32 && (key0 == CFRK_EMPTY_KEY || (two && key1 == CFRK_EMPTY_KEY))) {
+      // forward-strand all-T 32-mer collides with the EMPTY marker: side counter
+      if (key0 == CFRK_EMPTY_KEY) spill_kmer(t, key0, add);
+      else lds_count_pair(keys, cnts, key0, key0, false, add, t);
+      if (two) {
+        if (key1 == CFRK_EMPTY_KEY) spill_kmer(t, key1, add);
+        else lds_count_pair(keys, cnts, key1, key1, false, add, t);
+      }
+      continue;
+    }
+    lds_count_pair(keys, cnts, key0, key1, two, add, t);
   }
 }
 
@@ -451,7 +476,7 @@ __device__ __noinline__ void count_record_slow(unsigned long long *keys, uint32_
 // meta = count << 6 | (n-1); meta == 0 empty, RT_LOCK while the claiming lane writes the bases.
 constexpr int RT_LOG = 10, RT = 1 << RT_LOG;
 constexpr uint32_t RT_LOCK = 0xFFFFFFFFu;
-constexpr int RT_PROBES = 8;
+constexpr int RT_PROBES = 24;
 
 __device__ __forceinline__ uint32_t rtab_slot(uint4 rec) {
   uint32_t h = (rec.x * 0x9E3779B1u) ^ (rec.y * 0x85EBCA77u) ^ (rec.z * 0xC2B2AE3Du) ^ ((rec.w & 63u) * 0x27D4EB2Fu);
@@ -459,34 +484,32 @@ __device__ __forceinline__ uint32_t rtab_slot(uint4 rec) {
   return h >> (32 - RT_LOG);
 }
 
-// true when the record was counted in the record table; e = rtab[h] as read by the caller
-// (several reads can then be in flight before the first is used; a stale e only costs a retry)
-__device__ __forceinline__ bool rtab_insert(uint4 *rtab, uint4 rec, uint32_t h, uint4 e, int dbg) {
+// one probe step of a record-table insert, written flat (classification in VALU, three
+// shallow ifs) because exec-mask bookkeeping on the scalar unit is what bounds this kernel.
+// pend: still to be placed; fail: gave up (table region full) -> caller expands the record.
+__device__ __forceinline__ void rtab_step(uint4 *rtab, uint4 rec, uint32_t &h, uint4 e, bool &pend,
+                                          bool &fail, int &probes) {
   uint32_t *rmeta = reinterpret_cast<uint32_t *>(rtab);
   const uint32_t nm1 = rec.w & 63u;
-  int probes = 0, spins = 0;
-  while (probes < RT_PROBES && spins < 4096) {
-    if (e.w == 0u) {
-      const uint32_t old = atomicCAS(&rmeta[4 * h + 3], 0u, RT_LOCK);
-      if (old == 0u) {
-        rmeta[4 * h + 0] = rec.x; rmeta[4 * h + 1] = rec.y; rmeta[4 * h + 2] = rec.z;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        atomicExch(&rmeta[4 * h + 3], (1u << 6) | nm1);
-        return true;
-      }
-      ++spins;             // somebody else is claiming it: look again
-    } else if (e.w == RT_LOCK) {
-      ++spins;
-    } else if ((e.w & 63u) == nm1 && e.x == rec.x && e.y == rec.y && e.z == rec.z) {
-      if (!(dbg & 64)) atomicAdd(&rmeta[4 * h + 3], 1u << 6);
-      return true;
-    } else {
-      h = (h + 1) & (RT - 1);
-      ++probes;
+  const bool empty = e.w == 0u, locked = e.w == RT_LOCK;
+  const bool match = !empty && !locked && (e.w & 63u) == nm1 && e.x == rec.x && e.y == rec.y && e.z == rec.z;
+  if (pend && match) atomicAdd(&rmeta[4 * h + 3], 1u << 6);
+  bool won = false;
+  if (pend && empty) {
+    const uint32_t old = atomicCAS(&rmeta[4 * h + 3], 0u, RT_LOCK);
+    if (old == 0u) {
+      rmeta[4 * h + 0] = rec.x; rmeta[4 * h + 1] = rec.y; rmeta[4 * h + 2] = rec.z;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      atomicExch(&rmeta[4 * h + 3], (1u << 6) | nm1);
+      won = true;
     }
-    e = rtab[h];
   }
-  return false;
+  const bool adv = pend && !match && !empty && !locked;     // someone else's record: next slot
+  h = adv ? ((h + 1) & (RT - 1)) : h;
+  probes += (adv || (pend && locked)) ? 1 : 0;               // a locked slot is re-read, bounded too
+  const bool giveup = probes >= RT_PROBES;
+  fail = fail || (pend && !match && !won && giveup);
+  pend = pend && !match && !won && !giveup;
 }
 
 template <bool CANON>
@@ -513,40 +536,24 @@ __global__ __launch_bounds__(P3_THREADS) void msp_p3_kernel(int k, MspView v, Ta
   // ---- phase 1a: complete runs, one record-table update per record (every lane busy);
   //      a record that finds no room is expanded on the spot
   if (!(dbg & 1)) {
-    // four records per trip: four global loads, then four LDS reads, in flight together
+    // two records per trip, one wave-uniform probe loop for both
     const uint4 *src = leaf_rec;
-    constexpr int U = 4;
-    for (uint64_t r = tid; r < n1; r += (uint64_t)U * P3_THREADS) {
-      uint4 rec[U], e[U];
-      uint32_t h[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const uint64_t ru = r + (uint64_t)u * P3_THREADS;
-        rec[u] = make_uint4(0u, 0u, 0u, 0u);
-        if (ru < n1) rec[u] = src[ru];
-      }
-      if (dbg & 16) {      // timing ablation: loads only
-        uint32_t acc = 0;
-#pragma unroll
-        for (int u = 0; u < U; ++u) acc += rec[u].x ^ rec[u].y ^ rec[u].z ^ rec[u].w;
-        if (acc == 0x12345678u) cnts[tid] = acc;
-        continue;
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) { h[u] = rtab_slot(rec[u]); e[u] = rtab[h[u]]; }
-      if (dbg & 32) {      // timing ablation: loads + table reads, no updates
-        uint32_t acc = 0;
-#pragma unroll
-        for (int u = 0; u < U; ++u) acc += e[u].x ^ e[u].w ^ h[u];
-        if (acc == 0x12345678u) cnts[tid] = acc;
-        continue;
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const uint64_t ru = r + (uint64_t)u * P3_THREADS;
-        if (ru < n1 && !rtab_insert(rtab, rec[u], h[u], e[u], dbg))
-          count_record_slow<CANON>(keys, cnts, rec[u], 1u, k, t);
-      }
+    for (uint64_t r = tid; r < n1; r += 2ull * P3_THREADS) {
+      const uint64_t r1 = r + P3_THREADS;
+      const uint4 rec0 = src[r];
+      uint4 rec1 = make_uint4(0u, 0u, 0u, 0u);
+      bool p0 = true, p1 = r1 < n1, f0 = false, f1 = false;
+      if (p1) rec1 = src[r1];
+      uint32_t h0 = rtab_slot(rec0), h1 = rtab_slot(rec1);
+      int pr0 = 0, pr1 = 0;
+      do {
+        const uint4 e0 = rtab[h0];
+        const uint4 e1 = rtab[h1];
+        rtab_step(rtab, rec0, h0, e0, p0, f0, pr0);
+        rtab_step(rtab, rec1, h1, e1, p1, f1, pr1);
+      } while (__ballot(p0 | p1));
+      if (f0) count_record_slow<CANON>(keys, cnts, rec0, 1u, k, t);
+      if (f1) count_record_slow<CANON>(keys, cnts, rec1, 1u, k, t);
     }
   }
   __syncthreads();
