@@ -31,6 +31,10 @@ def parse():
     p.add_argument("--cpu-reads", type=int, default=2_000_000,
                    help="reads of the same generator timed on the host cores (0: skip)")
     p.add_argument("--cpu-threads", type=int, default=0)
+    p.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                   help="gloo: rehearsal mode -- collectives staged through host memory, every "
+                        "rank may sit on the same GPU (--same-gpu)")
+    p.add_argument("--same-gpu", action="store_true", help="all ranks use cuda:0 (rehearsal)")
     return p.parse_args()
 
 
@@ -60,9 +64,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.same_gpu:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
+    wire = "cpu" if args.dist_backend == "gloo" else None
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
@@ -96,8 +106,8 @@ def main():
             n = self.g.finish()
             if self.bufs is None or self.bufs[0].numel() < n:
                 cap = int(n * 1.1) + 1024
-                self.bufs = (torch.empty(cap, dtype=torch.uint64, device=dev), None,
-                             torch.empty(cap, dtype=torch.uint32, device=dev))
+                self.bufs = (torch.empty(cap, dtype=torch.int64, device=dev), None,
+                             torch.empty(cap, dtype=torch.int32, device=dev))
             lo, hi, cnt = self.bufs
             pc = self.g.export_device(lo.data_ptr(), 0, cnt.data_ptr(), lo.numel(), parts)
             return lo, hi, cnt, pc
@@ -111,7 +121,7 @@ def main():
         if world == 1:
             ctx.sync()
             return eng.g
-        rlo, rhi, rcnt = sharded.exchange_by_owner(eng, world, dev)
+        rlo, rhi, rcnt = sharded.exchange_by_owner(eng, world, dev, wire)
         og = cfrk_amd.GlobalCounter(owner_ctx, k, flags, hint // world + 1024)
         og.merge_device(rlo.data_ptr(), 0, rcnt.data_ptr(), rlo.numel())
         owner_ctx.sync()
@@ -132,14 +142,14 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if wire else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     info = eng.g.msp_info() if os.environ.get("CFRK_BENCH_INFO") else None
     digest = final.digest()
     if world > 1:
-        digest = sharded.merge_digests(digest, dev)
+        digest = sharded.merge_digests(digest, "cpu" if wire else dev)
 
     kmers_total = R * (L - k + 1)
     D = digest[0]

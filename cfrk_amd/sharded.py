@@ -21,22 +21,27 @@ def shard_range(total, rank, world):
     return (total * rank) // world, (total * (rank + 1)) // world
 
 
-def exchange_by_owner(engine, world, device):
-    """all-to-all of the owner segments; returns (lo, hi, cnt) received by this rank"""
+def exchange_by_owner(engine, world, device, wire_device=None):
+    """all-to-all of the owner segments; returns (lo, hi, cnt) received by this rank.
+
+    Keys travel as int64 bit patterns, counts as int32 (no unsigned collectives needed).
+    wire_device: where the collective runs (default: `device`, i.e. RCCL on GPU tensors);
+    "cpu" stages through host memory so that the same code runs over gloo."""
+    wire = torch.device(wire_device) if wire_device is not None else torch.device(device)
     lo, hi, cnt, part_counts = engine.export_parts(world)
-    send = torch.tensor(part_counts, dtype=torch.int64, device=device)
+    send = torch.tensor(part_counts, dtype=torch.int64, device=wire)
     recv = torch.empty_like(send)
     dist.all_to_all_single(recv, send)
     send_l = [int(x) for x in part_counts]
     recv_l = [int(x) for x in recv.cpu().tolist()]
-    n_recv = sum(recv_l)
+    n_send, n_recv = sum(send_l), sum(recv_l)
 
     def a2a(t):
-        out = torch.empty(n_recv, dtype=t.dtype, device=device)
-        dist.all_to_all_single(out, t[:sum(send_l)].contiguous(), recv_l, send_l)
-        return out
+        src = t[:n_send].contiguous().to(wire)
+        out = torch.empty(n_recv, dtype=t.dtype, device=wire)
+        dist.all_to_all_single(out, src, recv_l, send_l)
+        return out.to(device)
 
-    # torch has no uint64 collectives everywhere: move keys as int64 bit patterns
     rlo = a2a(lo.view(torch.int64))
     rhi = a2a(hi.view(torch.int64)) if hi is not None else None
     rcnt = a2a(cnt.view(torch.int32))
@@ -46,6 +51,7 @@ def exchange_by_owner(engine, world, device):
 def merge_digests(local, device):
     """combine per-rank digests (owners hold disjoint key sets): sums mod 2^64 and xor"""
     world = dist.get_world_size()
+    device = torch.device(device)
     mine = torch.tensor([_to_i64(x) for x in local], dtype=torch.int64, device=device)
     allv = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(allv, mine)
