@@ -37,6 +37,10 @@ namespace {
 
 constexpr int B1_LOG = 8, B2_LOG = 8;
 constexpr int B1 = 1 << B1_LOG, B2 = 1 << B2_LOG;
+// Workgroups b and b+8 land on the same XCD (observed round-robin dispatch; speed only, never
+// correctness).  A leaf stream that is appended to from ONE XCD has its partially written
+// 64-byte sectors merged in that XCD's L2 before they reach HBM.
+constexpr int NXG = 8;
 constexpr int NLEAF = B1 * B2;
 
 constexpr int P1_THREADS = 512;
@@ -49,7 +53,7 @@ constexpr int TS_LOG = 12, TS = 1 << TS_LOG;   // LDS table slots per leaf
 constexpr int P3_PROBE_LIMIT = 48;      // buckets probed before a key is counted in HBM instead
 
 struct MspView {
-  uint4 *rec1; uint32_t *cnt1; uint64_t cap1;
+  uint4 *rec1; uint32_t *cnt1; uint64_t cap1;   // B1 x NXG sub-regions of cap1 records each
   uint4 *rec2; uint32_t *cnt2; uint64_t cap2c, cap2t;   // per leaf: complete stream, then truncated stream
   uint64_t *out_keys; uint32_t *out_cnt; uint64_t out_cap;
   uint64_t *stats;
@@ -277,8 +281,9 @@ __global__ __launch_bounds__(P1_THREADS) void msp_p1_kernel(const int8_t *__rest
       atomicAdd(&hist[bin1], 1u);
     } else {
       // LDS staging full (pathological tile): append directly
-      const uint32_t dst = atomicAdd(&v.cnt1[bin1], 1u);
-      if (dst < v.cap1) v.rec1[(uint64_t)bin1 * v.cap1 + dst] = rec;
+      const uint32_t reg = bin1 * NXG + (blockIdx.x & (NXG - 1));
+      const uint32_t dst = atomicAdd(&v.cnt1[reg], 1u);
+      if (dst < v.cap1) v.rec1[(uint64_t)reg * v.cap1 + dst] = rec;
       else spill_record(rec, k, canon != 0, t);
     }
   }
@@ -287,7 +292,7 @@ __global__ __launch_bounds__(P1_THREADS) void msp_p1_kernel(const int8_t *__rest
   // ---- C: one global reservation per non-empty bin; LDS offsets for a bin-sorted order ----
   if (tid < B1) {
     const uint32_t c = hist[tid];
-    gbase[tid] = c ? atomicAdd(&v.cnt1[tid], c) : 0u;
+    gbase[tid] = c ? atomicAdd(&v.cnt1[tid * NXG + (blockIdx.x & (NXG - 1))], c) : 0u;
   }
   block_scan<B1>(hist, loff, wtot);
   const uint32_t nrec = min(nrec_s, (uint32_t)P1_RCAP);
@@ -303,7 +308,7 @@ __global__ __launch_bounds__(P1_THREADS) void msp_p1_kernel(const int8_t *__rest
     const uint32_t b = bin_tmp[s];
     const uint32_t dst = gbase[b] + (p - loff[b]);
     const uint4 rec = rec_tmp[s];
-    if (dst < v.cap1) v.rec1[(uint64_t)b * v.cap1 + dst] = rec;
+    if (dst < v.cap1) v.rec1[((uint64_t)b * NXG + (blockIdx.x & (NXG - 1))) * v.cap1 + dst] = rec;
     else spill_record(rec, k, canon != 0, t);
   }
 }
@@ -315,21 +320,29 @@ __global__ __launch_bounds__(P1_THREADS) void msp_p1_kernel(const int8_t *__rest
 constexpr int NSUB = 2 * B2;
 __device__ __forceinline__ uint32_t sub_of(uint32_t w) { return (((w >> 8) & (B2 - 1)) << 1) | ((w >> 6) & 1u); }
 
-__global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int tiles_per_bin, int k, int canon,
+// Grid = B1 * NXG * tiles_per_sub workgroups.  blockIdx % 8 picks the XCD group, and each group
+// walks ITS bins (b1 = group, group+8, ...) one after the other, so that at any moment the
+// workgroups of one XCD append to the leaf streams of very few level-1 bins: a leaf stream is only
+// ever written from one XCD and its frontier sectors merge in L2 (P2: 11.6 -> 10.0 ms).
+__global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int tiles_per_sub, int k, int canon,
                                                             MspView v, TableView t) {
   __shared__ uint4 sorted[P2_TILE];
   __shared__ uint32_t hist[NSUB], loff[NSUB], gbase[NSUB], fill[NSUB];
   __shared__ uint32_t wtot[NSUB / 64];
   const int tid = threadIdx.x;
-  const uint32_t b1 = blockIdx.x / (uint32_t)tiles_per_bin;
-  const uint32_t tile = blockIdx.x % (uint32_t)tiles_per_bin;
-  const uint64_t n = min((uint64_t)v.cnt1[b1], v.cap1);
+  const uint32_t xg = blockIdx.x & (NXG - 1), seq = blockIdx.x / NXG;
+  const uint32_t per_bin = (uint32_t)NXG * (uint32_t)tiles_per_sub;
+  const uint32_t b1 = xg + NXG * (seq / per_bin);
+  const uint32_t sub = (seq % per_bin) / (uint32_t)tiles_per_sub;
+  const uint32_t tile = (seq % per_bin) % (uint32_t)tiles_per_sub;
+  const uint32_t reg = b1 * NXG + sub;
+  const uint64_t n = min((uint64_t)v.cnt1[reg], v.cap1);
   const uint64_t r0 = (uint64_t)tile * P2_TILE;
   if (r0 >= n) return;
   const uint32_t nt = (uint32_t)min((uint64_t)P2_TILE, n - r0);
   if (tid < NSUB) { hist[tid] = 0; fill[tid] = 0; }
   __syncthreads();
-  const uint4 *src = v.rec1 + (uint64_t)b1 * v.cap1 + r0;
+  const uint4 *src = v.rec1 + (uint64_t)reg * v.cap1 + r0;
   uint4 r[P2_PER];
 #pragma unroll
   for (int i = 0; i < P2_PER; ++i) {
@@ -612,7 +625,7 @@ __global__ void msp_info_kernel(MspView v, uint64_t *out) {
   __shared__ unsigned long long tot1, max1, tot2, max2;
   if (threadIdx.x == 0) { tot1 = max1 = tot2 = max2 = 0; }
   __syncthreads();
-  for (int i = threadIdx.x; i < B1; i += blockDim.x) {
+  for (int i = threadIdx.x; i < B1 * NXG; i += blockDim.x) {
     atomicAdd(&tot1, (unsigned long long)v.cnt1[i]);
     atomicMax(&max1, (unsigned long long)v.cnt1[i]);
   }
@@ -684,21 +697,21 @@ int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   // expected records: one per minimizer change (2/(W+1) per position) plus read ends
   const double dens = 2.0 / (W + 1) + 1.0 / 64.0;
   const double expect = (double)nN * dens;
-  const uint64_t cap1 = (uint64_t)(expect / B1 * 1.3) + 4096;
+  const uint64_t cap1 = (uint64_t)(expect / (B1 * NXG) * 1.35) + 2048;   // per sub-region
   // per leaf: complete runs dominate at depth; truncated ones are ~2 per read plus invalid bases
   const uint64_t cap2c = (uint64_t)(expect / NLEAF * 1.8) + 96;
   const uint64_t cap2t = (uint64_t)(expect / NLEAF * 0.7) + 96;
-  const int64_t tiles_per_bin = (int64_t)((cap1 + P2_TILE - 1) / P2_TILE);
-  if (tiles_per_bin * B1 > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
+  const int64_t tiles_per_sub = (int64_t)((cap1 + P2_TILE - 1) / P2_TILE);
+  if (tiles_per_sub * B1 * NXG > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
 
   void *p;
   MspView &v = ms->view;
-  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L1, (size_t)B1 * cap1 * sizeof(uint4), &p))) return rc;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L1, (size_t)B1 * NXG * cap1 * sizeof(uint4), &p))) return rc;
   v.rec1 = (uint4 *)p; v.cap1 = cap1;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)NLEAF * (cap2c + cap2t) * sizeof(uint4), &p))) return rc;
   v.rec2 = (uint4 *)p; v.cap2c = cap2c; v.cap2t = cap2t;
-  if ((rc = cfrk_pool_get(ctx, BUF_MSP_AUX, (size_t)(B1 + 2 * NLEAF) * sizeof(uint32_t), &p))) return rc;
-  v.cnt1 = (uint32_t *)p; v.cnt2 = v.cnt1 + B1;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_AUX, (size_t)(B1 * NXG + 2 * NLEAF) * sizeof(uint32_t), &p))) return rc;
+  v.cnt1 = (uint32_t *)p; v.cnt2 = v.cnt1 + B1 * NXG;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTK, (size_t)ctx->g_cap * 8, &p))) return rc;
   v.out_keys = (uint64_t *)p;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTC, (size_t)ctx->g_cap * 4, &p))) return rc;
@@ -706,7 +719,7 @@ int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   v.stats = ctx->g_stats;
   TableView t = cfrk_table_view(ctx);
 
-  HIP_TRY(ctx, hipMemsetAsync(v.cnt1, 0, (size_t)(B1 + 2 * NLEAF) * sizeof(uint32_t), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(v.cnt1, 0, (size_t)(B1 * NXG + 2 * NLEAF) * sizeof(uint32_t), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_CURSOR, 0, sizeof(uint64_t), ctx->stream));
 
   const int64_t nchunks = (nN + 31) / 32;
@@ -722,8 +735,8 @@ int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
     default: hipLaunchKernelGGL((msp_p1_kernel<6>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, v, t); break;
   }
   HIP_TRY(ctx, hipGetLastError());
-  hipLaunchKernelGGL(msp_p2_kernel, dim3((unsigned)(tiles_per_bin * B1)), dim3(P2_THREADS), 0, ctx->stream,
-                     (int)tiles_per_bin, k, canon, v, t);
+  hipLaunchKernelGGL(msp_p2_kernel, dim3((unsigned)(tiles_per_sub * B1 * NXG)), dim3(P2_THREADS), 0, ctx->stream,
+                     (int)tiles_per_sub, k, canon, v, t);
   HIP_TRY(ctx, hipGetLastError());
   const char *dbg_env = getenv("CFRK_DEBUG_P3");     // timing ablations only (results are wrong)
   const int dbg = dbg_env ? atoi(dbg_env) : 0;
