@@ -263,9 +263,14 @@ int cfrk_global_add_device(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   int rc;
-  if (cfrk_msp_usable(ctx)) {
-    rc = cfrk_msp_count(ctx, d_data, nN);
-  } else {
+  rc = CFRK_ERR_NOMEM;
+  if (cfrk_msp_usable(ctx)) rc = cfrk_msp_count(ctx, d_data, nN);
+  if (rc == CFRK_ERR_NOMEM) {
+    // no partitioned path for this k, or its record buffers (about 7 bytes per input byte) do
+    // not fit next to the caller's data: count with the general HBM-table path instead
+    (void)hipGetLastError();
+    rc = cfrk_msp_flush_to_table(ctx);
+    if (rc) return rc;
     cfrk_msp_note_table_write(ctx);
     rc = cfrk_hash_count(ctx, d_data, nN);
   }

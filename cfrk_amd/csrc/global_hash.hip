@@ -160,6 +160,10 @@ __device__ __forceinline__ uint32_t owner_of(uint64_t lo, uint64_t hi, bool two,
   return (uint32_t)((m & 0xFFFFFFFFull) % (uint32_t)parts);
 }
 
+// Owner partition, both passes wave-aggregated: one atomic per (wave, part) instead of one per
+// entry -- 10^8 entries hammering `parts` cursor words would serialise on those few addresses.
+constexpr int MAX_FAST_PARTS = 16;
+
 // pass 1: entries per owner part
 __global__ __launch_bounds__(256) void result_export_count_kernel(ResultSrc r, int parts,
                                                                   unsigned long long *part_n) {
@@ -171,11 +175,14 @@ __global__ __launch_bounds__(256) void result_export_count_kernel(ResultSrc r, i
     const uint64_t i = base + lane;
     uint64_t lo = 0, hi = 0; uint32_t c = 0;
     const bool occ = (i < r.n) && src_read(r, i, lo, hi, c);
-    if (parts == 1) {
-      const unsigned long long m = __ballot(occ);
-      if (lane == 0 && m) atomicAdd(&part_n[0], (unsigned long long)__popcll(m));
+    const uint32_t own = (occ && parts > 1) ? owner_of(lo, hi, two, parts) : 0u;
+    if (parts <= MAX_FAST_PARTS) {
+      for (int p = 0; p < parts; ++p) {
+        const unsigned long long m = __ballot(occ && own == (uint32_t)p);
+        if (lane == 0 && m) atomicAdd(&part_n[p], (unsigned long long)__popcll(m));
+      }
     } else if (occ) {
-      atomicAdd(&part_n[owner_of(lo, hi, two, parts)], 1ull);
+      atomicAdd(&part_n[own], 1ull);
     }
   }
   if (tid == 0 && !two && r.stats[ST_ONES])
@@ -196,15 +203,19 @@ __global__ __launch_bounds__(256) void result_export_scatter_kernel(ResultSrc r,
     const uint64_t i = base + lane;
     uint64_t lo = 0, hi = 0; uint32_t c = 0;
     const bool occ = (i < r.n) && src_read(r, i, lo, hi, c);
-    unsigned long long dst;
-    if (parts == 1) {
-      const unsigned long long m = __ballot(occ);
-      unsigned long long b = 0;
-      if (lane == 0 && m) b = atomicAdd(&part_cursor[0], (unsigned long long)__popcll(m));
-      b = __shfl((unsigned long long)b, 0);
-      dst = b + __popcll(m & ((1ull << lane) - 1));
-    } else {
-      dst = occ ? atomicAdd(&part_cursor[owner_of(lo, hi, two, parts)], 1ull) : 0;
+    const uint32_t own = (occ && parts > 1) ? owner_of(lo, hi, two, parts) : 0u;
+    unsigned long long dst = 0;
+    if (parts <= MAX_FAST_PARTS) {
+      for (int p = 0; p < parts; ++p) {
+        const bool mine = occ && own == (uint32_t)p;
+        const unsigned long long m = __ballot(mine);
+        unsigned long long b = 0;
+        if (lane == 0 && m) b = atomicAdd(&part_cursor[p], (unsigned long long)__popcll(m));
+        b = __shfl((unsigned long long)b, 0);
+        if (mine) dst = b + __popcll(m & ((1ull << lane) - 1));
+      }
+    } else if (occ) {
+      dst = atomicAdd(&part_cursor[own], 1ull);
     }
     if (occ) {
       out_lo[dst] = lo;

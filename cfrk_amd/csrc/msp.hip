@@ -689,6 +689,21 @@ int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   if (!ms) return cfrk_fail(ctx, CFRK_ERR_NOMEM, "host allocation failed");
   int rc;
   if (ms->pending && (rc = cfrk_msp_flush_to_table(ctx))) return rc;
+  // every buffer this call needs must fit: check before touching the pool so that a refusal
+  // leaves the context usable for the fallback path
+  {
+    int W0, m0;
+    msp_params(ctx->g_k, &W0, &m0);
+    const double expect0 = (double)nN * (2.0 / (W0 + 1) + 1.0 / 64.0);
+    const size_t need = (size_t)(expect0 * 1.35 * 16) + (size_t)B1 * NXG * 2048 * 16 +
+                        (size_t)(expect0 * 2.5 * 16) + (size_t)NLEAF * 192 * 16 + (size_t)ctx->g_cap * 12;
+    size_t have = ctx->pool[BUF_MSP_L1].cap + ctx->pool[BUF_MSP_L2].cap + ctx->pool[BUF_MSP_OUTK].cap +
+                  ctx->pool[BUF_MSP_OUTC].cap;
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+    if (need > have + free_b)
+      return cfrk_fail(ctx, CFRK_ERR_NOMEM, "partitioned path needs %zu B, %zu B available", need, have + free_b);
+  }
   const int k = ctx->g_k;
   int W, m;
   msp_params(k, &W, &m);
