@@ -35,6 +35,8 @@ def parse():
                    help="gloo: rehearsal mode -- collectives staged through host memory, every "
                         "rank may sit on the same GPU (--same-gpu)")
     p.add_argument("--same-gpu", action="store_true", help="all ranks use cuda:0 (rehearsal)")
+    p.add_argument("--owner-hash", action="store_true",
+                   help="force the generic hash-owner exchange + HBM-table merge")
     return p.parse_args()
 
 
@@ -52,6 +54,21 @@ def cpu_baseline(args, glen):
     return {"value": kmers / dt, "unit": "k-mers/s", "cores": threads, "kind": "port",
             "sample": f"first {R} reads of the same generator ({kmers} k-mers, {dt:.2f} s, "
                       f"{len(lo)} distinct), oracle/cfrk_oracle.c orc_global_count_mt"}, (lo, hi, cnt)
+
+
+def measured_traffic(R, L, k, canonical):
+    """HBM bytes per launch from the committed PMC measurement of this exact workload
+    (profiles/*/traffic_*.json, produced by tools/traffic.sh); None when there is none."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic_*.json")), reverse=True):
+        try:
+            t = json.load(open(f))
+        except Exception:
+            continue
+        w = t.get("workload", {})
+        if (w.get("reads"), w.get("read_len"), w.get("k"), w.get("canonical")) == (R, L, k, canonical):
+            return t.get("hbm_bytes_per_launch"), os.path.relpath(f, ROOT)
+    return None, None
 
 
 def main():
@@ -101,6 +118,25 @@ def main():
         def __init__(self):
             self.g = None
             self.bufs = None
+            self.lbufs = None
+
+        def export_leaves(self, parts):
+            n = self.g.finish()
+            lpp = self.g.leaves_per_part(parts)
+            if self.lbufs is None or self.lbufs[0].numel() < n:
+                cap = int(n * 1.1) + 1024
+                self.lbufs = (torch.empty(cap, dtype=torch.int64, device=dev),
+                              torch.empty(cap, dtype=torch.int32, device=dev),
+                              torch.empty(parts * lpp, dtype=torch.int32, device=dev))
+            keys, cnt, lc = self.lbufs
+            try:
+                pc = self.g.export_leaves_device(keys.data_ptr(), cnt.data_ptr(), keys.numel(), parts,
+                                                 lc.data_ptr())
+            except cfrk_amd.CfrkError as e:
+                if e.code != -4:
+                    raise
+                return None
+            return keys, cnt, pc, lc
 
         def export_parts(self, parts):
             n = self.g.finish()
@@ -121,9 +157,14 @@ def main():
         if world == 1:
             ctx.sync()
             return eng.g
-        rlo, rhi, rcnt = sharded.exchange_by_owner(eng, world, dev, wire)
         og = cfrk_amd.GlobalCounter(owner_ctx, k, flags, hint // world + 1024)
-        og.merge_device(rlo.data_ptr(), 0, rcnt.data_ptr(), rlo.numel())
+        got = None if args.owner_hash else sharded.exchange_by_leaf(eng, world, dev, wire)
+        if got is not None:       # per-leaf lists, added in LDS on the owner
+            rkeys, rcnt, recv_l, rlc = got
+            og.merge_leaves_device(rkeys.data_ptr(), rcnt.data_ptr(), recv_l, rlc.data_ptr())
+        else:                     # generic: owner = hash(key), HBM-table merge
+            rlo, rhi, rcnt = sharded.exchange_by_owner(eng, world, dev, wire)
+            og.merge_device(rlo.data_ptr(), 0, rcnt.data_ptr(), rlo.numel())
         owner_ctx.sync()
         return og
 
@@ -161,6 +202,7 @@ def main():
         b_alg = Rl * (L + 1) + 12 * Rl + 2 * (D // world if world > 1 else D) * S
         avg_ms = sum(kernel_ms) / len(kernel_ms)
         achieved = b_alg / (avg_ms * 1e-3) / 1e9
+        traffic, traffic_src = (measured_traffic(R, L, k, bool(flags)) if world == 1 else (None, None))
         out = {
             "metric": "k-mers/sec", "value": kmers_total * args.steps / dt, "unit": "k-mers/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -172,7 +214,7 @@ def main():
                        "reads": R, "read_len": L, "k": k, "parallelism": f"read-shard x{world}"
                        + (" + owner all-to-all" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None,
+                         "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "counting kernels of cfrk_global_add_device (HIP events)",
                          "kernel_ms": avg_ms, "algorithmic_bytes": b_alg},
             "distinct": D, "sum_count_ok": ok,

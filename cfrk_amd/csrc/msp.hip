@@ -32,6 +32,7 @@
 
 #include <algorithm>
 #include <new>
+#include <vector>
 
 namespace {
 
@@ -56,6 +57,7 @@ struct MspView {
   uint4 *rec1; uint32_t *cnt1; uint64_t cap1;   // B1 x NXG sub-regions of cap1 records each
   uint4 *rec2; uint32_t *cnt2; uint64_t cap2c, cap2t;   // per leaf: complete stream, then truncated stream
   uint64_t *out_keys; uint32_t *out_cnt; uint64_t out_cap;
+  uint64_t *leaf_off; uint32_t *leaf_n;        // where each leaf's entries sit in the result list
   uint64_t *stats;
 };
 
@@ -603,6 +605,85 @@ __global__ __launch_bounds__(P3_THREADS) void msp_p3_kernel(int k, MspView v, Ta
     wbase[i] = __shfl(b, 0);
   }
   __syncthreads();
+  if (tid == 0) {
+    wg_base = atomicAdd((unsigned long long *)&v.stats[ST_CURSOR], (unsigned long long)wg_total);
+    v.leaf_off[leaf] = wg_base;
+    v.leaf_n[leaf] = wg_total;
+  }
+  __syncthreads();
+  const unsigned long long gb = wg_base;
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int s = i * P3_THREADS + tid;
+    const unsigned long long key = keys[s];
+    const bool occ = key != CFRK_EMPTY_KEY;
+    const unsigned long long m = __ballot(occ);
+    if (occ) {
+      const unsigned long long dst = gb + wbase[i] + __popcll(m & ((1ull << lane) - 1ull));
+      if (dst < v.out_cap) { v.out_keys[dst] = key; v.out_cnt[dst] = cnts[s]; }
+      else v.stats[ST_OVERFLOW] = 1;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------- multi-GPU by leaf
+// Leaves are disjoint in key space on EVERY rank (same k -> same minimizer -> same leaf), so the
+// owner of a key can be the owner of its leaf: owner(leaf) = leaf % parts.  Each rank ships its
+// leaves' (key,count) lists to their owners, and the owner adds the lists of one leaf in an LDS
+// table exactly like P3 does -- no HBM atomics in the merge.
+
+// copy every leaf's entries into owner-major order (dst_off from the host's prefix sum)
+__global__ __launch_bounds__(256) void msp_gather_kernel(MspView v, const uint64_t *__restrict__ dst_off,
+                                                         uint64_t *__restrict__ out_keys,
+                                                         uint32_t *__restrict__ out_cnt) {
+  const uint32_t leaf = blockIdx.x;
+  const uint32_t n = v.leaf_n[leaf];
+  const uint64_t so = v.leaf_off[leaf], dof = dst_off[leaf];
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    out_keys[dof + i] = v.out_keys[so + i];
+    out_cnt[dof + i] = v.out_cnt[so + i];
+  }
+}
+
+// one workgroup per owned leaf: add the `parts` incoming lists of that leaf in LDS
+__global__ __launch_bounds__(P3_THREADS) void msp_merge_kernel(const uint64_t *__restrict__ in_keys,
+                                                               const uint32_t *__restrict__ in_cnt,
+                                                               const uint64_t *__restrict__ seg_off,
+                                                               const uint32_t *__restrict__ seg_n,
+                                                               int parts, int leaves_per_part,
+                                                               MspView v, TableView t) {
+  __shared__ unsigned long long keys[TS];
+  __shared__ uint32_t cnts[TS];
+  __shared__ uint32_t wg_total;
+  __shared__ unsigned long long wg_base;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const uint32_t ll = blockIdx.x;                       // local leaf index on this owner
+  uint32_t total = 0;
+  for (int p = 0; p < parts; ++p) total += seg_n[(size_t)p * leaves_per_part + ll];
+  if (total == 0) return;
+  for (int s = tid; s < TS; s += P3_THREADS) { keys[s] = CFRK_EMPTY_KEY; cnts[s] = 0; }
+  if (tid == 0) wg_total = 0;
+  __syncthreads();
+  for (int p = 0; p < parts; ++p) {
+    const uint32_t n = seg_n[(size_t)p * leaves_per_part + ll];
+    const uint64_t off = seg_off[(size_t)p * leaves_per_part + ll];
+    for (uint32_t i = tid; i < n; i += P3_THREADS) {
+      const uint64_t key = in_keys[off + i];
+      const uint32_t c = in_cnt[off + i];
+      if (c) lds_count_pair(keys, cnts, key, key, false, c, t);
+    }
+  }
+  __syncthreads();
+  constexpr int NIT = TS / P3_THREADS;
+  uint32_t wbase[NIT];
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const unsigned long long m = __ballot(keys[i * P3_THREADS + tid] != CFRK_EMPTY_KEY);
+    uint32_t b = 0;
+    if (lane == 0 && m) b = atomicAdd(&wg_total, (uint32_t)__popcll(m));
+    wbase[i] = __shfl(b, 0);
+  }
+  __syncthreads();
   if (tid == 0) wg_base = atomicAdd((unsigned long long *)&v.stats[ST_CURSOR], (unsigned long long)wg_total);
   __syncthreads();
   const unsigned long long gb = wg_base;
@@ -725,8 +806,9 @@ int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   v.rec1 = (uint4 *)p; v.cap1 = cap1;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)NLEAF * (cap2c + cap2t) * sizeof(uint4), &p))) return rc;
   v.rec2 = (uint4 *)p; v.cap2c = cap2c; v.cap2t = cap2t;
-  if ((rc = cfrk_pool_get(ctx, BUF_MSP_AUX, (size_t)(B1 * NXG + 2 * NLEAF) * sizeof(uint32_t), &p))) return rc;
-  v.cnt1 = (uint32_t *)p; v.cnt2 = v.cnt1 + B1 * NXG;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_AUX, (size_t)NLEAF * 8 + (size_t)(B1 * NXG + 3 * NLEAF) * sizeof(uint32_t), &p))) return rc;
+  v.leaf_off = (uint64_t *)p;
+  v.cnt1 = (uint32_t *)(v.leaf_off + NLEAF); v.cnt2 = v.cnt1 + B1 * NXG; v.leaf_n = v.cnt2 + 2 * NLEAF;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTK, (size_t)ctx->g_cap * 8, &p))) return rc;
   v.out_keys = (uint64_t *)p;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTC, (size_t)ctx->g_cap * 4, &p))) return rc;
@@ -734,7 +816,7 @@ int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   v.stats = ctx->g_stats;
   TableView t = cfrk_table_view(ctx);
 
-  HIP_TRY(ctx, hipMemsetAsync(v.cnt1, 0, (size_t)(B1 * NXG + 2 * NLEAF) * sizeof(uint32_t), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(v.cnt1, 0, (size_t)(B1 * NXG + 3 * NLEAF) * sizeof(uint32_t), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_CURSOR, 0, sizeof(uint64_t), ctx->stream));
 
   const int64_t nchunks = (nN + 31) / 32;
@@ -816,5 +898,101 @@ extern "C" int cfrk_debug_msp_info(cfrk_ctx *ctx, uint64_t out[9]) {
   rc = msp_sync_stats(ctx, st);
   if (rc) return rc;
   out[6] = st[ST_AUX0]; out[7] = st[ST_AUX1]; out[8] = st[ST_CURSOR];
+  return CFRK_OK;
+}
+
+// ------------------------------------------------------------------ multi-GPU exchange by leaf
+extern "C" int cfrk_global_export_leaves_device(cfrk_ctx *ctx, uint64_t *d_keys, uint32_t *d_counts,
+                                                uint64_t cap, int parts, uint64_t *part_counts,
+                                                uint32_t *d_leaf_counts) {
+  if (!ctx || !part_counts || parts < 1 || parts > NLEAF) return CFRK_ERR_ARG;
+  cfrk_msp *ms = ctx->msp;
+  if (!ctx->g_active || !ms || !ms->pending || ms->table_dirty)
+    return cfrk_fail(ctx, CFRK_ERR_STATE, "result is not in per-leaf list form");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  uint64_t st[ST_NWORDS];
+  int rc = msp_sync_stats(ctx, st);
+  if (rc) return rc;
+  if (st[ST_OVERFLOW]) return cfrk_fail(ctx, CFRK_ERR_TABLE_FULL, "result list overflowed");
+  if (st[ST_SPILLED] || st[ST_ONES]) return cfrk_fail(ctx, CFRK_ERR_STATE, "part of the result lives in the HBM table");
+  const int lpp = (NLEAF + parts - 1) / parts;           // leaves per part (owner p: leaves p, p+parts, ...)
+  std::vector<uint32_t> ln(NLEAF), ordered((size_t)parts * lpp, 0u);
+  std::vector<uint64_t> doff(NLEAF);
+  HIP_TRY(ctx, hipMemcpyAsync(ln.data(), ms->view.leaf_n, NLEAF * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  uint64_t run = 0;
+  for (int p = 0; p < parts; ++p) {
+    uint64_t pc = 0;
+    for (int j = 0; j < lpp; ++j) {
+      const int leaf = p + j * parts;
+      if (leaf >= NLEAF) break;
+      doff[leaf] = run;
+      run += ln[leaf]; pc += ln[leaf];
+      ordered[(size_t)p * lpp + j] = ln[leaf];
+    }
+    part_counts[p] = pc;
+  }
+  if (run != st[ST_CURSOR]) return cfrk_fail(ctx, CFRK_ERR_STATE, "leaf index does not cover the list");
+  if (run > cap) return cfrk_fail(ctx, CFRK_ERR_SMALL_BUF, "%llu entries, room for %llu", (unsigned long long)run, (unsigned long long)cap);
+  void *p;
+  if ((rc = cfrk_pool_get(ctx, BUF_SCRATCH, NLEAF * sizeof(uint64_t), &p))) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(p, doff.data(), NLEAF * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+  if (d_leaf_counts)
+    HIP_TRY(ctx, hipMemcpyAsync(d_leaf_counts, ordered.data(), ordered.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+  if (run) {
+    hipLaunchKernelGGL(msp_gather_kernel, dim3(NLEAF), dim3(256), 0, ctx->stream, ms->view, (const uint64_t *)p, d_keys, d_counts);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // doff / ordered are host temporaries
+  return CFRK_OK;
+}
+
+extern "C" int cfrk_global_leaves_per_part(int parts) { return parts >= 1 ? (NLEAF + parts - 1) / parts : 0; }
+
+extern "C" int cfrk_global_merge_leaves_device(cfrk_ctx *ctx, const uint64_t *d_keys, const uint32_t *d_counts,
+                                               const uint64_t *recv_counts, const uint32_t *d_leaf_counts,
+                                               int parts) {
+  if (!ctx || parts < 1 || parts > NLEAF || !recv_counts || !d_leaf_counts) return CFRK_ERR_ARG;
+  if (!ctx->g_active || ctx->g_two) return cfrk_fail(ctx, CFRK_ERR_STATE, "merge_leaves needs an active one-word job");
+  cfrk_msp *ms = msp_get(ctx);
+  if (!ms) return cfrk_fail(ctx, CFRK_ERR_NOMEM, "host allocation failed");
+  if (ms->pending || ms->table_dirty) return cfrk_fail(ctx, CFRK_ERR_STATE, "merge_leaves needs an empty job (call cfrk_global_begin first)");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int lpp = (NLEAF + parts - 1) / parts;
+  int rc;
+  void *p;
+  MspView &v = ms->view;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTK, (size_t)ctx->g_cap * 8, &p))) return rc;
+  v.out_keys = (uint64_t *)p;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTC, (size_t)ctx->g_cap * 4, &p))) return rc;
+  v.out_cnt = (uint32_t *)p; v.out_cap = ctx->g_cap;
+  v.stats = ctx->g_stats;
+  // segment (source rank, local leaf): counts arrive as [parts][lpp]; data as rank-major runs
+  const size_t nseg = (size_t)parts * lpp;
+  std::vector<uint32_t> sn(nseg);
+  std::vector<uint64_t> so(nseg);
+  HIP_TRY(ctx, hipMemcpyAsync(sn.data(), d_leaf_counts, nseg * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  uint64_t run = 0;
+  for (int r = 0; r < parts; ++r) {
+    uint64_t got = 0;
+    for (int j = 0; j < lpp; ++j) { so[(size_t)r * lpp + j] = run; run += sn[(size_t)r * lpp + j]; got += sn[(size_t)r * lpp + j]; }
+    if (got != recv_counts[r]) return cfrk_fail(ctx, CFRK_ERR_ARG, "rank %d sent %llu entries but its leaf counts add up to %llu", r, (unsigned long long)recv_counts[r], (unsigned long long)got);
+  }
+  if ((rc = cfrk_pool_get(ctx, BUF_SCRATCH, nseg * (sizeof(uint64_t) + sizeof(uint32_t)), &p))) return rc;
+  uint64_t *d_so = (uint64_t *)p;
+  uint32_t *d_sn = (uint32_t *)(d_so + nseg);
+  HIP_TRY(ctx, hipMemcpyAsync(d_so, so.data(), nseg * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_sn, sn.data(), nseg * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_CURSOR, 0, sizeof(uint64_t), ctx->stream));
+  TableView t = cfrk_table_view(ctx);
+  if (run) {
+    hipLaunchKernelGGL(msp_merge_kernel, dim3(lpp), dim3(P3_THREADS), 0, ctx->stream, d_keys, d_counts,
+                       (const uint64_t *)d_so, (const uint32_t *)d_sn, parts, lpp, v, t);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // so / sn are host temporaries
+  ms->pending = true;
+  ms->list_n_valid = false;
   return CFRK_OK;
 }

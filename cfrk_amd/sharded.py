@@ -48,6 +48,40 @@ def exchange_by_owner(engine, world, device, wire_device=None):
     return rlo, rhi, rcnt
 
 
+def exchange_by_leaf(engine, world, device, wire_device=None):
+    """Owner exchange at leaf granularity (the partitioned path's result form): returns
+    (keys, counts, recv_counts, leaf_counts) for engine-side `merge_leaves`, or None when some
+    rank cannot export by leaf -- every rank then takes the generic exchange_by_owner path.
+
+    engine.export_leaves(parts) -> (keys, counts, part_counts, leaf_counts) or None."""
+    wire = torch.device(wire_device) if wire_device is not None else torch.device(device)
+    exp = engine.export_leaves(world)
+    ok = torch.tensor([1 if exp is not None else 0], dtype=torch.int32, device=wire)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 0:
+        return None
+    keys, cnt, part_counts, leaf_counts = exp
+    send = torch.tensor(part_counts, dtype=torch.int64, device=wire)
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send)
+    send_l = [int(x) for x in part_counts]
+    recv_l = [int(x) for x in recv.cpu().tolist()]
+    n_send, n_recv = sum(send_l), sum(recv_l)
+
+    def a2a(t):
+        src = t[:n_send].contiguous().to(wire)
+        out = torch.empty(n_recv, dtype=t.dtype, device=wire)
+        dist.all_to_all_single(out, src, recv_l, send_l)
+        return out.to(device)
+
+    rkeys = a2a(keys.view(torch.int64))
+    rcnt = a2a(cnt.view(torch.int32))
+    lc = leaf_counts.view(torch.int32).contiguous().to(wire)        # [world][leaves_per_part]
+    rlc = torch.empty_like(lc)
+    dist.all_to_all_single(rlc, lc)
+    return rkeys, rcnt, recv_l, rlc.to(device)
+
+
 def merge_digests(local, device):
     """combine per-rank digests (owners hold disjoint key sets): sums mod 2^64 and xor"""
     world = dist.get_world_size()

@@ -31,6 +31,9 @@ class OracleEngine:
         cnt = torch.from_numpy(self.cnt[order].astype(np.uint32).view(np.int32).copy())
         return lo, None, cnt, pc
 
+    def export_leaves(self, parts):
+        return None                     # the oracle has no leaf form: exercises the fallback vote
+
     def merge(self, lo, hi, cnt):
         for k_, c in zip(lo.numpy().view(np.uint64), cnt.numpy().view(np.uint32)):
             self.merged[int(k_)] = self.merged.get(int(k_), 0) + int(c)
@@ -51,6 +54,7 @@ def _worker(rank, world, port, q):
     r0, r1 = sharded.shard_range(R, rank, world)
     data, _, _ = orc.synth_reads(r0, r1 - r0, L, G)
     eng = OracleEngine(data, K)
+    assert sharded.exchange_by_leaf(eng, world, torch.device("cpu")) is None   # all ranks agree
     rlo, rhi, rcnt = sharded.exchange_by_owner(eng, world, torch.device("cpu"))
     eng.merge(rlo, rhi, rcnt)
     # every received key must be owned by this rank
