@@ -121,10 +121,9 @@ def main():
             self.lbufs = None
 
         def export_leaves(self, parts):
-            n = self.g.finish()
             lpp = self.g.leaves_per_part(parts)
-            if self.lbufs is None or self.lbufs[0].numel() < n:
-                cap = int(n * 1.1) + 1024
+            if self.lbufs is None:
+                cap = hint           # distinct keys of a shard never exceed the hint
                 self.lbufs = (torch.empty(cap, dtype=torch.int64, device=dev),
                               torch.empty(cap, dtype=torch.int32, device=dev),
                               torch.empty(parts * lpp, dtype=torch.int32, device=dev))
@@ -139,9 +138,8 @@ def main():
             return keys, cnt, pc, lc
 
         def export_parts(self, parts):
-            n = self.g.finish()
-            if self.bufs is None or self.bufs[0].numel() < n:
-                cap = int(n * 1.1) + 1024
+            if self.bufs is None:
+                cap = hint
                 self.bufs = (torch.empty(cap, dtype=torch.int64, device=dev), None,
                              torch.empty(cap, dtype=torch.int32, device=dev))
             lo, hi, cnt = self.bufs
