@@ -4,19 +4,26 @@
 // rate (~2e10/s), two orders of magnitude under what HBM bandwidth allows.  Here HBM only sees
 // streams, and every occurrence is counted with LDS atomics:
 //
-//   P1  partition_l1   read the flat code buffer once (2 x dwordx4 per lane, 2-bit packing in
+//   P1  msp_p1_kernel  read the flat code buffer once (2 x dwordx4 per lane, 2-bit packing in
 //                      registers), compute for every k-mer the minimum hash over its W = k-m+1
-//                      canonical m-mers (its minimizer), cut each lane's 32 window starts into
-//                      runs of equal minimizer ("super-k-mers"), and append each run as one 16-B
-//                      record {48 bases, leaf id, n} to L1 bin = leaf >> 8.  A workgroup stages
-//                      its records in LDS, reserves space with ONE global atomic per non-empty
-//                      bin per 16 KiB tile, then copies out in bin order (coalesced).
-//   P2  partition_l2   stream every L1 bin, split it 256 ways on the leaf's low byte
-//                      (LDS histogram, one global atomic per bin per 4096 records).
-//   P3  count_leaf     one workgroup per leaf (65536 leaves): an open-addressing table of 4096
-//                      {u64 key, u32 count} slots in LDS; expand records to (canonical) k-mers,
-//                      ds_cmpst_b64 to claim, ds_add_u32 to count; then compact the occupied
-//                      slots to the output list with one wave-aggregated cursor atomic.
+//                      canonical m-mers (its minimizer), cut the k-mers into runs that share one
+//                      minimizer occurrence ("super-k-mers"; content-defined, they may cross into
+//                      the next lane's chunk), and append each run as one 16-B record
+//                      {48 bases, leaf id, complete flag, n} to level-1 bin = leaf >> 8.  A
+//                      workgroup stages its records in LDS, reserves space with ONE global
+//                      atomic per non-empty bin per 15.6 KB of input, then copies out in bin
+//                      order (coalesced).
+//   P2  msp_p2_kernel  stream every level-1 region, split it 512 ways: leaf low byte x
+//                      {truncated run, complete run} (LDS counting sort of 4096-record tiles,
+//                      one global atomic per stream per tile, coalesced copy-out).
+//   P3  msp_p3_kernel  one workgroup per leaf (65536 leaves), everything in LDS: complete runs
+//                      are counted per RECORD in a record table (at depth most are identical),
+//                      then every distinct record is expanded once with its multiplicity, and
+//                      truncated runs with weight 1, into a bucketized k-mer table
+//                      (ds_cmpst_b64 to claim, ds_add_u32 to count); the occupied slots are
+//                      compacted to the output list with one cursor atomic per workgroup.
+//   multi-GPU          leaves are disjoint in key space on every rank, so lists are exchanged
+//                      and added per leaf, again in LDS (msp_gather_kernel, msp_merge_kernel).
 //
 // All occurrences of a k-mer share its minimizer, hence its leaf, so leaves are disjoint in key
 // space and the output list is the final result.  Anything that does not fit (bin capacity, LDS
@@ -27,8 +34,6 @@
 // /root/reference/src/kmer_kernel.cu:52-70 summed over reads).
 #include "msp.h"
 #include "table.h"
-
-#include <stdlib.h>
 
 #include <algorithm>
 #include <new>
@@ -528,7 +533,7 @@ __device__ __forceinline__ void rtab_step(uint4 *rtab, uint4 rec, uint32_t &h, u
 }
 
 template <bool CANON>
-__global__ __launch_bounds__(P3_THREADS) void msp_p3_kernel(int k, MspView v, TableView t, int dbg) {
+__global__ __launch_bounds__(P3_THREADS) void msp_p3_kernel(int k, MspView v, TableView t) {
   __shared__ unsigned long long keys[TS];
   __shared__ uint32_t cnts[TS];
   __shared__ uint4 rtab[RT];
@@ -550,7 +555,7 @@ __global__ __launch_bounds__(P3_THREADS) void msp_p3_kernel(int k, MspView v, Ta
 
   // ---- phase 1a: complete runs, one record-table update per record (every lane busy);
   //      a record that finds no room is expanded on the spot
-  if (!(dbg & 1)) {
+  {
     // two records per trip, one wave-uniform probe loop for both
     const uint4 *src = leaf_rec;
     for (uint64_t r = tid; r < n1; r += 2ull * P3_THREADS) {
@@ -575,7 +580,7 @@ __global__ __launch_bounds__(P3_THREADS) void msp_p3_kernel(int k, MspView v, Ta
   // ---- phase 2: k-mer by k-mer -- the truncated runs (weight 1) and every distinct complete
   //      record of the record table (weight = its multiplicity), in ONE loop (one copy of the
   //      expansion code)
-  if (!(dbg & 2)) {
+  {
     const uint4 *src = leaf_rec + v.cap2c;
     for (uint64_t i = tid; i < n0 + RT; i += P3_THREADS) {
       uint4 rec;
@@ -594,7 +599,6 @@ __global__ __launch_bounds__(P3_THREADS) void msp_p3_kernel(int k, MspView v, Ta
 
   // ---- compact occupied slots to the output list: ONE cursor atomic per workgroup (a global
   //      atomic per wave on the single cursor word serialises the whole grid)
-  if (dbg & 8) return;
   constexpr int NIT = TS / P3_THREADS;
   uint32_t wbase[NIT];
 #pragma unroll
@@ -835,10 +839,8 @@ int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   hipLaunchKernelGGL(msp_p2_kernel, dim3((unsigned)(tiles_per_sub * B1 * NXG)), dim3(P2_THREADS), 0, ctx->stream,
                      (int)tiles_per_sub, k, canon, v, t);
   HIP_TRY(ctx, hipGetLastError());
-  const char *dbg_env = getenv("CFRK_DEBUG_P3");     // timing ablations only (results are wrong)
-  const int dbg = dbg_env ? atoi(dbg_env) : 0;
-  if (canon) hipLaunchKernelGGL((msp_p3_kernel<true>), dim3(NLEAF), dim3(P3_THREADS), 0, ctx->stream, k, v, t, dbg);
-  else hipLaunchKernelGGL((msp_p3_kernel<false>), dim3(NLEAF), dim3(P3_THREADS), 0, ctx->stream, k, v, t, dbg);
+  if (canon) hipLaunchKernelGGL((msp_p3_kernel<true>), dim3(NLEAF), dim3(P3_THREADS), 0, ctx->stream, k, v, t);
+  else hipLaunchKernelGGL((msp_p3_kernel<false>), dim3(NLEAF), dim3(P3_THREADS), 0, ctx->stream, k, v, t);
   HIP_TRY(ctx, hipGetLastError());
   ms->pending = true;
   ms->list_n_valid = false;
