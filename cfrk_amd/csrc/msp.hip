@@ -495,6 +495,7 @@ __device__ __noinline__ void count_record_slow(unsigned long long *keys, uint32_
 // (the same genome locus seen by many reads).  Entries are {R0,R1,R2,meta},
 // meta = count << 6 | (n-1); meta == 0 empty, RT_LOCK while the claiming lane writes the bases.
 constexpr int RT_LOG = 10, RT = 1 << RT_LOG;
+static_assert(RT == P3_THREADS, "phase 2 lists the record table with one slot per thread");
 constexpr uint32_t RT_LOCK = 0xFFFFFFFFu;
 constexpr int RT_PROBES = 24;
 
@@ -537,6 +538,8 @@ __global__ __launch_bounds__(P3_THREADS) void msp_p3_kernel(int k, MspView v, Ta
   __shared__ unsigned long long keys[TS];
   __shared__ uint32_t cnts[TS];
   __shared__ uint4 rtab[RT];
+  __shared__ uint16_t occ_list[RT];
+  __shared__ uint32_t nocc;
   __shared__ uint32_t wg_total;
   __shared__ unsigned long long wg_base;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -547,7 +550,7 @@ __global__ __launch_bounds__(P3_THREADS) void msp_p3_kernel(int k, MspView v, Ta
   if (n0 + n1 == 0) return;
   for (int s = tid; s < TS; s += P3_THREADS) { keys[s] = CFRK_EMPTY_KEY; cnts[s] = 0; }
   for (int s = tid; s < RT; s += P3_THREADS) rtab[s] = make_uint4(0u, 0u, 0u, 0u);
-  if (tid == 0) wg_total = 0;
+  if (tid == 0) { wg_total = 0; nocc = 0; }
   __syncthreads();
 
   const uint64_t kmask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1ull);
@@ -579,18 +582,29 @@ __global__ __launch_bounds__(P3_THREADS) void msp_p3_kernel(int k, MspView v, Ta
   __syncthreads();
   // ---- phase 2: k-mer by k-mer -- the truncated runs (weight 1) and every distinct complete
   //      record of the record table (weight = its multiplicity), in ONE loop (one copy of the
-  //      expansion code)
+  //      expansion code).  The occupied record-table slots are first listed densely (the table
+  //      is ~30 % full: walking it directly leaves two thirds of the lanes idle).
+  {
+    const uint4 e = rtab[tid];                       // RT == P3_THREADS
+    const bool occ = e.w != 0u;
+    const unsigned long long m = __ballot(occ);
+    uint32_t b = 0;
+    if (lane == 0 && m) b = atomicAdd(&nocc, (uint32_t)__popcll(m));
+    b = __shfl(b, 0);
+    if (occ) occ_list[b + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)tid;
+  }
+  __syncthreads();
   {
     const uint4 *src = leaf_rec + v.cap2c;
-    for (uint64_t i = tid; i < n0 + RT; i += P3_THREADS) {
+    const uint64_t nlist = nocc;
+    for (uint64_t i = tid; i < n0 + nlist; i += P3_THREADS) {
       uint4 rec;
       uint32_t wgt = 1u;
-      if (i < n0) {
-        rec = src[i];
-      } else {
-        rec = rtab[i - n0];
+      if (i < nlist) {
+        rec = rtab[occ_list[i]];
         wgt = rec.w >> 6;
-        if (rec.w == 0u) continue;
+      } else {
+        rec = src[i - nlist];
       }
       count_record<CANON>(keys, cnts, rec, wgt, k, kmask, rcsh, t);
     }
