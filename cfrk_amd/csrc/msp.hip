@@ -60,7 +60,7 @@ constexpr int P3_PROBE_LIMIT = 48;      // buckets probed before a key is counte
 
 struct MspView {
   uint4 *rec1; uint32_t *cnt1; uint64_t cap1;   // B1 x NXG sub-regions of cap1 records each
-  uint4 *rec2; uint32_t *cnt2; uint64_t cap2c, cap2t;   // per leaf: complete stream, then truncated stream
+  uint4 *rec2; uint32_t *cnt2; uint64_t cap2c, cap2t;   // per leaf: complete stream (cap2c), then 3 truncated length classes (cap2t each)
   uint64_t *out_keys; uint32_t *out_cnt; uint64_t out_cap;
   uint64_t *leaf_off; uint32_t *leaf_n;        // where each leaf's entries sit in the result list
   uint64_t *stats;
@@ -324,8 +324,15 @@ __global__ __launch_bounds__(P1_THREADS) void msp_p1_kernel(const int8_t *__rest
 // sub-bin of a record inside its level-1 bin: leaf low byte x {truncated run, complete run}.
 // Complete runs get a stream of their own so that P3 can count them per RECORD with every lane
 // busy, instead of k-mer by k-mer.
-constexpr int NSUB = 2 * B2;
-__device__ __forceinline__ uint32_t sub_of(uint32_t w) { return (((w >> 8) & (B2 - 1)) << 1) | ((w >> 6) & 1u); }
+// Truncated runs are split by length class as well, so that in P3 the lanes of a wave expand
+// records of similar length (the expansion loop runs max(n)/2 trips per wave).
+constexpr int NCLS = 4;                                   // 0..2 truncated (n<=4, <=10, >10), 3 complete
+constexpr int NSUB = NCLS * B2;
+__device__ __forceinline__ uint32_t cls_of(uint32_t w) {
+  const uint32_t n = (w & 63u) + 1u;
+  return (w & 64u) ? 3u : (n <= 4u ? 0u : (n <= 10u ? 1u : 2u));
+}
+__device__ __forceinline__ uint32_t sub_of(uint32_t w) { return (((w >> 8) & (B2 - 1)) << 2) | cls_of(w); }
 
 // Grid = B1 * NXG * tiles_per_sub workgroups.  blockIdx % 8 picks the XCD group, and each group
 // walks ITS bins (b1 = group, group+8, ...) one after the other, so that at any moment the
@@ -334,8 +341,9 @@ __device__ __forceinline__ uint32_t sub_of(uint32_t w) { return (((w >> 8) & (B2
 __global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int tiles_per_sub, int k, int canon,
                                                             MspView v, TableView t) {
   __shared__ uint4 sorted[P2_TILE];
-  __shared__ uint32_t hist[NSUB], loff[NSUB], gbase[NSUB], fill[NSUB];
-  __shared__ uint32_t wtot[NSUB / 64];
+  __shared__ uint32_t hist[NSUB], loff[NSUB], gbase[NSUB];   // hist doubles as the fill cursor
+  __shared__ uint32_t wtot[P2_THREADS / 64];
+  static_assert(NSUB == 2 * P2_THREADS, "the scan below gives every thread two sub-bins");
   const int tid = threadIdx.x;
   const uint32_t xg = blockIdx.x & (NXG - 1), seq = blockIdx.x / NXG;
   const uint32_t per_bin = (uint32_t)NXG * (uint32_t)tiles_per_sub;
@@ -347,7 +355,7 @@ __global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int tiles_per_sub, i
   const uint64_t r0 = (uint64_t)tile * P2_TILE;
   if (r0 >= n) return;
   const uint32_t nt = (uint32_t)min((uint64_t)P2_TILE, n - r0);
-  if (tid < NSUB) { hist[tid] = 0; fill[tid] = 0; }
+  hist[2 * tid] = 0; hist[2 * tid + 1] = 0;
   __syncthreads();
   const uint4 *src = v.rec1 + (uint64_t)reg * v.cap1 + r0;
   uint4 r[P2_PER];
@@ -360,18 +368,34 @@ __global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int tiles_per_sub, i
     if (idx < nt) atomicAdd(&hist[sub_of(x.w)], 1u);
   }
   __syncthreads();
-  if (tid < NSUB) {
-    const uint32_t c = hist[tid];
-    gbase[tid] = c ? atomicAdd(&v.cnt2[b1 * NSUB + tid], c) : 0u;
+  {
+    // per-stream reservation + exclusive scan of the 1024 sub-bin sizes (two per thread)
+    const int lane = tid & 63, wave = tid >> 6;
+    const uint32_t x0 = hist[2 * tid], x1 = hist[2 * tid + 1];
+    gbase[2 * tid] = x0 ? atomicAdd(&v.cnt2[b1 * NSUB + 2 * tid], x0) : 0u;
+    gbase[2 * tid + 1] = x1 ? atomicAdd(&v.cnt2[b1 * NSUB + 2 * tid + 1], x1) : 0u;
+    uint32_t incl = x0 + x1;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t y = __shfl_up(incl, d);
+      if (lane >= d) incl += y;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wave; ++w) base += wtot[w];
+    loff[2 * tid] = base + incl - x0 - x1;
+    loff[2 * tid + 1] = base + incl - x1;
+    hist[2 * tid] = 0; hist[2 * tid + 1] = 0;             // from here on: fill cursors
+    __syncthreads();
   }
-  block_scan<NSUB>(hist, loff, wtot);
   // counting sort of the tile by sub-bin, in LDS
 #pragma unroll
   for (int i = 0; i < P2_PER; ++i) {
     const uint32_t idx = (uint32_t)i * P2_THREADS + tid;
     if (idx < nt) {
       const uint32_t sb = sub_of(r[i].w);
-      sorted[loff[sb] + atomicAdd(&fill[sb], 1u)] = r[i];
+      sorted[loff[sb] + atomicAdd(&hist[sb], 1u)] = r[i];
     }
   }
   __syncthreads();
@@ -380,9 +404,10 @@ __global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int tiles_per_sub, i
     const uint4 rec = sorted[p];
     const uint32_t sb = sub_of(rec.w);
     const uint32_t dst = gbase[sb] + (p - loff[sb]);
-    const uint64_t leaf = ((uint64_t)b1 * NSUB + sb) >> 1;
-    const uint64_t cap = (sb & 1u) ? v.cap2c : v.cap2t;
-    const uint64_t at = leaf * (v.cap2c + v.cap2t) + ((sb & 1u) ? 0 : v.cap2c);
+    const uint64_t leaf = ((uint64_t)b1 * NSUB + sb) >> 2;
+    const uint32_t cls = sb & 3u;
+    const uint64_t cap = (cls == 3u) ? v.cap2c : v.cap2t;
+    const uint64_t at = leaf * (v.cap2c + 3 * v.cap2t) + ((cls == 3u) ? 0 : v.cap2c + cls * v.cap2t);
     if (dst < cap) v.rec2[at + dst] = rec;
     else spill_record(rec, k, canon != 0, t);
   }
@@ -544,9 +569,12 @@ __global__ __launch_bounds__(P3_THREADS) void msp_p3_kernel(int k, MspView v, Ta
   __shared__ unsigned long long wg_base;
   const int tid = threadIdx.x, lane = tid & 63;
   const uint32_t leaf = blockIdx.x;
-  const uint64_t n0 = min((uint64_t)v.cnt2[2 * leaf], v.cap2t);       // truncated runs
-  const uint64_t n1 = min((uint64_t)v.cnt2[2 * leaf + 1], v.cap2c);   // complete runs
-  const uint4 *leaf_rec = v.rec2 + (uint64_t)leaf * (v.cap2c + v.cap2t);
+  const uint64_t nt0 = min((uint64_t)v.cnt2[NCLS * leaf + 0], v.cap2t);   // truncated runs, n <= 4
+  const uint64_t nt1 = min((uint64_t)v.cnt2[NCLS * leaf + 1], v.cap2t);   //                 n <= 10
+  const uint64_t nt2 = min((uint64_t)v.cnt2[NCLS * leaf + 2], v.cap2t);   //                 n > 10
+  const uint64_t n1 = min((uint64_t)v.cnt2[NCLS * leaf + 3], v.cap2c);    // complete runs
+  const uint64_t n0 = nt0 + nt1 + nt2;
+  const uint4 *leaf_rec = v.rec2 + (uint64_t)leaf * (v.cap2c + 3 * v.cap2t);
   if (n0 + n1 == 0) return;
   for (int s = tid; s < TS; s += P3_THREADS) { keys[s] = CFRK_EMPTY_KEY; cnts[s] = 0; }
   for (int s = tid; s < RT; s += P3_THREADS) rtab[s] = make_uint4(0u, 0u, 0u, 0u);
@@ -595,16 +623,30 @@ __global__ __launch_bounds__(P3_THREADS) void msp_p3_kernel(int k, MspView v, Ta
   }
   __syncthreads();
   {
+    // index space: [record-table list | long | medium | short truncated], every segment padded
+    // to a multiple of 64 so that one wave never mixes segments
     const uint4 *src = leaf_rec + v.cap2c;
     const uint64_t nlist = nocc;
-    for (uint64_t i = tid; i < n0 + nlist; i += P3_THREADS) {
+    const uint64_t e0 = (nlist + 63) & ~63ull;
+    const uint64_t e1 = e0 + ((nt2 + 63) & ~63ull);
+    const uint64_t e2 = e1 + ((nt1 + 63) & ~63ull);
+    const uint64_t e3 = e2 + ((nt0 + 63) & ~63ull);
+    for (uint64_t i = tid; i < e3; i += P3_THREADS) {
       uint4 rec;
       uint32_t wgt = 1u;
-      if (i < nlist) {
+      if (i < e0) {
+        if (i >= nlist) continue;
         rec = rtab[occ_list[i]];
         wgt = rec.w >> 6;
+      } else if (i < e1) {
+        if (i - e0 >= nt2) continue;
+        rec = src[2 * v.cap2t + (i - e0)];
+      } else if (i < e2) {
+        if (i - e1 >= nt1) continue;
+        rec = src[v.cap2t + (i - e1)];
       } else {
-        rec = src[i - nlist];
+        if (i - e2 >= nt0) continue;
+        rec = src[i - e2];
       }
       count_record<CANON>(keys, cnts, rec, wgt, k, kmask, rcsh, t);
     }
@@ -728,7 +770,7 @@ __global__ void msp_info_kernel(MspView v, uint64_t *out) {
     atomicAdd(&tot1, (unsigned long long)v.cnt1[i]);
     atomicMax(&max1, (unsigned long long)v.cnt1[i]);
   }
-  for (int i = threadIdx.x; i < 2 * NLEAF; i += blockDim.x) {
+  for (int i = threadIdx.x; i < NCLS * NLEAF; i += blockDim.x) {
     atomicAdd(&tot2, (unsigned long long)v.cnt2[i]);
     atomicMax(&max2, (unsigned long long)v.cnt2[i]);
   }
@@ -795,7 +837,7 @@ int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
     msp_params(ctx->g_k, &W0, &m0);
     const double expect0 = (double)nN * (2.0 / (W0 + 1) + 1.0 / 64.0);
     const size_t need = (size_t)(expect0 * 1.35 * 16) + (size_t)B1 * NXG * 2048 * 16 +
-                        (size_t)(expect0 * 2.5 * 16) + (size_t)NLEAF * 192 * 16 + (size_t)ctx->g_cap * 12;
+                        (size_t)(expect0 * 3.0 * 16) + (size_t)NLEAF * 384 * 16 + (size_t)ctx->g_cap * 12;
     size_t have = ctx->pool[BUF_MSP_L1].cap + ctx->pool[BUF_MSP_L2].cap + ctx->pool[BUF_MSP_OUTK].cap +
                   ctx->pool[BUF_MSP_OUTC].cap;
     size_t free_b = 0, total_b = 0;
@@ -814,7 +856,7 @@ int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   const uint64_t cap1 = (uint64_t)(expect / (B1 * NXG) * 1.35) + 2048;   // per sub-region
   // per leaf: complete runs dominate at depth; truncated ones are ~2 per read plus invalid bases
   const uint64_t cap2c = (uint64_t)(expect / NLEAF * 1.8) + 96;
-  const uint64_t cap2t = (uint64_t)(expect / NLEAF * 0.7) + 96;
+  const uint64_t cap2t = (uint64_t)(expect / NLEAF * 0.4) + 96;     // each of the 3 length classes
   const int64_t tiles_per_sub = (int64_t)((cap1 + P2_TILE - 1) / P2_TILE);
   if (tiles_per_sub * B1 * NXG > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
 
@@ -822,11 +864,11 @@ int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   MspView &v = ms->view;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_L1, (size_t)B1 * NXG * cap1 * sizeof(uint4), &p))) return rc;
   v.rec1 = (uint4 *)p; v.cap1 = cap1;
-  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)NLEAF * (cap2c + cap2t) * sizeof(uint4), &p))) return rc;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)NLEAF * (cap2c + 3 * cap2t) * sizeof(uint4), &p))) return rc;
   v.rec2 = (uint4 *)p; v.cap2c = cap2c; v.cap2t = cap2t;
-  if ((rc = cfrk_pool_get(ctx, BUF_MSP_AUX, (size_t)NLEAF * 8 + (size_t)(B1 * NXG + 3 * NLEAF) * sizeof(uint32_t), &p))) return rc;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_AUX, (size_t)NLEAF * 8 + (size_t)(B1 * NXG + (NCLS + 1) * NLEAF) * sizeof(uint32_t), &p))) return rc;
   v.leaf_off = (uint64_t *)p;
-  v.cnt1 = (uint32_t *)(v.leaf_off + NLEAF); v.cnt2 = v.cnt1 + B1 * NXG; v.leaf_n = v.cnt2 + 2 * NLEAF;
+  v.cnt1 = (uint32_t *)(v.leaf_off + NLEAF); v.cnt2 = v.cnt1 + B1 * NXG; v.leaf_n = v.cnt2 + NCLS * NLEAF;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTK, (size_t)ctx->g_cap * 8, &p))) return rc;
   v.out_keys = (uint64_t *)p;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTC, (size_t)ctx->g_cap * 4, &p))) return rc;
@@ -834,7 +876,7 @@ int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   v.stats = ctx->g_stats;
   TableView t = cfrk_table_view(ctx);
 
-  HIP_TRY(ctx, hipMemsetAsync(v.cnt1, 0, (size_t)(B1 * NXG + 3 * NLEAF) * sizeof(uint32_t), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(v.cnt1, 0, (size_t)(B1 * NXG + (NCLS + 1) * NLEAF) * sizeof(uint32_t), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_CURSOR, 0, sizeof(uint64_t), ctx->stream));
 
   const int64_t nchunks = (nN + 31) / 32;
