@@ -50,7 +50,7 @@ constexpr int NXG = 8;
 constexpr int NLEAF = B1 * B2;
 
 constexpr int P1_THREADS = 512;
-constexpr int P1_RCAP = 2816;              // records staged in LDS per workgroup (expected ~1800 at W=18)
+constexpr int P1_RCAP = 2304;              // records staged in LDS per workgroup (expected ~1800 at W=18); 3 workgroups per CU
 
 constexpr int P2_THREADS = 512, P2_PER = 8, P2_TILE = P2_THREADS * P2_PER;
 
@@ -157,7 +157,7 @@ constexpr int P1_OWN = 61;                       // owner lanes per wave
 constexpr int P1_WAVES = P1_THREADS / 64;
 
 template <int W>
-__global__ __launch_bounds__(P1_THREADS) void msp_p1_kernel(const int8_t *__restrict__ data,
+__global__ __launch_bounds__(P1_THREADS, 6) void msp_p1_kernel(const int8_t *__restrict__ data,
                                                             int64_t nN, int k, int m, int canon,
                                                             MspView v, TableView t) {
   constexpr int NH = 32 + W - 1;                 // positions a lane looks at: its own 32 + W-1 ahead
@@ -297,9 +297,12 @@ __global__ __launch_bounds__(P1_THREADS) void msp_p1_kernel(const int8_t *__rest
   __syncthreads();
 
   // ---- C: one global reservation per non-empty bin; LDS offsets for a bin-sorted order ----
+  // The returning atomics are issued first and consumed last: their latency (microseconds under
+  // load) flies under the scan and the LDS permutation.
+  uint32_t my_base = 0;
   if (tid < B1) {
     const uint32_t c = hist[tid];
-    gbase[tid] = c ? atomicAdd(&v.cnt1[tid * NXG + (blockIdx.x & (NXG - 1))], c) : 0u;
+    if (c) my_base = atomicAdd(&v.cnt1[tid * NXG + (blockIdx.x & (NXG - 1))], c);
   }
   block_scan<B1>(hist, loff, wtot);
   const uint32_t nrec = min(nrec_s, (uint32_t)P1_RCAP);
@@ -307,6 +310,7 @@ __global__ __launch_bounds__(P1_THREADS) void msp_p1_kernel(const int8_t *__rest
     const uint32_t b = bin_tmp[s];
     perm[loff[b] + atomicAdd(&fill[b], 1u)] = (uint16_t)s;
   }
+  if (tid < B1) gbase[tid] = my_base;
   __syncthreads();
 
   // ---- D: copy out in bin order: consecutive lanes write consecutive 16-byte records ----
