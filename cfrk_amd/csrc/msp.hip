@@ -71,13 +71,10 @@ __device__ __forceinline__ uint32_t hash_mmer(uint32_t c) {
   uint32_t h = c * 0x9E3779B1u;
   return h ^ (h >> 16);
 }
-// minimizer hash -> leaf id (16 bits); re-mixed because the minimum of W hashes is skewed low
-__device__ __forceinline__ uint32_t leaf_of(uint32_t wmin) {
-  uint32_t x = wmin * 0x85EBCA77u;
-  x ^= x >> 15;
-  x *= 0xC2B2AE3Du;
-  return x >> 16;
-}
+// minimizer -> leaf id (16 bits).  The window minimum is skewed low in its TOP bits only (that is
+// what the comparison looks at); bits 7..22 of the winning hash stay uniform (simulated: same
+// leaf balance as a full re-mix), and bits 0..6 hold the position tag.
+__device__ __forceinline__ uint32_t leaf_of(uint32_t wmin) { return (wmin >> 7) & 0xFFFFu; }
 
 // count every k-mer of a record straight into the global HBM table
 __device__ __noinline__ void spill_record(uint4 rec, int k, bool canon, const TableView &t) {
@@ -262,7 +259,7 @@ __global__ __launch_bounds__(P1_THREADS, 6) void msp_p1_kernel(const int8_t *__r
     // this locus emits the same record
     const uint32_t pv = a ? ((V >> (32 - a)) & 1u) : prevV;
     const uint32_t complete = (pv & (uint32_t)(Vx >> (63 - (a + n))) & 1u) << 6;
-    const uint32_t leaf = leaf_of(pick32(H, a) & ~127u);
+    const uint32_t leaf = leaf_of(pick32(H, a));
     const uint32_t bin1 = leaf >> B2_LOG;
     uint4 rec;
     const uint64_t r01 = a ? ((hi << (2 * a)) | (mid >> (64 - 2 * a))) : hi;
