@@ -45,6 +45,7 @@ def exchange_by_owner(engine, world, device, wire_device=None):
     rlo = a2a(lo.view(torch.int64))
     rhi = a2a(hi.view(torch.int64)) if hi is not None else None
     rcnt = a2a(cnt.view(torch.int32))
+    _fence(device)
     return rlo, rhi, rcnt
 
 
@@ -79,7 +80,16 @@ def exchange_by_leaf(engine, world, device, wire_device=None):
     lc = leaf_counts.view(torch.int32).contiguous().to(wire)        # [world][leaves_per_part]
     rlc = torch.empty_like(lc)
     dist.all_to_all_single(rlc, lc)
-    return rkeys, rcnt, recv_l, rlc.to(device)
+    rlc = rlc.to(device)
+    _fence(device)
+    return rkeys, rcnt, recv_l, rlc
+
+
+def _fence(device):
+    """The collectives are ordered on torch's current stream; the counting library launches on
+    its own HIP stream.  Drain torch's stream before handing the received buffers over."""
+    if torch.device(device).type == "cuda":
+        torch.cuda.current_stream(torch.device(device)).synchronize()
 
 
 def merge_digests(local, device):
