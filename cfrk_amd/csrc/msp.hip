@@ -369,12 +369,14 @@ __global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int tiles_per_sub, i
     if (idx < nt) atomicAdd(&hist[sub_of(x.w)], 1u);
   }
   __syncthreads();
+  uint32_t g0 = 0, g1 = 0;
   {
     // per-stream reservation + exclusive scan of the 1024 sub-bin sizes (two per thread)
     const int lane = tid & 63, wave = tid >> 6;
     const uint32_t x0 = hist[2 * tid], x1 = hist[2 * tid + 1];
-    gbase[2 * tid] = x0 ? atomicAdd(&v.cnt2[b1 * NSUB + 2 * tid], x0) : 0u;
-    gbase[2 * tid + 1] = x1 ? atomicAdd(&v.cnt2[b1 * NSUB + 2 * tid + 1], x1) : 0u;
+    // returning atomics: issued here, consumed after the sort (their latency flies under it)
+    if (x0) g0 = atomicAdd(&v.cnt2[b1 * NSUB + 2 * tid], x0);
+    if (x1) g1 = atomicAdd(&v.cnt2[b1 * NSUB + 2 * tid + 1], x1);
     uint32_t incl = x0 + x1;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -399,6 +401,7 @@ __global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int tiles_per_sub, i
       sorted[loff[sb] + atomicAdd(&hist[sb], 1u)] = r[i];
     }
   }
+  gbase[2 * tid] = g0; gbase[2 * tid + 1] = g1;
   __syncthreads();
   // copy out: consecutive lanes -> consecutive records of the same stream
   for (uint32_t p = tid; p < nt; p += P2_THREADS) {
