@@ -52,7 +52,7 @@ constexpr int NLEAF = B1 * B2;
 constexpr int P1_THREADS = 512;
 constexpr int P1_RCAP = 2304;              // records staged in LDS per workgroup (expected ~1800 at W=18); 3 workgroups per CU
 
-constexpr int P2_THREADS = 512, P2_PER = 8, P2_TILE = P2_THREADS * P2_PER;
+constexpr int P2_THREADS = 1024, P2_PER = 4, P2_TILE = P2_THREADS * P2_PER;
 
 constexpr int P3_THREADS = 1024;
 constexpr int TS_LOG = 12, TS = 1 << TS_LOG;   // LDS table slots per leaf
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int tiles_per_sub, i
   __shared__ uint4 sorted[P2_TILE];
   __shared__ uint32_t hist[NSUB], loff[NSUB], gbase[NSUB];   // hist doubles as the fill cursor
   __shared__ uint32_t wtot[P2_THREADS / 64];
-  static_assert(NSUB == 2 * P2_THREADS, "the scan below gives every thread two sub-bins");
+  static_assert(NSUB == P2_THREADS, "the scan below gives every thread one sub-bin");
   const int tid = threadIdx.x;
   const uint32_t xg = blockIdx.x & (NXG - 1), seq = blockIdx.x / NXG;
   const uint32_t per_bin = (uint32_t)NXG * (uint32_t)tiles_per_sub;
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int tiles_per_sub, i
   const uint64_t r0 = (uint64_t)tile * P2_TILE;
   if (r0 >= n) return;
   const uint32_t nt = (uint32_t)min((uint64_t)P2_TILE, n - r0);
-  hist[2 * tid] = 0; hist[2 * tid + 1] = 0;
+  hist[tid] = 0;
   __syncthreads();
   const uint4 *src = v.rec1 + (uint64_t)reg * v.cap1 + r0;
   uint4 r[P2_PER];
@@ -369,15 +369,14 @@ __global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int tiles_per_sub, i
     if (idx < nt) atomicAdd(&hist[sub_of(x.w)], 1u);
   }
   __syncthreads();
-  uint32_t g0 = 0, g1 = 0;
+  uint32_t g0 = 0;
   {
-    // per-stream reservation + exclusive scan of the 1024 sub-bin sizes (two per thread)
+    // per-stream reservation + exclusive scan of the 1024 sub-bin sizes (one per thread)
     const int lane = tid & 63, wave = tid >> 6;
-    const uint32_t x0 = hist[2 * tid], x1 = hist[2 * tid + 1];
-    // returning atomics: issued here, consumed after the sort (their latency flies under it)
-    if (x0) g0 = atomicAdd(&v.cnt2[b1 * NSUB + 2 * tid], x0);
-    if (x1) g1 = atomicAdd(&v.cnt2[b1 * NSUB + 2 * tid + 1], x1);
-    uint32_t incl = x0 + x1;
+    const uint32_t x0 = hist[tid];
+    // returning atomic: issued here, consumed after the sort (its latency flies under it)
+    if (x0) g0 = atomicAdd(&v.cnt2[b1 * NSUB + tid], x0);
+    uint32_t incl = x0;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
       const uint32_t y = __shfl_up(incl, d);
@@ -387,9 +386,8 @@ __global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int tiles_per_sub, i
     __syncthreads();
     uint32_t base = 0;
     for (int w = 0; w < wave; ++w) base += wtot[w];
-    loff[2 * tid] = base + incl - x0 - x1;
-    loff[2 * tid + 1] = base + incl - x1;
-    hist[2 * tid] = 0; hist[2 * tid + 1] = 0;             // from here on: fill cursors
+    loff[tid] = base + incl - x0;
+    hist[tid] = 0;                                         // from here on: fill cursor
     __syncthreads();
   }
   // counting sort of the tile by sub-bin, in LDS
@@ -401,7 +399,7 @@ __global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int tiles_per_sub, i
       sorted[loff[sb] + atomicAdd(&hist[sb], 1u)] = r[i];
     }
   }
-  gbase[2 * tid] = g0; gbase[2 * tid + 1] = g1;
+  gbase[tid] = g0;
   __syncthreads();
   // copy out: consecutive lanes -> consecutive records of the same stream
   for (uint32_t p = tid; p < nt; p += P2_THREADS) {
