@@ -158,7 +158,7 @@ __global__ __launch_bounds__(P1_THREADS, 6) void msp_p1_kernel(const int8_t *__r
                                                             int64_t nN, int k, int m, int canon,
                                                             MspView v, TableView t) {
   constexpr int NH = 32 + W - 1;                 // positions a lane looks at: its own 32 + W-1 ahead
-  constexpr int P = (W >= 16) ? 16 : (W >= 8) ? 8 : 4;
+  constexpr int P = (W >= 16) ? 16 : (W >= 8) ? 8 : (W >= 4) ? 4 : 2;
   __shared__ uint4 rec_tmp[P1_RCAP];
   __shared__ uint16_t perm[P1_RCAP];
   __shared__ uint8_t bin_tmp[P1_RCAP];
@@ -188,12 +188,22 @@ __global__ __launch_bounds__(P1_THREADS, 6) void msp_p1_kernel(const int8_t *__r
   // Vx bit(63-p): the k-mer starting at position p (0..63 relative to this chunk) has k valid
   // bases; only p <= 31 + W - 1 is used
   uint64_t Yh = ((uint64_t)bad << 32) | nbad, Yl = (uint64_t)nnbad << 32;
+  {
+    // OR over the k bases starting at each position: doubling, then one closing step
+    int w = 1;
 #pragma unroll
-  for (int sft = 1; sft <= 8; sft <<= 1) {                    // OR over the 16 following bases
-    Yh |= (Yh << sft) | (Yl >> (64 - sft));
-    Yl |= Yl << sft;
+    for (int st = 0; st < 5; ++st) {
+      if (2 * w <= k) {
+        Yh |= (Yh << w) | (Yl >> (64 - w));
+        Yl |= Yl << w;
+        w *= 2;
+      }
+    }
+    if (k > w) {
+      Yh |= (Yh << (k - w)) | (Yl >> (64 - (k - w)));
+      Yl |= Yl << (k - w);
+    }
   }
-  if (k > 16) { Yh |= (Yh << (k - 16)) | (Yl >> (64 - (k - 16))); }
   const uint64_t Vx = ~Yh;
   const uint32_t V = (uint32_t)(Vx >> 32);
   const uint32_t prevV = __shfl_up(V, 1) & 1u;                // validity of position -1
@@ -820,10 +830,12 @@ void cfrk_msp_destroy(cfrk_ctx *ctx) {
 }
 
 static void msp_params(int k, int *W, int *m) {
-  // m = k - W + 1 stays in 11..16 (32-bit m-mers) and >= 13 wherever k allows: with too few
-  // distinct minimizers the leaves get lumpy (several genome loci share one minimizer value)
-  // W never exceeds what a 48-base record holds (48 - k + 1 k-mers): k = 32 -> W = 17
-  if (k == 32) *W = 17; else if (k >= 30) *W = 18; else if (k >= 26) *W = 14; else if (k >= 22) *W = 10; else *W = 6;
+  // The longer the window, the longer the runs (fewer, fuller records): W = k - 12 keeps
+  // m = k - W + 1 = 13, the smallest m-mer whose canonical values (3.4e7) rarely repeat across
+  // the loci of a genome -- with fewer distinct minimizers the leaves get lumpy (m = 11 gave a
+  // 10x heavier leaf, m = 12 2.3x).  W is capped by what a 48-base record holds (49 - k k-mers),
+  // which raises m to 14 / 16 for k = 31 / 32.
+  *W = std::min(k - 12, 49 - k);
   *m = k - *W + 1;
 }
 
@@ -839,7 +851,7 @@ int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
     msp_params(ctx->g_k, &W0, &m0);
     const double expect0 = (double)nN * (2.0 / (W0 + 1) + 1.0 / 64.0);
     const size_t need = (size_t)(expect0 * 1.35 * 16) + (size_t)B1 * NXG * 2048 * 16 +
-                        (size_t)(expect0 * 3.0 * 16) + (size_t)NLEAF * 384 * 16 + (size_t)ctx->g_cap * 12;
+                        (size_t)(expect0 * 3.3 * 16) + (size_t)NLEAF * 384 * 16 + (size_t)ctx->g_cap * 12;
     size_t have = ctx->pool[BUF_MSP_L1].cap + ctx->pool[BUF_MSP_L2].cap + ctx->pool[BUF_MSP_OUTK].cap +
                   ctx->pool[BUF_MSP_OUTC].cap;
     size_t free_b = 0, total_b = 0;
@@ -857,7 +869,7 @@ int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   const double expect = (double)nN * dens;
   const uint64_t cap1 = (uint64_t)(expect / (B1 * NXG) * 1.35) + 2048;   // per sub-region
   // per leaf: complete runs dominate at depth; truncated ones are ~2 per read plus invalid bases
-  const uint64_t cap2c = (uint64_t)(expect / NLEAF * 1.8) + 96;
+  const uint64_t cap2c = (uint64_t)(expect / NLEAF * 2.1) + 96;
   const uint64_t cap2t = (uint64_t)(expect / NLEAF * 0.4) + 96;     // each of the 3 length classes
   const int64_t tiles_per_sub = (int64_t)((cap1 + P2_TILE - 1) / P2_TILE);
   if (tiles_per_sub * B1 * NXG > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
@@ -886,13 +898,15 @@ int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   const int64_t ntiles = (nwaves + P1_WAVES - 1) / P1_WAVES;
   if (ntiles > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
   const dim3 g1((unsigned)ntiles), b1(P1_THREADS);
+#define CFRK_P1_CASE(WW) \
+  case WW: hipLaunchKernelGGL((msp_p1_kernel<WW>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, v, t); break;
   switch (W) {
-    case 18: hipLaunchKernelGGL((msp_p1_kernel<18>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, v, t); break;
-    case 17: hipLaunchKernelGGL((msp_p1_kernel<17>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, v, t); break;
-    case 14: hipLaunchKernelGGL((msp_p1_kernel<14>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, v, t); break;
-    case 10: hipLaunchKernelGGL((msp_p1_kernel<10>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, v, t); break;
-    default: hipLaunchKernelGGL((msp_p1_kernel<6>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, v, t); break;
+    CFRK_P1_CASE(4) CFRK_P1_CASE(5) CFRK_P1_CASE(6) CFRK_P1_CASE(7) CFRK_P1_CASE(8) CFRK_P1_CASE(9)
+    CFRK_P1_CASE(10) CFRK_P1_CASE(11) CFRK_P1_CASE(12) CFRK_P1_CASE(13) CFRK_P1_CASE(14)
+    CFRK_P1_CASE(15) CFRK_P1_CASE(16) CFRK_P1_CASE(17) CFRK_P1_CASE(18)
+    default: return cfrk_fail(ctx, CFRK_ERR_ARG, "no partition kernel for W=%d", W);
   }
+#undef CFRK_P1_CASE
   HIP_TRY(ctx, hipGetLastError());
   hipLaunchKernelGGL(msp_p2_kernel, dim3((unsigned)(tiles_per_sub * B1 * NXG)), dim3(P2_THREADS), 0, ctx->stream,
                      (int)tiles_per_sub, k, canon, v, t);
