@@ -37,13 +37,6 @@ int cfrk_pool_get(cfrk_ctx *ctx, int slot, size_t bytes, void **out) {
   return CFRK_OK;
 }
 
-static int pool_release(cfrk_ctx *ctx, int slot) {
-  cfrk_buf &b = ctx->pool[slot];
-  if (b.p) { HIP_TRY(ctx, hipFree(b.p)); }
-  b.p = nullptr; b.cap = 0;
-  return CFRK_OK;
-}
-
 extern "C" {
 
 int cfrk_abi_version(void) { return CFRK_ABI_VERSION; }
@@ -124,6 +117,8 @@ void cfrk_ctx_destroy(cfrk_ctx *ctx) {
     if (ctx->pool[i].p) hipFree(ctx->pool[i].p);
   if (ctx->pinned) hipHostFree(ctx->pinned);
   if (ctx->g_stats) hipFree(ctx->g_stats);
+  if (ctx->stage_ev[0]) hipEventDestroy(ctx->stage_ev[0]);
+  if (ctx->stage_ev[1]) hipEventDestroy(ctx->stage_ev[1]);
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);
   if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
@@ -313,9 +308,11 @@ int cfrk_global_add(cfrk_ctx *ctx, const int8_t *data, const int64_t *start, con
     HIP_TRY(ctx, hipHostMalloc(&ctx->pinned, 2 * chunk, hipHostMallocDefault));
     ctx->pinned_cap = 2 * chunk;
   }
-  hipEvent_t done[2];
-  HIP_TRY(ctx, hipEventCreateWithFlags(&done[0], hipEventDisableTiming));
-  HIP_TRY(ctx, hipEventCreateWithFlags(&done[1], hipEventDisableTiming));
+  if (!ctx->stage_ev[0]) {
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->stage_ev[0], hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->stage_ev[1], hipEventDisableTiming));
+  }
+  hipEvent_t *done = ctx->stage_ev;
   bool used[2] = {false, false};
   int which = 0;
   for (size_t off = 0; off < (size_t)nN; off += chunk, which ^= 1) {
@@ -327,10 +324,7 @@ int cfrk_global_add(cfrk_ctx *ctx, const int8_t *data, const int64_t *start, con
     HIP_TRY(ctx, hipEventRecord(done[which], ctx->stream));
     used[which] = true;
   }
-  rc = cfrk_global_add_device(ctx, (const int8_t *)d_data, nN);
-  hipEventDestroy(done[0]);
-  hipEventDestroy(done[1]);
-  return rc;
+  return cfrk_global_add_device(ctx, (const int8_t *)d_data, nN);
 }
 
 int cfrk_global_merge_device(cfrk_ctx *ctx, const uint64_t *d_lo, const uint64_t *d_hi,

@@ -44,6 +44,7 @@ struct cfrk_ctx {
   uint64_t *g_stats;     // device, ST_NWORDS
   hipEvent_t ev0, ev1;
   bool ev_valid;
+  hipEvent_t stage_ev[2];   // H2D staging (cfrk_global_add)
   // minimizer-partitioned fast path (msp.hip)
   struct cfrk_msp *msp;
 };

@@ -87,6 +87,29 @@ def test_dense_chunk_of_8192_reads_k4(ctx):
     assert (got == want).all()
 
 
+def test_dense_device_resident_variant(ctx):
+    """cfrk_per_read_dense_device: same result with every buffer already on the device"""
+    import ctypes as C
+    import cfrk_amd
+    rng = np.random.default_rng(9)
+    reads = _random_reads(rng, 500, 1, 300)
+    data, start, length = refsem.flatten(reads)
+    for k, compat in ((3, True), (6, False), (8, True)):
+        want = orc.per_read_dense(data, start, length, k, orc.ORC_COMPAT if compat else 0)
+        dd, ds, dl = ctx.alloc(len(data) + 64), ctx.alloc(len(start) * 8), ctx.alloc(len(length) * 4)
+        df = ctx.alloc(want.size * 4)
+        ctx.h2d(dd, data); ctx.h2d(ds, start); ctx.h2d(dl, length)
+        ctx.check(ctx._L.cfrk_per_read_dense_device(ctx._h, C.c_void_p(dd), C.c_void_p(ds), C.c_void_p(dl),
+                                                    len(data), len(length), k,
+                                                    cfrk_amd.CFRK_COMPAT if compat else 0, C.c_void_p(df)),
+                  "cfrk_per_read_dense_device")
+        got = np.empty(want.size, np.int32)
+        ctx.d2h(got, df)
+        assert (got.reshape(want.shape) == want).all()
+        for p in (dd, ds, dl, df):
+            ctx.free(p)
+
+
 def test_dense_errors(ctx):
     import cfrk_amd
     data, start, length = refsem.flatten([np.array([0, 1, 2, 3], np.int8)])
