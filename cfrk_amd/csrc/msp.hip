@@ -259,6 +259,22 @@ __global__ __launch_bounds__(P1_THREADS, 6) void msp_p1_kernel(const int8_t *__r
   if (!owner) S = 0;
 
   // ---- B: one 16-byte record per run, staged in LDS ----
+  // Staging slots: the lane's run count is known (popcount of S), so one wave-level prefix sum
+  // and ONE LDS atomic per wave hand out all slots (an atomic per loop trip would put an LDS
+  // round trip on the critical path of every trip).
+  uint32_t slot;
+  {
+    const uint32_t mine = (uint32_t)__popc(S);
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t y = __shfl_up(incl, d);
+      if (lane >= d) incl += y;
+    }
+    uint32_t wbase = 0;
+    if (lane == 63 && incl) wbase = atomicAdd(&nrec_s, incl);
+    slot = __shfl(wbase, 63) + incl - mine;
+  }
   while (S) {
     const int a = __clz(S);
     S &= ~(0x80000000u >> a);
@@ -283,12 +299,6 @@ __global__ __launch_bounds__(P1_THREADS, 6) void msp_p1_kernel(const int8_t *__r
     rec.z = (uint32_t)r12;
     rec.w = (leaf << 8) | complete | (uint32_t)(n - 1);
 
-    const unsigned long long act = __ballot(1);
-    const int leader = __ffsll(act) - 1;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(&nrec_s, (uint32_t)__popcll(act));
-    base = __shfl(base, leader);
-    const uint32_t slot = base + (uint32_t)__popcll(act & ((1ull << lane) - 1ull));
     if (slot < (uint32_t)P1_RCAP) {
       rec_tmp[slot] = rec;
       bin_tmp[slot] = (uint8_t)bin1;
@@ -300,6 +310,7 @@ __global__ __launch_bounds__(P1_THREADS, 6) void msp_p1_kernel(const int8_t *__r
       if (dst < v.cap1) v.rec1[(uint64_t)reg * v.cap1 + dst] = rec;
       else spill_record(rec, k, canon != 0, t);
     }
+    ++slot;
   }
   __syncthreads();
 
