@@ -35,6 +35,9 @@ def parse():
                    help="gloo: rehearsal mode -- collectives staged through host memory, every "
                         "rank may sit on the same GPU (--same-gpu)")
     p.add_argument("--same-gpu", action="store_true", help="all ranks use cuda:0 (rehearsal)")
+    p.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                   help="strong (default, BASELINE configs[3]): the --reads reads are split over the "
+                        "GPUs; weak: every GPU gets --reads reads of the same genome")
     p.add_argument("--owner-hash", action="store_true",
                    help="force the generic hash-owner exchange + HBM-table merge")
     return p.parse_args()
@@ -95,8 +98,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    R, L, k = args.reads, args.L, args.k
-    glen = args.glen or R
+    L, k = args.L, args.k
+    glen = args.glen or args.reads
+    R = args.reads * world if args.scaling == "weak" else args.reads   # total reads of the job
     flags = 0 if args.no_canonical else cfrk_amd.CFRK_CANONICAL
     r0, r1 = sharded.shard_range(R, rank, world)       # strong scaling: the R reads are split
     Rl = r1 - r0
@@ -204,7 +208,7 @@ def main():
         out = {
             "metric": "k-mers/sec", "value": kmers_total * args.steps / dt, "unit": "k-mers/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"{R} synthetic {L} bp reads, k={k}, "
                                    f"{'canonical' if flags else 'forward'}, genome {glen} "

@@ -105,6 +105,7 @@ static void global_release(cfrk_ctx *ctx) {
   ctx->g_counts = nullptr;
   ctx->g_cap = 0;
   ctx->g_active = false;
+  ctx->g_table_cleared = false;
 }
 
 void cfrk_ctx_destroy(cfrk_ctx *ctx) {
@@ -220,6 +221,14 @@ int cfrk_global_begin(cfrk_ctx *ctx, int k, int flags, uint64_t capacity_hint) {
   if (k < 1 || k > 64) return cfrk_fail(ctx, CFRK_ERR_ARG, "k=%d outside 1..64", k);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  // Was the HBM table left untouched by the previous job (the partitioned path only writes it
+  // on spill)?  Then it is still all-empty and the 12 B/slot clear below can be skipped.
+  bool table_clean = false;
+  if (ctx->g_table_cleared && !cfrk_msp_table_written(ctx)) {
+    uint64_t st[ST_NWORDS];
+    HIP_TRY(ctx, hipMemcpy(st, ctx->g_stats, sizeof st, hipMemcpyDeviceToHost));
+    table_clean = st[ST_SPILLED] == 0;
+  }
   cfrk_msp_reset(ctx);
   if (capacity_hint == 0) capacity_hint = 1ull << 24;
   // distinct keys cannot exceed 4^k
@@ -234,14 +243,19 @@ int cfrk_global_begin(cfrk_ctx *ctx, int k, int flags, uint64_t capacity_hint) {
     if (two) HIP_TRY(ctx, hipMalloc((void **)&ctx->g_keys_hi, cap * 8));
     HIP_TRY(ctx, hipMalloc((void **)&ctx->g_counts, cap * 4));
     ctx->g_cap = cap;
+    table_clean = false;
   }
+  if (two != ctx->g_two) table_clean = false;
   ctx->g_log2cap = lg;
   ctx->g_k = k;
   ctx->g_flags = flags;
   ctx->g_two = two;
   // one-word: empty = all-ones key.  two-word: the COUNT word is the slot state (0 = empty).
-  if (!two) HIP_TRY(ctx, hipMemsetAsync(ctx->g_keys_lo, 0xFF, cap * 8, ctx->stream));
-  HIP_TRY(ctx, hipMemsetAsync(ctx->g_counts, 0, cap * 4, ctx->stream));
+  if (!table_clean) {
+    if (!two) HIP_TRY(ctx, hipMemsetAsync(ctx->g_keys_lo, 0xFF, cap * 8, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->g_counts, 0, cap * 4, ctx->stream));
+  }
+  ctx->g_table_cleared = true;
   HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats, 0, ST_NWORDS * 8, ctx->stream));
   ctx->g_active = true;
   ctx->ev_valid = false;

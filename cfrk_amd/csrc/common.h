@@ -42,6 +42,7 @@ struct cfrk_ctx {
   uint64_t *g_keys_lo, *g_keys_hi;
   uint32_t *g_counts;
   uint64_t *g_stats;     // device, ST_NWORDS
+  bool g_table_cleared;  // the table was cleared by the last begin()
   hipEvent_t ev0, ev1;
   bool ev_valid;
   hipEvent_t stage_ev[2];   // H2D staging (cfrk_global_add)

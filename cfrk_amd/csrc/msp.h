@@ -13,6 +13,7 @@ int  cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN);
 int  cfrk_msp_resolve(cfrk_ctx *ctx, ResultSrc *src, bool *use_list);
 int  cfrk_msp_flush_to_table(cfrk_ctx *ctx);               // fold a pending list into the table
 void cfrk_msp_note_table_write(cfrk_ctx *ctx);             // table now holds counts of its own
+bool cfrk_msp_table_written(const cfrk_ctx *ctx);          // ... since the last begin()?
 void cfrk_msp_reset(cfrk_ctx *ctx);
 void cfrk_msp_destroy(cfrk_ctx *ctx);
 

@@ -835,6 +835,11 @@ void cfrk_msp_note_table_write(cfrk_ctx *ctx) {
   if (m) m->table_dirty = true;
 }
 
+bool cfrk_msp_table_written(const cfrk_ctx *ctx) {
+  // without msp state nobody tracked the writes: assume written
+  return !ctx->msp || ctx->msp->table_dirty;
+}
+
 void cfrk_msp_destroy(cfrk_ctx *ctx) {
   delete ctx->msp;
   ctx->msp = nullptr;
