@@ -89,7 +89,8 @@ int cfrk_ctx_create(int device, void *hip_stream, cfrk_ctx **out) {
     ctx->own_stream = true;
   }
   if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
-      hipMalloc((void **)&ctx->g_stats, ST_NWORDS * sizeof(uint64_t)) != hipSuccess) {
+      hipMalloc((void **)&ctx->g_stats, ST_NWORDS * sizeof(uint64_t)) != hipSuccess ||
+      hipHostMalloc((void **)&ctx->h_stats, ST_NWORDS * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) {
     cfrk_ctx_destroy(ctx);
     return CFRK_ERR_HIP;
   }
@@ -118,6 +119,7 @@ void cfrk_ctx_destroy(cfrk_ctx *ctx) {
     if (ctx->pool[i].p) hipFree(ctx->pool[i].p);
   if (ctx->pinned) hipHostFree(ctx->pinned);
   if (ctx->g_stats) hipFree(ctx->g_stats);
+  if (ctx->h_stats) hipHostFree(ctx->h_stats);
   if (ctx->stage_ev[0]) hipEventDestroy(ctx->stage_ev[0]);
   if (ctx->stage_ev[1]) hipEventDestroy(ctx->stage_ev[1]);
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
@@ -223,12 +225,11 @@ int cfrk_global_begin(cfrk_ctx *ctx, int k, int flags, uint64_t capacity_hint) {
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   // Was the HBM table left untouched by the previous job (the partitioned path only writes it
   // on spill)?  Then it is still all-empty and the 12 B/slot clear below can be skipped.
-  bool table_clean = false;
-  if (ctx->g_table_cleared && !cfrk_msp_table_written(ctx)) {
-    uint64_t st[ST_NWORDS];
-    HIP_TRY(ctx, hipMemcpy(st, ctx->g_stats, sizeof st, hipMemcpyDeviceToHost));
-    table_clean = st[ST_SPILLED] == 0;
-  }
+  // (h_stats = pinned snapshot of the device flags, copied at the end of the last add.)
+  const bool table_clean_prev = ctx->g_table_cleared && !cfrk_msp_table_written(ctx) &&
+                                ctx->h_stats_valid && ctx->h_stats[ST_SPILLED] == 0;
+  bool table_clean = table_clean_prev;
+  ctx->h_stats_valid = false;
   cfrk_msp_reset(ctx);
   if (capacity_hint == 0) capacity_hint = 1ull << 24;
   // distinct keys cannot exceed 4^k
@@ -286,6 +287,9 @@ int cfrk_global_add_device(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   if (rc) return rc;
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   ctx->ev_valid = true;
+  // snapshot of the flags for the next begin(); lands before its stream synchronisation
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_stats, ctx->g_stats, ST_NWORDS * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  ctx->h_stats_valid = true;
   return CFRK_OK;
 }
 

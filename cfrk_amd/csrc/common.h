@@ -43,6 +43,8 @@ struct cfrk_ctx {
   uint32_t *g_counts;
   uint64_t *g_stats;     // device, ST_NWORDS
   bool g_table_cleared;  // the table was cleared by the last begin()
+  uint64_t *h_stats;     // pinned host snapshot of g_stats taken at the end of the last add
+  bool h_stats_valid;
   hipEvent_t ev0, ev1;
   bool ev_valid;
   hipEvent_t stage_ev[2];   // H2D staging (cfrk_global_add)

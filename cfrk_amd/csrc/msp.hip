@@ -870,10 +870,12 @@ int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
                         (size_t)(expect0 * 3.3 * 16) + (size_t)NLEAF * 384 * 16 + (size_t)ctx->g_cap * 12;
     size_t have = ctx->pool[BUF_MSP_L1].cap + ctx->pool[BUF_MSP_L2].cap + ctx->pool[BUF_MSP_OUTK].cap +
                   ctx->pool[BUF_MSP_OUTC].cap;
-    size_t free_b = 0, total_b = 0;
-    HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
-    if (need > have + free_b)
-      return cfrk_fail(ctx, CFRK_ERR_NOMEM, "partitioned path needs %zu B, %zu B available", need, have + free_b);
+    if (need > have) {       // only ask the driver when the pool has to grow
+      size_t free_b = 0, total_b = 0;
+      HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+      if (need > have + free_b)
+        return cfrk_fail(ctx, CFRK_ERR_NOMEM, "partitioned path needs %zu B, %zu B available", need, have + free_b);
+    }
   }
   const int k = ctx->g_k;
   int W, m;
@@ -1082,6 +1084,7 @@ extern "C" int cfrk_global_merge_leaves_device(cfrk_ctx *ctx, const uint64_t *d_
     HIP_TRY(ctx, hipGetLastError());
   }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // so / sn are host temporaries
+  ctx->h_stats_valid = false;                          // this kernel may have spilled into the table
   ms->pending = true;
   ms->list_n_valid = false;
   return CFRK_OK;
