@@ -18,3 +18,30 @@ void cfrk_msp_reset(cfrk_ctx *ctx);
 void cfrk_msp_destroy(cfrk_ctx *ctx);
 
 TableView cfrk_table_view(const cfrk_ctx *ctx);
+
+// device-side view of the partitioned path's buffers (msp.hip) and of the result list that
+// msp.hip and radix.hip both produce
+struct MspView {
+  uint4 *rec1; uint32_t *cnt1; uint64_t cap1;   // B1 x NXG sub-regions of cap1 records each
+  uint4 *rec2; uint32_t *cnt2; uint64_t cap2c, cap2t;   // per leaf: complete stream (cap2c), then 3 truncated length classes (cap2t each)
+  uint64_t *out_keys; uint32_t *out_cnt; uint64_t out_cap;
+  uint64_t *leaf_off; uint32_t *leaf_n;        // where each leaf's entries sit in the result list
+  uint64_t *stats;
+};
+
+struct cfrk_msp {
+  bool leaf_form;      // the list is grouped by minimizer leaf (msp.hip); false for radix.hip
+  bool pending;        // a leaf-output list exists that has not been folded into the table
+  bool table_dirty;    // the table holds counts of its own since begin()
+  uint64_t list_n;     // entries in the list (valid after resolve)
+  bool list_n_valid;
+  MspView view;
+};
+
+cfrk_msp *cfrk_msp_get(cfrk_ctx *ctx);
+int cfrk_msp_sync_stats(cfrk_ctx *ctx, uint64_t st[ST_NWORDS]);
+
+// radix.hip: k <= 15
+bool cfrk_radix_usable(const cfrk_ctx *ctx);
+int  cfrk_radix_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN);
+

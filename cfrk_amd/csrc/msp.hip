@@ -58,14 +58,6 @@ constexpr int P3_THREADS = 1024;
 constexpr int TS_LOG = 12, TS = 1 << TS_LOG;   // LDS table slots per leaf
 constexpr int P3_PROBE_LIMIT = 48;      // buckets probed before a key is counted in HBM instead
 
-struct MspView {
-  uint4 *rec1; uint32_t *cnt1; uint64_t cap1;   // B1 x NXG sub-regions of cap1 records each
-  uint4 *rec2; uint32_t *cnt2; uint64_t cap2c, cap2t;   // per leaf: complete stream (cap2c), then 3 truncated length classes (cap2t each)
-  uint64_t *out_keys; uint32_t *out_cnt; uint64_t out_cap;
-  uint64_t *leaf_off; uint32_t *leaf_n;        // where each leaf's entries sit in the result list
-  uint64_t *stats;
-};
-
 // ordering hash of a canonical m-mer (bijective: odd multiplier, xorshift)
 __device__ __forceinline__ uint32_t hash_mmer(uint32_t c) {
   uint32_t h = c * 0x9E3779B1u;
@@ -806,15 +798,7 @@ __global__ void msp_info_kernel(MspView v, uint64_t *out) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------ host
-struct cfrk_msp {
-  bool pending;        // a leaf-output list exists that has not been folded into the table
-  bool table_dirty;    // the table holds counts of its own since begin()
-  uint64_t list_n;     // entries in the list (valid after resolve)
-  bool list_n_valid;
-  MspView view;
-};
-
-static cfrk_msp *msp_get(cfrk_ctx *ctx) {
+cfrk_msp *cfrk_msp_get(cfrk_ctx *ctx) {
   if (!ctx->msp) {
     ctx->msp = new (std::nothrow) cfrk_msp();
     if (ctx->msp) memset(ctx->msp, 0, sizeof(cfrk_msp));
@@ -831,7 +815,7 @@ void cfrk_msp_reset(cfrk_ctx *ctx) {
 }
 
 void cfrk_msp_note_table_write(cfrk_ctx *ctx) {
-  cfrk_msp *m = msp_get(ctx);
+  cfrk_msp *m = cfrk_msp_get(ctx);
   if (m) m->table_dirty = true;
 }
 
@@ -856,7 +840,7 @@ static void msp_params(int k, int *W, int *m) {
 }
 
 int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
-  cfrk_msp *ms = msp_get(ctx);
+  cfrk_msp *ms = cfrk_msp_get(ctx);
   if (!ms) return cfrk_fail(ctx, CFRK_ERR_NOMEM, "host allocation failed");
   int rc;
   if (ms->pending && (rc = cfrk_msp_flush_to_table(ctx))) return rc;
@@ -933,11 +917,12 @@ int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   else hipLaunchKernelGGL((msp_p3_kernel<false>), dim3(NLEAF), dim3(P3_THREADS), 0, ctx->stream, k, v, t);
   HIP_TRY(ctx, hipGetLastError());
   ms->pending = true;
+  ms->leaf_form = true;
   ms->list_n_valid = false;
   return CFRK_OK;
 }
 
-static int msp_sync_stats(cfrk_ctx *ctx, uint64_t st[ST_NWORDS]) {
+int cfrk_msp_sync_stats(cfrk_ctx *ctx, uint64_t st[ST_NWORDS]) {
   HIP_TRY(ctx, hipMemcpyAsync(st, ctx->g_stats, ST_NWORDS * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return CFRK_OK;
@@ -947,7 +932,7 @@ int cfrk_msp_flush_to_table(cfrk_ctx *ctx) {
   cfrk_msp *ms = ctx->msp;
   if (!ms || !ms->pending) return CFRK_OK;
   uint64_t st[ST_NWORDS];
-  int rc = msp_sync_stats(ctx, st);
+  int rc = cfrk_msp_sync_stats(ctx, st);
   if (rc) return rc;
   if (st[ST_OVERFLOW]) return cfrk_fail(ctx, CFRK_ERR_TABLE_FULL, "result list of %llu entries overflowed", (unsigned long long)ms->view.out_cap);
   const uint64_t n = st[ST_CURSOR];
@@ -962,7 +947,7 @@ int cfrk_msp_resolve(cfrk_ctx *ctx, ResultSrc *src, bool *use_list) {
   cfrk_msp *ms = ctx->msp;
   if (!ms || !ms->pending) return CFRK_OK;
   uint64_t st[ST_NWORDS];
-  int rc = msp_sync_stats(ctx, st);
+  int rc = cfrk_msp_sync_stats(ctx, st);
   if (rc) return rc;
   if (st[ST_OVERFLOW]) return cfrk_fail(ctx, CFRK_ERR_TABLE_FULL, "result list of %llu entries overflowed", (unsigned long long)ms->view.out_cap);
   if (st[ST_SPILLED] || ms->table_dirty) return cfrk_msp_flush_to_table(ctx);
@@ -987,7 +972,7 @@ extern "C" int cfrk_debug_msp_info(cfrk_ctx *ctx, uint64_t out[9]) {
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(out, p, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
   uint64_t st[ST_NWORDS];
-  rc = msp_sync_stats(ctx, st);
+  rc = cfrk_msp_sync_stats(ctx, st);
   if (rc) return rc;
   out[6] = st[ST_AUX0]; out[7] = st[ST_AUX1]; out[8] = st[ST_CURSOR];
   return CFRK_OK;
@@ -999,11 +984,11 @@ extern "C" int cfrk_global_export_leaves_device(cfrk_ctx *ctx, uint64_t *d_keys,
                                                 uint32_t *d_leaf_counts) {
   if (!ctx || !part_counts || parts < 1 || parts > NLEAF) return CFRK_ERR_ARG;
   cfrk_msp *ms = ctx->msp;
-  if (!ctx->g_active || !ms || !ms->pending || ms->table_dirty)
+  if (!ctx->g_active || !ms || !ms->pending || !ms->leaf_form || ms->table_dirty)
     return cfrk_fail(ctx, CFRK_ERR_STATE, "result is not in per-leaf list form");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   uint64_t st[ST_NWORDS];
-  int rc = msp_sync_stats(ctx, st);
+  int rc = cfrk_msp_sync_stats(ctx, st);
   if (rc) return rc;
   if (st[ST_OVERFLOW]) return cfrk_fail(ctx, CFRK_ERR_TABLE_FULL, "result list overflowed");
   if (st[ST_SPILLED] || st[ST_ONES]) return cfrk_fail(ctx, CFRK_ERR_STATE, "part of the result lives in the HBM table");
@@ -1046,7 +1031,7 @@ extern "C" int cfrk_global_merge_leaves_device(cfrk_ctx *ctx, const uint64_t *d_
                                                int parts) {
   if (!ctx || parts < 1 || parts > NLEAF || !recv_counts || !d_leaf_counts) return CFRK_ERR_ARG;
   if (!ctx->g_active || ctx->g_two) return cfrk_fail(ctx, CFRK_ERR_STATE, "merge_leaves needs an active one-word job");
-  cfrk_msp *ms = msp_get(ctx);
+  cfrk_msp *ms = cfrk_msp_get(ctx);
   if (!ms) return cfrk_fail(ctx, CFRK_ERR_NOMEM, "host allocation failed");
   if (ms->pending || ms->table_dirty) return cfrk_fail(ctx, CFRK_ERR_STATE, "merge_leaves needs an empty job (call cfrk_global_begin first)");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1086,6 +1071,7 @@ extern "C" int cfrk_global_merge_leaves_device(cfrk_ctx *ctx, const uint64_t *d_
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // so / sn are host temporaries
   ctx->h_stats_valid = false;                          // this kernel may have spilled into the table
   ms->pending = true;
+  ms->leaf_form = false;
   ms->list_n_valid = false;
   return CFRK_OK;
 }

@@ -1,0 +1,417 @@
+// radix.hip -- global k-mer counting for k <= 15 on gfx950: keys fit 30 bits, so instead of
+// hashing the key is radix-partitioned and counted by DIRECT ADDRESS in LDS.
+//
+//   keys are first scrambled by an invertible mix of the 2k-bit value (odd multiply, xorshift by
+//   k) -- canonical k-mers are skewed low and real genomes are not uniform, scrambled keys are;
+//   RX1  extract (canonical) k-mers (2 x dwordx4 per lane, 2-bit packing in registers), counting
+//        sort a tile of 8192 keys by the top b1 bits in LDS, one HBM atomic per bin per tile,
+//        coalesced copy-out of 4-byte keys;
+//   RX2  split every region by the next b2 bits the same way;
+//   RX3  one workgroup per leaf: an LDS array of 2^idx counters, ds_add_u32 by the low idx bits,
+//        then the non-zero counters are un-scrambled and appended to the result list.
+//   8 <= k <= 15: b1 = 8, idx = min(13, 2k - 11), b2 = 2k - 8 - idx (3..9): >= 2048 leaves.
+//   k <= 7 (at most 16384 keys): no partition at all, every workgroup counts into a replicated
+//   LDS table and adds it to a dense HBM array once.
+//
+// HBM sees 4 bytes per k-mer per pass; every occurrence is one LDS atomic.  Same semantics and
+// the same result-list form as msp.hip (which covers 16 <= k <= 32); overflowing regions spill
+// into the HBM table.
+#include "msp.h"
+#include "table.h"
+
+#include <algorithm>
+
+namespace {
+
+constexpr int RX_NXG = 8;                 // per-bin sub-regions by workgroup-id mod 8 (XCD affinity, speed only)
+constexpr int RX1_THREADS = 256, RX1_KEYS = RX1_THREADS * 32;
+constexpr int RX2_THREADS = 512, RX2_PER = 16, RX2_KEYS = RX2_THREADS * RX2_PER;
+constexpr int RX3_THREADS = 256;
+constexpr int RX_IDX_MAX = 13;
+
+struct RxView {
+  uint32_t *key1; uint32_t *cnt1; uint64_t cap1;      // 2^b1 x RX_NXG regions
+  uint32_t *key2; uint32_t *cnt2; uint64_t cap2;      // 2^(b1+b2) leaves
+  uint64_t *out_keys; uint32_t *out_cnt; uint64_t out_cap;
+  uint64_t *stats;
+  int k, b1, b2, idx;
+  uint32_t mul, inv, kmask;                           // scramble: x * mul mod 4^k, x ^= x >> k
+};
+
+__device__ __forceinline__ uint32_t rx_mix(const RxView &v, uint32_t key) {
+  uint32_t x = (key * v.mul) & v.kmask;
+  return x ^ (x >> v.k);
+}
+__device__ __forceinline__ uint32_t rx_unmix(const RxView &v, uint32_t x) {
+  x ^= x >> v.k;                                       // k = half the width: an involution
+  return (x * v.inv) & v.kmask;
+}
+
+template <int NB>
+__device__ __forceinline__ void rx_scan(const uint32_t *cnt, uint32_t *off, uint32_t *wtot) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t x = 0, incl = 0;
+  if (tid < NB) {
+    x = cnt[tid];
+    incl = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t y = __shfl_up(incl, d);
+      if (lane >= d) incl += y;
+    }
+    if (lane == 63) wtot[wave] = incl;
+  }
+  __syncthreads();
+  if (tid < NB) {
+    uint32_t base = 0;
+    for (int w = 0; w < wave; ++w) base += wtot[w];
+    off[tid] = base + incl - x;
+  }
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------ RX1
+template <bool CANON>
+__global__ __launch_bounds__(RX1_THREADS) void rx1_kernel(const int8_t *__restrict__ data, int64_t nN,
+                                                          RxView v, TableView t) {
+  __shared__ uint32_t sorted[RX1_KEYS];
+  __shared__ uint32_t hist[256], loff[256], gbase[256], fill[256];
+  __shared__ uint32_t wtot[4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int k = v.k;
+  hist[tid] = 0; fill[tid] = 0;
+  __syncthreads();
+
+  const int64_t off = ((int64_t)blockIdx.x * RX1_THREADS + tid) * 32;
+  uint32_t b0, b1w, bad;
+  dev_load_chunk32(data, off, nN, b0, b1w, bad);
+  uint32_t n0 = __shfl_down(b0, 1), n1 = __shfl_down(b1w, 1), nbad = __shfl_down(bad, 1);
+  if (lane == 63) dev_load_chunk32(data, off + 32, nN, n0, n1, nbad);
+  const uint64_t hi = ((uint64_t)b0 << 32) | b1w;
+  const uint64_t lo = ((uint64_t)n0 << 32) | n1;
+  const uint64_t M = ((uint64_t)bad << 32) | nbad;
+  const int sh1 = 2 * k - v.b1;
+
+  uint32_t keys[32];
+  uint32_t V = 0;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const uint64_t x = i ? ((hi << (2 * i)) | (lo >> (64 - 2 * i))) : hi;
+    const bool ok = ((M << i) >> (64 - k)) == 0;
+    uint32_t key = (uint32_t)(x >> (64 - 2 * k));
+    if (CANON) {
+      const uint32_t rc = (uint32_t)dev_revcomp64((uint64_t)key, k);
+      key = min(key, rc);
+    }
+    key = rx_mix(v, key);
+    keys[i] = key;
+    if (ok) { V |= 1u << i; atomicAdd(&hist[key >> sh1], 1u); }
+  }
+  __syncthreads();
+  uint32_t my_base = 0;
+  {
+    const uint32_t c = hist[tid];
+    if (c) my_base = atomicAdd(&v.cnt1[tid * RX_NXG + (blockIdx.x & (RX_NXG - 1))], c);
+  }
+  rx_scan<256>(hist, loff, wtot);
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    if (V & (1u << i)) {
+      const uint32_t b = keys[i] >> sh1;
+      sorted[loff[b] + atomicAdd(&fill[b], 1u)] = keys[i];
+    }
+  }
+  gbase[tid] = my_base;
+  __syncthreads();
+  const uint32_t total = loff[255] + hist[255];
+  for (uint32_t p = tid; p < total; p += RX1_THREADS) {
+    const uint32_t key = sorted[p];
+    const uint32_t b = key >> sh1;
+    const uint32_t dst = gbase[b] + (p - loff[b]);
+    if (dst < v.cap1) v.key1[((uint64_t)b * RX_NXG + (blockIdx.x & (RX_NXG - 1))) * v.cap1 + dst] = key;
+    else { t.stats[ST_SPILLED] = 1; table_add1(t, (uint64_t)rx_unmix(v, key), 1u); }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ RX2
+__global__ __launch_bounds__(RX2_THREADS) void rx2_kernel(int tiles_per_sub, RxView v, TableView t) {
+  __shared__ uint32_t sorted[RX2_KEYS];
+  __shared__ uint32_t hist[512], loff[512], gbase[512], fill[512];
+  __shared__ uint32_t wtot[8];
+  const int tid = threadIdx.x;
+  const uint32_t nb1 = 1u << v.b1;
+  const uint32_t xg = blockIdx.x & (RX_NXG - 1), seq = blockIdx.x / RX_NXG;
+  const uint32_t per_bin = (uint32_t)RX_NXG * (uint32_t)tiles_per_sub;
+  // bins are dealt to the 8 workgroup-id groups round robin (nb1 may be smaller than 8)
+  const uint32_t bins_per_group = (nb1 + RX_NXG - 1) / RX_NXG;
+  const uint32_t bl = seq / per_bin;
+  if (bl >= bins_per_group) return;
+  const uint32_t bin1 = xg + RX_NXG * bl;
+  if (bin1 >= nb1) return;
+  const uint32_t sub = (seq % per_bin) / (uint32_t)tiles_per_sub;
+  const uint32_t tile = (seq % per_bin) % (uint32_t)tiles_per_sub;
+  const uint32_t reg = bin1 * RX_NXG + sub;
+  const uint64_t n = min((uint64_t)v.cnt1[reg], v.cap1);
+  const uint64_t r0 = (uint64_t)tile * RX2_KEYS;
+  if (r0 >= n) return;
+  const uint32_t nt = (uint32_t)min((uint64_t)RX2_KEYS, n - r0);
+  hist[tid] = 0; fill[tid] = 0;
+  __syncthreads();
+  const uint32_t *src = v.key1 + (uint64_t)reg * v.cap1 + r0;
+  const uint32_t m2 = (1u << v.b2) - 1u;
+  uint32_t kk[RX2_PER];
+#pragma unroll
+  for (int i = 0; i < RX2_PER; ++i) {
+    const uint32_t idx = (uint32_t)i * RX2_THREADS + tid;
+    uint32_t x = 0;
+    if (idx < nt) x = src[idx];
+    kk[i] = x;
+    if (idx < nt) atomicAdd(&hist[(x >> v.idx) & m2], 1u);
+  }
+  __syncthreads();
+  uint32_t my_base = 0;
+  {
+    const uint32_t c = hist[tid];
+    if (c) my_base = atomicAdd(&v.cnt2[((uint64_t)bin1 << v.b2) + tid], c);
+  }
+  rx_scan<512>(hist, loff, wtot);
+#pragma unroll
+  for (int i = 0; i < RX2_PER; ++i) {
+    const uint32_t idx = (uint32_t)i * RX2_THREADS + tid;
+    if (idx < nt) {
+      const uint32_t b = (kk[i] >> v.idx) & m2;
+      sorted[loff[b] + atomicAdd(&fill[b], 1u)] = kk[i];
+    }
+  }
+  gbase[tid] = my_base;
+  __syncthreads();
+  for (uint32_t p = tid; p < nt; p += RX2_THREADS) {
+    const uint32_t key = sorted[p];
+    const uint32_t b = (key >> v.idx) & m2;
+    const uint32_t dst = gbase[b] + (p - loff[b]);
+    const uint64_t leaf = ((uint64_t)bin1 << v.b2) + b;
+    if (dst < v.cap2) v.key2[leaf * v.cap2 + dst] = key;
+    else { t.stats[ST_SPILLED] = 1; table_add1(t, (uint64_t)rx_unmix(v, key), 1u); }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ RX3
+__global__ __launch_bounds__(RX3_THREADS) void rx3_kernel(RxView v) {
+  __shared__ uint32_t cnt[1 << RX_IDX_MAX];
+  __shared__ uint32_t wg_total;
+  __shared__ unsigned long long wg_base;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const uint32_t leaf = blockIdx.x;
+  const uint64_t n = min((uint64_t)v.cnt2[leaf], v.cap2);
+  if (n == 0) return;
+  const uint32_t nidx = 1u << v.idx, imask = nidx - 1u;
+  // few counters per leaf (small k): every thread group gets its own replica, or all 256 threads
+  // would serialise on a handful of LDS words
+  const int rlog = min(RX_IDX_MAX - v.idx, 8);
+  const uint32_t rmask = (1u << rlog) - 1u;
+  for (uint32_t s = tid; s < (nidx << rlog); s += RX3_THREADS) cnt[s] = 0;
+  if (tid == 0) wg_total = 0;
+  __syncthreads();
+  const uint32_t *src = v.key2 + (uint64_t)leaf * v.cap2;
+  for (uint64_t i = tid; i < n; i += RX3_THREADS)
+    atomicAdd(&cnt[((src[i] & imask) << rlog) | ((uint32_t)tid & rmask)], 1u);
+  __syncthreads();
+  if (rlog) {                       // fold the replicas into replica 0
+    for (uint32_t s = tid; s < nidx; s += RX3_THREADS) {
+      uint32_t c = 0;
+      for (uint32_t r = 0; r <= rmask; ++r) c += cnt[(s << rlog) | r];
+      cnt[s << rlog] = c;
+    }
+    __syncthreads();
+  }
+  // compaction: count, reserve once per workgroup, then write
+  for (uint32_t s0 = 0; s0 < nidx; s0 += RX3_THREADS) {
+    const uint32_t s = s0 + tid;
+    const uint32_t c = (s < nidx) ? cnt[s << rlog] : 0u;
+    const unsigned long long m = __ballot(c != 0u);
+    if (lane == 0 && m) atomicAdd(&wg_total, (uint32_t)__popcll(m));
+  }
+  __syncthreads();
+  if (tid == 0) { wg_base = atomicAdd((unsigned long long *)&v.stats[ST_CURSOR], (unsigned long long)wg_total); wg_total = 0; }
+  __syncthreads();
+  const unsigned long long gb = wg_base;
+  for (uint32_t s0 = 0; s0 < nidx; s0 += RX3_THREADS) {
+    const uint32_t s = s0 + tid;
+    const uint32_t c = (s < nidx) ? cnt[s << rlog] : 0u;
+    const unsigned long long m = __ballot(c != 0u);
+    uint32_t b = 0;
+    if (lane == 0 && m) b = atomicAdd(&wg_total, (uint32_t)__popcll(m));
+    b = __shfl(b, 0);
+    if (c) {
+      const unsigned long long dst = gb + b + __popcll(m & ((1ull << lane) - 1ull));
+      const uint32_t mixed = (leaf << v.idx) | s;
+      if (dst < v.out_cap) { v.out_keys[dst] = (uint64_t)rx_unmix(v, mixed); v.out_cnt[dst] = c; }
+      else v.stats[ST_OVERFLOW] = 1;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------- k <= 7: direct
+// 4^k <= 16384 counters: every workgroup keeps the whole (replicated) table in LDS over a
+// grid-stride of tiles and adds it to a dense HBM array once; a one-workgroup kernel turns the
+// dense array into the result list.
+constexpr int RXS_THREADS = 256;
+template <bool CANON>
+__global__ __launch_bounds__(RXS_THREADS) void rxs_count_kernel(const int8_t *__restrict__ data, int64_t nN,
+                                                                int k, uint32_t *__restrict__ dense) {
+  __shared__ uint32_t cnt[16384];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const uint32_t nkey = 1u << (2 * k);
+  int rlog = 14 - 2 * k;           // k = 7: the table fills the 64 KiB, no replicas
+  if (rlog > 6) rlog = 6;
+  const uint32_t rmask = (1u << rlog) - 1u;
+  for (uint32_t s = tid; s < (nkey << rlog); s += RXS_THREADS) cnt[s] = 0;
+  __syncthreads();
+  const int64_t ntiles = (nN + RXS_THREADS * 32 - 1) / (RXS_THREADS * 32);
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t off = (tile * RXS_THREADS + tid) * 32;
+    uint32_t b0, b1w, bad;
+    dev_load_chunk32(data, off, nN, b0, b1w, bad);
+    uint32_t n0 = __shfl_down(b0, 1), n1 = __shfl_down(b1w, 1), nbad = __shfl_down(bad, 1);
+    if (lane == 63) dev_load_chunk32(data, off + 32, nN, n0, n1, nbad);
+    const uint64_t hi = ((uint64_t)b0 << 32) | b1w;
+    const uint64_t lo = ((uint64_t)n0 << 32) | n1;
+    const uint64_t M = ((uint64_t)bad << 32) | nbad;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const uint64_t x = i ? ((hi << (2 * i)) | (lo >> (64 - 2 * i))) : hi;
+      if (((M << i) >> (64 - k)) == 0) {
+        uint32_t key = (uint32_t)(x >> (64 - 2 * k));
+        if (CANON) key = min(key, (uint32_t)dev_revcomp64((uint64_t)key, k));
+        atomicAdd(&cnt[(key << rlog) | ((uint32_t)lane & rmask)], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (uint32_t s = tid; s < nkey; s += RXS_THREADS) {
+    uint32_t c = 0;
+    for (uint32_t r = 0; r <= rmask; ++r) c += cnt[(s << rlog) | r];
+    if (c) atomicAdd(&dense[s], c);
+  }
+}
+
+__global__ __launch_bounds__(1024) void rxs_emit_kernel(const uint32_t *__restrict__ dense, uint32_t nkey,
+                                                        RxView v) {
+  __shared__ uint32_t total;
+  if (threadIdx.x == 0) total = 0;
+  __syncthreads();
+  for (uint32_t s = threadIdx.x; s < nkey; s += blockDim.x) {
+    const uint32_t c = dense[s];
+    if (c) {
+      const uint32_t dst = atomicAdd(&total, 1u);
+      if (dst < v.out_cap) { v.out_keys[dst] = s; v.out_cnt[dst] = c; }
+      else v.stats[ST_OVERFLOW] = 1;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) v.stats[ST_CURSOR] = total;
+}
+
+uint32_t inv_odd32(uint32_t a) {        // a * x == 1 (mod 2^32), Newton
+  uint32_t x = a;
+  for (int i = 0; i < 5; ++i) x *= 2u - a * x;
+  return x;
+}
+
+}  // namespace
+
+bool cfrk_radix_usable(const cfrk_ctx *ctx) {
+  return !ctx->g_two && ctx->g_k >= 1 && ctx->g_k <= 15 && !(ctx->g_flags & CFRK_FORCE_HASH);
+}
+
+int cfrk_radix_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
+  cfrk_msp *ms = cfrk_msp_get(ctx);
+  if (!ms) return cfrk_fail(ctx, CFRK_ERR_NOMEM, "host allocation failed");
+  int rc;
+  if (ms->pending && (rc = cfrk_msp_flush_to_table(ctx))) return rc;
+  const int k = ctx->g_k;
+  RxView v;
+  memset(&v, 0, sizeof v);
+  v.k = k;
+  if (k <= 7) {
+    void *p;
+    const uint32_t nkey = 1u << (2 * k);
+    if ((rc = cfrk_pool_get(ctx, BUF_MSP_AUX, (size_t)nkey * 4, &p))) return rc;
+    uint32_t *dense = (uint32_t *)p;
+    if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTK, (size_t)ctx->g_cap * 8, &p))) return rc;
+    v.out_keys = (uint64_t *)p;
+    if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTC, (size_t)ctx->g_cap * 4, &p))) return rc;
+    v.out_cnt = (uint32_t *)p; v.out_cap = ctx->g_cap;
+    v.stats = ctx->g_stats;
+    HIP_TRY(ctx, hipMemsetAsync(dense, 0, (size_t)nkey * 4, ctx->stream));
+    const int64_t ntiles = (nN + RXS_THREADS * 32 - 1) / (RXS_THREADS * 32);
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, (int64_t)ctx->num_cus * 8));
+    if (ctx->g_flags & CFRK_CANONICAL) hipLaunchKernelGGL((rxs_count_kernel<true>), dim3(grid), dim3(RXS_THREADS), 0, ctx->stream, d_data, nN, k, dense);
+    else hipLaunchKernelGGL((rxs_count_kernel<false>), dim3(grid), dim3(RXS_THREADS), 0, ctx->stream, d_data, nN, k, dense);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(rxs_emit_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)dense, nkey, v);
+    HIP_TRY(ctx, hipGetLastError());
+    ms->view.out_keys = v.out_keys; ms->view.out_cnt = v.out_cnt; ms->view.out_cap = v.out_cap;
+    ms->view.stats = v.stats;
+    ms->view.cnt1 = nullptr;
+    ms->pending = true;
+    ms->leaf_form = false;
+    ms->list_n_valid = false;
+    return CFRK_OK;
+  }
+  // at least 2048 leaves (one workgroup each in RX3), at most 2^13 counters per leaf
+  v.b1 = 8;
+  v.idx = std::max(0, std::min(RX_IDX_MAX, 2 * k - 11));
+  v.b2 = 2 * k - v.b1 - v.idx;
+  v.kmask = (uint32_t)((1ull << (2 * k)) - 1ull);
+  v.mul = 0x9E3779B1u;
+  v.inv = inv_odd32(v.mul);
+  const uint64_t nb1 = 1ull << v.b1, nleaf = 1ull << (v.b1 + v.b2);
+  const uint64_t cap1 = (uint64_t)((double)nN / (double)(nb1 * RX_NXG) * 1.3) + 4096;
+  const uint64_t cap2 = (uint64_t)((double)nN / (double)nleaf * 1.5) + 1024;
+  const size_t need = (size_t)nb1 * RX_NXG * cap1 * 4 + (size_t)nleaf * cap2 * 4 + (size_t)ctx->g_cap * 12;
+  const size_t have = ctx->pool[BUF_MSP_L1].cap + ctx->pool[BUF_MSP_L2].cap + ctx->pool[BUF_MSP_OUTK].cap + ctx->pool[BUF_MSP_OUTC].cap;
+  if (need > have) {
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+    if (need > have + free_b) return cfrk_fail(ctx, CFRK_ERR_NOMEM, "radix path needs %zu B, %zu B available", need, have + free_b);
+  }
+  void *p;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L1, (size_t)nb1 * RX_NXG * cap1 * 4, &p))) return rc;
+  v.key1 = (uint32_t *)p; v.cap1 = cap1;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)nleaf * cap2 * 4, &p))) return rc;
+  v.key2 = (uint32_t *)p; v.cap2 = cap2;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_AUX, (size_t)(nb1 * RX_NXG + nleaf) * 4, &p))) return rc;
+  v.cnt1 = (uint32_t *)p; v.cnt2 = v.cnt1 + nb1 * RX_NXG;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTK, (size_t)ctx->g_cap * 8, &p))) return rc;
+  v.out_keys = (uint64_t *)p;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTC, (size_t)ctx->g_cap * 4, &p))) return rc;
+  v.out_cnt = (uint32_t *)p; v.out_cap = ctx->g_cap;
+  v.stats = ctx->g_stats;
+  TableView t = cfrk_table_view(ctx);
+
+  HIP_TRY(ctx, hipMemsetAsync(v.cnt1, 0, (size_t)(nb1 * RX_NXG + nleaf) * 4, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_CURSOR, 0, sizeof(uint64_t), ctx->stream));
+  const int64_t tiles = (nN + (int64_t)RX1_KEYS - 1) / RX1_KEYS;
+  if (tiles > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
+  const bool canon = (ctx->g_flags & CFRK_CANONICAL) != 0;
+  if (canon) hipLaunchKernelGGL((rx1_kernel<true>), dim3((unsigned)tiles), dim3(RX1_THREADS), 0, ctx->stream, d_data, nN, v, t);
+  else hipLaunchKernelGGL((rx1_kernel<false>), dim3((unsigned)tiles), dim3(RX1_THREADS), 0, ctx->stream, d_data, nN, v, t);
+  HIP_TRY(ctx, hipGetLastError());
+  const int64_t tiles_per_sub = (int64_t)((cap1 + RX2_KEYS - 1) / RX2_KEYS);
+  const int64_t bins_per_group = (int64_t)((nb1 + RX_NXG - 1) / RX_NXG);
+  const int64_t g2 = bins_per_group * RX_NXG * RX_NXG * tiles_per_sub;
+  if (g2 > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
+  hipLaunchKernelGGL(rx2_kernel, dim3((unsigned)g2), dim3(RX2_THREADS), 0, ctx->stream, (int)tiles_per_sub, v, t);
+  HIP_TRY(ctx, hipGetLastError());
+  hipLaunchKernelGGL(rx3_kernel, dim3((unsigned)nleaf), dim3(RX3_THREADS), 0, ctx->stream, v);
+  HIP_TRY(ctx, hipGetLastError());
+  // the result list lives where msp.hip keeps its own: digest / export / fold are shared
+  ms->view.out_keys = v.out_keys; ms->view.out_cnt = v.out_cnt; ms->view.out_cap = v.out_cap;
+  ms->view.stats = v.stats;
+  ms->view.cnt1 = nullptr;
+  ms->pending = true;
+  ms->leaf_form = false;
+  ms->list_n_valid = false;
+  return CFRK_OK;
+}
