@@ -1,0 +1,61 @@
+"""Randomised parity of the global paths against the oracle: random k, read lengths (including
+reads shorter than k and empty reads), invalid-base densities, homopolymer / tandem-repeat
+stretches, buffer sizes around the 32-byte chunk and wave-tile edges, one or two adds."""
+import numpy as np
+import pytest
+
+from . import oracle_lib as orc
+from . import refsem
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import cfrk_amd
+    c = cfrk_amd.Context(0)
+    yield c
+    c.close()
+
+
+def _case(rng):
+    k = int(rng.choice([1, 3, 6, 7, 8, 9, 12, 15, 16, 17, 20, 23, 26, 29, 30, 31, 32, 33, 40, 64]))
+    nreads = int(rng.integers(1, 400))
+    style = rng.integers(0, 4)
+    reads = []
+    for _ in range(nreads):
+        L = int(rng.integers(0, 3 * k + 40)) if style != 3 else int(rng.integers(0, k + 3))
+        if style == 1 and rng.random() < 0.3:        # low complexity
+            unit = rng.integers(0, 4, int(rng.integers(1, 5))).astype(np.int8)
+            r = np.tile(unit, L // len(unit) + 1)[:L]
+        else:
+            r = rng.integers(0, 4, L).astype(np.int8)
+        p_bad = [0.0, 0.01, 0.2][int(rng.integers(0, 3))]
+        if p_bad and L:
+            r = r.copy()
+            r[rng.random(L) < p_bad] = -1
+        reads.append(r)
+    return k, reads
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_inputs_match_oracle(ctx, seed):
+    import cfrk_amd
+    rng = np.random.default_rng(1000 + seed)
+    k, reads = _case(rng)
+    canonical = bool(rng.integers(0, 2))
+    data, start, length = refsem.flatten(reads)
+    flags = cfrk_amd.CFRK_CANONICAL if canonical else 0
+    g = cfrk_amd.GlobalCounter(ctx, k, flags, 0)
+    if rng.random() < 0.3 and len(reads) > 1:          # two adds: the second forces the fold path
+        h = len(reads) // 2
+        d1, s1, l1 = refsem.flatten(reads[:h])
+        d2, s2, l2 = refsem.flatten(reads[h:])
+        g.add(d1, s1, l1)
+        g.add(d2, s2, l2)
+    else:
+        g.add(data, start, length)
+    lo, hi, cnt = g.export()
+    wlo, whi, wcnt = orc.global_count(data, k, orc.ORC_CANONICAL if canonical else 0)
+    assert len(lo) == len(wlo)
+    assert (lo == wlo).all() and (hi == whi).all() and (cnt.astype(np.uint64) == wcnt).all()
