@@ -59,3 +59,25 @@ def test_random_inputs_match_oracle(ctx, seed):
     wlo, whi, wcnt = orc.global_count(data, k, orc.ORC_CANONICAL if canonical else 0)
     assert len(lo) == len(wlo)
     assert (lo == wlo).all() and (hi == whi).all() and (cnt.astype(np.uint64) == wcnt).all()
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_dense_matches_oracle(ctx, seed):
+    """per-read dense path (kmer_main drop-in): random k <= 9, compat and native semantics"""
+    import cfrk_amd
+    rng = np.random.default_rng(5000 + seed)
+    k = int(rng.integers(1, 10))
+    nreads = int(rng.integers(1, 120))
+    reads = []
+    for _ in range(nreads):
+        L = int(rng.choice([0, 1, 2, k - 1, k, k + 1, 150, 300, 1024, 1025, 1026, 1500]))
+        L = max(L, 0)
+        r = rng.integers(0, 4, L).astype(np.int8)
+        if L and rng.random() < 0.5:
+            r[rng.random(L) < 0.05] = -1
+        reads.append(r)
+    data, start, length = refsem.flatten(reads)
+    for compat in (True, False):
+        got = ctx.per_read_dense(data, start, length, k, cfrk_amd.CFRK_COMPAT if compat else 0)
+        want = orc.per_read_dense(data, start, length, k, orc.ORC_COMPAT if compat else 0)
+        assert (got == want).all()
