@@ -1,0 +1,144 @@
+// msp_dev.h -- device helpers shared by the partitioned counting kernels (msp.hip: one-word keys,
+// msp2.hip: two-word keys).
+#pragma once
+#include "common.h"
+
+constexpr int B1_LOG = 8, B2_LOG = 8;
+constexpr int B1 = 1 << B1_LOG, B2 = 1 << B2_LOG;
+// Workgroups b and b+8 land on the same XCD (observed round-robin dispatch; speed only, never
+// correctness).  A leaf stream that is appended to from ONE XCD has its partially written
+// 64-byte sectors merged in that XCD's L2 before they reach HBM.
+constexpr int NXG = 8;
+constexpr int NLEAF = B1 * B2;
+
+
+// ordering hash of a canonical m-mer (bijective: odd multiplier, xorshift)
+__device__ __forceinline__ uint32_t hash_mmer(uint32_t c) {
+  uint32_t h = c * 0x9E3779B1u;
+  return h ^ (h >> 16);
+}
+// minimizer -> leaf id (16 bits).  The window minimum is skewed low in its TOP bits only (that is
+// what the comparison looks at); bits 7..22 of the winning hash stay uniform (simulated: same
+// leaf balance as a full re-mix), and bits 0..6 hold the position tag.
+__device__ __forceinline__ uint32_t leaf_of(uint32_t wmin) { return (wmin >> 7) & 0xFFFFu; }
+
+
+// w[a] for a lane-varying a in 0..31, as a 5-level select tree on VALUES (31 v_cndmask);
+// selecting between array elements directly makes clang select pointers and park the
+// arrays in scratch/LDS.
+template <int N>
+__device__ __forceinline__ uint32_t pick32(const uint32_t (&w)[N], int a) {
+  const bool c16 = (a & 16) != 0, c8 = (a & 8) != 0, c4 = (a & 4) != 0, c2 = (a & 2) != 0, c1 = (a & 1) != 0;
+#define CFRK_SEL(c, hi_, lo_) ({ const uint32_t x_ = (lo_), y_ = (hi_); (c) ? y_ : x_; })
+  const uint32_t s0 = CFRK_SEL(c16, w[16], w[0]), s1 = CFRK_SEL(c16, w[17], w[1]);
+  const uint32_t s2 = CFRK_SEL(c16, w[18], w[2]), s3 = CFRK_SEL(c16, w[19], w[3]);
+  const uint32_t s4 = CFRK_SEL(c16, w[20], w[4]), s5 = CFRK_SEL(c16, w[21], w[5]);
+  const uint32_t s6 = CFRK_SEL(c16, w[22], w[6]), s7 = CFRK_SEL(c16, w[23], w[7]);
+  const uint32_t s8 = CFRK_SEL(c16, w[24], w[8]), s9 = CFRK_SEL(c16, w[25], w[9]);
+  const uint32_t s10 = CFRK_SEL(c16, w[26], w[10]), s11 = CFRK_SEL(c16, w[27], w[11]);
+  const uint32_t s12 = CFRK_SEL(c16, w[28], w[12]), s13 = CFRK_SEL(c16, w[29], w[13]);
+  const uint32_t s14 = CFRK_SEL(c16, w[30], w[14]), s15 = CFRK_SEL(c16, w[31], w[15]);
+  const uint32_t e0 = CFRK_SEL(c8, s8, s0), e1 = CFRK_SEL(c8, s9, s1), e2 = CFRK_SEL(c8, s10, s2);
+  const uint32_t e3 = CFRK_SEL(c8, s11, s3), e4 = CFRK_SEL(c8, s12, s4), e5 = CFRK_SEL(c8, s13, s5);
+  const uint32_t e6 = CFRK_SEL(c8, s14, s6), e7 = CFRK_SEL(c8, s15, s7);
+  const uint32_t f0 = CFRK_SEL(c4, e4, e0), f1 = CFRK_SEL(c4, e5, e1), f2 = CFRK_SEL(c4, e6, e2);
+  const uint32_t f3 = CFRK_SEL(c4, e7, e3);
+  const uint32_t g0 = CFRK_SEL(c2, f2, f0), g1 = CFRK_SEL(c2, f3, f1);
+#undef CFRK_SEL
+  return c1 ? g1 : g0;
+}
+
+// exclusive prefix sum of cnt[0..NB) into off[0..NB); every thread of the block must call it
+// (blockDim >= NB, NB a multiple of 64, NB <= 512); wtot is NB/64 words of LDS scratch
+template <int NB>
+__device__ __forceinline__ void block_scan(const uint32_t *cnt, uint32_t *off, uint32_t *wtot) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t x = 0, incl = 0;
+  if (tid < NB) {
+    x = cnt[tid];
+    incl = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t y = __shfl_up(incl, d);
+      if (lane >= d) incl += y;
+    }
+    if (lane == 63) wtot[wave] = incl;
+  }
+  __syncthreads();
+  if (tid < NB) {
+    uint32_t base = 0;
+    for (int w = 0; w < wave; ++w) base += wtot[w];
+    off[tid] = base + incl - x;
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------- P1
+
+// Truncated runs are split by length class as well, so that in P3 the lanes of a wave expand
+// records of similar length (the expansion loop runs max(n)/2 trips per wave).
+constexpr int NCLS = 4;                                   // 0..2 truncated (n<=4, <=10, >10), 3 complete
+constexpr int NSUB = NCLS * B2;
+__device__ __forceinline__ uint32_t cls_of(uint32_t w) {
+  const uint32_t n = (w & 63u) + 1u;
+  return (w & 64u) ? 3u : (n <= 4u ? 0u : (n <= 10u ? 1u : 2u));
+}
+__device__ __forceinline__ uint32_t sub_of(uint32_t w) { return (((w >> 8) & (B2 - 1)) << 2) | cls_of(w); }
+
+
+// Minimizers of one lane's 32 window starts (shared by msp.hip and msp2.hip).
+// hi / mid = the lane's own 32 bases and the next lane's 32 bases, 2 bits each, first base in the
+// top bits; chunk = index of the lane's 32-byte chunk (for the absolute-position tag).
+// On return H[0..31] = packed minimizer (hash & ~127 | position tag) of the windows starting at
+// the own positions, H[32..32+W-2] = the next lane's first W-1; the result is the change mask:
+// bit(63-p) set when the minimizer OCCURRENCE differs between positions p-1 and p
+// (p = 0: against the previous lane's last position).
+template <int W>
+__device__ __forceinline__ uint64_t msp_minimizers(uint64_t hi, uint64_t mid, int64_t chunk, int m,
+                                                   uint32_t (&H)[32 + W - 1]) {
+  constexpr int NH = 32 + W - 1;
+  constexpr int P = (W >= 16) ? 16 : (W >= 8) ? 8 : (W >= 4) ? 4 : 2;
+  // canonical m-mer hashes of the own 32 positions, rolled one base at a time; the low 7 bits
+  // carry the absolute position (mod 128) so that equal packed values mean the SAME m-mer
+  // occurrence: a run then never exceeds W k-mers
+  {
+    const uint64_t Shi = (hi << (2 * m)) | (mid >> (64 - 2 * m));   // bases m.. of the string
+    uint32_t fm = (uint32_t)(hi >> (64 - 2 * m));
+    uint32_t rm = (uint32_t)dev_revcomp64((uint64_t)fm, m);
+    const uint32_t mmask = (m == 16) ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1u);
+    const int rsh = 2 * m - 2;
+    const uint32_t pos0 = ((uint32_t)chunk & 3u) << 5;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      H[j] = (hash_mmer(min(fm, rm)) & ~127u) | (pos0 + j);
+      if (j + 1 < 32) {
+        const uint32_t nb = (uint32_t)(Shi >> (62 - 2 * j)) & 3u;
+        fm = ((fm << 2) | nb) & mmask;
+        rm = (rm >> 2) | ((3u - nb) << rsh);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < W - 1; ++j) H[32 + j] = __shfl_down(H[j], 1);   // next lane's first W-1 hashes
+  // sliding-window minimum over W by doubling: H[j] <- min H[j .. j+P), then one combine
+#pragma unroll
+  for (int s = 1; s < P; s <<= 1) {
+#pragma unroll
+    for (int j = 0; j + s < NH; ++j) H[j] = min(H[j], H[j + s]);
+  }
+  if (W > P) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) H[i] = min(H[i], H[i + W - P]);
+  }
+  // H[0..31] = minimizers of the own k-mers; fetch the next lane's first W-1 and the previous
+  // lane's last one
+  const uint32_t prevW = __shfl_up(H[31], 1);
+#pragma unroll
+  for (int j = 0; j < W - 1; ++j) H[32 + j] = __shfl_down(H[j], 1);
+
+  // Cx bit(63-p): minimizer occurrence changes between positions p-1 and p (p = 0..NH-1)
+  uint64_t Cx = (H[0] != prevW) ? (1ull << 63) : 0ull;
+#pragma unroll
+  for (int p = 1; p < NH; ++p) Cx |= (H[p] != H[p - 1]) ? (1ull << (63 - p)) : 0ull;
+  return Cx;
+}
