@@ -276,6 +276,7 @@ int cfrk_global_add_device(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   rc = CFRK_ERR_NOMEM;
   if (cfrk_msp_usable(ctx)) rc = cfrk_msp_count(ctx, d_data, nN);
   else if (cfrk_radix_usable(ctx)) rc = cfrk_radix_count(ctx, d_data, nN);
+  else if (cfrk_msp2_usable(ctx)) rc = cfrk_msp2_count(ctx, d_data, nN);
   if (rc == CFRK_ERR_NOMEM) {
     // no partitioned path for this k, or its record buffers (about 7 bytes per input byte) do
     // not fit next to the caller's data: count with the general HBM-table path instead

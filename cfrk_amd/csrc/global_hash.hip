@@ -105,7 +105,7 @@ __device__ __forceinline__ bool src_read(const ResultSrc &r, uint64_t s, uint64_
                                          uint32_t &c) {
   c = r.cnt[s];
   hi = 0;
-  if (r.kind == 1) {
+  if (r.kind == 1 || r.kind == 3) {     // two-word table (count word = slot state) / two-word list
     if (c == 0) return false;
     lo = r.lo[s]; hi = r.hi[s];
     return true;
@@ -128,7 +128,7 @@ __device__ __forceinline__ uint64_t wave_xor64(uint64_t v) {
 __global__ __launch_bounds__(256) void result_scan_kernel(ResultSrc r) {
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
-  const bool two = r.kind == 1;
+  const bool two = r.kind == 1 || r.kind == 3;
   uint64_t d = 0, s = 0, w = 0, x = 0;
   for (uint64_t i = tid; i < r.n; i += nthreads) {
     uint64_t lo, hi; uint32_t c;
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void result_export_count_kernel(ResultSrc r, i
   const int lane = threadIdx.x & 63;
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
-  const bool two = r.kind == 1;
+  const bool two = r.kind == 1 || r.kind == 3;
   for (uint64_t base = (uint64_t)tid - lane; base < r.n; base += nthreads) {
     const uint64_t i = base + lane;
     uint64_t lo = 0, hi = 0; uint32_t c = 0;
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void result_export_scatter_kernel(ResultSrc r,
   const int lane = threadIdx.x & 63;
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
-  const bool two = r.kind == 1;
+  const bool two = r.kind == 1 || r.kind == 3;
   for (uint64_t base = (uint64_t)tid - lane; base < r.n; base += nthreads) {
     const uint64_t i = base + lane;
     uint64_t lo = 0, hi = 0; uint32_t c = 0;

@@ -25,6 +25,7 @@ struct MspView {
   uint4 *rec1; uint32_t *cnt1; uint64_t cap1;   // B1 x NXG sub-regions of cap1 records each
   uint4 *rec2; uint32_t *cnt2; uint64_t cap2c, cap2t;   // per leaf: complete stream (cap2c), then 3 truncated length classes (cap2t each)
   uint64_t *out_keys; uint32_t *out_cnt; uint64_t out_cap;
+  uint64_t *out_hi;                           // high key words of the list (two-word keys only)
   uint64_t *leaf_off; uint32_t *leaf_n;        // where each leaf's entries sit in the result list
   uint64_t *stats;
 };
@@ -40,6 +41,10 @@ struct cfrk_msp {
 
 cfrk_msp *cfrk_msp_get(cfrk_ctx *ctx);
 int cfrk_msp_sync_stats(cfrk_ctx *ctx, uint64_t st[ST_NWORDS]);
+
+// msp2.hip: 33 <= k <= 64
+bool cfrk_msp2_usable(const cfrk_ctx *ctx);
+int  cfrk_msp2_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN);
 
 // radix.hip: k <= 15
 bool cfrk_radix_usable(const cfrk_ctx *ctx);

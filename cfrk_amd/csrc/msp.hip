@@ -820,7 +820,7 @@ int cfrk_msp_flush_to_table(cfrk_ctx *ctx) {
   ms->pending = false;
   ms->table_dirty = true;
   if (n == 0) return CFRK_OK;
-  return cfrk_hash_merge(ctx, ms->view.out_keys, nullptr, ms->view.out_cnt, (int64_t)n);
+  return cfrk_hash_merge(ctx, ms->view.out_keys, ctx->g_two ? ms->view.out_hi : nullptr, ms->view.out_cnt, (int64_t)n);
 }
 
 int cfrk_msp_resolve(cfrk_ctx *ctx, ResultSrc *src, bool *use_list) {
@@ -832,8 +832,8 @@ int cfrk_msp_resolve(cfrk_ctx *ctx, ResultSrc *src, bool *use_list) {
   if (rc) return rc;
   if (st[ST_OVERFLOW]) return cfrk_fail(ctx, CFRK_ERR_TABLE_FULL, "result list of %llu entries overflowed", (unsigned long long)ms->view.out_cap);
   if (st[ST_SPILLED] || ms->table_dirty) return cfrk_msp_flush_to_table(ctx);
-  src->lo = ms->view.out_keys; src->hi = nullptr; src->cnt = ms->view.out_cnt;
-  src->n = st[ST_CURSOR]; src->kind = 2; src->stats = ctx->g_stats;
+  src->lo = ms->view.out_keys; src->hi = ctx->g_two ? ms->view.out_hi : nullptr; src->cnt = ms->view.out_cnt;
+  src->n = st[ST_CURSOR]; src->kind = ctx->g_two ? 3 : 2; src->stats = ctx->g_stats;
   *use_list = true;
   return CFRK_OK;
 }

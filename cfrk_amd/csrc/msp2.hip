@@ -1,0 +1,499 @@
+// msp2.hip -- minimizer-partitioned global k-mer counting for 33 <= k <= 64 (two-word keys).
+//
+// Same pipeline as msp.hip (which covers 16 <= k <= 32) with three differences:
+//   * the minimizer of a k-mer is taken over the CENTRAL 18 of its k-m+1 canonical m-mers
+//     (m = 13 for even k, 14 for odd k, so that the margin c on both sides is equal: the choice is
+//     then strand-symmetric).  A run (same minimizer occurrence) still holds at most 18 k-mers,
+//     so the minimizer front end of msp.hip (msp_dev.h: msp_minimizers<18>) is reused as is --
+//     a lane owns the 32 WINDOW positions y of its chunk, i.e. the k-mers starting at y - c;
+//   * records are 32 bytes: 96 bases (6 dwords; a run spans at most 18 + 63 bases) + header;
+//   * the leaf kernel keeps 16-byte keys in LDS (claimed through the count word: 0 empty,
+//     LOCK while the claiming lane writes the key) and counts k-mer by k-mer (no record table
+//     yet), results go to a two-word list.
+// Anything that does not fit is counted in the two-word HBM table (table_add2).
+//
+// Semantics: the guarded ComputeFreq of /root/reference/src/kmer_kernel.cu:52-70 summed over
+// reads, like global_hash.hip.
+#include "msp.h"
+#include "table.h"
+#include "msp_dev.h"
+
+#include <algorithm>
+
+namespace {
+
+constexpr int W2 = 18;
+constexpr int Q1_THREADS = 512, Q1_WAVES = Q1_THREADS / 64;
+constexpr int Q1_OWN = 60;                 // owner lanes 1..60; lane 0 and lanes 61..63 are halo lanes
+constexpr int Q1_RCAP = 2048;              // 32-byte records staged in LDS per workgroup
+constexpr int Q2_THREADS = 1024, Q2_PER = 2, Q2_TILE = Q2_THREADS * Q2_PER;
+constexpr int Q3_THREADS = 1024;
+constexpr int T2_LOG = 12, T2 = 1 << T2_LOG;   // LDS slots per leaf (16-byte keys)
+constexpr uint32_t T2_LOCK = 0xFFFFFFFFu;
+constexpr int Q3_PROBE_LIMIT = 64;
+
+struct Rec2 { uint4 a, b; };               // a = bases dwords 0..3, b = {dwords 4, 5, 0, header}
+
+struct View2 {
+  Rec2 *rec1; uint32_t *cnt1; uint64_t cap1;            // B1 x NXG regions
+  Rec2 *rec2; uint32_t *cnt2; uint64_t cap2c, cap2t;    // per leaf: complete stream, 3 truncated classes
+  uint64_t *out_lo, *out_hi; uint32_t *out_cnt; uint64_t out_cap;
+  uint64_t *stats;
+};
+
+typedef unsigned __int128 u128;
+
+// k-mers of a record, one by one: fwd / rc rolling over the 192-bit base string
+struct Roll2 {
+  u128 fwd, rc, kmask;
+  uint64_t t0, t1, t2;     // bases not yet consumed, first one in the top bits of t0
+  int rcsh;
+  __device__ __forceinline__ void init(const Rec2 &r, int k) {
+    const uint64_t s0 = ((uint64_t)r.a.x << 32) | r.a.y, s1 = ((uint64_t)r.a.z << 32) | r.a.w;
+    const uint64_t s2 = ((uint64_t)r.b.x << 32) | r.b.y;
+    kmask = (k == 64) ? ~(u128)0 : ((((u128)1) << (2 * k)) - 1);
+    rcsh = 2 * k - 2;
+    const u128 top = ((u128)s0 << 64) | s1;            // bases 0..63
+    fwd = top >> (128 - 2 * k);                         // k <= 64
+    {
+      // reverse complement of the 2k-bit value: reverse all 128 bits, swap the bits of every
+      // pair back, complement, drop the 128-2k low bits
+      uint64_t rh = __brevll((uint64_t)fwd), rl = __brevll((uint64_t)(fwd >> 64));
+      rh = ((rh >> 1) & 0x5555555555555555ull) | ((rh & 0x5555555555555555ull) << 1);
+      rl = ((rl >> 1) & 0x5555555555555555ull) | ((rl & 0x5555555555555555ull) << 1);
+      rc = ((((u128)~rh) << 64) | (u128)~rl) >> (128 - 2 * k);
+    }
+    // remaining bases start at base k (33..64)
+    const int sh = 2 * k - 64;                          // 2..64 bits into s1
+    if (sh == 64) { t0 = s2; t1 = 0; }
+    else { t0 = (s1 << sh) | (s2 >> (64 - sh)); t1 = s2 << sh; }
+    t2 = 0;
+  }
+  __device__ __forceinline__ void next() {
+    const unsigned nb = (unsigned)(t0 >> 62);
+    t0 = (t0 << 2) | (t1 >> 62);
+    t1 <<= 2;
+    fwd = ((fwd << 2) | (u128)nb) & kmask;
+    rc = (rc >> 2) | ((u128)(3u - nb) << rcsh);
+  }
+};
+
+__device__ __noinline__ void spill_record2(const Rec2 &rec, int k, bool canon, const TableView &t) {
+  t.stats[ST_SPILLED] = 1;
+  atomicAdd((unsigned long long *)&t.stats[ST_AUX0], 1ull);
+  const int nk = (int)(rec.b.w & 63u) + 1;
+  Roll2 r;
+  r.init(rec, k);
+  for (int j = 0; j < nk; ++j) {
+    const u128 key = (canon && r.rc < r.fwd) ? r.rc : r.fwd;
+    table_add2(t, (uint64_t)key, (uint64_t)(key >> 64), 1u);
+    r.next();
+  }
+}
+
+// ---------------------------------------------------------------------------------------- Q1
+__global__ __launch_bounds__(Q1_THREADS) void msp2_p1_kernel(const int8_t *__restrict__ data, int64_t nN,
+                                                             int k, int m, int c, int canon, View2 v,
+                                                             TableView t) {
+  constexpr int NH = 32 + W2 - 1;
+  __shared__ Rec2 rec_tmp[Q1_RCAP];
+  __shared__ uint16_t perm[Q1_RCAP];
+  __shared__ uint8_t bin_tmp[Q1_RCAP];
+  __shared__ uint32_t hist[B1], loff[B1], gbase[B1], fill[B1];
+  __shared__ uint32_t wtot[4];
+  __shared__ uint32_t nrec_s;
+  const int tid = threadIdx.x, lane = tid & 63;
+
+  if (tid < B1) { hist[tid] = 0; fill[tid] = 0; }
+  if (tid == 0) nrec_s = 0;
+  __syncthreads();
+
+  // ---- A: own chunk, the previous one and the next three (by shuffle) ----
+  const int64_t wave_g = (int64_t)blockIdx.x * Q1_WAVES + (tid >> 6);
+  const int64_t chunk = wave_g * Q1_OWN + lane - 1;
+  const int64_t off = chunk * 32;
+  uint32_t R[10], bd[5];                       // bases / invalid masks of chunks -1, 0, 1, 2, 3
+  R[2] = 0; R[3] = 0; bd[1] = 0xFFFFFFFFu;
+  if (chunk >= 0) dev_load_chunk32(data, off, nN, R[2], R[3], bd[1]);
+  R[0] = __shfl_up(R[2], 1); R[1] = __shfl_up(R[3], 1); bd[0] = __shfl_up(bd[1], 1);
+  R[4] = __shfl_down(R[2], 1); R[5] = __shfl_down(R[3], 1); bd[2] = __shfl_down(bd[1], 1);
+  R[6] = __shfl_down(R[2], 2); R[7] = __shfl_down(R[3], 2); bd[3] = __shfl_down(bd[1], 2);
+  R[8] = __shfl_down(R[2], 3); R[9] = __shfl_down(R[3], 3); bd[4] = __shfl_down(bd[1], 3);
+  const uint64_t hi = ((uint64_t)R[2] << 32) | R[3];
+  const uint64_t mid = ((uint64_t)R[4] << 32) | R[5];
+
+  // validity of the k-mer that belongs to window position y: bases y-c .. y-c+k-1.  I = invalid
+  // mask with origin at base -32; smear over the k following bases, then read at offset 32-c.
+  uint64_t I0 = ((uint64_t)bd[0] << 32) | bd[1], I1 = ((uint64_t)bd[2] << 32) | bd[3], I2 = (uint64_t)bd[4] << 32;
+  {
+    int w = 1;
+#pragma unroll
+    for (int st = 0; st < 6; ++st) {
+      if (2 * w <= k) {
+        I0 |= (I0 << w) | (I1 >> (64 - w));
+        I1 |= (I1 << w) | (I2 >> (64 - w));
+        I2 |= I2 << w;
+        w *= 2;
+      }
+    }
+    if (k > w) {
+      const int s = k - w;
+      I0 |= (I0 << s) | (I1 >> (64 - s));
+      I1 |= (I1 << s) | (I2 >> (64 - s));
+    }
+  }
+  const int o = 32 - c;                                        // 15..31
+  const uint64_t Vx = ~((I0 << o) | (I1 >> (64 - o)));
+  const uint32_t V = (uint32_t)(Vx >> 32);
+  const uint32_t prevV = __shfl_up(V, 1) & 1u;
+
+  uint32_t H[NH];
+  const uint64_t Cx = msp_minimizers<W2>(hi, mid, chunk, m, H);
+  const uint64_t E = Cx | ~Vx | (1ull << (63 - NH));
+  const uint32_t Vprev = (V >> 1) | (prevV << 31);
+  uint32_t S = V & ((uint32_t)(Cx >> 32) | ~Vprev);
+  const bool owner = lane >= 1 && lane <= Q1_OWN && off < nN + 32;   // a k-mer may START in the previous chunk
+  if (!owner) S = 0;
+
+  // ---- B: one 32-byte record per run, staged in LDS ----
+  uint32_t slot;
+  {
+    const uint32_t mine = (uint32_t)__popc(S);
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t y = __shfl_up(incl, d);
+      if (lane >= d) incl += y;
+    }
+    uint32_t wbase = 0;
+    if (lane == 63 && incl) wbase = atomicAdd(&nrec_s, incl);
+    slot = __shfl(wbase, 63) + incl - mine;
+  }
+  while (S) {
+    const int a = __clz(S);
+    S &= ~(0x80000000u >> a);
+    const uint64_t rest = E << (a + 1);
+    const int n = min(__clzll(rest) + 1, W2);
+    const uint32_t pv = a ? ((V >> (32 - a)) & 1u) : prevV;
+    const uint32_t complete = (pv & (uint32_t)(Vx >> (63 - (a + n))) & 1u) << 6;
+    const uint32_t leaf = leaf_of(pick32(H, a));
+    const uint32_t bin1 = leaf >> B2_LOG;
+    // bases of the run: 96 bases from string offset 32 + a - c (origin = chunk -1)
+    const int o2 = 32 + a - c;                                  // 15..63
+    const int q = o2 >> 4, sb = 2 * (o2 & 15);
+    uint32_t T[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const uint32_t x0 = R[i], x1 = R[i + 1], x2 = R[i + 2], x3 = R[i + 3];
+      const uint32_t lo_ = (q & 1) ? x1 : x0, hi_ = (q & 1) ? x3 : x2;
+      T[i] = (q & 2) ? hi_ : lo_;
+    }
+    uint32_t D[6];
+    const int nb = n + k - 1;                                   // bases that belong to the run
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      uint32_t d = sb ? ((T[i] << sb) | (T[i + 1] >> (32 - sb))) : T[i];
+      const int keep = 2 * nb - 32 * i;                         // bits of this dword inside the run
+      d = (keep >= 32) ? d : ((keep <= 0) ? 0u : (d & (~0u << (32 - keep))));
+      D[i] = d;
+    }
+    Rec2 rec;
+    rec.a = make_uint4(D[0], D[1], D[2], D[3]);
+    rec.b = make_uint4(D[4], D[5], 0u, (leaf << 8) | complete | (uint32_t)(n - 1));
+    if (slot < (uint32_t)Q1_RCAP) {
+      rec_tmp[slot] = rec;
+      bin_tmp[slot] = (uint8_t)bin1;
+      atomicAdd(&hist[bin1], 1u);
+    } else {
+      const uint32_t reg = bin1 * NXG + (blockIdx.x & (NXG - 1));
+      const uint32_t dst = atomicAdd(&v.cnt1[reg], 1u);
+      if (dst < v.cap1) v.rec1[(uint64_t)reg * v.cap1 + dst] = rec;
+      else spill_record2(rec, k, canon != 0, t);
+    }
+    ++slot;
+  }
+  __syncthreads();
+
+  // ---- C / D: reservation, bin-ordered copy-out (as msp.hip) ----
+  uint32_t my_base = 0;
+  if (tid < B1) {
+    const uint32_t cnum = hist[tid];
+    if (cnum) my_base = atomicAdd(&v.cnt1[tid * NXG + (blockIdx.x & (NXG - 1))], cnum);
+  }
+  block_scan<B1>(hist, loff, wtot);
+  const uint32_t nrec = min(nrec_s, (uint32_t)Q1_RCAP);
+  for (uint32_t s = tid; s < nrec; s += Q1_THREADS) {
+    const uint32_t b = bin_tmp[s];
+    perm[loff[b] + atomicAdd(&fill[b], 1u)] = (uint16_t)s;
+  }
+  if (tid < B1) gbase[tid] = my_base;
+  __syncthreads();
+  for (uint32_t p = tid; p < nrec; p += Q1_THREADS) {
+    const uint32_t s = perm[p];
+    const uint32_t b = bin_tmp[s];
+    const uint32_t dst = gbase[b] + (p - loff[b]);
+    const Rec2 rec = rec_tmp[s];
+    if (dst < v.cap1) v.rec1[((uint64_t)b * NXG + (blockIdx.x & (NXG - 1))) * v.cap1 + dst] = rec;
+    else spill_record2(rec, k, canon != 0, t);
+  }
+}
+
+// ---------------------------------------------------------------------------------------- Q2
+// msp.hip's P2 on 32-byte records (same header word, same sub-bins, same XCD-affine order)
+__global__ __launch_bounds__(Q2_THREADS) void msp2_p2_kernel(int tiles_per_sub, int k, int canon, View2 v,
+                                                             TableView t) {
+  __shared__ Rec2 sorted[Q2_TILE];
+  __shared__ uint32_t hist[NSUB], loff[NSUB], gbase[NSUB];
+  __shared__ uint32_t wtot[Q2_THREADS / 64];
+  static_assert(NSUB == Q2_THREADS, "one sub-bin per thread");
+  const int tid = threadIdx.x;
+  const uint32_t xg = blockIdx.x & (NXG - 1), seq = blockIdx.x / NXG;
+  const uint32_t per_bin = (uint32_t)NXG * (uint32_t)tiles_per_sub;
+  const uint32_t b1 = xg + NXG * (seq / per_bin);
+  const uint32_t sub = (seq % per_bin) / (uint32_t)tiles_per_sub;
+  const uint32_t tile = (seq % per_bin) % (uint32_t)tiles_per_sub;
+  const uint32_t reg = b1 * NXG + sub;
+  const uint64_t n = min((uint64_t)v.cnt1[reg], v.cap1);
+  const uint64_t r0 = (uint64_t)tile * Q2_TILE;
+  if (r0 >= n) return;
+  const uint32_t nt = (uint32_t)min((uint64_t)Q2_TILE, n - r0);
+  hist[tid] = 0;
+  __syncthreads();
+  const Rec2 *src = v.rec1 + (uint64_t)reg * v.cap1 + r0;
+  Rec2 r[Q2_PER];
+#pragma unroll
+  for (int i = 0; i < Q2_PER; ++i) {
+    const uint32_t idx = (uint32_t)i * Q2_THREADS + tid;
+    Rec2 x;
+    x.a = make_uint4(0u, 0u, 0u, 0u); x.b = make_uint4(0u, 0u, 0u, 0u);
+    if (idx < nt) x = src[idx];
+    r[i] = x;
+    if (idx < nt) atomicAdd(&hist[sub_of(x.b.w)], 1u);
+  }
+  __syncthreads();
+  uint32_t g0 = 0;
+  {
+    const int lane = tid & 63, wave = tid >> 6;
+    const uint32_t x0 = hist[tid];
+    if (x0) g0 = atomicAdd(&v.cnt2[b1 * NSUB + tid], x0);
+    uint32_t incl = x0;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t y = __shfl_up(incl, d);
+      if (lane >= d) incl += y;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wave; ++w) base += wtot[w];
+    loff[tid] = base + incl - x0;
+    hist[tid] = 0;
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < Q2_PER; ++i) {
+    const uint32_t idx = (uint32_t)i * Q2_THREADS + tid;
+    if (idx < nt) {
+      const uint32_t sb = sub_of(r[i].b.w);
+      sorted[loff[sb] + atomicAdd(&hist[sb], 1u)] = r[i];
+    }
+  }
+  gbase[tid] = g0;
+  __syncthreads();
+  for (uint32_t p = tid; p < nt; p += Q2_THREADS) {
+    const Rec2 rec = sorted[p];
+    const uint32_t sb = sub_of(rec.b.w);
+    const uint32_t dst = gbase[sb] + (p - loff[sb]);
+    const uint64_t leaf = ((uint64_t)b1 * NSUB + sb) >> 2;
+    const uint32_t cls = sb & 3u;
+    const uint64_t cap = (cls == 3u) ? v.cap2c : v.cap2t;
+    const uint64_t at = leaf * (v.cap2c + 3 * v.cap2t) + ((cls == 3u) ? 0 : v.cap2c + cls * v.cap2t);
+    if (dst < cap) v.rec2[at + dst] = rec;
+    else spill_record2(rec, k, canon != 0, t);
+  }
+}
+
+// ---------------------------------------------------------------------------------------- Q3
+__device__ __forceinline__ uint32_t t2_slot(uint64_t lo, uint64_t hi) {
+  const uint32_t x = (uint32_t)lo ^ (uint32_t)(lo >> 32) ^ ((uint32_t)hi * 0x85EBCA77u) ^ (uint32_t)(hi >> 32);
+  return (x * 0x9E3779B1u) >> (32 - T2_LOG);
+}
+
+// one probe step (flat control flow, see msp.hip): cnts[h] is the slot state -- 0 empty, T2_LOCK
+// while the claiming lane writes the key, else the count
+__device__ __forceinline__ void t2_step(ulonglong2 *keys, uint32_t *cnts, uint64_t lo, uint64_t hi,
+                                        uint32_t &h, bool &pend, bool &fail, int &probes) {
+  const uint32_t cst = cnts[h];
+  // the key may only be read after the state: a published count vouches for the key words
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  const ulonglong2 kk = keys[h];
+  const bool empty = cst == 0u, locked = cst == T2_LOCK;
+  const bool match = !empty && !locked && kk.x == lo && kk.y == hi;
+  if (pend && match) atomicAdd(&cnts[h], 1u);
+  bool won = false;
+  if (pend && empty) {
+    const uint32_t old = atomicCAS(&cnts[h], 0u, T2_LOCK);
+    if (old == 0u) {
+      keys[h] = make_ulonglong2(lo, hi);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      atomicExch(&cnts[h], 1u);
+      won = true;
+    }
+  }
+  const bool adv = pend && !match && !empty && !locked;
+  h = adv ? ((h + 1) & (T2 - 1)) : h;
+  probes += (adv || (pend && locked)) ? 1 : 0;
+  const bool giveup = probes >= Q3_PROBE_LIMIT;
+  fail = fail || (pend && !match && !won && giveup);
+  pend = pend && !match && !won && !giveup;
+}
+
+template <bool CANON>
+__global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, TableView t) {
+  __shared__ ulonglong2 keys[T2];
+  __shared__ uint32_t cnts[T2];
+  __shared__ uint32_t wg_total;
+  __shared__ unsigned long long wg_base;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const uint32_t leaf = blockIdx.x;
+  uint64_t ns[NCLS];
+  uint64_t total = 0;
+#pragma unroll
+  for (int cl = 0; cl < NCLS; ++cl) {
+    ns[cl] = min((uint64_t)v.cnt2[NCLS * leaf + cl], cl == 3 ? v.cap2c : v.cap2t);
+    total += ns[cl];
+  }
+  if (total == 0) return;
+  for (int s = tid; s < T2; s += Q3_THREADS) cnts[s] = 0;
+  if (tid == 0) wg_total = 0;
+  __syncthreads();
+
+  const Rec2 *leaf_rec = v.rec2 + (uint64_t)leaf * (v.cap2c + 3 * v.cap2t);
+  // streams in the order complete, long, medium, short: lanes of a wave expand similar lengths
+  for (int cl = 3; cl >= 0; --cl) {
+    const Rec2 *src = (cl == 3) ? leaf_rec : leaf_rec + v.cap2c + (uint64_t)cl * v.cap2t;
+    for (uint64_t r = tid; r < ns[cl]; r += Q3_THREADS) {
+      const Rec2 rec = src[r];
+      const int nk = (int)(rec.b.w & 63u) + 1;
+      Roll2 roll;
+      roll.init(rec, k);
+      for (int j = 0; j < nk; ++j) {
+        const u128 key = (CANON && roll.rc < roll.fwd) ? roll.rc : roll.fwd;
+        const uint64_t lo = (uint64_t)key, hi = (uint64_t)(key >> 64);
+        uint32_t h = t2_slot(lo, hi);
+        bool pend = true, fail = false;
+        int probes = 0;
+        do {
+          t2_step(keys, cnts, lo, hi, h, pend, fail, probes);
+        } while (__ballot(pend));
+        if (fail) {
+          t.stats[ST_SPILLED] = 1;
+          atomicAdd((unsigned long long *)&t.stats[ST_AUX1], 1ull);
+          table_add2(t, lo, hi, 1u);
+        }
+        roll.next();
+      }
+    }
+  }
+  __syncthreads();
+
+  // compaction to the two-word result list: one cursor atomic per workgroup
+  constexpr int NIT = T2 / Q3_THREADS;
+  uint32_t wbase[NIT];
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const unsigned long long mm = __ballot(cnts[i * Q3_THREADS + tid] != 0u);
+    uint32_t b = 0;
+    if (lane == 0 && mm) b = atomicAdd(&wg_total, (uint32_t)__popcll(mm));
+    wbase[i] = __shfl(b, 0);
+  }
+  __syncthreads();
+  if (tid == 0) wg_base = atomicAdd((unsigned long long *)&v.stats[ST_CURSOR], (unsigned long long)wg_total);
+  __syncthreads();
+  const unsigned long long gb = wg_base;
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int s = i * Q3_THREADS + tid;
+    const uint32_t cval = cnts[s];
+    const bool occ = cval != 0u;
+    const unsigned long long mm = __ballot(occ);
+    if (occ) {
+      const unsigned long long dst = gb + wbase[i] + __popcll(mm & ((1ull << lane) - 1ull));
+      if (dst < v.out_cap) { v.out_lo[dst] = keys[s].x; v.out_hi[dst] = keys[s].y; v.out_cnt[dst] = cval; }
+      else v.stats[ST_OVERFLOW] = 1;
+    }
+  }
+}
+
+}  // namespace
+
+bool cfrk_msp2_usable(const cfrk_ctx *ctx) {
+  return ctx->g_two && ctx->g_k >= 33 && ctx->g_k <= 64 && !(ctx->g_flags & CFRK_FORCE_HASH);
+}
+
+int cfrk_msp2_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
+  cfrk_msp *ms = cfrk_msp_get(ctx);
+  if (!ms) return cfrk_fail(ctx, CFRK_ERR_NOMEM, "host allocation failed");
+  int rc;
+  if (ms->pending && (rc = cfrk_msp_flush_to_table(ctx))) return rc;
+  const int k = ctx->g_k;
+  const int m = (k & 1) ? 14 : 13;                       // k - m + 1 - 18 must be even
+  const int c = (k - m + 1 - W2) / 2;                    // 1..17
+  const int canon = (ctx->g_flags & CFRK_CANONICAL) ? 1 : 0;
+
+  const double dens = 2.0 / (W2 + 1) + 1.0 / 64.0;
+  const double expect = (double)nN * dens;
+  const uint64_t cap1 = (uint64_t)(expect / (B1 * NXG) * 1.35) + 2048;
+  const uint64_t cap2c = (uint64_t)(expect / NLEAF * 2.1) + 96;
+  const uint64_t cap2t = (uint64_t)(expect / NLEAF * 0.4) + 96;
+  const int64_t tiles_per_sub = (int64_t)((cap1 + Q2_TILE - 1) / Q2_TILE);
+  if (tiles_per_sub * B1 * NXG > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
+  {
+    const size_t need = (size_t)B1 * NXG * cap1 * 32 + (size_t)NLEAF * (cap2c + 3 * cap2t) * 32 + (size_t)ctx->g_cap * 20;
+    const size_t have = ctx->pool[BUF_MSP_L1].cap + ctx->pool[BUF_MSP_L2].cap + ctx->pool[BUF_MSP_OUTK].cap +
+                        ctx->pool[BUF_MSP_OUTC].cap + ctx->pool[BUF_MSP_OUTH].cap;
+    if (need > have) {
+      size_t free_b = 0, total_b = 0;
+      HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+      if (need > have + free_b) return cfrk_fail(ctx, CFRK_ERR_NOMEM, "partitioned path needs %zu B, %zu B available", need, have + free_b);
+    }
+  }
+  void *p;
+  View2 v;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L1, (size_t)B1 * NXG * cap1 * sizeof(Rec2), &p))) return rc;
+  v.rec1 = (Rec2 *)p; v.cap1 = cap1;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)NLEAF * (cap2c + 3 * cap2t) * sizeof(Rec2), &p))) return rc;
+  v.rec2 = (Rec2 *)p; v.cap2c = cap2c; v.cap2t = cap2t;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_AUX, (size_t)(B1 * NXG + NCLS * NLEAF) * sizeof(uint32_t), &p))) return rc;
+  v.cnt1 = (uint32_t *)p; v.cnt2 = v.cnt1 + B1 * NXG;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTK, (size_t)ctx->g_cap * 8, &p))) return rc;
+  v.out_lo = (uint64_t *)p;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTH, (size_t)ctx->g_cap * 8, &p))) return rc;
+  v.out_hi = (uint64_t *)p;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTC, (size_t)ctx->g_cap * 4, &p))) return rc;
+  v.out_cnt = (uint32_t *)p; v.out_cap = ctx->g_cap;
+  v.stats = ctx->g_stats;
+  TableView t = cfrk_table_view(ctx);
+
+  HIP_TRY(ctx, hipMemsetAsync(v.cnt1, 0, (size_t)(B1 * NXG + NCLS * NLEAF) * sizeof(uint32_t), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_CURSOR, 0, sizeof(uint64_t), ctx->stream));
+  const int64_t nchunks = (nN + 31) / 32 + 1;              // + the chunk that only holds k-mer tails
+  const int64_t nwaves = (nchunks + Q1_OWN - 1) / Q1_OWN;
+  const int64_t ntiles = (nwaves + Q1_WAVES - 1) / Q1_WAVES;
+  if (ntiles > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
+  hipLaunchKernelGGL(msp2_p1_kernel, dim3((unsigned)ntiles), dim3(Q1_THREADS), 0, ctx->stream, d_data, nN, k, m, c,
+                     canon, v, t);
+  HIP_TRY(ctx, hipGetLastError());
+  hipLaunchKernelGGL(msp2_p2_kernel, dim3((unsigned)(tiles_per_sub * B1 * NXG)), dim3(Q2_THREADS), 0, ctx->stream,
+                     (int)tiles_per_sub, k, canon, v, t);
+  HIP_TRY(ctx, hipGetLastError());
+  if (canon) hipLaunchKernelGGL((msp2_p3_kernel<true>), dim3(NLEAF), dim3(Q3_THREADS), 0, ctx->stream, k, v, t);
+  else hipLaunchKernelGGL((msp2_p3_kernel<false>), dim3(NLEAF), dim3(Q3_THREADS), 0, ctx->stream, k, v, t);
+  HIP_TRY(ctx, hipGetLastError());
+  ms->view.out_keys = v.out_lo; ms->view.out_hi = v.out_hi; ms->view.out_cnt = v.out_cnt;
+  ms->view.out_cap = v.out_cap; ms->view.stats = v.stats; ms->view.cnt1 = nullptr;
+  ms->pending = true;
+  ms->leaf_form = false;
+  ms->list_n_valid = false;
+  return CFRK_OK;
+}

@@ -76,6 +76,6 @@ struct ResultSrc {
   const uint64_t *lo, *hi;
   const uint32_t *cnt;
   uint64_t n;        // slots (table) or entries (list)
-  int kind;          // 0: one-word table, 1: two-word table, 2: one-word list
+  int kind;          // 0: one-word table, 1: two-word table, 2: one-word list, 3: two-word list
   uint64_t *stats;
 };

@@ -134,12 +134,10 @@ def _cmp_global(ctx, data, k, canonical, hint=0, start=None, length=None, force_
     return g
 
 
-@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 6, 7, 8, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 47, 63, 64])
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 6, 7, 8, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 40, 47, 48, 55, 62, 63, 64])
 @pytest.mark.parametrize("canonical", [False, True])
 @pytest.mark.parametrize("force_hash", [False, True])
 def test_global_vs_oracle(ctx, k, canonical, force_hash):
-    if force_hash and k > 32:
-        pytest.skip("the HBM hash path is the only path for this k")
     rng = np.random.default_rng(200 + k)
     reads = _random_reads(rng, 400, 1, 300)
     reads.append(np.full(200, 3, np.int8))      # poly-T: the all-ones key at k=32
@@ -156,7 +154,7 @@ def test_global_ragged_tail_sizes(ctx):
         data = rng.integers(0, 4, n).astype(np.int8)
         data[rng.random(n) < 0.01] = -1
         data[-1] = -1
-        for k in (1, 7, 12, 16, 22, 31, 32):
+        for k in (1, 7, 12, 16, 22, 31, 32, 33, 64):
             _cmp_global(ctx, data, k, True)
             _cmp_global(ctx, data, k, False, force_hash=True)
 
@@ -351,7 +349,7 @@ def test_msp_low_complexity_and_many_invalid(ctx):
              np.tile(np.array([0, 1], np.int8), 3000), np.tile(np.array([0, 1, 2, 3, 3, 2], np.int8), 1500)]
     reads += _random_reads(rng, 200, 20, 400, 0.05)
     data, _, _ = refsem.flatten(reads)
-    for k in (3, 9, 15, 16, 18, 21, 24, 27, 31, 32):
+    for k in (3, 9, 15, 16, 18, 21, 24, 27, 31, 32, 33, 50, 63):
         for canonical in (False, True):
             _cmp_global(ctx, data, k, canonical)
 
