@@ -8,8 +8,8 @@
 //     a lane owns the 32 WINDOW positions y of its chunk, i.e. the k-mers starting at y - c;
 //   * records are 32 bytes: 96 bases (6 dwords; a run spans at most 18 + 63 bases) + header;
 //   * the leaf kernel keeps 16-byte keys in LDS (claimed through the count word: 0 empty,
-//     LOCK while the claiming lane writes the key) and counts k-mer by k-mer (no record table
-//     yet), results go to a two-word list.
+//     LOCK while the claiming lane writes the key); complete runs go through a record table
+//     first, as in msp.hip; results go to a two-word list.
 // Anything that does not fit is counted in the two-word HBM table (table_add2).
 //
 // Semantics: the guarded ComputeFreq of /root/reference/src/kmer_kernel.cu:52-70 summed over
@@ -322,21 +322,21 @@ __device__ __forceinline__ uint32_t t2_slot(uint64_t lo, uint64_t hi) {
 // one probe step (flat control flow, see msp.hip): cnts[h] is the slot state -- 0 empty, T2_LOCK
 // while the claiming lane writes the key, else the count
 __device__ __forceinline__ void t2_step(ulonglong2 *keys, uint32_t *cnts, uint64_t lo, uint64_t hi,
-                                        uint32_t &h, bool &pend, bool &fail, int &probes) {
+                                        uint32_t add, uint32_t &h, bool &pend, bool &fail, int &probes) {
   const uint32_t cst = cnts[h];
   // the key may only be read after the state: a published count vouches for the key words
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   const ulonglong2 kk = keys[h];
   const bool empty = cst == 0u, locked = cst == T2_LOCK;
   const bool match = !empty && !locked && kk.x == lo && kk.y == hi;
-  if (pend && match) atomicAdd(&cnts[h], 1u);
+  if (pend && match) atomicAdd(&cnts[h], add);
   bool won = false;
   if (pend && empty) {
     const uint32_t old = atomicCAS(&cnts[h], 0u, T2_LOCK);
     if (old == 0u) {
       keys[h] = make_ulonglong2(lo, hi);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      atomicExch(&cnts[h], 1u);
+      atomicExch(&cnts[h], add);
       won = true;
     }
   }
@@ -348,10 +348,83 @@ __device__ __forceinline__ void t2_step(ulonglong2 *keys, uint32_t *cnts, uint64
   pend = pend && !match && !won && !giveup;
 }
 
+// expand one record, every k-mer counted `add` times
+template <bool CANON>
+__device__ __forceinline__ void count_record2(ulonglong2 *keys, uint32_t *cnts, const Rec2 &rec, uint32_t add,
+                                              int k, const TableView &t) {
+  const int nk = (int)(rec.b.w & 63u) + 1;
+  Roll2 roll;
+  roll.init(rec, k);
+  for (int j = 0; j < nk; ++j) {
+    const u128 key = (CANON && roll.rc < roll.fwd) ? roll.rc : roll.fwd;
+    const uint64_t lo = (uint64_t)key, hi = (uint64_t)(key >> 64);
+    uint32_t h = t2_slot(lo, hi);
+    bool pend = true, fail = false;
+    int probes = 0;
+    do {
+      t2_step(keys, cnts, lo, hi, add, h, pend, fail, probes);
+    } while (__ballot(pend));
+    if (fail) {
+      t.stats[ST_SPILLED] = 1;
+      atomicAdd((unsigned long long *)&t.stats[ST_AUX1], (unsigned long long)add);
+      table_add2(t, lo, hi, add);
+    }
+    roll.next();
+  }
+}
+
+// Record table as in msp.hip: complete runs of a leaf are mostly byte-identical across reads.
+// Entry = Rec2 whose header word is the state: 0 empty, R2_LOCK while being written, else
+// count << 6 | (n-1).
+constexpr int R2_LOG = 10, R2 = 1 << R2_LOG;
+static_assert(R2 == Q3_THREADS, "phase 2 lists the record table with one slot per thread");
+constexpr uint32_t R2_LOCK = 0xFFFFFFFFu;
+constexpr int R2_PROBES = 24;
+
+__device__ __forceinline__ uint32_t r2_slot(const Rec2 &r) {
+  uint32_t h = (r.a.x * 0x9E3779B1u) ^ (r.a.y * 0x85EBCA77u) ^ (r.a.z * 0xC2B2AE3Du) ^ (r.a.w * 0x27D4EB2Fu) ^
+               (r.b.x * 0x165667B1u) ^ (r.b.y * 0xD3A2646Cu) ^ ((r.b.w & 63u) * 0xFD7046C5u);
+  h = (h ^ (h >> 15)) * 0x2C1B3C6Du;
+  return h >> (32 - R2_LOG);
+}
+
+__device__ __forceinline__ void r2_step(Rec2 *rtab, const Rec2 &rec, uint32_t &h, bool &pend, bool &fail,
+                                        int &probes) {
+  uint32_t *words = reinterpret_cast<uint32_t *>(rtab);
+  const uint32_t nm1 = rec.b.w & 63u;
+  const uint4 eb = rtab[h].b;                              // state word + bases 64..95
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // bases 0..63 only after the state
+  const uint4 ea = rtab[h].a;
+  const bool empty = eb.w == 0u, locked = eb.w == R2_LOCK;
+  const bool match = !empty && !locked && (eb.w & 63u) == nm1 && eb.x == rec.b.x && eb.y == rec.b.y &&
+                     ea.x == rec.a.x && ea.y == rec.a.y && ea.z == rec.a.z && ea.w == rec.a.w;
+  if (pend && match) atomicAdd(&words[8 * h + 7], 1u << 6);
+  bool won = false;
+  if (pend && empty) {
+    const uint32_t old = atomicCAS(&words[8 * h + 7], 0u, R2_LOCK);
+    if (old == 0u) {
+      rtab[h].a = rec.a;
+      words[8 * h + 4] = rec.b.x; words[8 * h + 5] = rec.b.y;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      atomicExch(&words[8 * h + 7], (1u << 6) | nm1);
+      won = true;
+    }
+  }
+  const bool adv = pend && !match && !empty && !locked;
+  h = adv ? ((h + 1) & (R2 - 1)) : h;
+  probes += (adv || (pend && locked)) ? 1 : 0;
+  const bool giveup = probes >= R2_PROBES;
+  fail = fail || (pend && !match && !won && giveup);
+  pend = pend && !match && !won && !giveup;
+}
+
 template <bool CANON>
 __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, TableView t) {
   __shared__ ulonglong2 keys[T2];
   __shared__ uint32_t cnts[T2];
+  __shared__ Rec2 rtab[R2];
+  __shared__ uint16_t occ_list[R2];
+  __shared__ uint32_t nocc;
   __shared__ uint32_t wg_total;
   __shared__ unsigned long long wg_base;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -365,35 +438,46 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
   }
   if (total == 0) return;
   for (int s = tid; s < T2; s += Q3_THREADS) cnts[s] = 0;
-  if (tid == 0) wg_total = 0;
+  {
+    Rec2 z;
+    z.a = make_uint4(0u, 0u, 0u, 0u); z.b = make_uint4(0u, 0u, 0u, 0u);
+    rtab[tid] = z;
+  }
+  if (tid == 0) { wg_total = 0; nocc = 0; }
   __syncthreads();
 
   const Rec2 *leaf_rec = v.rec2 + (uint64_t)leaf * (v.cap2c + 3 * v.cap2t);
-  // streams in the order complete, long, medium, short: lanes of a wave expand similar lengths
-  for (int cl = 3; cl >= 0; --cl) {
-    const Rec2 *src = (cl == 3) ? leaf_rec : leaf_rec + v.cap2c + (uint64_t)cl * v.cap2t;
-    for (uint64_t r = tid; r < ns[cl]; r += Q3_THREADS) {
-      const Rec2 rec = src[r];
-      const int nk = (int)(rec.b.w & 63u) + 1;
-      Roll2 roll;
-      roll.init(rec, k);
-      for (int j = 0; j < nk; ++j) {
-        const u128 key = (CANON && roll.rc < roll.fwd) ? roll.rc : roll.fwd;
-        const uint64_t lo = (uint64_t)key, hi = (uint64_t)(key >> 64);
-        uint32_t h = t2_slot(lo, hi);
-        bool pend = true, fail = false;
-        int probes = 0;
-        do {
-          t2_step(keys, cnts, lo, hi, h, pend, fail, probes);
-        } while (__ballot(pend));
-        if (fail) {
-          t.stats[ST_SPILLED] = 1;
-          atomicAdd((unsigned long long *)&t.stats[ST_AUX1], 1ull);
-          table_add2(t, lo, hi, 1u);
-        }
-        roll.next();
-      }
-    }
+  // ---- phase 1: complete runs, one record-table update per record
+  for (uint64_t r = tid; r < ns[3]; r += Q3_THREADS) {
+    const Rec2 rec = leaf_rec[r];
+    uint32_t h = r2_slot(rec);
+    bool pend = true, fail = false;
+    int probes = 0;
+    do {
+      r2_step(rtab, rec, h, pend, fail, probes);
+    } while (__ballot(pend));
+    if (fail) count_record2<CANON>(keys, cnts, rec, 1u, k, t);
+  }
+  __syncthreads();
+  // ---- phase 2: every distinct complete record once (weight = multiplicity), then the
+  //      truncated runs, long ones first
+  {
+    const uint32_t st = rtab[tid].b.w;
+    const bool occ = st != 0u;
+    const unsigned long long mm = __ballot(occ);
+    uint32_t b = 0;
+    if (lane == 0 && mm) b = atomicAdd(&nocc, (uint32_t)__popcll(mm));
+    b = __shfl(b, 0);
+    if (occ) occ_list[b + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull))] = (uint16_t)tid;
+  }
+  __syncthreads();
+  for (uint32_t i = tid; i < nocc; i += Q3_THREADS) {
+    const Rec2 rec = rtab[occ_list[i]];
+    count_record2<CANON>(keys, cnts, rec, rec.b.w >> 6, k, t);
+  }
+  for (int cl = 2; cl >= 0; --cl) {
+    const Rec2 *src = leaf_rec + v.cap2c + (uint64_t)cl * v.cap2t;
+    for (uint64_t r = tid; r < ns[cl]; r += Q3_THREADS) count_record2<CANON>(keys, cnts, src[r], 1u, k, t);
   }
   __syncthreads();
 

@@ -1,4 +1,7 @@
-import csv,sys,glob
-f=sorted(glob.glob(sys.argv[1]+"/*/*kernel_stats.csv"))[-1]
+"""Print the counting kernels of the newest rocprofv3 --stats run under a directory: name, calls, avg ms."""
+import csv, glob, re, sys
+f = sorted(glob.glob(sys.argv[1] + "/*/*kernel_stats.csv"))[-1]
 for r in csv.DictReader(open(f)):
-    if "msp_p" in r["Name"]: print(r["Name"].split("(")[0][-16:], r["Calls"], float(r["AverageNs"])/1e6)
+    m = re.search(r"(msp2?_\w+|rx\w*_\w+|hash_\w+|result_\w+|dense_\w+)", r["Name"])
+    if m:
+        print("%-28s calls=%-4s avg_ms=%.3f" % (m.group(1), r["Calls"], float(r["AverageNs"]) / 1e6))
