@@ -274,6 +274,7 @@ int cfrk_global_add_device(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   int rc;
   rc = CFRK_ERR_NOMEM;
+  ctx->last_passes = 0;
   if (cfrk_msp_usable(ctx)) rc = cfrk_msp_count(ctx, d_data, nN);
   else if (cfrk_radix_usable(ctx)) rc = cfrk_radix_count(ctx, d_data, nN);
   else if (cfrk_msp2_usable(ctx)) rc = cfrk_msp2_count(ctx, d_data, nN);

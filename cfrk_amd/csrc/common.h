@@ -50,6 +50,8 @@ struct cfrk_ctx {
   hipEvent_t stage_ev[2];   // H2D staging (cfrk_global_add)
   // minimizer-partitioned fast path (msp.hip)
   struct cfrk_msp *msp;
+  int last_passes;       // passes the most recent add took on a partitioned path (1 unless memory was short)
+  size_t mem_budget;     // 0 = what the device has free; else a cap on the partitioned paths' buffers (diagnostics)
 };
 
 int cfrk_fail(cfrk_ctx *ctx, int code, const char *fmt, ...);

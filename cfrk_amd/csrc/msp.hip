@@ -80,7 +80,7 @@ constexpr int P1_WAVES = P1_THREADS / 64;
 template <int W>
 __global__ __launch_bounds__(P1_THREADS, 6) void msp_p1_kernel(const int8_t *__restrict__ data,
                                                             int64_t nN, int k, int m, int canon,
-                                                            MspView v, TableView t) {
+                                                            int64_t tile0, MspView v, TableView t) {
   constexpr int NH = 32 + W - 1;                 // positions a lane looks at: its own 32 + W-1 ahead
   __shared__ uint4 rec_tmp[P1_RCAP];
   __shared__ uint16_t perm[P1_RCAP];
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(P1_THREADS, 6) void msp_p1_kernel(const int8_t *__r
   __syncthreads();
 
   // ---- A: this lane's chunk, packed 2 bits per base; neighbours' chunks by shuffle ----
-  const int64_t wave_g = (int64_t)blockIdx.x * P1_WAVES + (tid >> 6);
+  const int64_t wave_g = (tile0 + blockIdx.x) * P1_WAVES + (tid >> 6);
   const int64_t chunk = wave_g * P1_OWN + lane - 1;          // lane 0 of wave 0: chunk -1
   const int64_t off = chunk * 32;
   uint32_t b0 = 0, b1 = 0, bad = 0xFFFFFFFFu;
@@ -720,36 +720,30 @@ static void msp_params(int k, int *W, int *m) {
   *m = k - *W + 1;
 }
 
-int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
-  cfrk_msp *ms = cfrk_msp_get(ctx);
-  if (!ms) return cfrk_fail(ctx, CFRK_ERR_NOMEM, "host allocation failed");
+// bytes of pool memory one pipeline pass over `span` base positions needs (the caps below)
+static size_t msp_need(const cfrk_ctx *ctx, int64_t span) {
+  int W0, m0;
+  msp_params(ctx->g_k, &W0, &m0);
+  const double expect0 = (double)span * (2.0 / (W0 + 1) + 1.0 / 64.0);
+  return (size_t)(expect0 * 1.35 * 16) + (size_t)B1 * NXG * 2048 * 16 + (size_t)(expect0 * 3.3 * 16) +
+         (size_t)NLEAF * 384 * 16 + (size_t)ctx->g_cap * 12;
+}
+
+// one pass of P1 -> P2 -> P3 over the P1 tiles [tile0, tile0 + ntiles): the k-mers that START in
+// those tiles (P1 reads its neighbours' bases from the whole buffer, so a tile range produces
+// exactly the records it produces in a full launch)
+static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, int64_t nN, int64_t tile0,
+                           int64_t ntiles) {
   int rc;
-  if (ms->pending && (rc = cfrk_msp_flush_to_table(ctx))) return rc;
-  // every buffer this call needs must fit: check before touching the pool so that a refusal
-  // leaves the context usable for the fallback path
-  {
-    int W0, m0;
-    msp_params(ctx->g_k, &W0, &m0);
-    const double expect0 = (double)nN * (2.0 / (W0 + 1) + 1.0 / 64.0);
-    const size_t need = (size_t)(expect0 * 1.35 * 16) + (size_t)B1 * NXG * 2048 * 16 +
-                        (size_t)(expect0 * 3.3 * 16) + (size_t)NLEAF * 384 * 16 + (size_t)ctx->g_cap * 12;
-    size_t have = ctx->pool[BUF_MSP_L1].cap + ctx->pool[BUF_MSP_L2].cap + ctx->pool[BUF_MSP_OUTK].cap +
-                  ctx->pool[BUF_MSP_OUTC].cap;
-    if (need > have) {       // only ask the driver when the pool has to grow
-      size_t free_b = 0, total_b = 0;
-      HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
-      if (need > have + free_b)
-        return cfrk_fail(ctx, CFRK_ERR_NOMEM, "partitioned path needs %zu B, %zu B available", need, have + free_b);
-    }
-  }
   const int k = ctx->g_k;
   int W, m;
   msp_params(k, &W, &m);
   const int canon = (ctx->g_flags & CFRK_CANONICAL) ? 1 : 0;
+  const int64_t span = std::min(nN, ntiles * (int64_t)P1_WAVES * P1_OWN * 32);
 
   // expected records: one per minimizer change (2/(W+1) per position) plus read ends
   const double dens = 2.0 / (W + 1) + 1.0 / 64.0;
-  const double expect = (double)nN * dens;
+  const double expect = (double)span * dens;
   const uint64_t cap1 = (uint64_t)(expect / (B1 * NXG) * 1.35) + 2048;   // per sub-region
   // per leaf: complete runs dominate at depth; truncated ones are ~2 per read plus invalid bases
   const uint64_t cap2c = (uint64_t)(expect / NLEAF * 2.1) + 96;
@@ -776,13 +770,9 @@ int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   HIP_TRY(ctx, hipMemsetAsync(v.cnt1, 0, (size_t)(B1 * NXG + (NCLS + 1) * NLEAF) * sizeof(uint32_t), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_CURSOR, 0, sizeof(uint64_t), ctx->stream));
 
-  const int64_t nchunks = (nN + 31) / 32;
-  const int64_t nwaves = (nchunks + P1_OWN - 1) / P1_OWN;
-  const int64_t ntiles = (nwaves + P1_WAVES - 1) / P1_WAVES;
-  if (ntiles > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
   const dim3 g1((unsigned)ntiles), b1(P1_THREADS);
 #define CFRK_P1_CASE(WW) \
-  case WW: hipLaunchKernelGGL((msp_p1_kernel<WW>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, v, t); break;
+  case WW: hipLaunchKernelGGL((msp_p1_kernel<WW>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, tile0, v, t); break;
   switch (W) {
     CFRK_P1_CASE(4) CFRK_P1_CASE(5) CFRK_P1_CASE(6) CFRK_P1_CASE(7) CFRK_P1_CASE(8) CFRK_P1_CASE(9)
     CFRK_P1_CASE(10) CFRK_P1_CASE(11) CFRK_P1_CASE(12) CFRK_P1_CASE(13) CFRK_P1_CASE(14)
@@ -800,6 +790,58 @@ int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   ms->pending = true;
   ms->leaf_form = true;
   ms->list_n_valid = false;
+  return CFRK_OK;
+}
+
+// How many passes does a batch of `ntiles` tiles (tile_span base positions each) take so that one
+// pass's buffers fit the memory the pool may use?  0 = not even a minimal pass fits.
+int cfrk_msp_plan_groups(cfrk_ctx *ctx, int64_t nN, int64_t ntiles, int64_t tile_span,
+                         size_t (*need_fn)(const cfrk_ctx *, int64_t), size_t have, int *groups) {
+  *groups = 1;
+  if (need_fn(ctx, nN) <= have && !ctx->mem_budget) return CFRK_OK;   // fits what the pool already holds
+  size_t free_b = 0, total_b = 0;
+  HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+  size_t budget = have + free_b;
+  if (ctx->mem_budget) budget = std::min(budget, ctx->mem_budget);
+  int g = 1;
+  while (need_fn(ctx, std::min(nN, ((ntiles + g - 1) / g) * tile_span)) > budget) {
+    if ((ntiles + g - 1) / g <= 64 || g >= 4096) {
+      *groups = 0;
+      return CFRK_OK;
+    }
+    g += (g < 8) ? 1 : g / 4;
+  }
+  *groups = g;
+  return CFRK_OK;
+}
+
+int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
+  cfrk_msp *ms = cfrk_msp_get(ctx);
+  if (!ms) return cfrk_fail(ctx, CFRK_ERR_NOMEM, "host allocation failed");
+  int rc;
+  const int64_t nchunks = (nN + 31) / 32;
+  const int64_t nwaves = (nchunks + P1_OWN - 1) / P1_OWN;
+  const int64_t ntiles = (nwaves + P1_WAVES - 1) / P1_WAVES;
+  if (ntiles > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
+  // every buffer a pass needs must fit: decide before touching the pool so that a refusal leaves
+  // the context usable for the fallback path.  A batch too large for one pass is counted in
+  // several passes over tile ranges, each pass's list folded into the HBM table before the next.
+  const size_t have = ctx->pool[BUF_MSP_L1].cap + ctx->pool[BUF_MSP_L2].cap + ctx->pool[BUF_MSP_OUTK].cap +
+                      ctx->pool[BUF_MSP_OUTC].cap;
+  int groups = 1;
+  if ((rc = cfrk_msp_plan_groups(ctx, nN, ntiles, (int64_t)P1_WAVES * P1_OWN * 32, msp_need, have, &groups))) return rc;
+  if (groups == 0) return cfrk_fail(ctx, CFRK_ERR_NOMEM, "partitioned path does not fit device memory");
+  const int64_t per = (ntiles + groups - 1) / groups;
+  ctx->last_passes = (int)((ntiles + per - 1) / per);
+  for (int64_t t0 = 0; t0 < ntiles; t0 += per) {
+    if (ms->pending && (rc = cfrk_msp_flush_to_table(ctx))) return rc;
+    if ((rc = msp_count_tiles(ctx, ms, d_data, nN, t0, std::min(per, ntiles - t0)))) {
+      // a refusal after the first pass must not reach the caller's fallback (it would count
+      // the finished passes twice)
+      if (t0 > 0 && rc == CFRK_ERR_NOMEM) return cfrk_fail(ctx, CFRK_ERR_STATE, "out of device memory in pass %lld of a multi-pass add", (long long)(t0 / per));
+      return rc;
+    }
+  }
   return CFRK_OK;
 }
 
@@ -835,6 +877,18 @@ int cfrk_msp_resolve(cfrk_ctx *ctx, ResultSrc *src, bool *use_list) {
   src->lo = ms->view.out_keys; src->hi = ctx->g_two ? ms->view.out_hi : nullptr; src->cnt = ms->view.out_cnt;
   src->n = st[ST_CURSOR]; src->kind = ctx->g_two ? 3 : 2; src->stats = ctx->g_stats;
   *use_list = true;
+  return CFRK_OK;
+}
+
+extern "C" int cfrk_debug_set_mem_budget(cfrk_ctx *ctx, uint64_t bytes) {
+  if (!ctx) return CFRK_ERR_ARG;
+  ctx->mem_budget = (size_t)bytes;
+  return CFRK_OK;
+}
+
+extern "C" int cfrk_debug_last_add_passes(cfrk_ctx *ctx, int *out_passes) {
+  if (!ctx || !out_passes) return CFRK_ERR_ARG;
+  *out_passes = ctx->last_passes;
   return CFRK_OK;
 }
 

@@ -93,8 +93,8 @@ __device__ __noinline__ void spill_record2(const Rec2 &rec, int k, bool canon, c
 
 // ---------------------------------------------------------------------------------------- Q1
 __global__ __launch_bounds__(Q1_THREADS) void msp2_p1_kernel(const int8_t *__restrict__ data, int64_t nN,
-                                                             int k, int m, int c, int canon, View2 v,
-                                                             TableView t) {
+                                                             int k, int m, int c, int canon, int64_t tile0,
+                                                             View2 v, TableView t) {
   constexpr int NH = 32 + W2 - 1;
   __shared__ Rec2 rec_tmp[Q1_RCAP];
   __shared__ uint16_t perm[Q1_RCAP];
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(Q1_THREADS) void msp2_p1_kernel(const int8_t *__res
   __syncthreads();
 
   // ---- A: own chunk, the previous one and the next three (by shuffle) ----
-  const int64_t wave_g = (int64_t)blockIdx.x * Q1_WAVES + (tid >> 6);
+  const int64_t wave_g = (tile0 + blockIdx.x) * Q1_WAVES + (tid >> 6);
   const int64_t chunk = wave_g * Q1_OWN + lane - 1;
   const int64_t off = chunk * 32;
   uint32_t R[10], bd[5];                       // bases / invalid masks of chunks -1, 0, 1, 2, 3
@@ -515,33 +515,31 @@ bool cfrk_msp2_usable(const cfrk_ctx *ctx) {
   return ctx->g_two && ctx->g_k >= 33 && ctx->g_k <= 64 && !(ctx->g_flags & CFRK_FORCE_HASH);
 }
 
-int cfrk_msp2_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
-  cfrk_msp *ms = cfrk_msp_get(ctx);
-  if (!ms) return cfrk_fail(ctx, CFRK_ERR_NOMEM, "host allocation failed");
+static size_t msp2_need(const cfrk_ctx *ctx, int64_t span) {
+  const double expect = (double)span * (2.0 / (W2 + 1) + 1.0 / 64.0);
+  const uint64_t cap1 = (uint64_t)(expect / (B1 * NXG) * 1.35) + 2048;
+  const uint64_t cap2c = (uint64_t)(expect / NLEAF * 2.1) + 96;
+  const uint64_t cap2t = (uint64_t)(expect / NLEAF * 0.4) + 96;
+  return (size_t)B1 * NXG * cap1 * 32 + (size_t)NLEAF * (cap2c + 3 * cap2t) * 32 + (size_t)ctx->g_cap * 20;
+}
+
+// one pass of Q1 -> Q2 -> Q3 over the Q1 tiles [tile0, tile0 + ntiles)
+static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, int64_t nN, int64_t tile0,
+                            int64_t ntiles) {
   int rc;
-  if (ms->pending && (rc = cfrk_msp_flush_to_table(ctx))) return rc;
   const int k = ctx->g_k;
   const int m = (k & 1) ? 14 : 13;                       // k - m + 1 - 18 must be even
   const int c = (k - m + 1 - W2) / 2;                    // 1..17
   const int canon = (ctx->g_flags & CFRK_CANONICAL) ? 1 : 0;
+  const int64_t span = std::min(nN + 32, ntiles * (int64_t)Q1_WAVES * Q1_OWN * 32);
 
   const double dens = 2.0 / (W2 + 1) + 1.0 / 64.0;
-  const double expect = (double)nN * dens;
+  const double expect = (double)span * dens;
   const uint64_t cap1 = (uint64_t)(expect / (B1 * NXG) * 1.35) + 2048;
   const uint64_t cap2c = (uint64_t)(expect / NLEAF * 2.1) + 96;
   const uint64_t cap2t = (uint64_t)(expect / NLEAF * 0.4) + 96;
   const int64_t tiles_per_sub = (int64_t)((cap1 + Q2_TILE - 1) / Q2_TILE);
   if (tiles_per_sub * B1 * NXG > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
-  {
-    const size_t need = (size_t)B1 * NXG * cap1 * 32 + (size_t)NLEAF * (cap2c + 3 * cap2t) * 32 + (size_t)ctx->g_cap * 20;
-    const size_t have = ctx->pool[BUF_MSP_L1].cap + ctx->pool[BUF_MSP_L2].cap + ctx->pool[BUF_MSP_OUTK].cap +
-                        ctx->pool[BUF_MSP_OUTC].cap + ctx->pool[BUF_MSP_OUTH].cap;
-    if (need > have) {
-      size_t free_b = 0, total_b = 0;
-      HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
-      if (need > have + free_b) return cfrk_fail(ctx, CFRK_ERR_NOMEM, "partitioned path needs %zu B, %zu B available", need, have + free_b);
-    }
-  }
   void *p;
   View2 v;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_L1, (size_t)B1 * NXG * cap1 * sizeof(Rec2), &p))) return rc;
@@ -561,12 +559,8 @@ int cfrk_msp2_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
 
   HIP_TRY(ctx, hipMemsetAsync(v.cnt1, 0, (size_t)(B1 * NXG + NCLS * NLEAF) * sizeof(uint32_t), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_CURSOR, 0, sizeof(uint64_t), ctx->stream));
-  const int64_t nchunks = (nN + 31) / 32 + 1;              // + the chunk that only holds k-mer tails
-  const int64_t nwaves = (nchunks + Q1_OWN - 1) / Q1_OWN;
-  const int64_t ntiles = (nwaves + Q1_WAVES - 1) / Q1_WAVES;
-  if (ntiles > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
   hipLaunchKernelGGL(msp2_p1_kernel, dim3((unsigned)ntiles), dim3(Q1_THREADS), 0, ctx->stream, d_data, nN, k, m, c,
-                     canon, v, t);
+                     canon, tile0, v, t);
   HIP_TRY(ctx, hipGetLastError());
   hipLaunchKernelGGL(msp2_p2_kernel, dim3((unsigned)(tiles_per_sub * B1 * NXG)), dim3(Q2_THREADS), 0, ctx->stream,
                      (int)tiles_per_sub, k, canon, v, t);
@@ -579,5 +573,32 @@ int cfrk_msp2_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   ms->pending = true;
   ms->leaf_form = false;
   ms->list_n_valid = false;
+  return CFRK_OK;
+}
+
+int cfrk_msp2_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
+  cfrk_msp *ms = cfrk_msp_get(ctx);
+  if (!ms) return cfrk_fail(ctx, CFRK_ERR_NOMEM, "host allocation failed");
+  int rc;
+  const int64_t nchunks = (nN + 31) / 32 + 1;              // + the chunk that only holds k-mer tails
+  const int64_t nwaves = (nchunks + Q1_OWN - 1) / Q1_OWN;
+  const int64_t ntiles = (nwaves + Q1_WAVES - 1) / Q1_WAVES;
+  if (ntiles > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
+  const size_t have = ctx->pool[BUF_MSP_L1].cap + ctx->pool[BUF_MSP_L2].cap + ctx->pool[BUF_MSP_OUTK].cap +
+                      ctx->pool[BUF_MSP_OUTC].cap + ctx->pool[BUF_MSP_OUTH].cap;
+  int groups = 1;
+  if ((rc = cfrk_msp_plan_groups(ctx, nN + 32, ntiles, (int64_t)Q1_WAVES * Q1_OWN * 32, msp2_need, have, &groups))) return rc;
+  if (groups == 0) return cfrk_fail(ctx, CFRK_ERR_NOMEM, "partitioned path does not fit device memory");
+  const int64_t per = (ntiles + groups - 1) / groups;
+  ctx->last_passes = (int)((ntiles + per - 1) / per);
+  for (int64_t t0 = 0; t0 < ntiles; t0 += per) {
+    if (ms->pending && (rc = cfrk_msp_flush_to_table(ctx))) return rc;
+    if ((rc = msp2_count_tiles(ctx, ms, d_data, nN, t0, std::min(per, ntiles - t0)))) {
+      // a refusal after the first pass must not reach the caller's fallback (it would count
+      // the finished passes twice)
+      if (t0 > 0 && rc == CFRK_ERR_NOMEM) return cfrk_fail(ctx, CFRK_ERR_STATE, "out of device memory in pass %lld of a multi-pass add", (long long)(t0 / per));
+      return rc;
+    }
+  }
   return CFRK_OK;
 }

@@ -76,6 +76,8 @@ def load_library():
         "cfrk_global_export_leaves_device": ([vp, vp, vp, u64, C.c_int, C.POINTER(u64), vp], C.c_int),
         "cfrk_global_merge_leaves_device": ([vp, vp, vp, C.POINTER(u64), vp, C.c_int], C.c_int),
         "cfrk_debug_msp_info": ([vp, C.POINTER(u64)], C.c_int),
+        "cfrk_debug_set_mem_budget": ([vp, u64], C.c_int),
+        "cfrk_debug_last_add_passes": ([vp, C.POINTER(C.c_int)], C.c_int),
         "cfrk_synth_reads_device": ([vp, i64, i64, i32, i64, u64, u64, u64, i32, vp, vp, vp], C.c_int),
     }
     for name, (args, res) in sig.items():
@@ -225,6 +227,14 @@ class GlobalCounter:
         names = ("l1_records", "l1_max_bin", "l1_cap", "l2_records", "l2_max_leaf", "l2_cap",
                  "spilled_records", "spilled_kmers", "list_entries")
         return dict(zip(names, (int(x) for x in out)))
+
+    def set_mem_budget(self, nbytes):
+        self.ctx.check(self._L.cfrk_debug_set_mem_budget(self.ctx._h, int(nbytes)), "cfrk_debug_set_mem_budget")
+
+    def last_add_passes(self):
+        n = C.c_int()
+        self.ctx.check(self._L.cfrk_debug_last_add_passes(self.ctx._h, C.byref(n)), "cfrk_debug_last_add_passes")
+        return n.value
 
     def last_add_ms(self):
         ms = C.c_float()

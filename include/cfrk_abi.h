@@ -164,6 +164,14 @@ int cfrk_global_last_add_ms(cfrk_ctx *ctx, float *ms);
  * the HBM table instead (spill); out[8] = entries in the leaf-output list. */
 int cfrk_debug_msp_info(cfrk_ctx *ctx, uint64_t out[9]);
 
+/* Cap (bytes, 0 = none) on the device memory the partitioned counting paths may use for their
+ * record buffers.  A batch whose buffers exceed what is available is counted in several passes
+ * over ranges of the input, each pass folded into the HBM table; this knob makes that
+ * behaviour reachable with small inputs (tests) and lets a host that shares the GPU hold the
+ * library to a budget.  out_passes (may be NULL) receives the passes of the most recent add. */
+int cfrk_debug_set_mem_budget(cfrk_ctx *ctx, uint64_t bytes);
+int cfrk_debug_last_add_passes(cfrk_ctx *ctx, int *out_passes);
+
 /* ---- synthetic reads, generated on device ----------------------------------- */
 
 /* Reads [r0, r0+R) of the deterministic generator, struct-read layout: d_data R*(L+1) bytes,
