@@ -414,11 +414,11 @@ __device__ __noinline__ void count_record_slow(unsigned long long *keys, uint32_
 
 // Record table: at high coverage most complete super-k-mer records of a leaf are byte-identical
 // (the same genome locus seen by many reads).  Entries are {R0,R1,R2,meta},
-// meta = count << 6 | (n-1); meta == 0 empty, RT_LOCK while the claiming lane writes the bases.
+// meta = count << 6 | (n-1); meta == RT_EMPTY empty, RT_LOCK while the claiming lane writes the
+// bases.
 constexpr int RT_LOG = 10, RT = 1 << RT_LOG;
 static_assert(RT == P3_THREADS, "phase 2 lists the record table with one slot per thread");
 constexpr uint32_t RT_LOCK = 0xFFFFFFFFu;
-constexpr int RT_PROBES = 24;
 
 __device__ __forceinline__ uint32_t rtab_slot(uint4 rec) {
   uint32_t h = (rec.x * 0x9E3779B1u) ^ (rec.y * 0x85EBCA77u) ^ (rec.z * 0xC2B2AE3Du) ^ ((rec.w & 63u) * 0x27D4EB2Fu);
@@ -426,32 +426,41 @@ __device__ __forceinline__ uint32_t rtab_slot(uint4 rec) {
   return h >> (32 - RT_LOG);
 }
 
-// one probe step of a record-table insert, written flat (classification in VALU, three
-// shallow ifs) because exec-mask bookkeeping on the scalar unit is what bounds this kernel.
-// pend: still to be placed; fail: gave up (table region full) -> caller expands the record.
-__device__ __forceinline__ void rtab_step(uint4 *rtab, uint4 rec, uint32_t &h, uint4 e, bool &pend,
-                                          bool &fail, int &probes) {
+// Every instruction -- vector or scalar -- costs an issue slot here, so the probe step is written
+// for instruction count: identity is one OR-reduction of XORs (EMPTY and LOCK carry low header
+// bits no record has, so they never compare equal), and the loop is bounded by a wave-uniform
+// trip counter instead of per-lane probe counts.
+constexpr uint32_t RT_EMPTY = 62u;                 // n-1 = 62 does not occur (n <= 32)
+constexpr int RT_TRIPS = 96;
+
+__device__ __forceinline__ uint32_t rtab_diff(uint4 e, uint4 rec) {
+  return (e.x ^ rec.x) | (e.y ^ rec.y) | (e.z ^ rec.z) | ((e.w ^ rec.w) & 63u);
+}
+
+// insert-or-count the records of lanes with p set; on return p = lanes that found no place
+__device__ __forceinline__ void rtab_insert_loop(uint4 *rtab, uint4 rec, uint32_t h, bool &p) {
   uint32_t *rmeta = reinterpret_cast<uint32_t *>(rtab);
   const uint32_t nm1 = rec.w & 63u;
-  const bool empty = e.w == 0u, locked = e.w == RT_LOCK;
-  const bool match = !empty && !locked && (e.w & 63u) == nm1 && e.x == rec.x && e.y == rec.y && e.z == rec.z;
-  if (pend && match) atomicAdd(&rmeta[4 * h + 3], 1u << 6);
-  bool won = false;
-  if (pend && empty) {
-    const uint32_t old = atomicCAS(&rmeta[4 * h + 3], 0u, RT_LOCK);
-    if (old == 0u) {
-      rmeta[4 * h + 0] = rec.x; rmeta[4 * h + 1] = rec.y; rmeta[4 * h + 2] = rec.z;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      atomicExch(&rmeta[4 * h + 3], (1u << 6) | nm1);
-      won = true;
+  for (int it = 0; it < RT_TRIPS && __ballot(p); ++it) {
+    const uint4 e = rtab[h];
+    const bool match = rtab_diff(e, rec) == 0u;
+    const bool empty = e.w == RT_EMPTY;
+    if (p && match) atomicAdd(&rmeta[4 * h + 3], 1u << 6);
+    bool won = false;
+    if (p && empty) {
+      if (atomicCAS(&rmeta[4 * h + 3], RT_EMPTY, RT_LOCK) == RT_EMPTY) {
+        rmeta[4 * h + 0] = rec.x; rmeta[4 * h + 1] = rec.y; rmeta[4 * h + 2] = rec.z;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        atomicExch(&rmeta[4 * h + 3], (1u << 6) | nm1);
+        won = true;
+      }
     }
+    // an empty slot lost to another lane, or a locked one, is read again; a slot holding another
+    // record sends the lane on
+    const bool stay = match || empty || e.w == RT_LOCK;
+    h = stay ? h : ((h + 1) & (RT - 1));
+    p = p && !match && !won;
   }
-  const bool adv = pend && !match && !empty && !locked;     // someone else's record: next slot
-  h = adv ? ((h + 1) & (RT - 1)) : h;
-  probes += (adv || (pend && locked)) ? 1 : 0;               // a locked slot is re-read, bounded too
-  const bool giveup = probes >= RT_PROBES;
-  fail = fail || (pend && !match && !won && giveup);
-  pend = pend && !match && !won && !giveup;
 }
 
 template <bool CANON>
@@ -473,35 +482,62 @@ __global__ __launch_bounds__(P3_THREADS) void msp_p3_kernel(int k, MspView v, Ta
   const uint4 *leaf_rec = v.rec2 + (uint64_t)leaf * (v.cap2c + 3 * v.cap2t);
   if (n0 + n1 == 0) return;
   for (int s = tid; s < TS; s += P3_THREADS) { keys[s] = CFRK_EMPTY_KEY; cnts[s] = 0; }
-  for (int s = tid; s < RT; s += P3_THREADS) rtab[s] = make_uint4(0u, 0u, 0u, 0u);
+  for (int s = tid; s < RT; s += P3_THREADS) rtab[s] = make_uint4(0u, 0u, 0u, RT_EMPTY);
   if (tid == 0) { wg_total = 0; nocc = 0; }
   __syncthreads();
 
   const uint64_t kmask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1ull);
   const int rcsh = 2 * k - 2;
 
-  // ---- phase 1a: complete runs, one record-table update per record (every lane busy);
-  //      a record that finds no room is expanded on the spot
+  // ---- phase 1a: complete runs, one record-table update per record.  Most records find their
+  //      twin in the home slot: that case is one LDS read + one LDS add with every lane busy.
+  //      The rest (first sightings, displaced entries) are compacted into a wave-private
+  //      leftover set, 64 lanes wide, and only a full set runs the probe loop -- the loop's trip
+  //      count is the longest chain among its lanes, so it must not run for a handful of them.
   {
-    // two records per trip, one wave-uniform probe loop for both
     const uint4 *src = leaf_rec;
-    for (uint64_t r = tid; r < n1; r += 2ull * P3_THREADS) {
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+    const uint64_t n1a = n1;
+    uint32_t *rmeta = reinterpret_cast<uint32_t *>(rtab);
+    uint4 L = zero4;                 // leftover records, lanes [0, c)
+    uint32_t Lh = 0;
+    int c = 0;                       // wave-uniform
+    auto drain = [&](int cnt) {
+      bool p = lane < cnt;
+      rtab_insert_loop(rtab, L, Lh, p);
+      if (p) count_record_slow<CANON>(keys, cnts, L, 1u, k, t);
+    };
+    auto home = [&](const uint4 rec, bool valid) {
+      const uint32_t h = rtab_slot(rec);
+      const uint4 e = rtab[h];
+      const bool match = valid && rtab_diff(e, rec) == 0u;
+      if (match) atomicAdd(&rmeta[4 * h + 3], 1u << 6);
+      const bool left = valid && !match;
+      const unsigned long long mask = __ballot(left);
+      if (mask == 0ull) return;
+      const int n = __popcll(mask);
+      if (c + n > 64) { drain(c); c = 0; }
+      const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+      const int dst = left ? (c + rank) : ((c + n) & 63);      // the others aim at a lane nobody keeps
+      const int da = dst << 2;
+      const uint32_t px = __builtin_amdgcn_ds_permute(da, rec.x), py = __builtin_amdgcn_ds_permute(da, rec.y);
+      const uint32_t pz = __builtin_amdgcn_ds_permute(da, rec.z), pw = __builtin_amdgcn_ds_permute(da, rec.w);
+      const uint32_t ph = __builtin_amdgcn_ds_permute(da, h);
+      const bool take = lane >= c && lane < c + n;
+      L.x = take ? px : L.x; L.y = take ? py : L.y; L.z = take ? pz : L.z; L.w = take ? pw : L.w;
+      Lh = take ? ph : Lh;
+      c += n;
+    };
+    for (uint64_t r = tid; r < ((n1a + 63) & ~63ull); r += 2ull * P3_THREADS) {
       const uint64_t r1 = r + P3_THREADS;
-      const uint4 rec0 = src[r];
-      uint4 rec1 = make_uint4(0u, 0u, 0u, 0u);
-      bool p0 = true, p1 = r1 < n1, f0 = false, f1 = false;
-      if (p1) rec1 = src[r1];
-      uint32_t h0 = rtab_slot(rec0), h1 = rtab_slot(rec1);
-      int pr0 = 0, pr1 = 0;
-      do {
-        const uint4 e0 = rtab[h0];
-        const uint4 e1 = rtab[h1];
-        rtab_step(rtab, rec0, h0, e0, p0, f0, pr0);
-        rtab_step(rtab, rec1, h1, e1, p1, f1, pr1);
-      } while (__ballot(p0 | p1));
-      if (f0) count_record_slow<CANON>(keys, cnts, rec0, 1u, k, t);
-      if (f1) count_record_slow<CANON>(keys, cnts, rec1, 1u, k, t);
+      const bool v0 = r < n1a, v1 = r1 < n1a;
+      uint4 rec0 = zero4, rec1 = zero4;
+      if (v0) rec0 = src[r];
+      if (v1) rec1 = src[r1];
+      home(rec0, v0);
+      home(rec1, v1);
     }
+    if (c) drain(c);
   }
   __syncthreads();
   // ---- phase 2: k-mer by k-mer -- the truncated runs (weight 1) and every distinct complete
@@ -510,7 +546,7 @@ __global__ __launch_bounds__(P3_THREADS) void msp_p3_kernel(int k, MspView v, Ta
   //      is ~30 % full: walking it directly leaves two thirds of the lanes idle).
   {
     const uint4 e = rtab[tid];                       // RT == P3_THREADS
-    const bool occ = e.w != 0u;
+    const bool occ = e.w != RT_EMPTY;
     const unsigned long long m = __ballot(occ);
     uint32_t b = 0;
     if (lane == 0 && m) b = atomicAdd(&nocc, (uint32_t)__popcll(m));
