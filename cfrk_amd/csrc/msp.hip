@@ -412,11 +412,75 @@ __device__ __noinline__ void count_record_slow(unsigned long long *keys, uint32_
   count_record<CANON>(keys, cnts, rec, add, k, kmask, 2 * k - 2, t);
 }
 
+// ---- lean variants used by the leaf kernel's expansion phase.  Every instruction, vector or
+// scalar, costs an issue slot, and a wave runs a probe loop for as long as its slowest lane: the
+// step below is written for instruction count (one CAS-or-match decision per bucket, no per-lane
+// probe counter), and callers feed waves with records of equal length.
+constexpr int KT_TRIPS = 64;
+
+// one bucket attempt for the lanes with p set: count on a match, claim an empty slot, else move on
+__device__ __forceinline__ void kt_try(unsigned long long *keys, uint32_t *cnts, uint64_t key, uint32_t &b,
+                                       uint32_t add, bool &p) {
+  const ulonglong2 q = reinterpret_cast<const ulonglong2 *>(keys)[b];
+  const bool m0 = q.x == key, m1 = q.y == key;
+  const bool e0 = q.x == CFRK_EMPTY_KEY, e1 = q.y == CFRK_EMPTY_KEY;
+  const uint32_t s = 2 * b + ((m0 || (!m1 && e0)) ? 0u : 1u);
+  bool ok = m0 || m1;
+  if (p && !ok && (e0 || e1)) {
+    const unsigned long long old = atomicCAS(&keys[s], (unsigned long long)CFRK_EMPTY_KEY, (unsigned long long)key);
+    ok = old == CFRK_EMPTY_KEY || old == key;          // lost to another key: same bucket again
+  }
+  if (p && ok) atomicAdd(&cnts[s], add);
+  const bool full = !(m0 || m1 || e0 || e1);
+  b = full ? ((b + 1) & (NBUCKET - 1)) : b;
+  p = p && !ok;
+}
+
+// expand one record per lane (valid lanes), two k-mers per step; every lane of the wave must call
+template <bool CANON>
+__device__ __forceinline__ void count_record_v2(unsigned long long *keys, uint32_t *cnts, uint4 rec, uint32_t add,
+                                                bool valid, int k, uint64_t kmask, int rcsh,
+                                                const TableView &t) {
+  const int nk = valid ? (int)(rec.w & 63u) + 1 : 0;
+  const uint64_t hi = ((uint64_t)rec.x << 32) | rec.y;
+  const uint64_t lo = (uint64_t)rec.z << 32;
+  uint64_t fwd = hi >> (64 - 2 * k);
+  uint64_t rc = CANON ? dev_revcomp64(fwd, k) : 0;
+  uint64_t T = (k == 32) ? lo : ((hi << (2 * k)) | (lo >> (64 - 2 * k)));
+  for (int j = 0; __ballot(j < nk); j += 2) {
+    const uint64_t key0 = (CANON && rc < fwd) ? rc : fwd;
+    uint32_t nb = (uint32_t)(T >> 62);
+    T <<= 2;
+    fwd = ((fwd << 2) | nb) & kmask;
+    if (CANON) rc = (rc >> 2) | ((uint64_t)(3u - nb) << rcsh);
+    const uint64_t key1 = (CANON && rc < fwd) ? rc : fwd;
+    nb = (uint32_t)(T >> 62);
+    T <<= 2;
+    fwd = ((fwd << 2) | nb) & kmask;
+    if (CANON) rc = (rc >> 2) | ((uint64_t)(3u - nb) << rcsh);
+    bool p0 = j < nk, p1 = j + 1 < nk;
+    if (!CANON && k == 32) {
+      // forward-strand all-T 32-mer collides with the EMPTY marker: side counter
+      if (p0 && key0 == CFRK_EMPTY_KEY) { spill_kmer(t, key0, add); p0 = false; }
+      if (p1 && key1 == CFRK_EMPTY_KEY) { spill_kmer(t, key1, add); p1 = false; }
+    }
+    uint32_t b0 = lds_bucket(key0), b1 = lds_bucket(key1);
+    for (int it = 0; it < KT_TRIPS && __ballot(p0 || p1); ++it) {
+      kt_try(keys, cnts, key0, b0, add, p0);
+      kt_try(keys, cnts, key1, b1, add, p1);
+    }
+    if (p0) spill_kmer(t, key0, add);
+    if (p1) spill_kmer(t, key1, add);
+  }
+}
+
 // Record table: at high coverage most complete super-k-mer records of a leaf are byte-identical
 // (the same genome locus seen by many reads).  Entries are {R0,R1,R2,meta},
 // meta = count << 6 | (n-1); meta == RT_EMPTY empty, RT_LOCK while the claiming lane writes the
 // bases.
 constexpr int RT_LOG = 10, RT = 1 << RT_LOG;
+constexpr int TL_PER = 4, TL_CAP = TL_PER * 1024;     // length-sorted list of truncated runs (indices)
+static_assert(TL_CAP <= (1 << 14), "list positions are 14 bits");
 static_assert(RT == P3_THREADS, "phase 2 lists the record table with one slot per thread");
 constexpr uint32_t RT_LOCK = 0xFFFFFFFFu;
 
@@ -464,11 +528,13 @@ __device__ __forceinline__ void rtab_insert_loop(uint4 *rtab, uint4 rec, uint32_
 }
 
 template <bool CANON>
-__global__ __launch_bounds__(P3_THREADS) void msp_p3_kernel(int k, MspView v, TableView t) {
+__global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void msp_p3_kernel(int k, MspView v, TableView t) {
   __shared__ unsigned long long keys[TS];
   __shared__ uint32_t cnts[TS];
   __shared__ uint4 rtab[RT];
   __shared__ uint16_t occ_list[RT];
+  __shared__ uint16_t tlist[TL_CAP];
+  __shared__ uint32_t nhist[32], thist[32];
   __shared__ uint32_t nocc;
   __shared__ uint32_t wg_total;
   __shared__ unsigned long long wg_base;
@@ -484,10 +550,17 @@ __global__ __launch_bounds__(P3_THREADS) void msp_p3_kernel(int k, MspView v, Ta
   for (int s = tid; s < TS; s += P3_THREADS) { keys[s] = CFRK_EMPTY_KEY; cnts[s] = 0; }
   for (int s = tid; s < RT; s += P3_THREADS) rtab[s] = make_uint4(0u, 0u, 0u, RT_EMPTY);
   if (tid == 0) { wg_total = 0; nocc = 0; }
+  if (tid < 32) { nhist[tid] = 0; thist[tid] = 0; }
   __syncthreads();
 
   const uint64_t kmask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1ull);
   const int rcsh = 2 * k - 2;
+  // truncated runs that go through the length-sorted list: longest class first, as many as fit
+  // the list and its 14-bit positions
+  const uint4 *trunc = leaf_rec + v.cap2c;
+  const uint32_t tl2 = (uint32_t)min(nt2, (uint64_t)TL_CAP);
+  const uint32_t tl1 = (uint32_t)min(nt1, (uint64_t)(TL_CAP - tl2));
+  const uint32_t tl0 = (uint32_t)min(nt0, (uint64_t)(TL_CAP - tl2 - tl1));
 
   // ---- phase 1a: complete runs, one record-table update per record.  Most records find their
   //      twin in the home slot: that case is one LDS read + one LDS add with every lane busy.
@@ -540,47 +613,81 @@ __global__ __launch_bounds__(P3_THREADS) void msp_p3_kernel(int k, MspView v, Ta
     if (c) drain(c);
   }
   __syncthreads();
-  // ---- phase 2: k-mer by k-mer -- the truncated runs (weight 1) and every distinct complete
-  //      record of the record table (weight = its multiplicity), in ONE loop (one copy of the
-  //      expansion code).  The occupied record-table slots are first listed densely (the table
-  //      is ~30 % full: walking it directly leaves two thirds of the lanes idle).
+  // ---- phase 2: k-mer by k-mer -- every distinct complete record of the record table (weight =
+  //      its multiplicity) and the truncated runs (weight 1).  Both are first listed SORTED BY
+  //      LENGTH (counting sort of 16-bit indices in LDS): a wave expands 64 records in lock-step
+  //      for as many steps as its longest one, so equal lengths keep every lane busy.
   {
+    // (a) record table: occupied slots, longest first
     const uint4 e = rtab[tid];                       // RT == P3_THREADS
     const bool occ = e.w != RT_EMPTY;
-    const unsigned long long m = __ballot(occ);
-    uint32_t b = 0;
-    if (lane == 0 && m) b = atomicAdd(&nocc, (uint32_t)__popcll(m));
-    b = __shfl(b, 0);
-    if (occ) occ_list[b + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)tid;
+    uint32_t rank = 0;
+    if (occ) rank = atomicAdd(&nhist[e.w & 31u], 1u);
+    // (b) truncated runs: index = class << 14 | position, up to TL_CAP of them
+    uint32_t tw[TL_PER], trank[TL_PER], tidx[TL_PER];
+#pragma unroll
+    for (int i = 0; i < TL_PER; ++i) {
+      const uint32_t g = (uint32_t)(i * P3_THREADS + tid);           // position in [class2 | class1 | class0]
+      uint32_t cls = 2u, pos = g;
+      if (pos >= tl2) { pos -= tl2; cls = 1u; if (pos >= tl1) { pos -= tl1; cls = 0u; } }
+      const bool ok = g < tl2 + tl1 + tl0;
+      tidx[i] = ok ? ((cls << 14) | pos) : 0xFFFFFFFFu;
+      tw[i] = 0u; trank[i] = 0u;
+      if (ok) {
+        tw[i] = trunc[(uint64_t)cls * v.cap2t + pos].w & 31u;
+        trank[i] = atomicAdd(&thist[tw[i]], 1u);
+      }
+    }
+    __syncthreads();
+    if (tid < 64) {
+      // exclusive prefix over DEscending length, both histograms (lanes 0..31 / 32..63)
+      const uint32_t own = (tid < 32) ? nhist[31 - tid] : thist[63 - tid];
+      uint32_t incl = own;
+#pragma unroll
+      for (int d = 1; d < 32; d <<= 1) {
+        const uint32_t y = __shfl_up(incl, d, 32);
+        if ((tid & 31) >= d) incl += y;
+      }
+      if (tid < 32) nhist[31 - tid] = incl - own; else thist[63 - tid] = incl - own;
+      if (tid == 31) nocc = incl;
+    }
+    __syncthreads();
+    if (occ) occ_list[nhist[e.w & 31u] + rank] = (uint16_t)tid;
+#pragma unroll
+    for (int i = 0; i < TL_PER; ++i)
+      if (tidx[i] != 0xFFFFFFFFu) tlist[thist[tw[i]] + trank[i]] = (uint16_t)tidx[i];
   }
   __syncthreads();
   {
-    // index space: [record-table list | long | medium | short truncated], every segment padded
-    // to a multiple of 64 so that one wave never mixes segments
-    const uint4 *src = leaf_rec + v.cap2c;
-    const uint64_t nlist = nocc;
-    const uint64_t e0 = (nlist + 63) & ~63ull;
-    const uint64_t e1 = e0 + ((nt2 + 63) & ~63ull);
-    const uint64_t e2 = e1 + ((nt1 + 63) & ~63ull);
-    const uint64_t e3 = e2 + ((nt0 + 63) & ~63ull);
-    for (uint64_t i = tid; i < e3; i += P3_THREADS) {
-      uint4 rec;
-      uint32_t wgt = 1u;
-      if (i < e0) {
-        if (i >= nlist) continue;
-        rec = rtab[occ_list[i]];
-        wgt = rec.w >> 6;
-      } else if (i < e1) {
-        if (i - e0 >= nt2) continue;
-        rec = src[2 * v.cap2t + (i - e0)];
-      } else if (i < e2) {
-        if (i - e1 >= nt1) continue;
-        rec = src[v.cap2t + (i - e1)];
-      } else {
-        if (i - e2 >= nt0) continue;
-        rec = src[i - e2];
+    const uint32_t nlist = nocc;
+    for (uint32_t i = tid; i < ((nlist + 63u) & ~63u); i += P3_THREADS) {
+      const bool valid = i < nlist;
+      uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+      if (valid) rec = rtab[occ_list[i]];
+      count_record_v2<CANON>(keys, cnts, rec, rec.w >> 6, valid, k, kmask, rcsh, t);
+    }
+    const uint32_t ntl = tl2 + tl1 + tl0;
+    for (uint32_t i = tid; i < ((ntl + 63u) & ~63u); i += P3_THREADS) {
+      const bool valid = i < ntl;
+      uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+      if (valid) {
+        const uint32_t ix = tlist[i];
+        rec = trunc[(uint64_t)(ix >> 14) * v.cap2t + (ix & 0x3FFFu)];
       }
-      count_record<CANON>(keys, cnts, rec, wgt, k, kmask, rcsh, t);
+      count_record_v2<CANON>(keys, cnts, rec, 1u, valid, k, kmask, rcsh, t);
+    }
+    // truncated runs beyond the sorted list (very large leaves): in stream order
+#pragma unroll 1
+    for (int cls = 2; cls >= 0; --cls) {
+      const uint64_t from = (cls == 2) ? tl2 : (cls == 1) ? tl1 : tl0;
+      const uint64_t to = (cls == 2) ? nt2 : (cls == 1) ? nt1 : nt0;
+      const uint4 *src = trunc + (uint64_t)cls * v.cap2t;
+      for (uint64_t i = from + tid; i < ((to + 63) & ~63ull) && from < to; i += P3_THREADS) {
+        const bool valid = i < to;
+        uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+        if (valid) rec = src[i];
+        count_record_v2<CANON>(keys, cnts, rec, 1u, valid, k, kmask, rcsh, t);
+      }
     }
   }
   __syncthreads();
