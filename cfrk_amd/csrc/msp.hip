@@ -418,22 +418,31 @@ __device__ __noinline__ void count_record_slow(unsigned long long *keys, uint32_
 // probe counter), and callers feed waves with records of equal length.
 constexpr int KT_TRIPS = 64;
 
-// one bucket attempt for the lanes with p set: count on a match, claim an empty slot, else move on
+// One bucket attempt for one key per lane: count on a match, claim an empty slot, else move on.
+// The lane's state is its bucket index b with KT_DONE or-ed in once the key is counted (or the
+// lane had none): written to keep lane masks out of loop-carried values and control-flow merges
+// (each costs the compiler three scalar instructions) -- the only branch is the rare claim, its
+// outcome lands in a VGPR, and lanes with nothing to count add 0.
+constexpr uint32_t KT_DONE = 0x80000000u;
 __device__ __forceinline__ void kt_try(unsigned long long *keys, uint32_t *cnts, uint64_t key, uint32_t &b,
-                                       uint32_t add, bool &p) {
-  const ulonglong2 q = reinterpret_cast<const ulonglong2 *>(keys)[b];
+                                       uint32_t add) {
+  const bool p = (int32_t)b >= 0;
+  const uint32_t bb = b & (NBUCKET - 1);
+  const ulonglong2 q = reinterpret_cast<const ulonglong2 *>(keys)[bb];
   const bool m0 = q.x == key, m1 = q.y == key;
   const bool e0 = q.x == CFRK_EMPTY_KEY, e1 = q.y == CFRK_EMPTY_KEY;
-  const uint32_t s = 2 * b + ((m0 || (!m1 && e0)) ? 0u : 1u);
-  bool ok = m0 || m1;
-  if (p && !ok && (e0 || e1)) {
+  const bool hit = m0 || m1;
+  const uint32_t s = 2 * bb + ((m0 || (!m1 && e0)) ? 0u : 1u);  // matching slot, else first empty, else any
+  uint32_t won = 0u;
+  if (p && !hit && (e0 || e1)) {
     const unsigned long long old = atomicCAS(&keys[s], (unsigned long long)CFRK_EMPTY_KEY, (unsigned long long)key);
-    ok = old == CFRK_EMPTY_KEY || old == key;          // lost to another key: same bucket again
+    won = (old == CFRK_EMPTY_KEY || old == key) ? 1u : 0u;      // lost to another key: same bucket again
   }
-  if (p && ok) atomicAdd(&cnts[s], add);
-  const bool full = !(m0 || m1 || e0 || e1);
-  b = full ? ((b + 1) & (NBUCKET - 1)) : b;
-  p = p && !ok;
+  const bool ok = hit || won != 0u;
+  atomicAdd(&cnts[s], (p && ok) ? add : 0u);
+  const bool full = !(hit || e0 || e1);
+  const uint32_t nb = full ? ((bb + 1) & (NBUCKET - 1)) : bb;
+  b = (p && !ok) ? nb : (b | KT_DONE);
 }
 
 // expand one record per lane (valid lanes), two k-mers per step; every lane of the wave must call
@@ -464,13 +473,13 @@ __device__ __forceinline__ void count_record_v2(unsigned long long *keys, uint32
       if (p0 && key0 == CFRK_EMPTY_KEY) { spill_kmer(t, key0, add); p0 = false; }
       if (p1 && key1 == CFRK_EMPTY_KEY) { spill_kmer(t, key1, add); p1 = false; }
     }
-    uint32_t b0 = lds_bucket(key0), b1 = lds_bucket(key1);
-    for (int it = 0; it < KT_TRIPS && __ballot(p0 || p1); ++it) {
-      kt_try(keys, cnts, key0, b0, add, p0);
-      kt_try(keys, cnts, key1, b1, add, p1);
+    uint32_t b0 = lds_bucket(key0) | (p0 ? 0u : KT_DONE), b1 = lds_bucket(key1) | (p1 ? 0u : KT_DONE);
+    for (int it = 0; it < KT_TRIPS && __ballot((int32_t)(b0 & b1) >= 0); ++it) {
+      kt_try(keys, cnts, key0, b0, add);
+      kt_try(keys, cnts, key1, b1, add);
     }
-    if (p0) spill_kmer(t, key0, add);
-    if (p1) spill_kmer(t, key1, add);
+    if ((int32_t)b0 >= 0) spill_kmer(t, key0, add);
+    if ((int32_t)b1 >= 0) spill_kmer(t, key1, add);
   }
 }
 
@@ -501,29 +510,34 @@ __device__ __forceinline__ uint32_t rtab_diff(uint4 e, uint4 rec) {
   return (e.x ^ rec.x) | (e.y ^ rec.y) | (e.z ^ rec.z) | ((e.w ^ rec.w) & 63u);
 }
 
-// insert-or-count the records of lanes with p set; on return p = lanes that found no place
-__device__ __forceinline__ void rtab_insert_loop(uint4 *rtab, uint4 rec, uint32_t h, bool &p) {
+// insert-or-count one record per lane; the lane's state is its slot h with RT_DONE or-ed in once
+// the record is placed (lanes without a record start that way).  On return lanes still without
+// RT_DONE found no place.
+constexpr uint32_t RT_DONE = 0x80000000u;
+__device__ __forceinline__ void rtab_insert_loop(uint4 *rtab, uint4 rec, uint32_t &h) {
   uint32_t *rmeta = reinterpret_cast<uint32_t *>(rtab);
   const uint32_t nm1 = rec.w & 63u;
-  for (int it = 0; it < RT_TRIPS && __ballot(p); ++it) {
-    const uint4 e = rtab[h];
+  for (int it = 0; it < RT_TRIPS && __ballot((int32_t)h >= 0); ++it) {
+    const bool p = (int32_t)h >= 0;
+    const uint32_t hh = h & (RT - 1);
+    const uint4 e = rtab[hh];
     const bool match = rtab_diff(e, rec) == 0u;
     const bool empty = e.w == RT_EMPTY;
-    if (p && match) atomicAdd(&rmeta[4 * h + 3], 1u << 6);
-    bool won = false;
+    uint32_t won = 0u;
     if (p && empty) {
-      if (atomicCAS(&rmeta[4 * h + 3], RT_EMPTY, RT_LOCK) == RT_EMPTY) {
-        rmeta[4 * h + 0] = rec.x; rmeta[4 * h + 1] = rec.y; rmeta[4 * h + 2] = rec.z;
+      if (atomicCAS(&rmeta[4 * hh + 3], RT_EMPTY, RT_LOCK) == RT_EMPTY) {
+        rmeta[4 * hh + 0] = rec.x; rmeta[4 * hh + 1] = rec.y; rmeta[4 * hh + 2] = rec.z;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        atomicExch(&rmeta[4 * h + 3], (1u << 6) | nm1);
-        won = true;
+        atomicExch(&rmeta[4 * hh + 3], (1u << 6) | nm1);
+        won = 1u;
       }
     }
+    atomicAdd(&rmeta[4 * hh + 3], (p && match) ? (1u << 6) : 0u);
     // an empty slot lost to another lane, or a locked one, is read again; a slot holding another
     // record sends the lane on
     const bool stay = match || empty || e.w == RT_LOCK;
-    h = stay ? h : ((h + 1) & (RT - 1));
-    p = p && !match && !won;
+    const uint32_t nh = stay ? hh : ((hh + 1) & (RT - 1));
+    h = (p && !match && won == 0u) ? nh : (h | RT_DONE);
   }
 }
 
@@ -576,9 +590,9 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     uint32_t Lh = 0;
     int c = 0;                       // wave-uniform
     auto drain = [&](int cnt) {
-      bool p = lane < cnt;
-      rtab_insert_loop(rtab, L, Lh, p);
-      if (p) count_record_slow<CANON>(keys, cnts, L, 1u, k, t);
+      uint32_t h = Lh | ((lane < cnt) ? 0u : RT_DONE);
+      rtab_insert_loop(rtab, L, h);
+      if ((int32_t)h >= 0) count_record_slow<CANON>(keys, cnts, L, 1u, k, t);
     };
     auto home = [&](const uint4 rec, bool valid) {
       const uint32_t h = rtab_slot(rec);
