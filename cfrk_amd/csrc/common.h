@@ -83,6 +83,15 @@ int cfrk_result_export(cfrk_ctx *ctx, const ResultSrc *src, uint64_t *d_lo, uint
 // ---- device helpers -----------------------------------------------------------------------
 #ifdef __HIPCC__
 
+// Neighbour-lane reads as DPP wave shifts (one VALU instruction; __shfl_down(x, 1) compiles to
+// ds_bpermute + address arithmetic).  The lane without a neighbour reads 0.
+__device__ __forceinline__ uint32_t dev_lane_next(uint32_t x) {       // value of lane + 1
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x130, 0xF, 0xF, true);   // wave_shl:1
+}
+__device__ __forceinline__ uint32_t dev_lane_prev(uint32_t x) {       // value of lane - 1
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x138, 0xF, 0xF, true);   // wave_shr:1
+}
+
 __device__ __forceinline__ uint64_t dev_splitmix64(uint64_t x) {
   x += 0x9E3779B97F4A7C15ull;
   x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void hash_count1_kernel(const int8_t *__restri
     const int64_t off = (tile << 11) + 32 * lane;
     uint32_t b0, b1, bad;
     dev_load_chunk32(data, off, nN, b0, b1, bad);
-    uint32_t n0 = __shfl_down(b0, 1), n1 = __shfl_down(b1, 1), nbad = __shfl_down(bad, 1);
+    uint32_t n0 = dev_lane_next(b0), n1 = dev_lane_next(b1), nbad = dev_lane_next(bad);
     if (lane == 63) dev_load_chunk32(data, off + 32, nN, n0, n1, nbad);
     const uint64_t hi = ((uint64_t)b0 << 32) | b1;
     const uint64_t lo = ((uint64_t)n0 << 32) | n1;

@@ -102,8 +102,8 @@ __global__ __launch_bounds__(P1_THREADS, 6) void msp_p1_kernel(const int8_t *__r
   const int64_t off = chunk * 32;
   uint32_t b0 = 0, b1 = 0, bad = 0xFFFFFFFFu;
   if (chunk >= 0) dev_load_chunk32(data, off, nN, b0, b1, bad);
-  const uint32_t n0 = __shfl_down(b0, 1), n1 = __shfl_down(b1, 1), nn0 = __shfl_down(b0, 2);
-  const uint32_t nbad = __shfl_down(bad, 1), nnbad = __shfl_down(bad, 2);
+  const uint32_t n0 = dev_lane_next(b0), n1 = dev_lane_next(b1), nn0 = dev_lane_next(dev_lane_next(b0));
+  const uint32_t nbad = dev_lane_next(bad), nnbad = dev_lane_next(dev_lane_next(bad));
   const uint64_t hi = ((uint64_t)b0 << 32) | b1;              // bases 0..31
   const uint64_t mid = ((uint64_t)n0 << 32) | n1;             // bases 32..63
   const uint64_t lo = (uint64_t)nn0 << 32;                    // bases 64..79
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(P1_THREADS, 6) void msp_p1_kernel(const int8_t *__r
   }
   const uint64_t Vx = ~Yh;
   const uint32_t V = (uint32_t)(Vx >> 32);
-  const uint32_t prevV = __shfl_up(V, 1) & 1u;                // validity of position -1
+  const uint32_t prevV = dev_lane_prev(V) & 1u;                // validity of position -1
 
   // minimizers of the own k-mers (+ W-1 of the next lane) and the change mask
   uint32_t H[NH];

@@ -115,10 +115,10 @@ __global__ __launch_bounds__(Q1_THREADS) void msp2_p1_kernel(const int8_t *__res
   uint32_t R[10], bd[5];                       // bases / invalid masks of chunks -1, 0, 1, 2, 3
   R[2] = 0; R[3] = 0; bd[1] = 0xFFFFFFFFu;
   if (chunk >= 0) dev_load_chunk32(data, off, nN, R[2], R[3], bd[1]);
-  R[0] = __shfl_up(R[2], 1); R[1] = __shfl_up(R[3], 1); bd[0] = __shfl_up(bd[1], 1);
-  R[4] = __shfl_down(R[2], 1); R[5] = __shfl_down(R[3], 1); bd[2] = __shfl_down(bd[1], 1);
-  R[6] = __shfl_down(R[2], 2); R[7] = __shfl_down(R[3], 2); bd[3] = __shfl_down(bd[1], 2);
-  R[8] = __shfl_down(R[2], 3); R[9] = __shfl_down(R[3], 3); bd[4] = __shfl_down(bd[1], 3);
+  R[0] = dev_lane_prev(R[2]); R[1] = dev_lane_prev(R[3]); bd[0] = dev_lane_prev(bd[1]);
+  R[4] = dev_lane_next(R[2]); R[5] = dev_lane_next(R[3]); bd[2] = dev_lane_next(bd[1]);
+  R[6] = dev_lane_next(dev_lane_next(R[2])); R[7] = dev_lane_next(dev_lane_next(R[3])); bd[3] = dev_lane_next(dev_lane_next(bd[1]));
+  R[8] = dev_lane_next(dev_lane_next(dev_lane_next(R[2]))); R[9] = dev_lane_next(dev_lane_next(dev_lane_next(R[3]))); bd[4] = dev_lane_next(dev_lane_next(dev_lane_next(bd[1])));
   const uint64_t hi = ((uint64_t)R[2] << 32) | R[3];
   const uint64_t mid = ((uint64_t)R[4] << 32) | R[5];
 
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(Q1_THREADS) void msp2_p1_kernel(const int8_t *__res
   const int o = 32 - c;                                        // 15..31
   const uint64_t Vx = ~((I0 << o) | (I1 >> (64 - o)));
   const uint32_t V = (uint32_t)(Vx >> 32);
-  const uint32_t prevV = __shfl_up(V, 1) & 1u;
+  const uint32_t prevV = dev_lane_prev(V) & 1u;
 
   uint32_t H[NH];
   const uint64_t Cx = msp_minimizers<W2>(hi, mid, chunk, m, H);

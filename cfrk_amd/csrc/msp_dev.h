@@ -119,7 +119,7 @@ __device__ __forceinline__ uint64_t msp_minimizers(uint64_t hi, uint64_t mid, in
     }
   }
 #pragma unroll
-  for (int j = 0; j < W - 1; ++j) H[32 + j] = __shfl_down(H[j], 1);   // next lane's first W-1 hashes
+  for (int j = 0; j < W - 1; ++j) H[32 + j] = dev_lane_next(H[j]);   // next lane's first W-1 hashes
   // sliding-window minimum over W by doubling: H[j] <- min H[j .. j+P), then one combine
 #pragma unroll
   for (int s = 1; s < P; s <<= 1) {
@@ -132,13 +132,23 @@ __device__ __forceinline__ uint64_t msp_minimizers(uint64_t hi, uint64_t mid, in
   }
   // H[0..31] = minimizers of the own k-mers; fetch the next lane's first W-1 and the previous
   // lane's last one
-  const uint32_t prevW = __shfl_up(H[31], 1);
+  const uint32_t prevW = dev_lane_prev(H[31]);
 #pragma unroll
-  for (int j = 0; j < W - 1; ++j) H[32 + j] = __shfl_down(H[j], 1);
+  for (int j = 0; j < W - 1; ++j) H[32 + j] = dev_lane_next(H[j]);
 
   // Cx bit(63-p): minimizer occurrence changes between positions p-1 and p (p = 0..NH-1)
-  uint64_t Cx = (H[0] != prevW) ? (1ull << 63) : 0ull;
+  // Two VALU instructions per position: a compare into VCC and an add-with-carry that doubles
+  // the accumulator and takes the compare bit in (the first position ends up in the top bit).
+  // Inline asm: from C the compiler builds compare + select + or with a constant move each.
+  auto push = [](uint32_t &acc, uint32_t a, uint32_t b) {
+    asm("v_cmp_ne_u32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
+  };
+  uint32_t ch = 0, cl = 0;
+  push(ch, H[0], prevW);
 #pragma unroll
-  for (int p = 1; p < NH; ++p) Cx |= (H[p] != H[p - 1]) ? (1ull << (63 - p)) : 0ull;
-  return Cx;
+  for (int p = 1; p < 32; ++p) push(ch, H[p], H[p - 1]);
+#pragma unroll
+  for (int p = 32; p < NH; ++p) push(cl, H[p], H[p - 1]);
+  cl <<= (64 - NH);
+  return ((uint64_t)ch << 32) | cl;
 }

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(RX1_THREADS) void rx1_kernel(const int8_t *__restri
   const int64_t off = ((int64_t)blockIdx.x * RX1_THREADS + tid) * 32;
   uint32_t b0, b1w, bad;
   dev_load_chunk32(data, off, nN, b0, b1w, bad);
-  uint32_t n0 = __shfl_down(b0, 1), n1 = __shfl_down(b1w, 1), nbad = __shfl_down(bad, 1);
+  uint32_t n0 = dev_lane_next(b0), n1 = dev_lane_next(b1w), nbad = dev_lane_next(bad);
   if (lane == 63) dev_load_chunk32(data, off + 32, nN, n0, n1, nbad);
   const uint64_t hi = ((uint64_t)b0 << 32) | b1w;
   const uint64_t lo = ((uint64_t)n0 << 32) | n1;
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(RXS_THREADS) void rxs_count_kernel(const int8_t *__
     const int64_t off = (tile * RXS_THREADS + tid) * 32;
     uint32_t b0, b1w, bad;
     dev_load_chunk32(data, off, nN, b0, b1w, bad);
-    uint32_t n0 = __shfl_down(b0, 1), n1 = __shfl_down(b1w, 1), nbad = __shfl_down(bad, 1);
+    uint32_t n0 = dev_lane_next(b0), n1 = dev_lane_next(b1w), nbad = dev_lane_next(bad);
     if (lane == 63) dev_load_chunk32(data, off + 32, nN, n0, n1, nbad);
     const uint64_t hi = ((uint64_t)b0 << 32) | b1w;
     const uint64_t lo = ((uint64_t)n0 << 32) | n1;
