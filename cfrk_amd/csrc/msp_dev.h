@@ -98,19 +98,21 @@ __device__ __forceinline__ uint64_t msp_minimizers(uint64_t hi, uint64_t mid, in
                                                    uint32_t (&H)[32 + W - 1]) {
   constexpr int NH = 32 + W - 1;
   constexpr int P = (W >= 16) ? 16 : (W >= 8) ? 8 : (W >= 4) ? 4 : 2;
-  // canonical m-mer hashes of the own 32 positions, rolled one base at a time; the low 7 bits
-  // carry the absolute position (mod 128) so that equal packed values mean the SAME m-mer
-  // occurrence: a run then never exceeds W k-mers
+  static_assert(W < 32, "position tags are 5 bits");
+  // canonical m-mer hashes of the own 32 positions, rolled one base at a time; the low bits carry
+  // the position mod 32 so that equal packed values mean the SAME m-mer occurrence (a window is
+  // shorter than 32 positions, and only minima of overlapping windows are ever compared): a run
+  // then never exceeds W k-mers
   {
     const uint64_t Shi = (hi << (2 * m)) | (mid >> (64 - 2 * m));   // bases m.. of the string
     uint32_t fm = (uint32_t)(hi >> (64 - 2 * m));
     uint32_t rm = (uint32_t)dev_revcomp64((uint64_t)fm, m);
     const uint32_t mmask = (m == 16) ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1u);
     const int rsh = 2 * m - 2;
-    const uint32_t pos0 = ((uint32_t)chunk & 3u) << 5;
+    (void)chunk;
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
-      H[j] = (hash_mmer(min(fm, rm)) & ~127u) | (pos0 + j);
+      H[j] = (hash_mmer(min(fm, rm)) & ~127u) | (uint32_t)j;
       if (j + 1 < 32) {
         const uint32_t nb = (uint32_t)(Shi >> (62 - 2 * j)) & 3u;
         fm = ((fm << 2) | nb) & mmask;
@@ -121,6 +123,7 @@ __device__ __forceinline__ uint64_t msp_minimizers(uint64_t hi, uint64_t mid, in
 #pragma unroll
   for (int j = 0; j < W - 1; ++j) H[32 + j] = dev_lane_next(H[j]);   // next lane's first W-1 hashes
   // sliding-window minimum over W by doubling: H[j] <- min H[j .. j+P), then one combine
+  // (three-input v_min3_u32 steps need fewer instructions but measured slower)
 #pragma unroll
   for (int s = 1; s < P; s <<= 1) {
 #pragma unroll
