@@ -158,6 +158,7 @@ __global__ __launch_bounds__(P1_THREADS, 6) void msp_p1_kernel(const int8_t *__r
     if (lane == 63 && incl) wbase = atomicAdd(&nrec_s, incl);
     slot = __shfl(wbase, 63) + incl - mine;
   }
+  const LeafPack LP = leaf_pack(H);
   while (S) {
     const int a = __clz(S);
     S &= ~(0x80000000u >> a);
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(P1_THREADS, 6) void msp_p1_kernel(const int8_t *__r
     // this locus emits the same record
     const uint32_t pv = a ? ((V >> (32 - a)) & 1u) : prevV;
     const uint32_t complete = (pv & (uint32_t)(Vx >> (63 - (a + n))) & 1u) << 6;
-    const uint32_t leaf = leaf_of(pick32(H, a));
+    const uint32_t leaf = leaf_pick(LP, a);
     const uint32_t bin1 = leaf >> B2_LOG;
     uint4 rec;
     const uint64_t r01 = a ? ((hi << (2 * a)) | (mid >> (64 - 2 * a))) : hi;

@@ -169,6 +169,7 @@ __global__ __launch_bounds__(Q1_THREADS) void msp2_p1_kernel(const int8_t *__res
     if (lane == 63 && incl) wbase = atomicAdd(&nrec_s, incl);
     slot = __shfl(wbase, 63) + incl - mine;
   }
+  const LeafPack LP = leaf_pack(H);
   while (S) {
     const int a = __clz(S);
     S &= ~(0x80000000u >> a);
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(Q1_THREADS) void msp2_p1_kernel(const int8_t *__res
     const int n = min(__clzll(rest) + 1, W2);
     const uint32_t pv = a ? ((V >> (32 - a)) & 1u) : prevV;
     const uint32_t complete = (pv & (uint32_t)(Vx >> (63 - (a + n))) & 1u) << 6;
-    const uint32_t leaf = leaf_of(pick32(H, a));
+    const uint32_t leaf = leaf_pick(LP, a);
     const uint32_t bin1 = leaf >> B2_LOG;
     // bases of the run: 96 bases from string offset 32 + a - c (origin = chunk -1)
     const int o2 = 32 + a - c;                                  // 15..63

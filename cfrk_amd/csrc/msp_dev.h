@@ -18,34 +18,37 @@ __device__ __forceinline__ uint32_t hash_mmer(uint32_t c) {
   return h ^ (h >> 16);
 }
 // minimizer -> leaf id (16 bits).  The window minimum is skewed low in its TOP bits only (that is
-// what the comparison looks at); bits 7..22 of the winning hash stay uniform (simulated: same
-// leaf balance as a full re-mix), and bits 0..6 hold the position tag.
-__device__ __forceinline__ uint32_t leaf_of(uint32_t wmin) { return (wmin >> 7) & 0xFFFFu; }
+// what the comparison looks at); bits 8..23 of the winning hash stay uniform (simulated: same
+// leaf balance as a full re-mix), and the low bits hold the position tag.  Byte-aligned so that
+// one v_perm_b32 packs the leaf ids of two positions.
+__device__ __forceinline__ uint32_t leaf_of(uint32_t wmin) { return (wmin >> 8) & 0xFFFFu; }
 
-
-// w[a] for a lane-varying a in 0..31, as a 5-level select tree on VALUES (31 v_cndmask);
-// selecting between array elements directly makes clang select pointers and park the
-// arrays in scratch/LDS.
+// Leaf ids of a lane's 32 window minima, two per word (even position in the low half).
+struct LeafPack { uint32_t w[16]; };
 template <int N>
-__device__ __forceinline__ uint32_t pick32(const uint32_t (&w)[N], int a) {
-  const bool c16 = (a & 16) != 0, c8 = (a & 8) != 0, c4 = (a & 4) != 0, c2 = (a & 2) != 0, c1 = (a & 1) != 0;
+__device__ __forceinline__ LeafPack leaf_pack(const uint32_t (&H)[N]) {
+  LeafPack L;
+#pragma unroll
+  for (int i = 0; i < 16; ++i)   // bytes 1,2 of H[2i] -> bytes 0,1; bytes 1,2 of H[2i+1] -> bytes 2,3
+    L.w[i] = __builtin_amdgcn_perm(H[2 * i + 1], H[2 * i], 0x06050201u);
+  return L;
+}
+// leaf id at a lane-varying position a (0..31): a 4-level select tree on 16 VALUES plus a half
+// pick (19 selects/shifts; selecting between array elements directly makes clang select pointers
+// and park the arrays in scratch/LDS, and a tree over the 32 unpacked minima is twice as deep).
+__device__ __forceinline__ uint32_t leaf_pick(const LeafPack &L, int a) {
+  const bool c16 = (a & 16) != 0, c8 = (a & 8) != 0, c4 = (a & 4) != 0, c2 = (a & 2) != 0;
 #define CFRK_SEL(c, hi_, lo_) ({ const uint32_t x_ = (lo_), y_ = (hi_); (c) ? y_ : x_; })
-  const uint32_t s0 = CFRK_SEL(c16, w[16], w[0]), s1 = CFRK_SEL(c16, w[17], w[1]);
-  const uint32_t s2 = CFRK_SEL(c16, w[18], w[2]), s3 = CFRK_SEL(c16, w[19], w[3]);
-  const uint32_t s4 = CFRK_SEL(c16, w[20], w[4]), s5 = CFRK_SEL(c16, w[21], w[5]);
-  const uint32_t s6 = CFRK_SEL(c16, w[22], w[6]), s7 = CFRK_SEL(c16, w[23], w[7]);
-  const uint32_t s8 = CFRK_SEL(c16, w[24], w[8]), s9 = CFRK_SEL(c16, w[25], w[9]);
-  const uint32_t s10 = CFRK_SEL(c16, w[26], w[10]), s11 = CFRK_SEL(c16, w[27], w[11]);
-  const uint32_t s12 = CFRK_SEL(c16, w[28], w[12]), s13 = CFRK_SEL(c16, w[29], w[13]);
-  const uint32_t s14 = CFRK_SEL(c16, w[30], w[14]), s15 = CFRK_SEL(c16, w[31], w[15]);
-  const uint32_t e0 = CFRK_SEL(c8, s8, s0), e1 = CFRK_SEL(c8, s9, s1), e2 = CFRK_SEL(c8, s10, s2);
-  const uint32_t e3 = CFRK_SEL(c8, s11, s3), e4 = CFRK_SEL(c8, s12, s4), e5 = CFRK_SEL(c8, s13, s5);
-  const uint32_t e6 = CFRK_SEL(c8, s14, s6), e7 = CFRK_SEL(c8, s15, s7);
-  const uint32_t f0 = CFRK_SEL(c4, e4, e0), f1 = CFRK_SEL(c4, e5, e1), f2 = CFRK_SEL(c4, e6, e2);
-  const uint32_t f3 = CFRK_SEL(c4, e7, e3);
-  const uint32_t g0 = CFRK_SEL(c2, f2, f0), g1 = CFRK_SEL(c2, f3, f1);
+  const uint32_t s0 = CFRK_SEL(c16, L.w[8], L.w[0]), s1 = CFRK_SEL(c16, L.w[9], L.w[1]);
+  const uint32_t s2 = CFRK_SEL(c16, L.w[10], L.w[2]), s3 = CFRK_SEL(c16, L.w[11], L.w[3]);
+  const uint32_t s4 = CFRK_SEL(c16, L.w[12], L.w[4]), s5 = CFRK_SEL(c16, L.w[13], L.w[5]);
+  const uint32_t s6 = CFRK_SEL(c16, L.w[14], L.w[6]), s7 = CFRK_SEL(c16, L.w[15], L.w[7]);
+  const uint32_t e0 = CFRK_SEL(c8, s4, s0), e1 = CFRK_SEL(c8, s5, s1), e2 = CFRK_SEL(c8, s6, s2);
+  const uint32_t e3 = CFRK_SEL(c8, s7, s3);
+  const uint32_t f0 = CFRK_SEL(c4, e2, e0), f1 = CFRK_SEL(c4, e3, e1);
+  const uint32_t g = CFRK_SEL(c2, f1, f0);
 #undef CFRK_SEL
-  return c1 ? g1 : g0;
+  return (g >> ((a & 1) << 4)) & 0xFFFFu;
 }
 
 // exclusive prefix sum of cnt[0..NB) into off[0..NB); every thread of the block must call it
