@@ -23,7 +23,7 @@ TableView cfrk_table_view(const cfrk_ctx *ctx);
 // msp.hip and radix.hip both produce
 struct MspView {
   uint4 *rec1; uint32_t *cnt1; uint64_t cap1;   // B1 x NXG sub-regions of cap1 records each
-  uint4 *rec2; uint32_t *cnt2; uint64_t cap2c, cap2t;   // per leaf: complete stream (cap2c), then 3 truncated length classes (cap2t each)
+  uint4 *rec2; uint32_t *cnt2; uint64_t cap2c, cap2t;   // per leaf: complete stream (cap2c), then the truncated stream (cap2t)
   uint64_t *out_keys; uint32_t *out_cnt; uint64_t out_cap;
   uint64_t *out_hi;                           // high key words of the list (two-word keys only)
   uint64_t *leaf_off; uint32_t *leaf_n;        // where each leaf's entries sit in the result list

@@ -234,12 +234,18 @@ __global__ __launch_bounds__(P1_THREADS, 6) void msp_p1_kernel(const int8_t *__r
 // walks ITS bins (b1 = group, group+8, ...) one after the other, so that at any moment the
 // workgroups of one XCD append to the leaf streams of very few level-1 bins: a leaf stream is only
 // ever written from one XCD and its frontier sectors merge in L2 (P2: 11.6 -> 10.0 ms).
+// Two streams per leaf: truncated runs (class 0) and complete runs (class 1).  The leaf kernel
+// sorts records by length itself, so finer classes would only shorten P2's write segments.
+constexpr int NCLS = 2;
+constexpr int NSUB = NCLS * B2;                           // 512 sub-bins of a level-1 bin
+__device__ __forceinline__ uint32_t sub_of(uint32_t w) { return (((w >> 8) & (B2 - 1)) << 1) | ((w >> 6) & 1u); }
+
 __global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int tiles_per_sub, int k, int canon,
                                                             MspView v, TableView t) {
   __shared__ uint4 sorted[P2_TILE];
   __shared__ uint32_t hist[NSUB], loff[NSUB], gbase[NSUB];   // hist doubles as the fill cursor
   __shared__ uint32_t wtot[P2_THREADS / 64];
-  static_assert(NSUB == P2_THREADS, "the scan below gives every thread one sub-bin");
+  static_assert(NSUB <= P2_THREADS && NSUB % 64 == 0, "the scan below gives one thread per sub-bin");
   const int tid = threadIdx.x;
   const uint32_t xg = blockIdx.x & (NXG - 1), seq = blockIdx.x / NXG;
   const uint32_t per_bin = (uint32_t)NXG * (uint32_t)tiles_per_sub;
@@ -251,7 +257,7 @@ __global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int tiles_per_sub, i
   const uint64_t r0 = (uint64_t)tile * P2_TILE;
   if (r0 >= n) return;
   const uint32_t nt = (uint32_t)min((uint64_t)P2_TILE, n - r0);
-  hist[tid] = 0;
+  if (tid < NSUB) hist[tid] = 0;
   __syncthreads();
   const uint4 *src = v.rec1 + (uint64_t)reg * v.cap1 + r0;
   uint4 r[P2_PER];
@@ -266,9 +272,10 @@ __global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int tiles_per_sub, i
   __syncthreads();
   uint32_t g0 = 0;
   {
-    // per-stream reservation + exclusive scan of the 1024 sub-bin sizes (one per thread)
+    // per-stream reservation + exclusive scan of the sub-bin sizes (one per thread, tid < NSUB)
     const int lane = tid & 63, wave = tid >> 6;
-    const uint32_t x0 = hist[tid];
+    const bool mine = tid < NSUB;
+    const uint32_t x0 = mine ? hist[tid] : 0u;
     // returning atomic: issued here, consumed after the sort (its latency flies under it)
     if (x0) g0 = atomicAdd(&v.cnt2[b1 * NSUB + tid], x0);
     uint32_t incl = x0;
@@ -281,8 +288,10 @@ __global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int tiles_per_sub, i
     __syncthreads();
     uint32_t base = 0;
     for (int w = 0; w < wave; ++w) base += wtot[w];
-    loff[tid] = base + incl - x0;
-    hist[tid] = 0;                                         // from here on: fill cursor
+    if (mine) {
+      loff[tid] = base + incl - x0;
+      hist[tid] = 0;                                       // from here on: fill cursor
+    }
     __syncthreads();
   }
   // counting sort of the tile by sub-bin, in LDS
@@ -294,17 +303,17 @@ __global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int tiles_per_sub, i
       sorted[loff[sb] + atomicAdd(&hist[sb], 1u)] = r[i];
     }
   }
-  gbase[tid] = g0;
+  if (tid < NSUB) gbase[tid] = g0;
   __syncthreads();
   // copy out: consecutive lanes -> consecutive records of the same stream
   for (uint32_t p = tid; p < nt; p += P2_THREADS) {
     const uint4 rec = sorted[p];
     const uint32_t sb = sub_of(rec.w);
     const uint32_t dst = gbase[sb] + (p - loff[sb]);
-    const uint64_t leaf = ((uint64_t)b1 * NSUB + sb) >> 2;
-    const uint32_t cls = sb & 3u;
-    const uint64_t cap = (cls == 3u) ? v.cap2c : v.cap2t;
-    const uint64_t at = leaf * (v.cap2c + 3 * v.cap2t) + ((cls == 3u) ? 0 : v.cap2c + cls * v.cap2t);
+    const uint64_t leaf = ((uint64_t)b1 * NSUB + sb) >> 1;
+    const uint32_t cls = sb & 1u;
+    const uint64_t cap = cls ? v.cap2c : v.cap2t;
+    const uint64_t at = leaf * (v.cap2c + v.cap2t) + (cls ? 0 : v.cap2c);
     if (dst < cap) v.rec2[at + dst] = rec;
     else spill_record(rec, k, canon != 0, t);
   }
@@ -555,13 +564,10 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
   __shared__ unsigned long long wg_base;
   const int tid = threadIdx.x, lane = tid & 63;
   const uint32_t leaf = blockIdx.x;
-  const uint64_t nt0 = min((uint64_t)v.cnt2[NCLS * leaf + 0], v.cap2t);   // truncated runs, n <= 4
-  const uint64_t nt1 = min((uint64_t)v.cnt2[NCLS * leaf + 1], v.cap2t);   //                 n <= 10
-  const uint64_t nt2 = min((uint64_t)v.cnt2[NCLS * leaf + 2], v.cap2t);   //                 n > 10
-  const uint64_t n1 = min((uint64_t)v.cnt2[NCLS * leaf + 3], v.cap2c);    // complete runs
-  const uint64_t n0 = nt0 + nt1 + nt2;
-  const uint4 *leaf_rec = v.rec2 + (uint64_t)leaf * (v.cap2c + 3 * v.cap2t);
-  if (n0 + n1 == 0) return;
+  const uint64_t nt = min((uint64_t)v.cnt2[NCLS * leaf + 0], v.cap2t);     // truncated runs
+  const uint64_t n1 = min((uint64_t)v.cnt2[NCLS * leaf + 1], v.cap2c);     // complete runs
+  const uint4 *leaf_rec = v.rec2 + (uint64_t)leaf * (v.cap2c + v.cap2t);
+  if (nt + n1 == 0) return;
   for (int s = tid; s < TS; s += P3_THREADS) { keys[s] = CFRK_EMPTY_KEY; cnts[s] = 0; }
   for (int s = tid; s < RT; s += P3_THREADS) rtab[s] = make_uint4(0u, 0u, 0u, RT_EMPTY);
   if (tid == 0) { wg_total = 0; nocc = 0; }
@@ -570,12 +576,9 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
 
   const uint64_t kmask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1ull);
   const int rcsh = 2 * k - 2;
-  // truncated runs that go through the length-sorted list: longest class first, as many as fit
-  // the list and its 14-bit positions
+  // truncated runs that go through the length-sorted list: as many as fit
   const uint4 *trunc = leaf_rec + v.cap2c;
-  const uint32_t tl2 = (uint32_t)min(nt2, (uint64_t)TL_CAP);
-  const uint32_t tl1 = (uint32_t)min(nt1, (uint64_t)(TL_CAP - tl2));
-  const uint32_t tl0 = (uint32_t)min(nt0, (uint64_t)(TL_CAP - tl2 - tl1));
+  const uint32_t tl = (uint32_t)min(nt, (uint64_t)TL_CAP);
 
   // ---- phase 1a: complete runs, one record-table update per record.  Most records find their
   //      twin in the home slot: that case is one LDS read + one LDS add with every lane busy.
@@ -638,18 +641,14 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     const bool occ = e.w != RT_EMPTY;
     uint32_t rank = 0;
     if (occ) rank = atomicAdd(&nhist[e.w & 31u], 1u);
-    // (b) truncated runs: index = class << 14 | position, up to TL_CAP of them
-    uint32_t tw[TL_PER], trank[TL_PER], tidx[TL_PER];
+    // (b) truncated runs: the first TL_CAP of the stream, by position
+    uint32_t tw[TL_PER], trank[TL_PER];
 #pragma unroll
     for (int i = 0; i < TL_PER; ++i) {
-      const uint32_t g = (uint32_t)(i * P3_THREADS + tid);           // position in [class2 | class1 | class0]
-      uint32_t cls = 2u, pos = g;
-      if (pos >= tl2) { pos -= tl2; cls = 1u; if (pos >= tl1) { pos -= tl1; cls = 0u; } }
-      const bool ok = g < tl2 + tl1 + tl0;
-      tidx[i] = ok ? ((cls << 14) | pos) : 0xFFFFFFFFu;
-      tw[i] = 0u; trank[i] = 0u;
-      if (ok) {
-        tw[i] = trunc[(uint64_t)cls * v.cap2t + pos].w & 31u;
+      const uint32_t g = (uint32_t)(i * P3_THREADS + tid);
+      tw[i] = 0xFFFFFFFFu; trank[i] = 0u;
+      if (g < tl) {
+        tw[i] = trunc[g].w & 31u;
         trank[i] = atomicAdd(&thist[tw[i]], 1u);
       }
     }
@@ -670,7 +669,7 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     if (occ) occ_list[nhist[e.w & 31u] + rank] = (uint16_t)tid;
 #pragma unroll
     for (int i = 0; i < TL_PER; ++i)
-      if (tidx[i] != 0xFFFFFFFFu) tlist[thist[tw[i]] + trank[i]] = (uint16_t)tidx[i];
+      if (tw[i] != 0xFFFFFFFFu) tlist[thist[tw[i]] + trank[i]] = (uint16_t)(i * P3_THREADS + tid);
   }
   __syncthreads();
   {
@@ -681,28 +680,18 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
       if (valid) rec = rtab[occ_list[i]];
       count_record_v2<CANON>(keys, cnts, rec, rec.w >> 6, valid, k, kmask, rcsh, t);
     }
-    const uint32_t ntl = tl2 + tl1 + tl0;
-    for (uint32_t i = tid; i < ((ntl + 63u) & ~63u); i += P3_THREADS) {
-      const bool valid = i < ntl;
+    for (uint32_t i = tid; i < ((tl + 63u) & ~63u); i += P3_THREADS) {
+      const bool valid = i < tl;
       uint4 rec = make_uint4(0u, 0u, 0u, 0u);
-      if (valid) {
-        const uint32_t ix = tlist[i];
-        rec = trunc[(uint64_t)(ix >> 14) * v.cap2t + (ix & 0x3FFFu)];
-      }
+      if (valid) rec = trunc[tlist[i]];
       count_record_v2<CANON>(keys, cnts, rec, 1u, valid, k, kmask, rcsh, t);
     }
     // truncated runs beyond the sorted list (very large leaves): in stream order
-#pragma unroll 1
-    for (int cls = 2; cls >= 0; --cls) {
-      const uint64_t from = (cls == 2) ? tl2 : (cls == 1) ? tl1 : tl0;
-      const uint64_t to = (cls == 2) ? nt2 : (cls == 1) ? nt1 : nt0;
-      const uint4 *src = trunc + (uint64_t)cls * v.cap2t;
-      for (uint64_t i = from + tid; i < ((to + 63) & ~63ull) && from < to; i += P3_THREADS) {
-        const bool valid = i < to;
-        uint4 rec = make_uint4(0u, 0u, 0u, 0u);
-        if (valid) rec = src[i];
-        count_record_v2<CANON>(keys, cnts, rec, 1u, valid, k, kmask, rcsh, t);
-      }
+    for (uint64_t i = (uint64_t)tl + tid; i < ((nt + 63) & ~63ull) && tl < nt; i += P3_THREADS) {
+      const bool valid = i < nt;
+      uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+      if (valid) rec = trunc[i];
+      count_record_v2<CANON>(keys, cnts, rec, 1u, valid, k, kmask, rcsh, t);
     }
   }
   __syncthreads();
@@ -883,8 +872,8 @@ static size_t msp_need(const cfrk_ctx *ctx, int64_t span) {
   int W0, m0;
   msp_params(ctx->g_k, &W0, &m0);
   const double expect0 = (double)span * (2.0 / (W0 + 1) + 1.0 / 64.0);
-  return (size_t)(expect0 * 1.35 * 16) + (size_t)B1 * NXG * 2048 * 16 + (size_t)(expect0 * 3.3 * 16) +
-         (size_t)NLEAF * 384 * 16 + (size_t)ctx->g_cap * 12;
+  return (size_t)(expect0 * 1.35 * 16) + (size_t)B1 * NXG * 2048 * 16 + (size_t)(expect0 * 2.7 * 16) +
+         (size_t)NLEAF * 192 * 16 + (size_t)ctx->g_cap * 12;
 }
 
 // one pass of P1 -> P2 -> P3 over the P1 tiles [tile0, tile0 + ntiles): the k-mers that START in
@@ -905,7 +894,7 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
   const uint64_t cap1 = (uint64_t)(expect / (B1 * NXG) * 1.35) + 2048;   // per sub-region
   // per leaf: complete runs dominate at depth; truncated ones are ~2 per read plus invalid bases
   const uint64_t cap2c = (uint64_t)(expect / NLEAF * 2.1) + 96;
-  const uint64_t cap2t = (uint64_t)(expect / NLEAF * 0.4) + 96;     // each of the 3 length classes
+  const uint64_t cap2t = (uint64_t)(expect / NLEAF * 0.6) + 96;     // truncated runs: ~15 % of the records
   const int64_t tiles_per_sub = (int64_t)((cap1 + P2_TILE - 1) / P2_TILE);
   if (tiles_per_sub * B1 * NXG > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
 
@@ -913,7 +902,7 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
   MspView &v = ms->view;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_L1, (size_t)B1 * NXG * cap1 * sizeof(uint4), &p))) return rc;
   v.rec1 = (uint4 *)p; v.cap1 = cap1;
-  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)NLEAF * (cap2c + 3 * cap2t) * sizeof(uint4), &p))) return rc;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)NLEAF * (cap2c + cap2t) * sizeof(uint4), &p))) return rc;
   v.rec2 = (uint4 *)p; v.cap2c = cap2c; v.cap2t = cap2t;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_AUX, (size_t)NLEAF * 8 + (size_t)(B1 * NXG + (NCLS + 1) * NLEAF) * sizeof(uint32_t), &p))) return rc;
   v.leaf_off = (uint64_t *)p;

@@ -41,6 +41,16 @@ struct View2 {
   uint64_t *stats;
 };
 
+// Truncated runs are split by length class as well, so that in the leaf kernel the lanes of a
+// wave expand records of similar length.
+constexpr int NCLS = 4;                                   // 0..2 truncated (n<=4, <=10, >10), 3 complete
+constexpr int NSUB = NCLS * B2;
+__device__ __forceinline__ uint32_t cls_of(uint32_t w) {
+  const uint32_t n = (w & 63u) + 1u;
+  return (w & 64u) ? 3u : (n <= 4u ? 0u : (n <= 10u ? 1u : 2u));
+}
+__device__ __forceinline__ uint32_t sub_of(uint32_t w) { return (((w >> 8) & (B2 - 1)) << 2) | cls_of(w); }
+
 typedef unsigned __int128 u128;
 
 // k-mers of a record, one by one: fwd / rc rolling over the 192-bit base string

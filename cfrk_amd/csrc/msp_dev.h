@@ -76,19 +76,6 @@ __device__ __forceinline__ void block_scan(const uint32_t *cnt, uint32_t *off, u
   __syncthreads();
 }
 
-// ---------------------------------------------------------------------------------------- P1
-
-// Truncated runs are split by length class as well, so that in P3 the lanes of a wave expand
-// records of similar length (the expansion loop runs max(n)/2 trips per wave).
-constexpr int NCLS = 4;                                   // 0..2 truncated (n<=4, <=10, >10), 3 complete
-constexpr int NSUB = NCLS * B2;
-__device__ __forceinline__ uint32_t cls_of(uint32_t w) {
-  const uint32_t n = (w & 63u) + 1u;
-  return (w & 64u) ? 3u : (n <= 4u ? 0u : (n <= 10u ? 1u : 2u));
-}
-__device__ __forceinline__ uint32_t sub_of(uint32_t w) { return (((w >> 8) & (B2 - 1)) << 2) | cls_of(w); }
-
-
 // Minimizers of one lane's 32 window starts (shared by msp.hip and msp2.hip).
 // hi / mid = the lane's own 32 bases and the next lane's 32 bases, 2 bits each, first base in the
 // top bits; chunk = index of the lane's 32-byte chunk (for the absolute-position tag).

@@ -384,7 +384,7 @@ def test_msp_then_merge_and_second_add(ctx):
     assert a == orc.digest(*w1)
 
 
-@pytest.mark.parametrize("k,budget", [(31, 600 << 20), (21, 640 << 20), (63, 1250 << 20), (40, 1250 << 20)])
+@pytest.mark.parametrize("k,budget", [(31, 400 << 20), (21, 500 << 20), (63, 1250 << 20), (40, 1250 << 20)])
 def test_partitioned_path_counts_in_passes_when_memory_is_short(k, budget):
     """a batch whose record buffers exceed the memory budget is counted in several passes over
     ranges of the input (each pass folded into the HBM table): same result as one pass"""
