@@ -46,6 +46,7 @@ constexpr int P1_THREADS = 512;
 constexpr int P1_RCAP = 2304;              // records staged in LDS per workgroup (expected ~1800 at W=18); 3 workgroups per CU
 
 constexpr int P2_THREADS = 1024, P2_PER = 4, P2_TILE = P2_THREADS * P2_PER;
+constexpr int P2_GROUP = 4;                      // consecutive tiles per workgroup (next tile prefetched)
 
 constexpr int P3_THREADS = 1024;
 constexpr int TS_LOG = 12, TS = 1 << TS_LOG;   // LDS table slots per leaf
@@ -240,7 +241,7 @@ constexpr int NCLS = 2;
 constexpr int NSUB = NCLS * B2;                           // 512 sub-bins of a level-1 bin
 __device__ __forceinline__ uint32_t sub_of(uint32_t w) { return (((w >> 8) & (B2 - 1)) << 1) | ((w >> 6) & 1u); }
 
-__global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int tiles_per_sub, int k, int canon,
+__global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int groups_per_sub, int k, int canon,
                                                             MspView v, TableView t) {
   __shared__ uint4 sorted[P2_TILE];
   __shared__ uint32_t hist[NSUB], loff[NSUB], gbase[NSUB];   // hist doubles as the fill cursor
@@ -248,74 +249,96 @@ __global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int tiles_per_sub, i
   static_assert(NSUB <= P2_THREADS && NSUB % 64 == 0, "the scan below gives one thread per sub-bin");
   const int tid = threadIdx.x;
   const uint32_t xg = blockIdx.x & (NXG - 1), seq = blockIdx.x / NXG;
-  const uint32_t per_bin = (uint32_t)NXG * (uint32_t)tiles_per_sub;
+  const uint32_t per_bin = (uint32_t)NXG * (uint32_t)groups_per_sub;
   const uint32_t b1 = xg + NXG * (seq / per_bin);
-  const uint32_t sub = (seq % per_bin) / (uint32_t)tiles_per_sub;
-  const uint32_t tile = (seq % per_bin) % (uint32_t)tiles_per_sub;
+  const uint32_t sub = (seq % per_bin) / (uint32_t)groups_per_sub;
+  const uint32_t grp = (seq % per_bin) % (uint32_t)groups_per_sub;
   const uint32_t reg = b1 * NXG + sub;
   const uint64_t n = min((uint64_t)v.cnt1[reg], v.cap1);
-  const uint64_t r0 = (uint64_t)tile * P2_TILE;
-  if (r0 >= n) return;
-  const uint32_t nt = (uint32_t)min((uint64_t)P2_TILE, n - r0);
-  if (tid < NSUB) hist[tid] = 0;
-  __syncthreads();
-  const uint4 *src = v.rec1 + (uint64_t)reg * v.cap1 + r0;
-  uint4 r[P2_PER];
+  // a workgroup takes P2_GROUP consecutive tiles and asks for the next tile's records before it
+  // sorts and writes the current one: the load latency hides under the LDS work
+  const uint64_t g0r = (uint64_t)grp * P2_GROUP * P2_TILE;
+  if (g0r >= n) return;
+  const uint4 *base = v.rec1 + (uint64_t)reg * v.cap1;
+  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+  uint4 nx[P2_PER];
 #pragma unroll
   for (int i = 0; i < P2_PER; ++i) {
-    const uint32_t idx = (uint32_t)i * P2_THREADS + tid;
-    uint4 x = make_uint4(0u, 0u, 0u, 0u);
-    if (idx < nt) x = src[idx];
-    r[i] = x;
-    if (idx < nt) atomicAdd(&hist[sub_of(x.w)], 1u);
+    const uint64_t idx = g0r + (uint64_t)i * P2_THREADS + tid;
+    nx[i] = zero4;
+    if (idx < n) nx[i] = base[idx];
   }
-  __syncthreads();
-  uint32_t g0 = 0;
-  {
-    // per-stream reservation + exclusive scan of the sub-bin sizes (one per thread, tid < NSUB)
-    const int lane = tid & 63, wave = tid >> 6;
-    const bool mine = tid < NSUB;
-    const uint32_t x0 = mine ? hist[tid] : 0u;
-    // returning atomic: issued here, consumed after the sort (its latency flies under it)
-    if (x0) g0 = atomicAdd(&v.cnt2[b1 * NSUB + tid], x0);
-    uint32_t incl = x0;
+  for (int tt = 0; tt < P2_GROUP; ++tt) {
+    const uint64_t r0 = g0r + (uint64_t)tt * P2_TILE;
+    if (r0 >= n) break;
+    const uint32_t nt = (uint32_t)min((uint64_t)P2_TILE, n - r0);
+    uint4 r[P2_PER];
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t y = __shfl_up(incl, d);
-      if (lane >= d) incl += y;
+    for (int i = 0; i < P2_PER; ++i) r[i] = nx[i];
+    if (tt + 1 < P2_GROUP) {
+#pragma unroll
+      for (int i = 0; i < P2_PER; ++i) {
+        const uint64_t idx = r0 + P2_TILE + (uint64_t)i * P2_THREADS + tid;
+        nx[i] = zero4;
+        if (idx < n) nx[i] = base[idx];
+      }
     }
-    if (lane == 63) wtot[wave] = incl;
+    if (tid < NSUB) hist[tid] = 0;
     __syncthreads();
-    uint32_t base = 0;
-    for (int w = 0; w < wave; ++w) base += wtot[w];
-    if (mine) {
-      loff[tid] = base + incl - x0;
-      hist[tid] = 0;                                       // from here on: fill cursor
+#pragma unroll
+    for (int i = 0; i < P2_PER; ++i) {
+      const uint32_t idx = (uint32_t)i * P2_THREADS + tid;
+      if (idx < nt) atomicAdd(&hist[sub_of(r[i].w)], 1u);
     }
     __syncthreads();
-  }
-  // counting sort of the tile by sub-bin, in LDS
+    uint32_t g0 = 0;
+    {
+      // per-stream reservation + exclusive scan of the sub-bin sizes (one per thread, tid < NSUB)
+      const int lane = tid & 63, wave = tid >> 6;
+      const bool mine = tid < NSUB;
+      const uint32_t x0 = mine ? hist[tid] : 0u;
+      // returning atomic: issued here, consumed after the sort (its latency flies under it)
+      if (x0) g0 = atomicAdd(&v.cnt2[b1 * NSUB + tid], x0);
+      uint32_t incl = x0;
 #pragma unroll
-  for (int i = 0; i < P2_PER; ++i) {
-    const uint32_t idx = (uint32_t)i * P2_THREADS + tid;
-    if (idx < nt) {
-      const uint32_t sb = sub_of(r[i].w);
-      sorted[loff[sb] + atomicAdd(&hist[sb], 1u)] = r[i];
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(incl, d);
+        if (lane >= d) incl += y;
+      }
+      if (lane == 63) wtot[wave] = incl;
+      __syncthreads();
+      uint32_t bs = 0;
+      for (int w = 0; w < wave; ++w) bs += wtot[w];
+      if (mine) {
+        loff[tid] = bs + incl - x0;
+        hist[tid] = 0;                                     // from here on: fill cursor
+      }
+      __syncthreads();
     }
-  }
-  if (tid < NSUB) gbase[tid] = g0;
-  __syncthreads();
-  // copy out: consecutive lanes -> consecutive records of the same stream
-  for (uint32_t p = tid; p < nt; p += P2_THREADS) {
-    const uint4 rec = sorted[p];
-    const uint32_t sb = sub_of(rec.w);
-    const uint32_t dst = gbase[sb] + (p - loff[sb]);
-    const uint64_t leaf = ((uint64_t)b1 * NSUB + sb) >> 1;
-    const uint32_t cls = sb & 1u;
-    const uint64_t cap = cls ? v.cap2c : v.cap2t;
-    const uint64_t at = leaf * (v.cap2c + v.cap2t) + (cls ? 0 : v.cap2c);
-    if (dst < cap) v.rec2[at + dst] = rec;
-    else spill_record(rec, k, canon != 0, t);
+    // counting sort of the tile by sub-bin, in LDS
+#pragma unroll
+    for (int i = 0; i < P2_PER; ++i) {
+      const uint32_t idx = (uint32_t)i * P2_THREADS + tid;
+      if (idx < nt) {
+        const uint32_t sb = sub_of(r[i].w);
+        sorted[loff[sb] + atomicAdd(&hist[sb], 1u)] = r[i];
+      }
+    }
+    if (tid < NSUB) gbase[tid] = g0;
+    __syncthreads();
+    // copy out: consecutive lanes -> consecutive records of the same stream
+    for (uint32_t p = tid; p < nt; p += P2_THREADS) {
+      const uint4 rec = sorted[p];
+      const uint32_t sb = sub_of(rec.w);
+      const uint32_t dst = gbase[sb] + (p - loff[sb]);
+      const uint64_t leaf = ((uint64_t)b1 * NSUB + sb) >> 1;
+      const uint32_t cls = sb & 1u;
+      const uint64_t cap = cls ? v.cap2c : v.cap2t;
+      const uint64_t at = leaf * (v.cap2c + v.cap2t) + (cls ? 0 : v.cap2c);
+      if (dst < cap) v.rec2[at + dst] = rec;
+      else spill_record(rec, k, canon != 0, t);
+    }
+    __syncthreads();                                       // sorted/loff/gbase are reused by the next tile
   }
 }
 
@@ -895,7 +918,7 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
   // per leaf: complete runs dominate at depth; truncated ones are ~2 per read plus invalid bases
   const uint64_t cap2c = (uint64_t)(expect / NLEAF * 2.1) + 96;
   const uint64_t cap2t = (uint64_t)(expect / NLEAF * 0.6) + 96;     // truncated runs: ~15 % of the records
-  const int64_t tiles_per_sub = (int64_t)((cap1 + P2_TILE - 1) / P2_TILE);
+  const int64_t tiles_per_sub = (int64_t)((cap1 + (uint64_t)P2_TILE * P2_GROUP - 1) / ((uint64_t)P2_TILE * P2_GROUP));   // tile groups
   if (tiles_per_sub * B1 * NXG > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
 
   void *p;
