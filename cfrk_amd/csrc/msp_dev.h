@@ -94,20 +94,30 @@ __device__ __forceinline__ uint64_t msp_minimizers(uint64_t hi, uint64_t mid, in
   // shorter than 32 positions, and only minima of overlapping windows are ever compared): a run
   // then never exceeds W k-mers
   {
-    const uint64_t Shi = (hi << (2 * m)) | (mid >> (64 - 2 * m));   // bases m.. of the string
-    uint32_t fm = (uint32_t)(hi >> (64 - 2 * m));
-    uint32_t rm = (uint32_t)dev_revcomp64((uint64_t)fm, m);
-    const uint32_t mmask = (m == 16) ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1u);
-    const int rsh = 2 * m - 2;
+    // Both strands by extraction instead of rolling: the 16 bases from position j are one
+    // v_alignbit of two string words (static shift), the m-mer is their top 2m bits; its
+    // reverse complement is the low 2m bits of a 32-bit window of the reverse-complemented string
+    // ending where the m-mer starts.  Four instructions per position for the two m-mers.
     (void)chunk;
+    const uint32_t D[3] = {(uint32_t)(hi >> 32), (uint32_t)hi, (uint32_t)(mid >> 32)};
+    uint32_t R[4];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      uint32_t x = __brev(D[i]);
+      x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+      R[3 - i] = ~x;
+    }
+    R[0] = 0;
+    const uint32_t mmask = (m == 16) ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1u);
+    const int fsh = 32 - 2 * m;
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
+      const int o = 2 * j, q = o >> 5, r = o & 31;
+      const uint32_t X = r ? __builtin_amdgcn_alignbit(D[q], D[q + 1], 32 - r) : D[q];
+      const int o2 = 96 - 2 * j, q2 = o2 >> 5, r2 = o2 & 31;
+      const uint32_t Y = r2 ? __builtin_amdgcn_alignbit(R[q2], R[q2 + 1], 32 - r2) : R[q2];
+      const uint32_t fm = X >> fsh, rm = Y & mmask;
       H[j] = (hash_mmer(min(fm, rm)) & ~127u) | (uint32_t)j;
-      if (j + 1 < 32) {
-        const uint32_t nb = (uint32_t)(Shi >> (62 - 2 * j)) & 3u;
-        fm = ((fm << 2) | nb) & mmask;
-        rm = (rm >> 2) | ((3u - nb) << rsh);
-      }
     }
   }
 #pragma unroll
