@@ -355,100 +355,16 @@ __device__ __noinline__ void spill_kmer(const TableView &t, uint64_t key, uint32
 }
 
 // The leaf's k-mer table is TS/2 buckets of two keys (one ds_read_b128 fetches a bucket), linear
-// probing over buckets.  Control flow is kept flat on purpose: this kernel is bound by the CU's
-// scalar unit (exec-mask bookkeeping of divergent branches), not by LDS or VALU.
+// probing over buckets.
 constexpr int NBUCKET = TS / 2;
 __device__ __forceinline__ uint32_t lds_bucket(uint64_t key) {
   return (((uint32_t)key ^ (uint32_t)(key >> 32)) * 0x9E3779B1u) >> (32 - (TS_LOG - 1));
 }
 
-// one probe step for one pending key; q = the bucket as read by the caller (may be stale: a stale
-// view can only show EMPTY where a key now sits, and the CAS settles that)
-__device__ __forceinline__ void lds_step(unsigned long long *keys, uint32_t *cnts, uint64_t key,
-                                         uint32_t &b, ulonglong2 q, bool &pend, int &probes,
-                                         uint32_t add, const TableView &t) {
-  if (pend) {
-    const bool m0 = q.x == key, m1 = q.y == key;
-    const bool e0 = q.x == CFRK_EMPTY_KEY, e1 = q.y == CFRK_EMPTY_KEY;
-    if (m0 | m1) {
-      atomicAdd(&cnts[2 * b + (m0 ? 0u : 1u)], add);
-      pend = false;
-    } else if (e0 | e1) {
-      const uint32_t s = 2 * b + (e0 ? 0u : 1u);
-      const unsigned long long old = atomicCAS(&keys[s], (unsigned long long)CFRK_EMPTY_KEY, (unsigned long long)key);
-      if (old == CFRK_EMPTY_KEY || old == key) { atomicAdd(&cnts[s], add); pend = false; }
-      // else another key took that slot: look at the same bucket again
-    } else {
-      b = (b + 1) & (NBUCKET - 1);
-      if (++probes >= P3_PROBE_LIMIT) { spill_kmer(t, key, add); pend = false; }
-    }
-  }
-}
-
-// count key0 (and key1 when has1) `add` times each; one wave-uniform loop serves both keys
-__device__ __forceinline__ void lds_count_pair(unsigned long long *keys, uint32_t *cnts, uint64_t key0,
-                                               uint64_t key1, bool has1, uint32_t add,
-                                               const TableView &t) {
-  uint32_t b0 = lds_bucket(key0), b1 = lds_bucket(key1);
-  bool p0 = true, p1 = has1;
-  int pr0 = 0, pr1 = 0;
-  const ulonglong2 *buckets = reinterpret_cast<const ulonglong2 *>(keys);
-  do {
-    const ulonglong2 q0 = buckets[b0];
-    const ulonglong2 q1 = buckets[b1];
-    lds_step(keys, cnts, key0, b0, q0, p0, pr0, add, t);
-    lds_step(keys, cnts, key1, b1, q1, p1, pr1, add, t);
-  } while (__ballot(p0 | p1));
-}
-
-// expand one record into its k-mers (rolling), each counted `add` times
-template <bool CANON>
-__device__ __forceinline__ void count_record(unsigned long long *keys, uint32_t *cnts, uint4 rec,
-                                             uint32_t add, int k, uint64_t kmask, int rcsh,
-                                             const TableView &t) {
-  const int nk = (int)(rec.w & 63u) + 1;
-  const uint64_t hi = ((uint64_t)rec.x << 32) | rec.y;
-  const uint64_t lo = (uint64_t)rec.z << 32;
-  uint64_t fwd = hi >> (64 - 2 * k);
-  uint64_t rc = CANON ? dev_revcomp64(fwd, k) : 0;
-  uint64_t T = (k == 32) ? lo : ((hi << (2 * k)) | (lo >> (64 - 2 * k)));
-  for (int j = 0; j < nk; j += 2) {
-    const uint64_t key0 = (CANON && rc < fwd) ? rc : fwd;
-    uint32_t nb = (uint32_t)(T >> 62);
-    T <<= 2;
-    fwd = ((fwd << 2) | nb) & kmask;
-    if (CANON) rc = (rc >> 2) | ((uint64_t)(3u - nb) << rcsh);
-    const bool two = j + 1 < nk;
-    const uint64_t key1 = (CANON && rc < fwd) ? rc : fwd;
-    nb = (uint32_t)(T >> 62);
-    T <<= 2;
-    fwd = ((fwd << 2) | nb) & kmask;
-    if (CANON) rc = (rc >> 2) | ((uint64_t)(3u - nb) << rcsh);
-    if (!CANON && k == 32 && (key0 == CFRK_EMPTY_KEY || (two && key1 == CFRK_EMPTY_KEY))) {
-      // forward-strand all-T 32-mer collides with the EMPTY marker: side counter
-      if (key0 == CFRK_EMPTY_KEY) spill_kmer(t, key0, add);
-      else lds_count_pair(keys, cnts, key0, key0, false, add, t);
-      if (two) {
-        if (key1 == CFRK_EMPTY_KEY) spill_kmer(t, key1, add);
-        else lds_count_pair(keys, cnts, key1, key1, false, add, t);
-      }
-      continue;
-    }
-    lds_count_pair(keys, cnts, key0, key1, two, add, t);
-  }
-}
-
-template <bool CANON>
-__device__ __noinline__ void count_record_slow(unsigned long long *keys, uint32_t *cnts, uint4 rec,
-                                               uint32_t add, int k, const TableView &t) {
-  const uint64_t kmask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1ull);
-  count_record<CANON>(keys, cnts, rec, add, k, kmask, 2 * k - 2, t);
-}
-
-// ---- lean variants used by the leaf kernel's expansion phase.  Every instruction, vector or
-// scalar, costs an issue slot, and a wave runs a probe loop for as long as its slowest lane: the
-// step below is written for instruction count (one CAS-or-match decision per bucket, no per-lane
-// probe counter), and callers feed waves with records of equal length.
+// Every instruction, vector or scalar, costs an issue slot, and a wave runs a probe loop for as
+// long as its slowest lane: the step below is written for instruction count (one CAS-or-match
+// decision per bucket, no per-lane probe counter), and callers feed waves with records of equal
+// length.
 constexpr int KT_TRIPS = 64;
 
 // One bucket attempt for one key per lane: count on a match, claim an empty slot, else move on.
@@ -476,6 +392,14 @@ __device__ __forceinline__ void kt_try(unsigned long long *keys, uint32_t *cnts,
   const bool full = !(hit || e0 || e1);
   const uint32_t nb = full ? ((bb + 1) & (NBUCKET - 1)) : bb;
   b = (p && !ok) ? nb : (b | KT_DONE);
+}
+
+// count one key per lane (valid lanes) `add` times; every lane of the wave must call
+__device__ __forceinline__ void kt_count(unsigned long long *keys, uint32_t *cnts, uint64_t key, uint32_t add,
+                                         bool valid, const TableView &t) {
+  uint32_t b = lds_bucket(key) | (valid ? 0u : KT_DONE);
+  for (int it = 0; it < KT_TRIPS && __ballot((int32_t)b >= 0); ++it) kt_try(keys, cnts, key, b, add);
+  if ((int32_t)b >= 0) spill_kmer(t, key, add);
 }
 
 // expand one record per lane (valid lanes), two k-mers per step; every lane of the wave must call
@@ -619,7 +543,8 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     auto drain = [&](int cnt) {
       uint32_t h = Lh | ((lane < cnt) ? 0u : RT_DONE);
       rtab_insert_loop(rtab, L, h);
-      if ((int32_t)h >= 0) count_record_slow<CANON>(keys, cnts, L, 1u, k, t);
+      // no room in the record table (a leaf with more distinct runs than it holds): expand now
+      if (__ballot((int32_t)h >= 0)) count_record_v2<CANON>(keys, cnts, L, 1u, (int32_t)h >= 0, k, kmask, rcsh, t);
     };
     auto home = [&](const uint4 rec, bool valid) {
       const uint32_t h = rtab_slot(rec);
@@ -793,10 +718,11 @@ __global__ __launch_bounds__(P3_THREADS) void msp_merge_kernel(const uint64_t *_
   for (int p = 0; p < parts; ++p) {
     const uint32_t n = seg_n[(size_t)p * leaves_per_part + ll];
     const uint64_t off = seg_off[(size_t)p * leaves_per_part + ll];
-    for (uint32_t i = tid; i < n; i += P3_THREADS) {
-      const uint64_t key = in_keys[off + i];
-      const uint32_t c = in_cnt[off + i];
-      if (c) lds_count_pair(keys, cnts, key, key, false, c, t);
+    for (uint32_t i = tid; i < ((n + 63u) & ~63u); i += P3_THREADS) {
+      const bool valid = i < n;
+      const uint64_t key = valid ? in_keys[off + i] : 0ull;
+      const uint32_t c = valid ? in_cnt[off + i] : 0u;
+      kt_count(keys, cnts, key, c, valid && c != 0u, t);
     }
   }
   __syncthreads();
