@@ -27,10 +27,10 @@ constexpr int Q1_THREADS = 512, Q1_WAVES = Q1_THREADS / 64;
 constexpr int Q1_OWN = 60;                 // owner lanes 1..60; lane 0 and lanes 61..63 are halo lanes
 constexpr int Q1_RCAP = 2048;              // 32-byte records staged in LDS per workgroup
 constexpr int Q2_THREADS = 1024, Q2_PER = 2, Q2_TILE = Q2_THREADS * Q2_PER;
+constexpr int Q2_GROUP = 4;                      // consecutive tiles per workgroup (next tile prefetched)
 constexpr int Q3_THREADS = 1024;
 constexpr int T2_LOG = 12, T2 = 1 << T2_LOG;   // LDS slots per leaf (16-byte keys)
 constexpr uint32_t T2_LOCK = 0xFFFFFFFFu;
-constexpr int Q3_PROBE_LIMIT = 64;
 
 struct Rec2 { uint4 a, b; };               // a = bases dwords 0..3, b = {dwords 4, 5, 0, header}
 
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(Q1_THREADS) void msp2_p1_kernel(const int8_t *__res
 
 // ---------------------------------------------------------------------------------------- Q2
 // msp.hip's P2 on 32-byte records (same header word, same sub-bins, same XCD-affine order)
-__global__ __launch_bounds__(Q2_THREADS) void msp2_p2_kernel(int tiles_per_sub, int k, int canon, View2 v,
+__global__ __launch_bounds__(Q2_THREADS) void msp2_p2_kernel(int groups_per_sub, int k, int canon, View2 v,
                                                              TableView t) {
   __shared__ Rec2 sorted[Q2_TILE];
   __shared__ uint32_t hist[NSUB], loff[NSUB], gbase[NSUB];
@@ -259,68 +259,89 @@ __global__ __launch_bounds__(Q2_THREADS) void msp2_p2_kernel(int tiles_per_sub, 
   static_assert(NSUB == Q2_THREADS, "one sub-bin per thread");
   const int tid = threadIdx.x;
   const uint32_t xg = blockIdx.x & (NXG - 1), seq = blockIdx.x / NXG;
-  const uint32_t per_bin = (uint32_t)NXG * (uint32_t)tiles_per_sub;
+  const uint32_t per_bin = (uint32_t)NXG * (uint32_t)groups_per_sub;
   const uint32_t b1 = xg + NXG * (seq / per_bin);
-  const uint32_t sub = (seq % per_bin) / (uint32_t)tiles_per_sub;
-  const uint32_t tile = (seq % per_bin) % (uint32_t)tiles_per_sub;
+  const uint32_t sub = (seq % per_bin) / (uint32_t)groups_per_sub;
+  const uint32_t grp = (seq % per_bin) % (uint32_t)groups_per_sub;
   const uint32_t reg = b1 * NXG + sub;
   const uint64_t n = min((uint64_t)v.cnt1[reg], v.cap1);
-  const uint64_t r0 = (uint64_t)tile * Q2_TILE;
-  if (r0 >= n) return;
-  const uint32_t nt = (uint32_t)min((uint64_t)Q2_TILE, n - r0);
-  hist[tid] = 0;
-  __syncthreads();
-  const Rec2 *src = v.rec1 + (uint64_t)reg * v.cap1 + r0;
-  Rec2 r[Q2_PER];
+  // Q2_GROUP consecutive tiles per workgroup, the next tile's records requested before the
+  // current tile is sorted and written (as in msp.hip's P2)
+  const uint64_t g0r = (uint64_t)grp * Q2_GROUP * Q2_TILE;
+  if (g0r >= n) return;
+  const Rec2 *base = v.rec1 + (uint64_t)reg * v.cap1;
+  const Rec2 zrec = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
+  Rec2 nx[Q2_PER];
 #pragma unroll
   for (int i = 0; i < Q2_PER; ++i) {
-    const uint32_t idx = (uint32_t)i * Q2_THREADS + tid;
-    Rec2 x;
-    x.a = make_uint4(0u, 0u, 0u, 0u); x.b = make_uint4(0u, 0u, 0u, 0u);
-    if (idx < nt) x = src[idx];
-    r[i] = x;
-    if (idx < nt) atomicAdd(&hist[sub_of(x.b.w)], 1u);
+    const uint64_t idx = g0r + (uint64_t)i * Q2_THREADS + tid;
+    nx[i] = zrec;
+    if (idx < n) nx[i] = base[idx];
   }
-  __syncthreads();
-  uint32_t g0 = 0;
-  {
-    const int lane = tid & 63, wave = tid >> 6;
-    const uint32_t x0 = hist[tid];
-    if (x0) g0 = atomicAdd(&v.cnt2[b1 * NSUB + tid], x0);
-    uint32_t incl = x0;
+  for (int tt = 0; tt < Q2_GROUP; ++tt) {
+    const uint64_t r0 = g0r + (uint64_t)tt * Q2_TILE;
+    if (r0 >= n) break;
+    const uint32_t nt = (uint32_t)min((uint64_t)Q2_TILE, n - r0);
+    Rec2 r[Q2_PER];
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t y = __shfl_up(incl, d);
-      if (lane >= d) incl += y;
+    for (int i = 0; i < Q2_PER; ++i) r[i] = nx[i];
+    if (tt + 1 < Q2_GROUP) {
+#pragma unroll
+      for (int i = 0; i < Q2_PER; ++i) {
+        const uint64_t idx = r0 + Q2_TILE + (uint64_t)i * Q2_THREADS + tid;
+        nx[i] = zrec;
+        if (idx < n) nx[i] = base[idx];
+      }
     }
-    if (lane == 63) wtot[wave] = incl;
-    __syncthreads();
-    uint32_t base = 0;
-    for (int w = 0; w < wave; ++w) base += wtot[w];
-    loff[tid] = base + incl - x0;
     hist[tid] = 0;
     __syncthreads();
-  }
 #pragma unroll
-  for (int i = 0; i < Q2_PER; ++i) {
-    const uint32_t idx = (uint32_t)i * Q2_THREADS + tid;
-    if (idx < nt) {
-      const uint32_t sb = sub_of(r[i].b.w);
-      sorted[loff[sb] + atomicAdd(&hist[sb], 1u)] = r[i];
+    for (int i = 0; i < Q2_PER; ++i) {
+      const uint32_t idx = (uint32_t)i * Q2_THREADS + tid;
+      if (idx < nt) atomicAdd(&hist[sub_of(r[i].b.w)], 1u);
     }
-  }
-  gbase[tid] = g0;
-  __syncthreads();
-  for (uint32_t p = tid; p < nt; p += Q2_THREADS) {
-    const Rec2 rec = sorted[p];
-    const uint32_t sb = sub_of(rec.b.w);
-    const uint32_t dst = gbase[sb] + (p - loff[sb]);
-    const uint64_t leaf = ((uint64_t)b1 * NSUB + sb) >> 2;
-    const uint32_t cls = sb & 3u;
-    const uint64_t cap = (cls == 3u) ? v.cap2c : v.cap2t;
-    const uint64_t at = leaf * (v.cap2c + 3 * v.cap2t) + ((cls == 3u) ? 0 : v.cap2c + cls * v.cap2t);
-    if (dst < cap) v.rec2[at + dst] = rec;
-    else spill_record2(rec, k, canon != 0, t);
+    __syncthreads();
+    uint32_t g0 = 0;
+    {
+      const int lane = tid & 63, wave = tid >> 6;
+      const uint32_t x0 = hist[tid];
+      if (x0) g0 = atomicAdd(&v.cnt2[b1 * NSUB + tid], x0);
+      uint32_t incl = x0;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(incl, d);
+        if (lane >= d) incl += y;
+      }
+      if (lane == 63) wtot[wave] = incl;
+      __syncthreads();
+      uint32_t bs = 0;
+      for (int w = 0; w < wave; ++w) bs += wtot[w];
+      loff[tid] = bs + incl - x0;
+      hist[tid] = 0;
+      __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < Q2_PER; ++i) {
+      const uint32_t idx = (uint32_t)i * Q2_THREADS + tid;
+      if (idx < nt) {
+        const uint32_t sb = sub_of(r[i].b.w);
+        sorted[loff[sb] + atomicAdd(&hist[sb], 1u)] = r[i];
+      }
+    }
+    gbase[tid] = g0;
+    __syncthreads();
+    for (uint32_t p = tid; p < nt; p += Q2_THREADS) {
+      const Rec2 rec = sorted[p];
+      const uint32_t sb = sub_of(rec.b.w);
+      const uint32_t dst = gbase[sb] + (p - loff[sb]);
+      const uint64_t leaf = ((uint64_t)b1 * NSUB + sb) >> 2;
+      const uint32_t cls = sb & 3u;
+      const uint64_t cap = (cls == 3u) ? v.cap2c : v.cap2t;
+      const uint64_t at = leaf * (v.cap2c + 3 * v.cap2t) + ((cls == 3u) ? 0 : v.cap2c + cls * v.cap2t);
+      if (dst < cap) v.rec2[at + dst] = rec;
+      else spill_record2(rec, k, canon != 0, t);
+    }
+    __syncthreads();                                       // the LDS buffers are reused by the next tile
   }
 }
 
@@ -330,52 +351,51 @@ __device__ __forceinline__ uint32_t t2_slot(uint64_t lo, uint64_t hi) {
   return (x * 0x9E3779B1u) >> (32 - T2_LOG);
 }
 
-// one probe step (flat control flow, see msp.hip): cnts[h] is the slot state -- 0 empty, T2_LOCK
-// while the claiming lane writes the key, else the count
+// One probe step for one key per lane (see msp.hip's kt_try for why it is written this way):
+// cnts[h] is the slot state -- 0 empty, T2_LOCK while the claiming lane writes the key, else the
+// count.  The lane's state is its slot h with T2_DONE or-ed in once the key is counted.
+constexpr uint32_t T2_DONE = 0x80000000u;
+constexpr int T2_TRIPS = 96;
 __device__ __forceinline__ void t2_step(ulonglong2 *keys, uint32_t *cnts, uint64_t lo, uint64_t hi,
-                                        uint32_t add, uint32_t &h, bool &pend, bool &fail, int &probes) {
-  const uint32_t cst = cnts[h];
+                                        uint32_t add, uint32_t &h) {
+  const bool p = (int32_t)h >= 0;
+  const uint32_t hh = h & (T2 - 1);
+  const uint32_t cst = cnts[hh];
   // the key may only be read after the state: a published count vouches for the key words
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  const ulonglong2 kk = keys[h];
+  const ulonglong2 kk = keys[hh];
   const bool empty = cst == 0u, locked = cst == T2_LOCK;
   const bool match = !empty && !locked && kk.x == lo && kk.y == hi;
-  if (pend && match) atomicAdd(&cnts[h], add);
-  bool won = false;
-  if (pend && empty) {
-    const uint32_t old = atomicCAS(&cnts[h], 0u, T2_LOCK);
-    if (old == 0u) {
-      keys[h] = make_ulonglong2(lo, hi);
+  uint32_t won = 0u;
+  if (p && empty) {
+    if (atomicCAS(&cnts[hh], 0u, T2_LOCK) == 0u) {
+      keys[hh] = make_ulonglong2(lo, hi);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      atomicExch(&cnts[h], add);
-      won = true;
+      atomicExch(&cnts[hh], add);
+      won = 1u;
     }
   }
-  const bool adv = pend && !match && !empty && !locked;
-  h = adv ? ((h + 1) & (T2 - 1)) : h;
-  probes += (adv || (pend && locked)) ? 1 : 0;
-  const bool giveup = probes >= Q3_PROBE_LIMIT;
-  fail = fail || (pend && !match && !won && giveup);
-  pend = pend && !match && !won && !giveup;
+  if (p && match) atomicAdd(&cnts[hh], add);
+  // an empty slot lost to another lane, or a locked one, is read again
+  const bool stay = match || empty || locked;
+  const uint32_t nh = stay ? hh : ((hh + 1) & (T2 - 1));
+  h = (p && !match && won == 0u) ? nh : (h | T2_DONE);
 }
 
-// expand one record, every k-mer counted `add` times
+// expand one record per lane (valid lanes), every k-mer counted `add` times; every lane of the
+// wave must call
 template <bool CANON>
 __device__ __forceinline__ void count_record2(ulonglong2 *keys, uint32_t *cnts, const Rec2 &rec, uint32_t add,
-                                              int k, const TableView &t) {
-  const int nk = (int)(rec.b.w & 63u) + 1;
+                                              bool valid, int k, const TableView &t) {
+  const int nk = valid ? (int)(rec.b.w & 63u) + 1 : 0;
   Roll2 roll;
   roll.init(rec, k);
-  for (int j = 0; j < nk; ++j) {
+  for (int j = 0; __ballot(j < nk); ++j) {
     const u128 key = (CANON && roll.rc < roll.fwd) ? roll.rc : roll.fwd;
     const uint64_t lo = (uint64_t)key, hi = (uint64_t)(key >> 64);
-    uint32_t h = t2_slot(lo, hi);
-    bool pend = true, fail = false;
-    int probes = 0;
-    do {
-      t2_step(keys, cnts, lo, hi, add, h, pend, fail, probes);
-    } while (__ballot(pend));
-    if (fail) {
+    uint32_t h = t2_slot(lo, hi) | ((j < nk) ? 0u : T2_DONE);
+    for (int it = 0; it < T2_TRIPS && __ballot((int32_t)h >= 0); ++it) t2_step(keys, cnts, lo, hi, add, h);
+    if ((int32_t)h >= 0) {
       t.stats[ST_SPILLED] = 1;
       atomicAdd((unsigned long long *)&t.stats[ST_AUX1], (unsigned long long)add);
       table_add2(t, lo, hi, add);
@@ -390,7 +410,9 @@ __device__ __forceinline__ void count_record2(ulonglong2 *keys, uint32_t *cnts, 
 constexpr int R2_LOG = 10, R2 = 1 << R2_LOG;
 static_assert(R2 == Q3_THREADS, "phase 2 lists the record table with one slot per thread");
 constexpr uint32_t R2_LOCK = 0xFFFFFFFFu;
-constexpr int R2_PROBES = 24;
+constexpr uint32_t R2_EMPTY = 62u;                 // n-1 = 62 does not occur
+constexpr uint32_t R2_DONE = 0x80000000u;
+constexpr int R2_TRIPS = 96;
 
 __device__ __forceinline__ uint32_t r2_slot(const Rec2 &r) {
   uint32_t h = (r.a.x * 0x9E3779B1u) ^ (r.a.y * 0x85EBCA77u) ^ (r.a.z * 0xC2B2AE3Du) ^ (r.a.w * 0x27D4EB2Fu) ^
@@ -399,34 +421,36 @@ __device__ __forceinline__ uint32_t r2_slot(const Rec2 &r) {
   return h >> (32 - R2_LOG);
 }
 
-__device__ __forceinline__ void r2_step(Rec2 *rtab, const Rec2 &rec, uint32_t &h, bool &pend, bool &fail,
-                                        int &probes) {
+// insert-or-count one record per lane; state = slot h with R2_DONE or-ed in once placed.  On
+// return lanes still without R2_DONE found no place.
+__device__ __forceinline__ void r2_insert_loop(Rec2 *rtab, const Rec2 &rec, uint32_t &h) {
   uint32_t *words = reinterpret_cast<uint32_t *>(rtab);
   const uint32_t nm1 = rec.b.w & 63u;
-  const uint4 eb = rtab[h].b;                              // state word + bases 64..95
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // bases 0..63 only after the state
-  const uint4 ea = rtab[h].a;
-  const bool empty = eb.w == 0u, locked = eb.w == R2_LOCK;
-  const bool match = !empty && !locked && (eb.w & 63u) == nm1 && eb.x == rec.b.x && eb.y == rec.b.y &&
-                     ea.x == rec.a.x && ea.y == rec.a.y && ea.z == rec.a.z && ea.w == rec.a.w;
-  if (pend && match) atomicAdd(&words[8 * h + 7], 1u << 6);
-  bool won = false;
-  if (pend && empty) {
-    const uint32_t old = atomicCAS(&words[8 * h + 7], 0u, R2_LOCK);
-    if (old == 0u) {
-      rtab[h].a = rec.a;
-      words[8 * h + 4] = rec.b.x; words[8 * h + 5] = rec.b.y;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      atomicExch(&words[8 * h + 7], (1u << 6) | nm1);
-      won = true;
+  for (int it = 0; it < R2_TRIPS && __ballot((int32_t)h >= 0); ++it) {
+    const bool p = (int32_t)h >= 0;
+    const uint32_t hh = h & (R2 - 1);
+    const uint4 eb = rtab[hh].b;                             // state word + bases 64..95
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // bases 0..63 only after the state
+    const uint4 ea = rtab[hh].a;
+    // EMPTY and LOCK carry low header bits no record has, so they never compare equal
+    const bool match = (((eb.w ^ rec.b.w) & 63u) | (eb.x ^ rec.b.x) | (eb.y ^ rec.b.y) | (ea.x ^ rec.a.x) |
+                        (ea.y ^ rec.a.y) | (ea.z ^ rec.a.z) | (ea.w ^ rec.a.w)) == 0u;
+    const bool empty = eb.w == R2_EMPTY;
+    uint32_t won = 0u;
+    if (p && empty) {
+      if (atomicCAS(&words[8 * hh + 7], R2_EMPTY, R2_LOCK) == R2_EMPTY) {
+        rtab[hh].a = rec.a;
+        words[8 * hh + 4] = rec.b.x; words[8 * hh + 5] = rec.b.y;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        atomicExch(&words[8 * hh + 7], (1u << 6) | nm1);
+        won = 1u;
+      }
     }
+    if (p && match) atomicAdd(&words[8 * hh + 7], 1u << 6);
+    const bool stay = match || empty || eb.w == R2_LOCK;
+    const uint32_t nh = stay ? hh : ((hh + 1) & (R2 - 1));
+    h = (p && !match && won == 0u) ? nh : (h | R2_DONE);
   }
-  const bool adv = pend && !match && !empty && !locked;
-  h = adv ? ((h + 1) & (R2 - 1)) : h;
-  probes += (adv || (pend && locked)) ? 1 : 0;
-  const bool giveup = probes >= R2_PROBES;
-  fail = fail || (pend && !match && !won && giveup);
-  pend = pend && !match && !won && !giveup;
 }
 
 template <bool CANON>
@@ -435,6 +459,7 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
   __shared__ uint32_t cnts[T2];
   __shared__ Rec2 rtab[R2];
   __shared__ uint16_t occ_list[R2];
+  __shared__ uint32_t nhist[32];
   __shared__ uint32_t nocc;
   __shared__ uint32_t wg_total;
   __shared__ unsigned long long wg_base;
@@ -451,44 +476,64 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
   for (int s = tid; s < T2; s += Q3_THREADS) cnts[s] = 0;
   {
     Rec2 z;
-    z.a = make_uint4(0u, 0u, 0u, 0u); z.b = make_uint4(0u, 0u, 0u, 0u);
+    z.a = make_uint4(0u, 0u, 0u, 0u); z.b = make_uint4(0u, 0u, 0u, R2_EMPTY);
     rtab[tid] = z;
   }
   if (tid == 0) { wg_total = 0; nocc = 0; }
+  if (tid < 32) nhist[tid] = 0;
   __syncthreads();
 
   const Rec2 *leaf_rec = v.rec2 + (uint64_t)leaf * (v.cap2c + 3 * v.cap2t);
-  // ---- phase 1: complete runs, one record-table update per record
-  for (uint64_t r = tid; r < ns[3]; r += Q3_THREADS) {
-    const Rec2 rec = leaf_rec[r];
-    uint32_t h = r2_slot(rec);
-    bool pend = true, fail = false;
-    int probes = 0;
-    do {
-      r2_step(rtab, rec, h, pend, fail, probes);
-    } while (__ballot(pend));
-    if (fail) count_record2<CANON>(keys, cnts, rec, 1u, k, t);
+  const Rec2 zrec = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
+  // ---- phase 1: complete runs, one record-table update per record; a record that finds no
+  //      room is expanded on the spot
+  for (uint64_t r = tid; r < ((ns[3] + 63) & ~63ull); r += Q3_THREADS) {
+    const bool valid = r < ns[3];
+    Rec2 rec = zrec;
+    if (valid) rec = leaf_rec[r];
+    uint32_t h = r2_slot(rec) | (valid ? 0u : R2_DONE);
+    r2_insert_loop(rtab, rec, h);
+    if (__ballot((int32_t)h >= 0)) count_record2<CANON>(keys, cnts, rec, 1u, (int32_t)h >= 0, k, t);
   }
   __syncthreads();
-  // ---- phase 2: every distinct complete record once (weight = multiplicity), then the
-  //      truncated runs, long ones first
+  // ---- phase 2: every distinct complete record once (weight = multiplicity), listed longest
+  //      first (a wave expands 64 records in lock-step for as many steps as its longest one),
+  //      then the truncated runs by length class, long ones first
   {
     const uint32_t st = rtab[tid].b.w;
-    const bool occ = st != 0u;
-    const unsigned long long mm = __ballot(occ);
-    uint32_t b = 0;
-    if (lane == 0 && mm) b = atomicAdd(&nocc, (uint32_t)__popcll(mm));
-    b = __shfl(b, 0);
-    if (occ) occ_list[b + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull))] = (uint16_t)tid;
+    const bool occ = st != R2_EMPTY;
+    uint32_t rank = 0;
+    if (occ) rank = atomicAdd(&nhist[st & 31u], 1u);
+    __syncthreads();
+    if (tid < 32) {
+      const uint32_t own = nhist[31 - tid];
+      uint32_t incl = own;
+#pragma unroll
+      for (int d = 1; d < 32; d <<= 1) {
+        const uint32_t y = __shfl_up(incl, d, 32);
+        if (tid >= d) incl += y;
+      }
+      nhist[31 - tid] = incl - own;
+      if (tid == 31) nocc = incl;
+    }
+    __syncthreads();
+    if (occ) occ_list[nhist[st & 31u] + rank] = (uint16_t)tid;
   }
   __syncthreads();
-  for (uint32_t i = tid; i < nocc; i += Q3_THREADS) {
-    const Rec2 rec = rtab[occ_list[i]];
-    count_record2<CANON>(keys, cnts, rec, rec.b.w >> 6, k, t);
+  for (uint32_t i = tid; i < ((nocc + 63u) & ~63u); i += Q3_THREADS) {
+    const bool valid = i < nocc;
+    Rec2 rec = zrec;
+    if (valid) rec = rtab[occ_list[i]];
+    count_record2<CANON>(keys, cnts, rec, rec.b.w >> 6, valid, k, t);
   }
   for (int cl = 2; cl >= 0; --cl) {
     const Rec2 *src = leaf_rec + v.cap2c + (uint64_t)cl * v.cap2t;
-    for (uint64_t r = tid; r < ns[cl]; r += Q3_THREADS) count_record2<CANON>(keys, cnts, src[r], 1u, k, t);
+    for (uint64_t r = tid; r < ((ns[cl] + 63) & ~63ull); r += Q3_THREADS) {
+      const bool valid = r < ns[cl];
+      Rec2 rec = zrec;
+      if (valid) rec = src[r];
+      count_record2<CANON>(keys, cnts, rec, 1u, valid, k, t);
+    }
   }
   __syncthreads();
 
@@ -549,7 +594,7 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
   const uint64_t cap1 = (uint64_t)(expect / (B1 * NXG) * 1.35) + 2048;
   const uint64_t cap2c = (uint64_t)(expect / NLEAF * 2.1) + 96;
   const uint64_t cap2t = (uint64_t)(expect / NLEAF * 0.4) + 96;
-  const int64_t tiles_per_sub = (int64_t)((cap1 + Q2_TILE - 1) / Q2_TILE);
+  const int64_t tiles_per_sub = (int64_t)((cap1 + (uint64_t)Q2_TILE * Q2_GROUP - 1) / ((uint64_t)Q2_TILE * Q2_GROUP));   // tile groups
   if (tiles_per_sub * B1 * NXG > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
   void *p;
   View2 v;
