@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=3)
+    p.add_argument("--steps", type=int, default=5)
     p.add_argument("--warmup", type=int, default=1)
     p.add_argument("--reads", type=int, default=100_000_000)
     p.add_argument("--L", type=int, default=150)

@@ -233,6 +233,25 @@ def test_c3_shape_properties_k31(ctx):
     ctx.free(d)
 
 
+@pytest.mark.parametrize("k", [15, 21, 31, 63])
+def test_c5_high_collision_variant_small_genome(ctx, k):
+    """SURVEY 8d's high-collision variant at reduced size: a tiny genome, so every key is hit
+    tens of thousands of times (one hot slot per key, every leaf table nearly empty) -- full
+    export compared with the oracle, and the partitioned path against the HBM-table path"""
+    import cfrk_amd
+    R, L, G = 300_000, 150, 1500
+    data, _, _ = orc.synth_reads(0, R, L, G)
+    wlo, whi, wcnt = orc.global_count(data, k, orc.ORC_CANONICAL, threads=8 if k <= 32 else 0)
+    assert int(wcnt.max()) > 10_000
+    g = cfrk_amd.GlobalCounter(ctx, k, cfrk_amd.CFRK_CANONICAL, 100_000)
+    g.add(data)
+    lo, hi, cnt = g.export()
+    assert (lo == wlo).all() and (hi == whi).all() and (cnt.astype(np.uint64) == wcnt).all()
+    gh = cfrk_amd.GlobalCounter(ctx, k, cfrk_amd.CFRK_CANONICAL | cfrk_amd.CFRK_FORCE_HASH, 100_000)
+    gh.add(data)
+    assert gh.digest() == g.digest() == orc.digest(wlo, whi, wcnt, two_word=k > 32)
+
+
 def test_export_partition_and_merge_roundtrip(ctx):
     """key-owner partitioned export, then count-add merge into another table"""
     import cfrk_amd
