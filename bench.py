@@ -152,6 +152,7 @@ def main():
 
     eng = Engine()
     kernel_ms = []
+    phase_s = [0.0, 0.0]      # N > 1: seconds until the exchange has returned / spent in the owner merge
 
     def step():
         eng.g = cfrk_amd.GlobalCounter(ctx, k, flags, hint)
@@ -160,15 +161,24 @@ def main():
             ctx.sync()
             return eng.g
         og = cfrk_amd.GlobalCounter(owner_ctx, k, flags, hint // world + 1024)
+        ta = time.perf_counter()
         got = None if args.owner_hash else sharded.exchange_by_leaf(eng, world, dev, wire)
         if got is not None:       # per-leaf lists, added in LDS on the owner
             rkeys, rcnt, recv_l, rlc = got
+            tb = time.perf_counter()
             og.merge_leaves_device(rkeys.data_ptr(), rcnt.data_ptr(), recv_l, rlc.data_ptr())
+            owner_ctx.sync()
+            phase_s[0] += tb - ta
+            phase_s[1] += time.perf_counter() - tb
+            return og
         else:                     # generic: owner = hash(key), HBM-table merge
             rlo, rhi, rcnt = sharded.exchange_by_owner(eng, world, dev, wire)
+            tb = time.perf_counter()      # the exchange ends with a stream sync: counting is done too
             og.merge_device(rlo.data_ptr(), 0, rcnt.data_ptr(), rlo.numel())
-        owner_ctx.sync()
-        return og
+            owner_ctx.sync()
+            phase_s[0] += tb - ta
+            phase_s[1] += time.perf_counter() - tb
+            return og
 
     def fence():
         if world > 1:
@@ -178,6 +188,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    phase_s[0] = phase_s[1] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         final = step()
@@ -212,7 +223,8 @@ def main():
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"{R} synthetic {L} bp reads, k={k}, "
                                    f"{'canonical' if flags else 'forward'}, genome {glen} "
-                                   f"(BASELINE.json configs[2]{'/[3]' if world > 1 else ''})",
+                                   + ("(BASELINE.json configs[3])" if world > 1 else "(BASELINE.json configs[2])"
+                                      if (R, L, k) == (100_000_000, 150, 31) and flags else "(off-config run)"),
                        "reads": R, "read_len": L, "k": k, "parallelism": f"read-shard x{world}"
                        + (" + owner all-to-all" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
@@ -222,6 +234,12 @@ def main():
             "distinct": D, "sum_count_ok": ok,
             "digest": [f"{x:016x}" for x in digest],
         }
+        if world > 1:
+            # rank 0's view of one step: counting kernels (HIP events), everything up to the
+            # return of the all-to-all (count + export + exchange), owner-side merge
+            out["step_breakdown_ms"] = {"count_kernels": avg_ms,
+                                        "count_export_exchange": phase_s[0] / args.steps * 1e3,
+                                        "owner_merge": phase_s[1] / args.steps * 1e3}
         if info:
             out["msp_info"] = info
         if world == 1 and args.cpu_reads > 0:
