@@ -35,9 +35,10 @@ def parse():
                    help="gloo: rehearsal mode -- collectives staged through host memory, every "
                         "rank may sit on the same GPU (--same-gpu)")
     p.add_argument("--same-gpu", action="store_true", help="all ranks use cuda:0 (rehearsal)")
-    p.add_argument("--scaling", default="strong", choices=["strong", "weak"],
-                   help="strong (default, BASELINE configs[3]): the --reads reads are split over the "
-                        "GPUs; weak: every GPU gets --reads reads of the same genome")
+    p.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                   help="weak (default): every GPU gets --reads reads of the same genome (the job "
+                        "grows with N); strong (BASELINE configs[3]): the --reads reads are split "
+                        "over the GPUs")
     p.add_argument("--owner-hash", action="store_true",
                    help="force the generic hash-owner exchange + HBM-table merge")
     return p.parse_args()
@@ -223,8 +224,10 @@ def main():
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"{R} synthetic {L} bp reads, k={k}, "
                                    f"{'canonical' if flags else 'forward'}, genome {glen} "
-                                   + ("(BASELINE.json configs[3])" if world > 1 else "(BASELINE.json configs[2])"
-                                      if (R, L, k) == (100_000_000, 150, 31) and flags else "(off-config run)"),
+                                   + (("(BASELINE.json configs[2])" if world == 1 else
+                                       "(BASELINE.json configs[3])" if args.scaling == "strong" else
+                                       f"(configs[2] per GPU x{world}: weak scaling)")
+                                      if (args.reads, L, k) == (100_000_000, 150, 31) and flags else "(off-config run)"),
                        "reads": R, "read_len": L, "k": k, "parallelism": f"read-shard x{world}"
                        + (" + owner all-to-all" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
