@@ -50,7 +50,6 @@ constexpr int P2_GROUP = 4;                      // consecutive tiles per workgr
 
 constexpr int P3_THREADS = 1024;
 constexpr int TS_LOG = 12, TS = 1 << TS_LOG;   // LDS table slots per leaf
-constexpr int P3_PROBE_LIMIT = 48;      // buckets probed before a key is counted in HBM instead
 
 // count every k-mer of a record straight into the global HBM table
 __device__ __noinline__ void spill_record(uint4 rec, int k, bool canon, const TableView &t) {

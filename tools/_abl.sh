@@ -1,2 +1,4 @@
-cd $GRAFT_REPO_ROOT
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 3 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 3 --steps 2 --warmup 1 --reads 2000000 --glen 2000000 --same-gpu --dist-backend gloo --cpu-reads 0 > gpurun_out/b2.log 2>&1; grep -o '"step_breakdown_ms": {[^}]*}' gpurun_out/b2.log; grep -o '"sum_count_ok": [a-z]*' gpurun_out/b2.log; grep -o '"scaling": "[a-z]*"' gpurun_out/b2.log; grep -o '"workload": "[^"]*"' gpurun_out/b2.log;  grep -o '"distinct": [0-9]*' gpurun_out/b2.log
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+timeout -k 10 700 python -m pytest tests -m gpu -x -q > gpurun_out/t.log 2>&1; tail -3 gpurun_out/t.log
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/abl0 -- python3 bench.py --cpu-reads 0 --steps 2 --warmup 1 > gpurun_out/abl0.log 2>&1
+python3 tools/kstat.py gpurun_out/abl0 | grep msp; grep -o '"digest": [^]]*]' gpurun_out/abl0.log
