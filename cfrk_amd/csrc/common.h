@@ -15,6 +15,7 @@
 enum {  // pool slots
   BUF_DATA = 0, BUF_START, BUF_LENGTH, BUF_FREQ, BUF_SPILL, BUF_EXPORT_LO, BUF_EXPORT_HI,
   BUF_EXPORT_CNT, BUF_SCRATCH, BUF_MSP_L1, BUF_MSP_L2, BUF_MSP_OUTK, BUF_MSP_OUTC, BUF_MSP_AUX, BUF_MSP_OUTH,
+  BUF_MSP_ACCK, BUF_MSP_ACCH, BUF_MSP_ACCC,   // lists of the passes of a multi-pass add, merged per leaf at the end
   BUF_NSLOTS
 };
 

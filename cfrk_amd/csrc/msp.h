@@ -43,8 +43,10 @@ cfrk_msp *cfrk_msp_get(cfrk_ctx *ctx);
 int cfrk_msp_sync_stats(cfrk_ctx *ctx, uint64_t st[ST_NWORDS]);
 
 // passes needed so that one pass's buffers (need_fn(span)) fit device memory; *groups = 0: none does
+// (acc_bytes = bytes a pass's result list adds to the accumulation buffers of a multi-pass add)
 int cfrk_msp_plan_groups(cfrk_ctx *ctx, int64_t nN, int64_t ntiles, int64_t tile_span,
-                         size_t (*need_fn)(const cfrk_ctx *, int64_t), size_t have, int *groups);
+                         size_t (*need_fn)(const cfrk_ctx *, int64_t), size_t acc_bytes, size_t have,
+                         int *groups);
 
 // msp2.hip: 33 <= k <= 64
 bool cfrk_msp2_usable(const cfrk_ctx *ctx);

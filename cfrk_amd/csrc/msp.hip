@@ -891,7 +891,8 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
 // How many passes does a batch of `ntiles` tiles (tile_span base positions each) take so that one
 // pass's buffers fit the memory the pool may use?  0 = not even a minimal pass fits.
 int cfrk_msp_plan_groups(cfrk_ctx *ctx, int64_t nN, int64_t ntiles, int64_t tile_span,
-                         size_t (*need_fn)(const cfrk_ctx *, int64_t), size_t have, int *groups) {
+                         size_t (*need_fn)(const cfrk_ctx *, int64_t), size_t acc_bytes, size_t have,
+                         int *groups) {
   *groups = 1;
   if (need_fn(ctx, nN) <= have && !ctx->mem_budget) return CFRK_OK;   // fits what the pool already holds
   size_t free_b = 0, total_b = 0;
@@ -899,7 +900,7 @@ int cfrk_msp_plan_groups(cfrk_ctx *ctx, int64_t nN, int64_t ntiles, int64_t tile
   size_t budget = have + free_b;
   if (ctx->mem_budget) budget = std::min(budget, ctx->mem_budget);
   int g = 1;
-  while (need_fn(ctx, std::min(nN, ((ntiles + g - 1) / g) * tile_span)) > budget) {
+  while (need_fn(ctx, std::min(nN, ((ntiles + g - 1) / g) * tile_span)) + (g > 1 ? (size_t)g * acc_bytes : 0) > budget) {
     if ((ntiles + g - 1) / g <= 64 || g >= 4096) {
       *groups = 0;
       return CFRK_OK;
@@ -920,23 +921,64 @@ int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   if (ntiles > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
   // every buffer a pass needs must fit: decide before touching the pool so that a refusal leaves
   // the context usable for the fallback path.  A batch too large for one pass is counted in
-  // several passes over tile ranges, each pass's list folded into the HBM table before the next.
+  // several passes over tile ranges; the passes' per-leaf lists are kept and added leaf by leaf
+  // in LDS at the end (the same kernel that merges the ranks' lists on a multi-GPU job).
   const size_t have = ctx->pool[BUF_MSP_L1].cap + ctx->pool[BUF_MSP_L2].cap + ctx->pool[BUF_MSP_OUTK].cap +
-                      ctx->pool[BUF_MSP_OUTC].cap;
+                      ctx->pool[BUF_MSP_OUTC].cap + ctx->pool[BUF_MSP_ACCK].cap + ctx->pool[BUF_MSP_ACCC].cap;
   int groups = 1;
-  if ((rc = cfrk_msp_plan_groups(ctx, nN, ntiles, (int64_t)P1_WAVES * P1_OWN * 32, msp_need, have, &groups))) return rc;
+  if ((rc = cfrk_msp_plan_groups(ctx, nN, ntiles, (int64_t)P1_WAVES * P1_OWN * 32, msp_need, (size_t)ctx->g_cap * 12,
+                                 have, &groups))) return rc;
   if (groups == 0) return cfrk_fail(ctx, CFRK_ERR_NOMEM, "partitioned path does not fit device memory");
   const int64_t per = (ntiles + groups - 1) / groups;
-  ctx->last_passes = (int)((ntiles + per - 1) / per);
-  for (int64_t t0 = 0; t0 < ntiles; t0 += per) {
-    if (ms->pending && (rc = cfrk_msp_flush_to_table(ctx))) return rc;
+  const int passes = (int)((ntiles + per - 1) / per);
+  ctx->last_passes = passes;
+  if (ms->pending && (rc = cfrk_msp_flush_to_table(ctx))) return rc;
+  if (passes == 1) return msp_count_tiles(ctx, ms, d_data, nN, 0, ntiles);
+
+  void *p;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_ACCK, (size_t)passes * ctx->g_cap * 8, &p))) return rc;
+  uint64_t *acc_k = (uint64_t *)p;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_ACCC, (size_t)passes * ctx->g_cap * 4, &p))) return rc;
+  uint32_t *acc_c = (uint32_t *)p;
+  const size_t nseg = (size_t)passes * NLEAF;
+  std::vector<uint64_t> so(nseg), lo1(NLEAF);
+  std::vector<uint32_t> sn(nseg);
+  uint64_t acc_n = 0;
+  int pass = 0;
+  for (int64_t t0 = 0; t0 < ntiles; t0 += per, ++pass) {
     if ((rc = msp_count_tiles(ctx, ms, d_data, nN, t0, std::min(per, ntiles - t0)))) {
       // a refusal after the first pass must not reach the caller's fallback (it would count
       // the finished passes twice)
-      if (t0 > 0 && rc == CFRK_ERR_NOMEM) return cfrk_fail(ctx, CFRK_ERR_STATE, "out of device memory in pass %lld of a multi-pass add", (long long)(t0 / per));
+      if (t0 > 0 && rc == CFRK_ERR_NOMEM) return cfrk_fail(ctx, CFRK_ERR_STATE, "out of device memory in pass %d of a multi-pass add", pass);
       return rc;
     }
+    uint64_t st[ST_NWORDS];
+    if ((rc = cfrk_msp_sync_stats(ctx, st))) return rc;
+    if (st[ST_OVERFLOW]) return cfrk_fail(ctx, CFRK_ERR_TABLE_FULL, "result list of %llu entries overflowed", (unsigned long long)ms->view.out_cap);
+    const uint64_t n = st[ST_CURSOR];
+    HIP_TRY(ctx, hipMemcpyAsync(acc_k + acc_n, ms->view.out_keys, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(acc_c + acc_n, ms->view.out_cnt, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(lo1.data(), ms->view.leaf_off, NLEAF * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(sn.data() + (size_t)pass * NLEAF, ms->view.leaf_n, NLEAF * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int l = 0; l < NLEAF; ++l) so[(size_t)pass * NLEAF + l] = acc_n + lo1[l];   // leaf_n == 0: offset unused
+    acc_n += n;
+    ms->pending = false;                     // the pass's list now lives in the accumulation buffers
   }
+  if ((rc = cfrk_pool_get(ctx, BUF_SCRATCH, nseg * (sizeof(uint64_t) + sizeof(uint32_t)), &p))) return rc;
+  uint64_t *d_so = (uint64_t *)p;
+  uint32_t *d_sn = (uint32_t *)(d_so + nseg);
+  HIP_TRY(ctx, hipMemcpyAsync(d_so, so.data(), nseg * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_sn, sn.data(), nseg * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_CURSOR, 0, sizeof(uint64_t), ctx->stream));
+  hipLaunchKernelGGL(msp_merge_kernel, dim3(NLEAF), dim3(P3_THREADS), 0, ctx->stream, (const uint64_t *)acc_k,
+                     (const uint32_t *)acc_c, (const uint64_t *)d_so, (const uint32_t *)d_sn, passes, (int)NLEAF,
+                     ms->view, cfrk_table_view(ctx));
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // so / sn are host temporaries
+  ms->pending = true;
+  ms->leaf_form = false;
+  ms->list_n_valid = false;
   return CFRK_OK;
 }
 

@@ -643,7 +643,7 @@ int cfrk_msp2_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   const size_t have = ctx->pool[BUF_MSP_L1].cap + ctx->pool[BUF_MSP_L2].cap + ctx->pool[BUF_MSP_OUTK].cap +
                       ctx->pool[BUF_MSP_OUTC].cap + ctx->pool[BUF_MSP_OUTH].cap;
   int groups = 1;
-  if ((rc = cfrk_msp_plan_groups(ctx, nN + 32, ntiles, (int64_t)Q1_WAVES * Q1_OWN * 32, msp2_need, have, &groups))) return rc;
+  if ((rc = cfrk_msp_plan_groups(ctx, nN + 32, ntiles, (int64_t)Q1_WAVES * Q1_OWN * 32, msp2_need, 0, have, &groups))) return rc;
   if (groups == 0) return cfrk_fail(ctx, CFRK_ERR_NOMEM, "partitioned path does not fit device memory");
   const int64_t per = (ntiles + groups - 1) / groups;
   ctx->last_passes = (int)((ntiles + per - 1) / per);
