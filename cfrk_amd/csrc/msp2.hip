@@ -19,6 +19,7 @@
 #include "msp_dev.h"
 
 #include <algorithm>
+#include <vector>
 
 namespace {
 
@@ -38,6 +39,7 @@ struct View2 {
   Rec2 *rec1; uint32_t *cnt1; uint64_t cap1;            // B1 x NXG regions
   Rec2 *rec2; uint32_t *cnt2; uint64_t cap2c, cap2t;    // per leaf: complete stream, 3 truncated classes
   uint64_t *out_lo, *out_hi; uint32_t *out_cnt; uint64_t out_cap;
+  uint64_t *leaf_off; uint32_t *leaf_n;                  // where each leaf's entries sit in the result list
   uint64_t *stats;
 };
 
@@ -548,6 +550,74 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
     wbase[i] = __shfl(b, 0);
   }
   __syncthreads();
+  if (tid == 0) {
+    wg_base = atomicAdd((unsigned long long *)&v.stats[ST_CURSOR], (unsigned long long)wg_total);
+    v.leaf_off[leaf] = wg_base;
+    v.leaf_n[leaf] = wg_total;
+  }
+  __syncthreads();
+  const unsigned long long gb = wg_base;
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int s = i * Q3_THREADS + tid;
+    const uint32_t cval = cnts[s];
+    const bool occ = cval != 0u;
+    const unsigned long long mm = __ballot(occ);
+    if (occ) {
+      const unsigned long long dst = gb + wbase[i] + __popcll(mm & ((1ull << lane) - 1ull));
+      if (dst < v.out_cap) { v.out_lo[dst] = keys[s].x; v.out_hi[dst] = keys[s].y; v.out_cnt[dst] = cval; }
+      else v.stats[ST_OVERFLOW] = 1;
+    }
+  }
+}
+
+// One workgroup per leaf: add the `parts` lists of that leaf (the passes of a multi-pass add) in
+// an LDS table, exactly like the leaf kernel does -- no HBM atomics.
+__global__ __launch_bounds__(Q3_THREADS) void msp2_merge_kernel(const uint64_t *__restrict__ in_lo,
+                                                                const uint64_t *__restrict__ in_hi,
+                                                                const uint32_t *__restrict__ in_cnt,
+                                                                const uint64_t *__restrict__ seg_off,
+                                                                const uint32_t *__restrict__ seg_n, int parts,
+                                                                int leaves_per_part, View2 v, TableView t) {
+  __shared__ ulonglong2 keys[T2];
+  __shared__ uint32_t cnts[T2];
+  __shared__ uint32_t wg_total;
+  __shared__ unsigned long long wg_base;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const uint32_t ll = blockIdx.x;
+  uint32_t total = 0;
+  for (int p = 0; p < parts; ++p) total += seg_n[(size_t)p * leaves_per_part + ll];
+  if (total == 0) return;
+  for (int s = tid; s < T2; s += Q3_THREADS) cnts[s] = 0;
+  if (tid == 0) wg_total = 0;
+  __syncthreads();
+  for (int p = 0; p < parts; ++p) {
+    const uint32_t n = seg_n[(size_t)p * leaves_per_part + ll];
+    const uint64_t off = seg_off[(size_t)p * leaves_per_part + ll];
+    for (uint32_t i = tid; i < ((n + 63u) & ~63u); i += Q3_THREADS) {
+      const bool valid = i < n;
+      const uint64_t lo = valid ? in_lo[off + i] : 0ull, hi = valid ? in_hi[off + i] : 0ull;
+      const uint32_t c = valid ? in_cnt[off + i] : 0u;
+      uint32_t h = t2_slot(lo, hi) | ((valid && c != 0u) ? 0u : T2_DONE);
+      for (int it = 0; it < T2_TRIPS && __ballot((int32_t)h >= 0); ++it) t2_step(keys, cnts, lo, hi, c, h);
+      if ((int32_t)h >= 0) {
+        t.stats[ST_SPILLED] = 1;
+        atomicAdd((unsigned long long *)&t.stats[ST_AUX1], (unsigned long long)c);
+        table_add2(t, lo, hi, c);
+      }
+    }
+  }
+  __syncthreads();
+  constexpr int NIT = T2 / Q3_THREADS;
+  uint32_t wbase[NIT];
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const unsigned long long mm = __ballot(cnts[i * Q3_THREADS + tid] != 0u);
+    uint32_t b = 0;
+    if (lane == 0 && mm) b = atomicAdd(&wg_total, (uint32_t)__popcll(mm));
+    wbase[i] = __shfl(b, 0);
+  }
+  __syncthreads();
   if (tid == 0) wg_base = atomicAdd((unsigned long long *)&v.stats[ST_CURSOR], (unsigned long long)wg_total);
   __syncthreads();
   const unsigned long long gb = wg_base;
@@ -602,8 +672,9 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
   v.rec1 = (Rec2 *)p; v.cap1 = cap1;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)NLEAF * (cap2c + 3 * cap2t) * sizeof(Rec2), &p))) return rc;
   v.rec2 = (Rec2 *)p; v.cap2c = cap2c; v.cap2t = cap2t;
-  if ((rc = cfrk_pool_get(ctx, BUF_MSP_AUX, (size_t)(B1 * NXG + NCLS * NLEAF) * sizeof(uint32_t), &p))) return rc;
-  v.cnt1 = (uint32_t *)p; v.cnt2 = v.cnt1 + B1 * NXG;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_AUX, (size_t)NLEAF * 8 + (size_t)(B1 * NXG + (NCLS + 1) * NLEAF) * sizeof(uint32_t), &p))) return rc;
+  v.leaf_off = (uint64_t *)p;
+  v.cnt1 = (uint32_t *)(v.leaf_off + NLEAF); v.cnt2 = v.cnt1 + B1 * NXG; v.leaf_n = v.cnt2 + NCLS * NLEAF;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTK, (size_t)ctx->g_cap * 8, &p))) return rc;
   v.out_lo = (uint64_t *)p;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTH, (size_t)ctx->g_cap * 8, &p))) return rc;
@@ -613,7 +684,7 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
   v.stats = ctx->g_stats;
   TableView t = cfrk_table_view(ctx);
 
-  HIP_TRY(ctx, hipMemsetAsync(v.cnt1, 0, (size_t)(B1 * NXG + NCLS * NLEAF) * sizeof(uint32_t), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(v.cnt1, 0, (size_t)(B1 * NXG + (NCLS + 1) * NLEAF) * sizeof(uint32_t), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_CURSOR, 0, sizeof(uint64_t), ctx->stream));
   hipLaunchKernelGGL(msp2_p1_kernel, dim3((unsigned)ntiles), dim3(Q1_THREADS), 0, ctx->stream, d_data, nN, k, m, c,
                      canon, tile0, v, t);
@@ -626,6 +697,7 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
   HIP_TRY(ctx, hipGetLastError());
   ms->view.out_keys = v.out_lo; ms->view.out_hi = v.out_hi; ms->view.out_cnt = v.out_cnt;
   ms->view.out_cap = v.out_cap; ms->view.stats = v.stats; ms->view.cnt1 = nullptr;
+  ms->view.leaf_off = v.leaf_off; ms->view.leaf_n = v.leaf_n;
   ms->pending = true;
   ms->leaf_form = false;
   ms->list_n_valid = false;
@@ -641,20 +713,70 @@ int cfrk_msp2_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   const int64_t ntiles = (nwaves + Q1_WAVES - 1) / Q1_WAVES;
   if (ntiles > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
   const size_t have = ctx->pool[BUF_MSP_L1].cap + ctx->pool[BUF_MSP_L2].cap + ctx->pool[BUF_MSP_OUTK].cap +
-                      ctx->pool[BUF_MSP_OUTC].cap + ctx->pool[BUF_MSP_OUTH].cap;
+                      ctx->pool[BUF_MSP_OUTC].cap + ctx->pool[BUF_MSP_OUTH].cap + ctx->pool[BUF_MSP_ACCK].cap +
+                      ctx->pool[BUF_MSP_ACCH].cap + ctx->pool[BUF_MSP_ACCC].cap;
   int groups = 1;
-  if ((rc = cfrk_msp_plan_groups(ctx, nN + 32, ntiles, (int64_t)Q1_WAVES * Q1_OWN * 32, msp2_need, 0, have, &groups))) return rc;
+  if ((rc = cfrk_msp_plan_groups(ctx, nN + 32, ntiles, (int64_t)Q1_WAVES * Q1_OWN * 32, msp2_need,
+                                 (size_t)ctx->g_cap * 20, have, &groups))) return rc;
   if (groups == 0) return cfrk_fail(ctx, CFRK_ERR_NOMEM, "partitioned path does not fit device memory");
   const int64_t per = (ntiles + groups - 1) / groups;
-  ctx->last_passes = (int)((ntiles + per - 1) / per);
-  for (int64_t t0 = 0; t0 < ntiles; t0 += per) {
-    if (ms->pending && (rc = cfrk_msp_flush_to_table(ctx))) return rc;
+  const int passes = (int)((ntiles + per - 1) / per);
+  ctx->last_passes = passes;
+  if (ms->pending && (rc = cfrk_msp_flush_to_table(ctx))) return rc;
+  if (passes == 1) return msp2_count_tiles(ctx, ms, d_data, nN, 0, ntiles);
+
+  // several passes over tile ranges: keep every pass's per-leaf list, add them leaf by leaf in
+  // LDS at the end (as msp.hip does)
+  void *p;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_ACCK, (size_t)passes * ctx->g_cap * 8, &p))) return rc;
+  uint64_t *acc_lo = (uint64_t *)p;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_ACCH, (size_t)passes * ctx->g_cap * 8, &p))) return rc;
+  uint64_t *acc_hi = (uint64_t *)p;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_ACCC, (size_t)passes * ctx->g_cap * 4, &p))) return rc;
+  uint32_t *acc_c = (uint32_t *)p;
+  const size_t nseg = (size_t)passes * NLEAF;
+  std::vector<uint64_t> so(nseg), lo1(NLEAF);
+  std::vector<uint32_t> sn(nseg);
+  uint64_t acc_n = 0;
+  int pass = 0;
+  for (int64_t t0 = 0; t0 < ntiles; t0 += per, ++pass) {
     if ((rc = msp2_count_tiles(ctx, ms, d_data, nN, t0, std::min(per, ntiles - t0)))) {
       // a refusal after the first pass must not reach the caller's fallback (it would count
       // the finished passes twice)
-      if (t0 > 0 && rc == CFRK_ERR_NOMEM) return cfrk_fail(ctx, CFRK_ERR_STATE, "out of device memory in pass %lld of a multi-pass add", (long long)(t0 / per));
+      if (t0 > 0 && rc == CFRK_ERR_NOMEM) return cfrk_fail(ctx, CFRK_ERR_STATE, "out of device memory in pass %d of a multi-pass add", pass);
       return rc;
     }
+    uint64_t st[ST_NWORDS];
+    if ((rc = cfrk_msp_sync_stats(ctx, st))) return rc;
+    if (st[ST_OVERFLOW]) return cfrk_fail(ctx, CFRK_ERR_TABLE_FULL, "result list of %llu entries overflowed", (unsigned long long)ms->view.out_cap);
+    const uint64_t n = st[ST_CURSOR];
+    HIP_TRY(ctx, hipMemcpyAsync(acc_lo + acc_n, ms->view.out_keys, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(acc_hi + acc_n, ms->view.out_hi, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(acc_c + acc_n, ms->view.out_cnt, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(lo1.data(), ms->view.leaf_off, NLEAF * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(sn.data() + (size_t)pass * NLEAF, ms->view.leaf_n, NLEAF * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int l = 0; l < NLEAF; ++l) so[(size_t)pass * NLEAF + l] = acc_n + lo1[l];   // leaf_n == 0: offset unused
+    acc_n += n;
+    ms->pending = false;                     // the pass's list now lives in the accumulation buffers
   }
+  if ((rc = cfrk_pool_get(ctx, BUF_SCRATCH, nseg * (sizeof(uint64_t) + sizeof(uint32_t)), &p))) return rc;
+  uint64_t *d_so = (uint64_t *)p;
+  uint32_t *d_sn = (uint32_t *)(d_so + nseg);
+  HIP_TRY(ctx, hipMemcpyAsync(d_so, so.data(), nseg * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_sn, sn.data(), nseg * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_CURSOR, 0, sizeof(uint64_t), ctx->stream));
+  View2 v;
+  v.rec1 = nullptr; v.cnt1 = nullptr; v.cap1 = 0; v.rec2 = nullptr; v.cnt2 = nullptr; v.cap2c = v.cap2t = 0;
+  v.out_lo = ms->view.out_keys; v.out_hi = ms->view.out_hi; v.out_cnt = ms->view.out_cnt; v.out_cap = ms->view.out_cap;
+  v.leaf_off = ms->view.leaf_off; v.leaf_n = ms->view.leaf_n; v.stats = ctx->g_stats;
+  hipLaunchKernelGGL(msp2_merge_kernel, dim3(NLEAF), dim3(Q3_THREADS), 0, ctx->stream, (const uint64_t *)acc_lo,
+                     (const uint64_t *)acc_hi, (const uint32_t *)acc_c, (const uint64_t *)d_so, (const uint32_t *)d_sn,
+                     passes, (int)NLEAF, v, cfrk_table_view(ctx));
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // so / sn are host temporaries
+  ms->pending = true;
+  ms->leaf_form = false;
+  ms->list_n_valid = false;
   return CFRK_OK;
 }
