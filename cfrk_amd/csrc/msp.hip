@@ -827,8 +827,9 @@ static size_t msp_need(const cfrk_ctx *ctx, int64_t span) {
 // one pass of P1 -> P2 -> P3 over the P1 tiles [tile0, tile0 + ntiles): the k-mers that START in
 // those tiles (P1 reads its neighbours' bases from the whole buffer, so a tile range produces
 // exactly the records it produces in a full launch)
+// slack >= 1 widens the per-leaf streams beyond what msp_need() accounts for (memory permitting)
 static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, int64_t nN, int64_t tile0,
-                           int64_t ntiles) {
+                           int64_t ntiles, double slack) {
   int rc;
   const int k = ctx->g_k;
   int W, m;
@@ -841,8 +842,8 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
   const double expect = (double)span * dens;
   const uint64_t cap1 = (uint64_t)(expect / (B1 * NXG) * 1.35) + 2048;   // per sub-region
   // per leaf: complete runs dominate at depth; truncated ones are ~2 per read plus invalid bases
-  const uint64_t cap2c = (uint64_t)(expect / NLEAF * 2.1) + 96;
-  const uint64_t cap2t = (uint64_t)(expect / NLEAF * 0.6) + 96;     // truncated runs: ~15 % of the records
+  const uint64_t cap2c = (uint64_t)(expect / NLEAF * 2.1 * slack) + 96;
+  const uint64_t cap2t = (uint64_t)(expect / NLEAF * 0.6 * slack) + 96;   // truncated runs: ~15 % of the records
   const int64_t tiles_per_sub = (int64_t)((cap1 + (uint64_t)P2_TILE * P2_GROUP - 1) / ((uint64_t)P2_TILE * P2_GROUP));   // tile groups
   if (tiles_per_sub * B1 * NXG > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
 
@@ -933,7 +934,23 @@ int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   const int passes = (int)((ntiles + per - 1) / per);
   ctx->last_passes = passes;
   if (ms->pending && (rc = cfrk_msp_flush_to_table(ctx))) return rc;
-  if (passes == 1) return msp_count_tiles(ctx, ms, d_data, nN, 0, ntiles);
+  if (passes == 1) {
+    // Leaves are lumpy when the genome is small (few distinct runs per leaf, each repeated by
+    // every read over it): with memory to spare the leaf streams get up to twice the room, so
+    // that an ordinary imbalance does not end in the spill path.
+    double slack = 1.0;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      int W0, m0;
+      msp_params(ctx->g_k, &W0, &m0);
+      const double l2 = (double)nN * (2.0 / (W0 + 1) + 1.0 / 64.0) * 2.7 * 16;
+      size_t budget = have + free_b;
+      if (ctx->mem_budget) budget = std::min(budget, ctx->mem_budget);
+      const double room = 0.5 * (double)budget - (double)msp_need(ctx, nN);
+      if (room > 0 && l2 > 0) slack = std::min(2.0, 1.0 + room / l2);
+    }
+    return msp_count_tiles(ctx, ms, d_data, nN, 0, ntiles, slack);
+  }
 
   void *p;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_ACCK, (size_t)passes * ctx->g_cap * 8, &p))) return rc;
@@ -946,7 +963,7 @@ int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   uint64_t acc_n = 0;
   int pass = 0;
   for (int64_t t0 = 0; t0 < ntiles; t0 += per, ++pass) {
-    if ((rc = msp_count_tiles(ctx, ms, d_data, nN, t0, std::min(per, ntiles - t0)))) {
+    if ((rc = msp_count_tiles(ctx, ms, d_data, nN, t0, std::min(per, ntiles - t0), 1.0))) {
       // a refusal after the first pass must not reach the caller's fallback (it would count
       // the finished passes twice)
       if (t0 > 0 && rc == CFRK_ERR_NOMEM) return cfrk_fail(ctx, CFRK_ERR_STATE, "out of device memory in pass %d of a multi-pass add", pass);

@@ -1,3 +1,4 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout -k 10 700 python -m pytest tests -m gpu -x -q > gpurun_out/t.log 2>&1; tail -3 gpurun_out/t.log
-CFRK_BENCH_INFO=1 timeout -k 10 300 python bench.py --cpu-reads 0 --steps 2 --warmup 1 --reads 125000000 --L 250 --k 63 > gpurun_out/big.log 2>&1; cut -c1-330 gpurun_out/big.log | tail -2
+bash tools/ksweep.sh 18 21 24 28 31 > gpurun_out/ks.log 2>&1; cat gpurun_out/ks.log
+python bench.py --cpu-reads 0 > gpurun_out/c3.log 2>&1; cut -c1-200 gpurun_out/c3.log | tail -1
