@@ -64,7 +64,12 @@ int main(int argc, char **argv) {
   if (!out) { fprintf(stderr, "cfrk: cannot write %s\n", pos[1]); return 1; }
 
   if (global) {
-    if ((rc = cfrk_global_begin(ctx, k, canonical ? CFRK_CANONICAL : 0, 0))) return die(ctx, rc, "cfrk_global_begin");
+    // distinct k-mers cannot exceed the number of window starts; the hint sizes the result list
+    // and the spill table (12 B per slot at load 0.5), so it is capped at 2^31 keys
+    uint64_t hint = (uint64_t)(batch.nN > 0 ? batch.nN : 1);
+    if (hint < (1ull << 20)) hint = 1ull << 20;
+    if (hint > (1ull << 31)) hint = 1ull << 31;
+    if ((rc = cfrk_global_begin(ctx, k, canonical ? CFRK_CANONICAL : 0, hint))) return die(ctx, rc, "cfrk_global_begin");
     if ((rc = cfrk_global_add(ctx, batch.data, batch.start, batch.length, batch.nN, batch.nS))) return die(ctx, rc, "cfrk_global_add");
     uint64_t n = 0;
     if ((rc = cfrk_global_finish(ctx, &n))) return die(ctx, rc, "cfrk_global_finish");
