@@ -130,25 +130,28 @@ def main():
             if self.lbufs is None:
                 cap = hint           # distinct keys of a shard never exceed the hint
                 self.lbufs = (torch.empty(cap, dtype=torch.int64, device=dev),
+                              torch.empty(cap, dtype=torch.int64, device=dev) if k > 32 else None,
                               torch.empty(cap, dtype=torch.int32, device=dev),
                               torch.empty(parts * lpp, dtype=torch.int32, device=dev))
-            keys, cnt, lc = self.lbufs
+            keys, hi, cnt, lc = self.lbufs
             try:
                 pc = self.g.export_leaves_device(keys.data_ptr(), cnt.data_ptr(), keys.numel(), parts,
-                                                 lc.data_ptr())
+                                                 lc.data_ptr(), hi.data_ptr() if hi is not None else 0)
             except cfrk_amd.CfrkError as e:
                 if e.code != -4:
                     raise
                 return None
-            return keys, cnt, pc, lc
+            return keys, hi, cnt, pc, lc
 
         def export_parts(self, parts):
             if self.bufs is None:
                 cap = hint
-                self.bufs = (torch.empty(cap, dtype=torch.int64, device=dev), None,
+                self.bufs = (torch.empty(cap, dtype=torch.int64, device=dev),
+                             torch.empty(cap, dtype=torch.int64, device=dev) if k > 32 else None,
                              torch.empty(cap, dtype=torch.int32, device=dev))
             lo, hi, cnt = self.bufs
-            pc = self.g.export_device(lo.data_ptr(), 0, cnt.data_ptr(), lo.numel(), parts)
+            pc = self.g.export_device(lo.data_ptr(), hi.data_ptr() if hi is not None else 0, cnt.data_ptr(),
+                                      lo.numel(), parts)
             return lo, hi, cnt, pc
 
     eng = Engine()
@@ -165,9 +168,10 @@ def main():
         ta = time.perf_counter()
         got = None if args.owner_hash else sharded.exchange_by_leaf(eng, world, dev, wire)
         if got is not None:       # per-leaf lists, added in LDS on the owner
-            rkeys, rcnt, recv_l, rlc = got
+            rkeys, rhi, rcnt, recv_l, rlc = got
             tb = time.perf_counter()
-            og.merge_leaves_device(rkeys.data_ptr(), rcnt.data_ptr(), recv_l, rlc.data_ptr())
+            og.merge_leaves_device(rkeys.data_ptr(), rcnt.data_ptr(), recv_l, rlc.data_ptr(),
+                                   rhi.data_ptr() if rhi is not None else 0)
             owner_ctx.sync()
             phase_s[0] += tb - ta
             phase_s[1] += time.perf_counter() - tb
@@ -175,7 +179,7 @@ def main():
         else:                     # generic: owner = hash(key), HBM-table merge
             rlo, rhi, rcnt = sharded.exchange_by_owner(eng, world, dev, wire)
             tb = time.perf_counter()      # the exchange ends with a stream sync: counting is done too
-            og.merge_device(rlo.data_ptr(), 0, rcnt.data_ptr(), rlo.numel())
+            og.merge_device(rlo.data_ptr(), rhi.data_ptr() if rhi is not None else 0, rcnt.data_ptr(), rlo.numel())
             owner_ctx.sync()
             phase_s[0] += tb - ta
             phase_s[1] += time.perf_counter() - tb

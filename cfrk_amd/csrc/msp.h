@@ -52,6 +52,10 @@ int cfrk_msp_plan_groups(cfrk_ctx *ctx, int64_t nN, int64_t ntiles, int64_t tile
 bool cfrk_msp2_usable(const cfrk_ctx *ctx);
 int  cfrk_msp2_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN);
 
+// msp2.hip: add the `parts` lists of every leaf (ll < leaves_per_part) in LDS into the result list
+int  cfrk_msp2_merge_lists(cfrk_ctx *ctx, const uint64_t *d_lo, const uint64_t *d_hi, const uint32_t *d_cnt,
+                           const uint64_t *d_seg_off, const uint32_t *d_seg_n, int parts, int leaves_per_part);
+
 // radix.hip: k <= 15
 bool cfrk_radix_usable(const cfrk_ctx *ctx);
 int  cfrk_radix_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN);

@@ -683,14 +683,17 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
 // table exactly like P3 does -- no HBM atomics in the merge.
 
 // copy every leaf's entries into owner-major order (dst_off from the host's prefix sum)
+// (out_hi: high key words of a two-word result, msp2.hip; NULL otherwise)
 __global__ __launch_bounds__(256) void msp_gather_kernel(MspView v, const uint64_t *__restrict__ dst_off,
                                                          uint64_t *__restrict__ out_keys,
+                                                         uint64_t *__restrict__ out_hi,
                                                          uint32_t *__restrict__ out_cnt) {
   const uint32_t leaf = blockIdx.x;
   const uint32_t n = v.leaf_n[leaf];
   const uint64_t so = v.leaf_off[leaf], dof = dst_off[leaf];
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
     out_keys[dof + i] = v.out_keys[so + i];
+    if (out_hi) out_hi[dof + i] = v.out_hi[so + i];
     out_cnt[dof + i] = v.out_cnt[so + i];
   }
 }
@@ -1068,10 +1071,11 @@ extern "C" int cfrk_debug_msp_info(cfrk_ctx *ctx, uint64_t out[9]) {
 }
 
 // ------------------------------------------------------------------ multi-GPU exchange by leaf
-extern "C" int cfrk_global_export_leaves_device(cfrk_ctx *ctx, uint64_t *d_keys, uint32_t *d_counts,
-                                                uint64_t cap, int parts, uint64_t *part_counts,
-                                                uint32_t *d_leaf_counts) {
+extern "C" int cfrk_global_export_leaves_device(cfrk_ctx *ctx, uint64_t *d_keys, uint64_t *d_keys_hi,
+                                                uint32_t *d_counts, uint64_t cap, int parts,
+                                                uint64_t *part_counts, uint32_t *d_leaf_counts) {
   if (!ctx || !part_counts || parts < 1 || parts > NLEAF) return CFRK_ERR_ARG;
+  if (ctx->g_active && ctx->g_two && !d_keys_hi && cap) return cfrk_fail(ctx, CFRK_ERR_ARG, "two-word keys need d_keys_hi");
   cfrk_msp *ms = ctx->msp;
   if (!ctx->g_active || !ms || !ms->pending || !ms->leaf_form || ms->table_dirty)
     return cfrk_fail(ctx, CFRK_ERR_STATE, "result is not in per-leaf list form");
@@ -1106,7 +1110,8 @@ extern "C" int cfrk_global_export_leaves_device(cfrk_ctx *ctx, uint64_t *d_keys,
   if (d_leaf_counts)
     HIP_TRY(ctx, hipMemcpyAsync(d_leaf_counts, ordered.data(), ordered.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
   if (run) {
-    hipLaunchKernelGGL(msp_gather_kernel, dim3(NLEAF), dim3(256), 0, ctx->stream, ms->view, (const uint64_t *)p, d_keys, d_counts);
+    hipLaunchKernelGGL(msp_gather_kernel, dim3(NLEAF), dim3(256), 0, ctx->stream, ms->view, (const uint64_t *)p, d_keys,
+                       ctx->g_two ? d_keys_hi : (uint64_t *)nullptr, d_counts);
     HIP_TRY(ctx, hipGetLastError());
   }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // doff / ordered are host temporaries
@@ -1115,11 +1120,12 @@ extern "C" int cfrk_global_export_leaves_device(cfrk_ctx *ctx, uint64_t *d_keys,
 
 extern "C" int cfrk_global_leaves_per_part(int parts) { return parts >= 1 ? (NLEAF + parts - 1) / parts : 0; }
 
-extern "C" int cfrk_global_merge_leaves_device(cfrk_ctx *ctx, const uint64_t *d_keys, const uint32_t *d_counts,
-                                               const uint64_t *recv_counts, const uint32_t *d_leaf_counts,
-                                               int parts) {
+extern "C" int cfrk_global_merge_leaves_device(cfrk_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_keys_hi,
+                                               const uint32_t *d_counts, const uint64_t *recv_counts,
+                                               const uint32_t *d_leaf_counts, int parts) {
   if (!ctx || parts < 1 || parts > NLEAF || !recv_counts || !d_leaf_counts) return CFRK_ERR_ARG;
-  if (!ctx->g_active || ctx->g_two) return cfrk_fail(ctx, CFRK_ERR_STATE, "merge_leaves needs an active one-word job");
+  if (!ctx->g_active) return cfrk_fail(ctx, CFRK_ERR_STATE, "merge_leaves needs an active job");
+  if (ctx->g_two && !d_keys_hi) return cfrk_fail(ctx, CFRK_ERR_ARG, "two-word keys need d_keys_hi");
   cfrk_msp *ms = cfrk_msp_get(ctx);
   if (!ms) return cfrk_fail(ctx, CFRK_ERR_NOMEM, "host allocation failed");
   if (ms->pending || ms->table_dirty) return cfrk_fail(ctx, CFRK_ERR_STATE, "merge_leaves needs an empty job (call cfrk_global_begin first)");
@@ -1130,6 +1136,10 @@ extern "C" int cfrk_global_merge_leaves_device(cfrk_ctx *ctx, const uint64_t *d_
   MspView &v = ms->view;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTK, (size_t)ctx->g_cap * 8, &p))) return rc;
   v.out_keys = (uint64_t *)p;
+  if (ctx->g_two) {
+    if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTH, (size_t)ctx->g_cap * 8, &p))) return rc;
+    v.out_hi = (uint64_t *)p;
+  }
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTC, (size_t)ctx->g_cap * 4, &p))) return rc;
   v.out_cnt = (uint32_t *)p; v.out_cap = ctx->g_cap;
   v.stats = ctx->g_stats;
@@ -1152,7 +1162,9 @@ extern "C" int cfrk_global_merge_leaves_device(cfrk_ctx *ctx, const uint64_t *d_
   HIP_TRY(ctx, hipMemcpyAsync(d_sn, sn.data(), nseg * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_CURSOR, 0, sizeof(uint64_t), ctx->stream));
   TableView t = cfrk_table_view(ctx);
-  if (run) {
+  if (run && ctx->g_two) {
+    if ((rc = cfrk_msp2_merge_lists(ctx, d_keys, d_keys_hi, d_counts, d_so, d_sn, parts, lpp))) return rc;
+  } else if (run) {
     hipLaunchKernelGGL(msp_merge_kernel, dim3(lpp), dim3(P3_THREADS), 0, ctx->stream, d_keys, d_counts,
                        (const uint64_t *)d_so, (const uint32_t *)d_sn, parts, lpp, v, t);
     HIP_TRY(ctx, hipGetLastError());

@@ -699,8 +699,23 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
   ms->view.out_cap = v.out_cap; ms->view.stats = v.stats; ms->view.cnt1 = nullptr;
   ms->view.leaf_off = v.leaf_off; ms->view.leaf_n = v.leaf_n;
   ms->pending = true;
-  ms->leaf_form = false;
+  ms->leaf_form = true;
   ms->list_n_valid = false;
+  return CFRK_OK;
+}
+
+// the result list buffers of ms->view must be set (out_keys / out_hi / out_cnt / out_cap)
+int cfrk_msp2_merge_lists(cfrk_ctx *ctx, const uint64_t *d_lo, const uint64_t *d_hi, const uint32_t *d_cnt,
+                          const uint64_t *d_seg_off, const uint32_t *d_seg_n, int parts, int leaves_per_part) {
+  cfrk_msp *ms = cfrk_msp_get(ctx);
+  if (!ms) return cfrk_fail(ctx, CFRK_ERR_NOMEM, "host allocation failed");
+  View2 v;
+  v.rec1 = nullptr; v.cnt1 = nullptr; v.cap1 = 0; v.rec2 = nullptr; v.cnt2 = nullptr; v.cap2c = v.cap2t = 0;
+  v.out_lo = ms->view.out_keys; v.out_hi = ms->view.out_hi; v.out_cnt = ms->view.out_cnt; v.out_cap = ms->view.out_cap;
+  v.leaf_off = nullptr; v.leaf_n = nullptr; v.stats = ctx->g_stats;
+  hipLaunchKernelGGL(msp2_merge_kernel, dim3(leaves_per_part), dim3(Q3_THREADS), 0, ctx->stream, d_lo, d_hi, d_cnt,
+                     d_seg_off, d_seg_n, parts, leaves_per_part, v, cfrk_table_view(ctx));
+  HIP_TRY(ctx, hipGetLastError());
   return CFRK_OK;
 }
 
@@ -766,14 +781,7 @@ int cfrk_msp2_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   HIP_TRY(ctx, hipMemcpyAsync(d_so, so.data(), nseg * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(d_sn, sn.data(), nseg * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_CURSOR, 0, sizeof(uint64_t), ctx->stream));
-  View2 v;
-  v.rec1 = nullptr; v.cnt1 = nullptr; v.cap1 = 0; v.rec2 = nullptr; v.cnt2 = nullptr; v.cap2c = v.cap2t = 0;
-  v.out_lo = ms->view.out_keys; v.out_hi = ms->view.out_hi; v.out_cnt = ms->view.out_cnt; v.out_cap = ms->view.out_cap;
-  v.leaf_off = ms->view.leaf_off; v.leaf_n = ms->view.leaf_n; v.stats = ctx->g_stats;
-  hipLaunchKernelGGL(msp2_merge_kernel, dim3(NLEAF), dim3(Q3_THREADS), 0, ctx->stream, (const uint64_t *)acc_lo,
-                     (const uint64_t *)acc_hi, (const uint32_t *)acc_c, (const uint64_t *)d_so, (const uint32_t *)d_sn,
-                     passes, (int)NLEAF, v, cfrk_table_view(ctx));
-  HIP_TRY(ctx, hipGetLastError());
+  if ((rc = cfrk_msp2_merge_lists(ctx, acc_lo, acc_hi, acc_c, d_so, d_sn, passes, (int)NLEAF))) return rc;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // so / sn are host temporaries
   ms->pending = true;
   ms->leaf_form = false;

@@ -73,8 +73,8 @@ def load_library():
         "cfrk_global_digest": ([vp, C.POINTER(u64)], C.c_int),
         "cfrk_global_last_add_ms": ([vp, C.POINTER(C.c_float)], C.c_int),
         "cfrk_global_leaves_per_part": ([C.c_int], C.c_int),
-        "cfrk_global_export_leaves_device": ([vp, vp, vp, u64, C.c_int, C.POINTER(u64), vp], C.c_int),
-        "cfrk_global_merge_leaves_device": ([vp, vp, vp, C.POINTER(u64), vp, C.c_int], C.c_int),
+        "cfrk_global_export_leaves_device": ([vp, vp, vp, vp, u64, C.c_int, C.POINTER(u64), vp], C.c_int),
+        "cfrk_global_merge_leaves_device": ([vp, vp, vp, vp, C.POINTER(u64), vp, C.c_int], C.c_int),
         "cfrk_debug_msp_info": ([vp, C.POINTER(u64)], C.c_int),
         "cfrk_debug_set_mem_budget": ([vp, u64], C.c_int),
         "cfrk_debug_last_add_passes": ([vp, C.POINTER(C.c_int)], C.c_int),
@@ -204,19 +204,22 @@ class GlobalCounter:
     def leaves_per_part(self, parts):
         return int(self._L.cfrk_global_leaves_per_part(parts))
 
-    def export_leaves_device(self, d_keys, d_cnt, cap, parts, d_leaf_counts):
-        """per-leaf owner export; raises CfrkError(code -4) when the result is not in leaf form"""
+    def export_leaves_device(self, d_keys, d_cnt, cap, parts, d_leaf_counts, d_keys_hi=0):
+        """per-leaf owner export (d_keys_hi: high key words, k > 32); raises CfrkError(code -4)
+        when the result is not in leaf form"""
         pc = (C.c_uint64 * parts)()
         self.ctx.check(self._L.cfrk_global_export_leaves_device(self.ctx._h, C.c_void_p(d_keys),
+                                                                C.c_void_p(d_keys_hi) if d_keys_hi else None,
                                                                 C.c_void_p(d_cnt), cap, parts, pc,
                                                                 C.c_void_p(d_leaf_counts)),
                        "cfrk_global_export_leaves_device")
         return [int(x) for x in pc]
 
-    def merge_leaves_device(self, d_keys, d_cnt, recv_counts, d_leaf_counts):
+    def merge_leaves_device(self, d_keys, d_cnt, recv_counts, d_leaf_counts, d_keys_hi=0):
         parts = len(recv_counts)
         rc = (C.c_uint64 * parts)(*[int(x) for x in recv_counts])
         self.ctx.check(self._L.cfrk_global_merge_leaves_device(self.ctx._h, C.c_void_p(d_keys),
+                                                               C.c_void_p(d_keys_hi) if d_keys_hi else None,
                                                                C.c_void_p(d_cnt), rc,
                                                                C.c_void_p(d_leaf_counts), parts),
                        "cfrk_global_merge_leaves_device")

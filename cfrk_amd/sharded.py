@@ -51,17 +51,18 @@ def exchange_by_owner(engine, world, device, wire_device=None):
 
 def exchange_by_leaf(engine, world, device, wire_device=None):
     """Owner exchange at leaf granularity (the partitioned path's result form): returns
-    (keys, counts, recv_counts, leaf_counts) for engine-side `merge_leaves`, or None when some
-    rank cannot export by leaf -- every rank then takes the generic exchange_by_owner path.
+    (keys, keys_hi_or_None, counts, recv_counts, leaf_counts) for engine-side `merge_leaves`, or
+    None when some rank cannot export by leaf -- every rank then takes the generic
+    exchange_by_owner path.
 
-    engine.export_leaves(parts) -> (keys, counts, part_counts, leaf_counts) or None."""
+    engine.export_leaves(parts) -> (keys, keys_hi_or_None, counts, part_counts, leaf_counts) or None."""
     wire = torch.device(wire_device) if wire_device is not None else torch.device(device)
     exp = engine.export_leaves(world)
     ok = torch.tensor([1 if exp is not None else 0], dtype=torch.int32, device=wire)
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     if int(ok.item()) == 0:
         return None
-    keys, cnt, part_counts, leaf_counts = exp
+    keys, hi, cnt, part_counts, leaf_counts = exp
     send = torch.tensor(part_counts, dtype=torch.int64, device=wire)
     recv = torch.empty_like(send)
     dist.all_to_all_single(recv, send)
@@ -76,13 +77,14 @@ def exchange_by_leaf(engine, world, device, wire_device=None):
         return out.to(device)
 
     rkeys = a2a(keys.view(torch.int64))
+    rhi = a2a(hi.view(torch.int64)) if hi is not None else None
     rcnt = a2a(cnt.view(torch.int32))
     lc = leaf_counts.view(torch.int32).contiguous().to(wire)        # [world][leaves_per_part]
     rlc = torch.empty_like(lc)
     dist.all_to_all_single(rlc, lc)
     rlc = rlc.to(device)
     _fence(device)
-    return rkeys, rcnt, recv_l, rlc
+    return rkeys, rhi, rcnt, recv_l, rlc
 
 
 def _fence(device):

@@ -138,16 +138,18 @@ int cfrk_global_export_device(cfrk_ctx *ctx, uint64_t *d_keys_lo, uint64_t *d_ke
  * leaf on every rank): owner(leaf) = leaf % parts.  Export writes this rank's result grouped by
  * owner (part p = leaves p, p+parts, ... in that order), part_counts[p] entries each, and the
  * per-leaf entry counts in the same order to d_leaf_counts (parts * cfrk_global_leaves_per_part
- * uint32).  CFRK_ERR_STATE when the result is not in per-leaf list form (k outside 16..32,
- * something spilled to the HBM table, several adds): use cfrk_global_export_device instead.
+ * uint32).  d_keys_hi receives / supplies the high key words for k > 32 and is NULL otherwise.
+ * CFRK_ERR_STATE when the result is not in per-leaf list form (k < 16, something spilled to the
+ * HBM table, several adds or passes): use cfrk_global_export_device instead.
  * Merge, on a context fresh from cfrk_global_begin: d_keys/d_counts = the received runs in rank
  * order (recv_counts[r] entries from rank r), d_leaf_counts = the received per-leaf counts
  * ([parts][leaves_per_part]); every leaf's lists are added in an LDS table (no HBM atomics). */
 int cfrk_global_leaves_per_part(int parts);
-int cfrk_global_export_leaves_device(cfrk_ctx *ctx, uint64_t *d_keys, uint32_t *d_counts, uint64_t cap,
-                                     int parts, uint64_t *part_counts, uint32_t *d_leaf_counts);
-int cfrk_global_merge_leaves_device(cfrk_ctx *ctx, const uint64_t *d_keys, const uint32_t *d_counts,
-                                    const uint64_t *recv_counts, const uint32_t *d_leaf_counts, int parts);
+int cfrk_global_export_leaves_device(cfrk_ctx *ctx, uint64_t *d_keys, uint64_t *d_keys_hi, uint32_t *d_counts,
+                                     uint64_t cap, int parts, uint64_t *part_counts, uint32_t *d_leaf_counts);
+int cfrk_global_merge_leaves_device(cfrk_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_keys_hi,
+                                    const uint32_t *d_counts, const uint64_t *recv_counts,
+                                    const uint32_t *d_leaf_counts, int parts);
 
 /* Order-independent digest: out[0]=distinct, out[1]=sum count,
  * out[2]=sum count*splitmix64(kh) mod 2^64, out[3]=xor splitmix64(kh ^ count);

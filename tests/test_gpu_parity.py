@@ -280,12 +280,14 @@ def test_export_partition_and_merge_roundtrip(ctx):
             ctx.free(p)
 
 
-def test_leaf_export_and_lds_merge_two_emulated_ranks(ctx):
+@pytest.mark.parametrize("k", [31, 63])
+def test_leaf_export_and_lds_merge_two_emulated_ranks(ctx, k):
     """SURVEY 8e with leaf owners: two shards counted on their own contexts, per-leaf export with
     owner(leaf) = leaf % 2, then each owner adds both incoming lists of its leaves in LDS; the
-    union of the two owners' results equals the single-context result."""
+    union of the two owners' results equals the single-context result.  k = 63: two-word keys."""
     import cfrk_amd
-    R, L, G, k = 40000, 150, 200000, 31
+    R, L, G = 40000, 150, 200000
+    two = k > 32
     whole, _, _ = orc.synth_reads(0, R, L, G)
     g0 = cfrk_amd.GlobalCounter(ctx, k, cfrk_amd.CFRK_CANONICAL, 2 * G)
     g0.add(whole)
@@ -299,26 +301,30 @@ def test_leaf_export_and_lds_merge_two_emulated_ranks(ctx):
         g.add(data)
         n = g.finish()
         lpp = g.leaves_per_part(parts)
-        dk, dc, dl = c.alloc(n * 8 + 8), c.alloc(n * 4 + 4), c.alloc(parts * lpp * 4)
-        pc = g.export_leaves_device(dk, dc, n, parts, dl)
+        dk, dh, dc, dl = c.alloc(n * 8 + 8), c.alloc(n * 8 + 8), c.alloc(n * 4 + 4), c.alloc(parts * lpp * 4)
+        pc = g.export_leaves_device(dk, dc, n, parts, dl, dh if two else 0)
         assert sum(pc) == n
-        keys = np.empty(n, np.uint64); cnt = np.empty(n, np.uint32); lc = np.empty(parts * lpp, np.uint32)
+        keys = np.empty(n, np.uint64); hi = np.zeros(n, np.uint64); cnt = np.empty(n, np.uint32)
+        lc = np.empty(parts * lpp, np.uint32)
         c.d2h(keys, dk); c.d2h(cnt, dc); c.d2h(lc, dl)
+        if two:
+            c.d2h(hi, dh)
         assert int(lc[:lpp].sum()) == pc[0] and int(lc[lpp:].sum()) == pc[1]
-        exports.append((keys, cnt, lc, pc, lpp))
+        exports.append((keys, hi, cnt, lc, pc, lpp))
     total = [0, 0, 0, 0]
     for owner in range(parts):                      # what the all-to-all would deliver to `owner`
-        rk, rc_, rl, rn = [], [], [], []
-        for keys, cnt, lc, pc, lpp in exports:
+        rk, rh, rc_, rl, rn = [], [], [], [], []
+        for keys, hi, cnt, lc, pc, lpp in exports:
             o = sum(pc[:owner])
-            rk.append(keys[o:o + pc[owner]]); rc_.append(cnt[o:o + pc[owner]])
+            rk.append(keys[o:o + pc[owner]]); rh.append(hi[o:o + pc[owner]]); rc_.append(cnt[o:o + pc[owner]])
             rl.append(lc[owner * lpp:(owner + 1) * lpp]); rn.append(pc[owner])
-        rk, rc_, rl = np.concatenate(rk), np.concatenate(rc_), np.concatenate(rl)
+        rk, rh, rc_, rl = np.concatenate(rk), np.concatenate(rh), np.concatenate(rc_), np.concatenate(rl)
         oc = cfrk_amd.Context(0)
         og = cfrk_amd.GlobalCounter(oc, k, cfrk_amd.CFRK_CANONICAL, 2 * G)
-        dk, dc, dl = oc.alloc(len(rk) * 8 + 8), oc.alloc(len(rk) * 4 + 4), oc.alloc(len(rl) * 4)
-        oc.h2d(dk, rk); oc.h2d(dc, rc_); oc.h2d(dl, rl)
-        og.merge_leaves_device(dk, dc, rn, dl)
+        dk, dh, dc, dl = (oc.alloc(len(rk) * 8 + 8), oc.alloc(len(rk) * 8 + 8), oc.alloc(len(rk) * 4 + 4),
+                          oc.alloc(len(rl) * 4))
+        oc.h2d(dk, rk); oc.h2d(dh, rh); oc.h2d(dc, rc_); oc.h2d(dl, rl)
+        og.merge_leaves_device(dk, dc, rn, dl, dh if two else 0)
         d = og.digest()
         total = [(total[0] + d[0]) & (2**64 - 1), (total[1] + d[1]) & (2**64 - 1),
                  (total[2] + d[2]) & (2**64 - 1), total[3] ^ d[3]]
