@@ -99,9 +99,9 @@ int cfrk_ctx_create(int device, void *hip_stream, cfrk_ctx **out) {
 }
 
 static void global_release(cfrk_ctx *ctx) {
-  if (ctx->g_keys_lo) hipFree(ctx->g_keys_lo);
-  if (ctx->g_keys_hi) hipFree(ctx->g_keys_hi);
-  if (ctx->g_counts) hipFree(ctx->g_counts);
+  if (ctx->g_keys_lo) (void)hipFree(ctx->g_keys_lo);
+  if (ctx->g_keys_hi) (void)hipFree(ctx->g_keys_hi);
+  if (ctx->g_counts) (void)hipFree(ctx->g_counts);
   ctx->g_keys_lo = ctx->g_keys_hi = nullptr;
   ctx->g_counts = nullptr;
   ctx->g_cap = 0;
@@ -111,20 +111,20 @@ static void global_release(cfrk_ctx *ctx) {
 
 void cfrk_ctx_destroy(cfrk_ctx *ctx) {
   if (!ctx) return;
-  hipSetDevice(ctx->device);
-  hipStreamSynchronize(ctx->stream);
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
   cfrk_msp_destroy(ctx);
   global_release(ctx);
   for (int i = 0; i < BUF_NSLOTS; ++i)
-    if (ctx->pool[i].p) hipFree(ctx->pool[i].p);
-  if (ctx->pinned) hipHostFree(ctx->pinned);
-  if (ctx->g_stats) hipFree(ctx->g_stats);
-  if (ctx->h_stats) hipHostFree(ctx->h_stats);
-  if (ctx->stage_ev[0]) hipEventDestroy(ctx->stage_ev[0]);
-  if (ctx->stage_ev[1]) hipEventDestroy(ctx->stage_ev[1]);
-  if (ctx->ev0) hipEventDestroy(ctx->ev0);
-  if (ctx->ev1) hipEventDestroy(ctx->ev1);
-  if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    if (ctx->pool[i].p) (void)hipFree(ctx->pool[i].p);
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->g_stats) (void)hipFree(ctx->g_stats);
+  if (ctx->h_stats) (void)hipHostFree(ctx->h_stats);
+  if (ctx->stage_ev[0]) (void)hipEventDestroy(ctx->stage_ev[0]);
+  if (ctx->stage_ev[1]) (void)hipEventDestroy(ctx->stage_ev[1]);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
 
