@@ -415,24 +415,18 @@ int cfrk_global_export(cfrk_ctx *ctx, uint64_t *keys_lo, uint64_t *keys_hi, uint
   uint64_t pc = 0;
   rc = cfrk_global_export_device(ctx, (uint64_t *)d_lo, (uint64_t *)d_hi, (uint32_t *)d_cnt, n, 1, &pc);
   if (rc) return rc;
-  std::vector<uint64_t> lo(n), hi(ctx->g_two ? n : 0);
-  std::vector<uint32_t> cnt(n);
-  HIP_TRY(ctx, hipMemcpyAsync(lo.data(), d_lo, n * 8, hipMemcpyDeviceToHost, ctx->stream));
-  if (ctx->g_two) HIP_TRY(ctx, hipMemcpyAsync(hi.data(), d_hi, n * 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(cnt.data(), d_cnt, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  std::vector<uint64_t> order(n);
-  std::iota(order.begin(), order.end(), 0);
-  const bool two = ctx->g_two;
-  std::sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) {
-    if (two && hi[a] != hi[b]) return hi[a] < hi[b];
-    return lo[a] < lo[b];
-  });
-  for (uint64_t i = 0; i < n; ++i) {
-    keys_lo[i] = lo[order[i]];
-    if (keys_hi) keys_hi[i] = two ? hi[order[i]] : 0;
-    counts[i] = cnt[order[i]];
+  // sorted on the device (export_sort.hip), then copied straight into the caller's buffers
+  const uint64_t *s_lo, *s_hi;
+  const uint32_t *s_cnt;
+  if ((rc = cfrk_sort_export(ctx, (const uint64_t *)d_lo, ctx->g_two ? (const uint64_t *)d_hi : nullptr,
+                             (const uint32_t *)d_cnt, n, &s_lo, &s_hi, &s_cnt))) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(keys_lo, s_lo, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (keys_hi) {
+    if (s_hi) HIP_TRY(ctx, hipMemcpyAsync(keys_hi, s_hi, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    else memset(keys_hi, 0, n * 8);
   }
+  HIP_TRY(ctx, hipMemcpyAsync(counts, s_cnt, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return CFRK_OK;
 }
 

@@ -76,6 +76,8 @@ int cfrk_launch_synth(cfrk_ctx *ctx, int64_t r0, int64_t R, int L, int64_t Glen,
 int cfrk_hash_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN);
 int cfrk_hash_merge(cfrk_ctx *ctx, const uint64_t *lo, const uint64_t *hi, const uint32_t *cnt,
                     int64_t n);
+int cfrk_sort_export(cfrk_ctx *ctx, const uint64_t *d_lo, const uint64_t *d_hi, const uint32_t *d_cnt, uint64_t n,
+                     const uint64_t **s_lo, const uint64_t **s_hi, const uint32_t **s_cnt);
 struct ResultSrc;   // table.h: the table itself (NULL) or a compact (key,count) list
 int cfrk_result_scan(cfrk_ctx *ctx, const ResultSrc *src, uint64_t stats_host[ST_NWORDS]);
 int cfrk_result_export(cfrk_ctx *ctx, const ResultSrc *src, uint64_t *d_lo, uint64_t *d_hi,
