@@ -21,6 +21,7 @@
 #include <string.h>
 
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/cfrk_abi.h"
@@ -49,6 +50,12 @@ int main(int argc, char **argv) {
     return 1;
   }
   const int k = atoi(pos[2]);
+  // <number of threads>: the reference spreads chunks over pthreads; here it is the number of host
+  // threads that format the .cfrk text (the GPU side needs none)
+  int threads = 12;
+  if (pos.size() >= 4) threads = atoi(pos[3]);
+  if (threads < 1) threads = 1;
+  { const unsigned hw = std::thread::hardware_concurrency(); if (hw && (unsigned)threads > hw) threads = (int)hw; }
   long chunk_size = 8192;
   if (pos.size() == 5) chunk_size = atol(pos[4]);     // argc == 6 in the reference
   if (chunk_size <= 0) { fprintf(stderr, "cfrk: chunkSize must be positive\n"); return 1; }
@@ -98,8 +105,8 @@ int main(int argc, char **argv) {
       freq.resize((size_t)count * fourk);
       if ((rc = cfrk_per_read_dense(ctx, data, start.data(), length, nN, count, k, flags, freq.data())))
         return die(ctx, rc, "cfrk_per_read_dense");
-      text.resize(cfrk_host_format_dense(freq.data(), count, k, nullptr, 0));
-      cfrk_host_format_dense(freq.data(), count, k, &text[0], text.size());
+      text.resize(cfrk_host_format_dense_mt(freq.data(), count, k, nullptr, 0, threads));
+      cfrk_host_format_dense_mt(freq.data(), count, k, &text[0], text.size(), threads);
       if (!first_row) fputc('\n', out);
       fwrite(text.data(), 1, text.size(), out);
       first_row = false;

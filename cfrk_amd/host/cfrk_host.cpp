@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -136,22 +137,20 @@ int cfrk_host_chunk(const cfrk_batch *b, int64_t first, int64_t count, const int
   return 0;
 }
 
-size_t cfrk_host_format_dense(const int32_t *freq, int64_t nS, int k, char *buf, size_t cap) {
-  const int64_t fourk = (int64_t)1 << (2 * k);
-  if (!buf) {
-    size_t n = 0;
-    for (int64_t i = 0; i < nS; ++i) {
-      if (i) ++n;
-      for (int64_t b = 0; b < fourk; ++b) {
-        int32_t v = freq[i * fourk + b];
-        n += len_u64((uint64_t)b) + 2 + (v < 0 ? 1 + len_u64((uint64_t)(-(int64_t)v)) : len_u64((uint64_t)v));
-      }
+// rows [r0, r1) of the dense text; row i > 0 starts with the '\n' that separates it from row i-1
+static size_t dense_rows_size(const int32_t *freq, int64_t r0, int64_t r1, int64_t fourk) {
+  size_t n = 0;
+  for (int64_t i = r0; i < r1; ++i) {
+    if (i) ++n;
+    for (int64_t b = 0; b < fourk; ++b) {
+      int32_t v = freq[i * fourk + b];
+      n += len_u64((uint64_t)b) + 2 + (v < 0 ? 1 + len_u64((uint64_t)(-(int64_t)v)) : len_u64((uint64_t)v));
     }
-    return n;
   }
-  char *p = buf;
-  (void)cap;
-  for (int64_t i = 0; i < nS; ++i) {
+  return n;
+}
+static char *dense_rows_put(const int32_t *freq, int64_t r0, int64_t r1, int64_t fourk, char *p) {
+  for (int64_t i = r0; i < r1; ++i) {
     if (i) *p++ = '\n';
     for (int64_t b = 0; b < fourk; ++b) {
       p = put_u64(p, (uint64_t)b);
@@ -160,7 +159,38 @@ size_t cfrk_host_format_dense(const int32_t *freq, int64_t nS, int k, char *buf,
       *p++ = ' ';
     }
   }
-  return (size_t)(p - buf);
+  return p;
+}
+
+size_t cfrk_host_format_dense(const int32_t *freq, int64_t nS, int k, char *buf, size_t cap) {
+  return cfrk_host_format_dense_mt(freq, nS, k, buf, cap, 1);
+}
+
+size_t cfrk_host_format_dense_mt(const int32_t *freq, int64_t nS, int k, char *buf, size_t cap, int threads) {
+  const int64_t fourk = (int64_t)1 << (2 * k);
+  (void)cap;
+  int T = threads < 1 ? 1 : threads;
+  if ((int64_t)T > nS) T = nS > 0 ? (int)nS : 1;
+  if (T == 1) {
+    if (!buf) return dense_rows_size(freq, 0, nS, fourk);
+    return (size_t)(dense_rows_put(freq, 0, nS, fourk, buf) - buf);
+  }
+  // row ranges per thread: sizes first (the text of a range starts where the previous ends)
+  std::vector<size_t> sz((size_t)T);
+  std::vector<std::thread> th;
+  auto r_of = [&](int t) { return nS * t / T; };
+  for (int t = 0; t < T; ++t)
+    th.emplace_back([&, t] { sz[(size_t)t] = dense_rows_size(freq, r_of(t), r_of(t + 1), fourk); });
+  for (auto &x : th) x.join();
+  size_t total = 0;
+  std::vector<size_t> off((size_t)T);
+  for (int t = 0; t < T; ++t) { off[(size_t)t] = total; total += sz[(size_t)t]; }
+  if (!buf) return total;
+  th.clear();
+  for (int t = 0; t < T; ++t)
+    th.emplace_back([&, t] { dense_rows_put(freq, r_of(t), r_of(t + 1), fourk, buf + off[(size_t)t]); });
+  for (auto &x : th) x.join();
+  return total;
 }
 
 size_t cfrk_host_format_sparse(const uint64_t *keys, const uint32_t *counts, uint64_t n, char *buf,

@@ -46,6 +46,8 @@ int cfrk_host_chunk(const cfrk_batch *b, int64_t first, int64_t count, const int
 /* PrintFreq (src/main.cu:26-62): "<idx>:<count> " for every bin, '\n' between rows, none at the
  * end.  Returns bytes needed/written (buf may be NULL to size). */
 size_t cfrk_host_format_dense(const int32_t *freq, int64_t nS, int k, char *buf, size_t cap);
+/* the same text, formatted by `threads` host threads (row ranges) */
+size_t cfrk_host_format_dense_mt(const int32_t *freq, int64_t nS, int k, char *buf, size_t cap, int threads);
 /* Sparse global form: "<key>:<count>\n" per distinct key, ascending (keys < 2^64, k <= 32). */
 size_t cfrk_host_format_sparse(const uint64_t *keys, const uint32_t *counts, uint64_t n, char *buf,
                                size_t cap);

@@ -28,6 +28,8 @@ def host():
     L.cfrk_host_free_batch.argtypes = [C.POINTER(Batch)]
     L.cfrk_host_format_dense.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_char_p, C.c_size_t]
     L.cfrk_host_format_dense.restype = C.c_size_t
+    L.cfrk_host_format_dense_mt.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_char_p, C.c_size_t, C.c_int]
+    L.cfrk_host_format_dense_mt.restype = C.c_size_t
     L.cfrk_host_format_sparse.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_char_p, C.c_size_t]
     L.cfrk_host_format_sparse.restype = C.c_size_t
     L.cfrk_host_chunk.argtypes = [C.POINTER(Batch), C.c_int64, C.c_int64, C.POINTER(C.POINTER(C.c_int8)),
@@ -120,3 +122,21 @@ def test_chunk_views_are_chunk_relative(host):
     assert data[0] == 0 and data[12] == -1
     assert host.cfrk_host_chunk(C.byref(b), 4, 2, C.byref(data), start, C.byref(length), C.byref(nN)) == -1
     host.cfrk_host_free_batch(C.byref(b))
+
+
+@pytest.mark.parametrize("threads", [2, 3, 8, 64])
+def test_dense_text_is_the_same_with_any_number_of_formatter_threads(host, threads):
+    rng = np.random.default_rng(threads)
+    nS, k = 37, 3
+    f = rng.integers(-5, 2000, nS * 4 ** k).astype(np.int32)
+    n = host.cfrk_host_format_dense(f.ctypes.data, nS, k, None, 0)
+    one = C.create_string_buffer(n)
+    host.cfrk_host_format_dense(f.ctypes.data, nS, k, one, n)
+    assert host.cfrk_host_format_dense_mt(f.ctypes.data, nS, k, None, 0, threads) == n
+    many = C.create_string_buffer(n)
+    assert host.cfrk_host_format_dense_mt(f.ctypes.data, nS, k, many, n, threads) == n
+    assert one.raw == many.raw
+    # fewer rows than threads, and no rows at all
+    assert host.cfrk_host_format_dense_mt(f.ctypes.data, 2, k, None, 0, threads) == \
+        host.cfrk_host_format_dense(f.ctypes.data, 2, k, None, 0)
+    assert host.cfrk_host_format_dense_mt(f.ctypes.data, 0, k, None, 0, threads) == 0
