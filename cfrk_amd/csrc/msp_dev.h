@@ -122,16 +122,37 @@ __device__ __forceinline__ uint64_t msp_minimizers(uint64_t hi, uint64_t mid, in
   }
 #pragma unroll
   for (int j = 0; j < W - 1; ++j) H[32 + j] = dev_lane_next(H[j]);   // next lane's first W-1 hashes
-  // sliding-window minimum over W by doubling: H[j] <- min H[j .. j+P), then one combine
-  // (three-input v_min3_u32 steps need fewer instructions but measured slower)
+  if (W >= 8) {
+    // Sliding-window minimum, van Herk / Gil-Werman: cut the positions into blocks of W; a window
+    // of W is a block suffix followed by a block prefix, so suffix minima S and prefix minima
+    // Pm within blocks give every window minimum with one more min -- about three minima per
+    // position whatever W is (doubling needs log2(W) + 1).
+    uint32_t Pm[32];                       // Pm[i] = min of H[block start .. q], q = i + W - 1 (i >= 1)
 #pragma unroll
-  for (int s = 1; s < P; s <<= 1) {
+    for (int i = 1; i < 32; ++i) {
+      const int q = i + W - 1;
+      Pm[i] = (q % W == 0) ? H[q] : min(Pm[(q % W == 0) ? i : i - 1], H[q]);
+    }
+    // Pm[1] starts at q = W, a block start, so the chain never reads Pm[0]; window 0 is block 0.
+    // S in place: H[j] <- min of H[j .. end of j's block], for j <= 31 (descending inside blocks)
+    constexpr int LASTB = (31 / W) * W + W - 1;        // end of the block that holds position 31
 #pragma unroll
-    for (int j = 0; j + s < NH; ++j) H[j] = min(H[j], H[j + s]);
-  }
-  if (W > P) {
+    for (int j = (LASTB < NH ? LASTB : NH - 1) - 1; j >= 0; --j)
+      if ((j + 1) % W != 0) H[j] = min(H[j], H[j + 1]);
 #pragma unroll
-    for (int i = 0; i < 32; ++i) H[i] = min(H[i], H[i + W - P]);
+    for (int i = 1; i < 32; ++i) H[i] = min(H[i], Pm[i]);
+  } else {
+    // sliding-window minimum over W by doubling: H[j] <- min H[j .. j+P), then one combine
+    // (three-input v_min3_u32 steps need fewer instructions but measured slower)
+#pragma unroll
+    for (int s = 1; s < P; s <<= 1) {
+#pragma unroll
+      for (int j = 0; j + s < NH; ++j) H[j] = min(H[j], H[j + s]);
+    }
+    if (W > P) {
+#pragma unroll
+      for (int i = 0; i < 32; ++i) H[i] = min(H[i], H[i + W - P]);
+    }
   }
   // H[0..31] = minimizers of the own k-mers; fetch the next lane's first W-1 and the previous
   // lane's last one
