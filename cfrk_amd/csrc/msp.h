@@ -22,7 +22,8 @@ TableView cfrk_table_view(const cfrk_ctx *ctx);
 // device-side view of the partitioned path's buffers (msp.hip) and of the result list that
 // msp.hip and radix.hip both produce
 struct MspView {
-  uint4 *rec1; uint32_t *cnt1; uint64_t cap1;   // B1 x NXG sub-regions of cap1 records each
+  uint4 *rec1; uint32_t *cnt1; uint64_t cap1;   // B1 x nxg sub-regions of cap1 records each
+  uint32_t nxg;                                 // sub-regions (cursors) per level-1 bin: 8 or NXG
   uint4 *rec2; uint32_t *cnt2; uint64_t cap2c, cap2t;   // per leaf: complete stream (cap2c), then the truncated stream (cap2t)
   uint64_t *out_keys; uint32_t *out_cnt; uint64_t out_cap;
   uint64_t *out_hi;                           // high key words of the list (two-word keys only)

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(P1_THREADS, 6) void msp_p1_kernel(const int8_t *__r
       atomicAdd(&hist[bin1], 1u);
     } else {
       // LDS staging full (pathological tile): append directly
-      const uint32_t reg = bin1 * NXG + (blockIdx.x & (NXG - 1));
+      const uint32_t reg = bin1 * v.nxg + (blockIdx.x & (v.nxg - 1));
       const uint32_t dst = atomicAdd(&v.cnt1[reg], 1u);
       if (dst < v.cap1) v.rec1[(uint64_t)reg * v.cap1 + dst] = rec;
       else spill_record(rec, k, canon != 0, t);
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(P1_THREADS, 6) void msp_p1_kernel(const int8_t *__r
   uint32_t my_base = 0;
   if (tid < B1) {
     const uint32_t c = hist[tid];
-    if (c) my_base = atomicAdd(&v.cnt1[tid * NXG + (blockIdx.x & (NXG - 1))], c);
+    if (c) my_base = atomicAdd(&v.cnt1[tid * v.nxg + (blockIdx.x & (v.nxg - 1))], c);
   }
   block_scan<B1>(hist, loff, wtot);
   const uint32_t nrec = min(nrec_s, (uint32_t)P1_RCAP);
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(P1_THREADS, 6) void msp_p1_kernel(const int8_t *__r
     const uint32_t b = bin_tmp[s];
     const uint32_t dst = gbase[b] + (p - loff[b]);
     const uint4 rec = rec_tmp[s];
-    if (dst < v.cap1) v.rec1[((uint64_t)b * NXG + (blockIdx.x & (NXG - 1))) * v.cap1 + dst] = rec;
+    if (dst < v.cap1) v.rec1[((uint64_t)b * v.nxg + (blockIdx.x & (v.nxg - 1))) * v.cap1 + dst] = rec;
     else spill_record(rec, k, canon != 0, t);
   }
 }
@@ -247,12 +247,12 @@ __global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int groups_per_sub, 
   __shared__ uint32_t wtot[P2_THREADS / 64];
   static_assert(NSUB <= P2_THREADS && NSUB % 64 == 0, "the scan below gives one thread per sub-bin");
   const int tid = threadIdx.x;
-  const uint32_t xg = blockIdx.x & (NXG - 1), seq = blockIdx.x / NXG;
-  const uint32_t per_bin = (uint32_t)NXG * (uint32_t)groups_per_sub;
-  const uint32_t b1 = xg + NXG * (seq / per_bin);
+  const uint32_t xg = blockIdx.x & (NXCD - 1), seq = blockIdx.x / NXCD;
+  const uint32_t per_bin = v.nxg * (uint32_t)groups_per_sub;
+  const uint32_t b1 = xg + NXCD * (seq / per_bin);
   const uint32_t sub = (seq % per_bin) / (uint32_t)groups_per_sub;
   const uint32_t grp = (seq % per_bin) % (uint32_t)groups_per_sub;
-  const uint32_t reg = b1 * NXG + sub;
+  const uint32_t reg = b1 * v.nxg + sub;
   const uint64_t n = min((uint64_t)v.cnt1[reg], v.cap1);
   // a workgroup takes P2_GROUP consecutive tiles and asks for the next tile's records before it
   // sorts and writes the current one: the load latency hides under the LDS work
@@ -760,7 +760,7 @@ __global__ void msp_info_kernel(MspView v, uint64_t *out) {
   __shared__ unsigned long long tot1, max1, tot2, max2;
   if (threadIdx.x == 0) { tot1 = max1 = tot2 = max2 = 0; }
   __syncthreads();
-  for (int i = threadIdx.x; i < B1 * NXG; i += blockDim.x) {
+  for (int i = threadIdx.x; i < B1 * (int)v.nxg; i += blockDim.x) {
     atomicAdd(&tot1, (unsigned long long)v.cnt1[i]);
     atomicMax(&max1, (unsigned long long)v.cnt1[i]);
   }
@@ -818,12 +818,18 @@ static void msp_params(int k, int *W, int *m) {
   *m = k - *W + 1;
 }
 
+// Sub-regions (cursors) per level-1 bin, from the expected number of records.  Many cursors keep
+// the chains of returning atomics on one address short and spread the write frontiers of a big
+// batch (msp_dev.h: NXG); a small batch is better off with few, fuller regions (10 M reads:
+// k = 31, 1.8e8 records expected: 5.3 ms with 8, 6.1 ms with 64; k = 21, 3.3e8: 12.4 vs 7.9 ms).
+static int msp_nxg(double expect_records) { return expect_records >= 2.5e8 ? NXG : NXCD; }
+
 // bytes of pool memory one pipeline pass over `span` base positions needs (the caps below)
 static size_t msp_need(const cfrk_ctx *ctx, int64_t span) {
   int W0, m0;
   msp_params(ctx->g_k, &W0, &m0);
   const double expect0 = (double)span * (2.0 / (W0 + 1) + 1.0 / 64.0);
-  return (size_t)(expect0 * 1.35 * 16) + (size_t)B1 * NXG * 2048 * 16 + (size_t)(expect0 * 2.7 * 16) +
+  return (size_t)(expect0 * 1.35 * 16) + (size_t)B1 * msp_nxg(expect0) * 2048 * 16 + (size_t)(expect0 * 2.7 * 16) +
          (size_t)NLEAF * 192 * 16 + (size_t)ctx->g_cap * 12;
 }
 
@@ -843,22 +849,23 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
   // expected records: one per minimizer change (2/(W+1) per position) plus read ends
   const double dens = 2.0 / (W + 1) + 1.0 / 64.0;
   const double expect = (double)span * dens;
-  const uint64_t cap1 = (uint64_t)(expect / (B1 * NXG) * 1.35) + 2048;   // per sub-region
+  const int nxg = msp_nxg(expect);
+  const uint64_t cap1 = (uint64_t)(expect / (B1 * nxg) * 1.35) + 2048;   // per sub-region
   // per leaf: complete runs dominate at depth; truncated ones are ~2 per read plus invalid bases
   const uint64_t cap2c = (uint64_t)(expect / NLEAF * 2.1 * slack) + 96;
   const uint64_t cap2t = (uint64_t)(expect / NLEAF * 0.6 * slack) + 96;   // truncated runs: ~15 % of the records
   const int64_t tiles_per_sub = (int64_t)((cap1 + (uint64_t)P2_TILE * P2_GROUP - 1) / ((uint64_t)P2_TILE * P2_GROUP));   // tile groups
-  if (tiles_per_sub * B1 * NXG > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
+  if (tiles_per_sub * B1 * nxg > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
 
   void *p;
   MspView &v = ms->view;
-  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L1, (size_t)B1 * NXG * cap1 * sizeof(uint4), &p))) return rc;
-  v.rec1 = (uint4 *)p; v.cap1 = cap1;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L1, (size_t)B1 * nxg * cap1 * sizeof(uint4), &p))) return rc;
+  v.rec1 = (uint4 *)p; v.cap1 = cap1; v.nxg = (uint32_t)nxg;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)NLEAF * (cap2c + cap2t) * sizeof(uint4), &p))) return rc;
   v.rec2 = (uint4 *)p; v.cap2c = cap2c; v.cap2t = cap2t;
-  if ((rc = cfrk_pool_get(ctx, BUF_MSP_AUX, (size_t)NLEAF * 8 + (size_t)(B1 * NXG + (NCLS + 1) * NLEAF) * sizeof(uint32_t), &p))) return rc;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_AUX, (size_t)NLEAF * 8 + (size_t)(B1 * nxg + (NCLS + 1) * NLEAF) * sizeof(uint32_t), &p))) return rc;
   v.leaf_off = (uint64_t *)p;
-  v.cnt1 = (uint32_t *)(v.leaf_off + NLEAF); v.cnt2 = v.cnt1 + B1 * NXG; v.leaf_n = v.cnt2 + NCLS * NLEAF;
+  v.cnt1 = (uint32_t *)(v.leaf_off + NLEAF); v.cnt2 = v.cnt1 + B1 * nxg; v.leaf_n = v.cnt2 + NCLS * NLEAF;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTK, (size_t)ctx->g_cap * 8, &p))) return rc;
   v.out_keys = (uint64_t *)p;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTC, (size_t)ctx->g_cap * 4, &p))) return rc;
@@ -866,7 +873,7 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
   v.stats = ctx->g_stats;
   TableView t = cfrk_table_view(ctx);
 
-  HIP_TRY(ctx, hipMemsetAsync(v.cnt1, 0, (size_t)(B1 * NXG + (NCLS + 1) * NLEAF) * sizeof(uint32_t), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(v.cnt1, 0, (size_t)(B1 * nxg + (NCLS + 1) * NLEAF) * sizeof(uint32_t), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_CURSOR, 0, sizeof(uint64_t), ctx->stream));
 
   const dim3 g1((unsigned)ntiles), b1(P1_THREADS);
@@ -880,7 +887,7 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
   }
 #undef CFRK_P1_CASE
   HIP_TRY(ctx, hipGetLastError());
-  hipLaunchKernelGGL(msp_p2_kernel, dim3((unsigned)(tiles_per_sub * B1 * NXG)), dim3(P2_THREADS), 0, ctx->stream,
+  hipLaunchKernelGGL(msp_p2_kernel, dim3((unsigned)(tiles_per_sub * B1 * nxg)), dim3(P2_THREADS), 0, ctx->stream,
                      (int)tiles_per_sub, k, canon, v, t);
   HIP_TRY(ctx, hipGetLastError());
   if (canon) hipLaunchKernelGGL((msp_p3_kernel<true>), dim3(NLEAF), dim3(P3_THREADS), 0, ctx->stream, k, v, t);

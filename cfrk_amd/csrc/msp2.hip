@@ -260,9 +260,9 @@ __global__ __launch_bounds__(Q2_THREADS) void msp2_p2_kernel(int groups_per_sub,
   __shared__ uint32_t wtot[Q2_THREADS / 64];
   static_assert(NSUB == Q2_THREADS, "one sub-bin per thread");
   const int tid = threadIdx.x;
-  const uint32_t xg = blockIdx.x & (NXG - 1), seq = blockIdx.x / NXG;
+  const uint32_t xg = blockIdx.x & (NXCD - 1), seq = blockIdx.x / NXCD;
   const uint32_t per_bin = (uint32_t)NXG * (uint32_t)groups_per_sub;
-  const uint32_t b1 = xg + NXG * (seq / per_bin);
+  const uint32_t b1 = xg + NXCD * (seq / per_bin);
   const uint32_t sub = (seq % per_bin) / (uint32_t)groups_per_sub;
   const uint32_t grp = (seq % per_bin) % (uint32_t)groups_per_sub;
   const uint32_t reg = b1 * NXG + sub;

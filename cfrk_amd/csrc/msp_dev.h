@@ -7,8 +7,15 @@ constexpr int B1_LOG = 8, B2_LOG = 8;
 constexpr int B1 = 1 << B1_LOG, B2 = 1 << B2_LOG;
 // Workgroups b and b+8 land on the same XCD (observed round-robin dispatch; speed only, never
 // correctness).  A leaf stream that is appended to from ONE XCD has its partially written
-// 64-byte sectors merged in that XCD's L2 before they reach HBM.
-constexpr int NXG = 8;
+// 64-byte sectors merged in that XCD's L2 before they reach HBM: the second-level kernels walk the
+// level-1 bins in NXCD groups.  A level-1 bin is split into NXG sub-regions, each with its own
+// cursor: a P1 workgroup appends to sub-region blockIdx % NXG (its XCD's, NXG / NXCD of them per
+// XCD).  Measured on C3 (P1 + P2 ms): NXG = 8: 19.0 + 8.4, 16: 19.3 + 8.5, 32: 17.4 + 9.2,
+// 64: 17.5 + 9.1, 128: 18.1 + 8.7 -- more cursors shorten the chains of returning atomics on one
+// address and spread the write frontiers over more HBM channels; P2 pays a little for the
+// additional partly filled last tiles.
+constexpr int NXCD = 8;
+constexpr int NXG = 64;
 constexpr int NLEAF = B1 * B2;
 
 

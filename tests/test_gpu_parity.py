@@ -409,10 +409,12 @@ def test_msp_then_merge_and_second_add(ctx):
     assert a == orc.digest(*w1)
 
 
-@pytest.mark.parametrize("k,budget", [(31, 380 << 20), (21, 480 << 20), (63, 1250 << 20), (40, 1250 << 20)])
-def test_partitioned_path_counts_in_passes_when_memory_is_short(k, budget):
+@pytest.mark.parametrize("k", [31, 21, 63, 40])
+def test_partitioned_path_counts_in_passes_when_memory_is_short(k):
     """a batch whose record buffers exceed the memory budget is counted in several passes over
-    ranges of the input (each pass folded into the HBM table): same result as one pass"""
+    ranges of the input (the passes' per-leaf lists are added in LDS at the end): same result as
+    one pass.  The budget is lowered step by step until the library needs more than one pass
+    (its fixed buffers depend on tuning constants this test should not know)."""
     import cfrk_amd
     c = cfrk_amd.Context(0)
     data, _, _ = orc.synth_reads(0, 200_000, 150, 300_000)
@@ -422,15 +424,21 @@ def test_partitioned_path_counts_in_passes_when_memory_is_short(k, budget):
     g.add_device(d_data, len(data))
     assert g.last_add_passes() == 1
     one = g.digest()
-    g = cfrk_amd.GlobalCounter(c, k, cfrk_amd.CFRK_CANONICAL, 400_000)
-    g.set_mem_budget(budget)
-    g.add_device(d_data, len(data))
-    assert g.last_add_passes() >= 2
+    wlo, whi, wcnt = orc.global_count(data, k, orc.ORC_CANONICAL)
+    assert one == orc.digest(wlo, whi, wcnt, two_word=k > 32)
+    budget, seen = 6 << 30, 1
+    while True:
+        g = cfrk_amd.GlobalCounter(c, k, cfrk_amd.CFRK_CANONICAL, 400_000)
+        g.set_mem_budget(budget)
+        g.add_device(d_data, len(data))
+        seen = g.last_add_passes()
+        if seen != 1:
+            break
+        budget = budget * 15 // 16
+    assert seen >= 2, "the budget fell below one minimal pass without a multi-pass add in between"
     lo, hi, cnt = g.export()
     g.set_mem_budget(0)
-    wlo, whi, wcnt = orc.global_count(data, k, orc.ORC_CANONICAL)
     assert (lo == wlo).all() and (hi == whi).all() and (cnt.astype(np.uint64) == wcnt).all()
-    assert one == orc.digest(wlo, whi, wcnt, two_word=k > 32)
     # a budget below one minimal pass: the general HBM-table path takes over, still exact
     g = cfrk_amd.GlobalCounter(c, k, cfrk_amd.CFRK_CANONICAL, 400_000)
     g.set_mem_budget(1 << 20)
