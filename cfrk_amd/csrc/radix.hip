@@ -23,7 +23,9 @@
 
 namespace {
 
-constexpr int RX_NXG = 8;                 // per-bin sub-regions by workgroup-id mod 8 (XCD affinity, speed only)
+constexpr int RX_NXG = 8;                 // workgroup-id groups (XCD affinity, speed only)
+constexpr int RX_NREG = 32;               // sub-regions (cursors) per level-1 bin, RX_NREG / RX_NXG per XCD:
+                                          // the returning atomics on one cursor serialise (see msp_dev.h: NXG)
 constexpr int RX1_THREADS = 256, RX1_KEYS = RX1_THREADS * 32;
 constexpr int RX2_THREADS = 512, RX2_PER = 16, RX2_KEYS = RX2_THREADS * RX2_PER;
 constexpr int RX3_THREADS = 256;
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(RX1_THREADS) void rx1_kernel(const int8_t *__restri
   uint32_t my_base = 0;
   {
     const uint32_t c = hist[tid];
-    if (c) my_base = atomicAdd(&v.cnt1[tid * RX_NXG + (blockIdx.x & (RX_NXG - 1))], c);
+    if (c) my_base = atomicAdd(&v.cnt1[tid * RX_NREG + (blockIdx.x & (RX_NREG - 1))], c);
   }
   rx_scan<256>(hist, loff, wtot);
 #pragma unroll
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(RX1_THREADS) void rx1_kernel(const int8_t *__restri
     const uint32_t key = sorted[p];
     const uint32_t b = key >> sh1;
     const uint32_t dst = gbase[b] + (p - loff[b]);
-    if (dst < v.cap1) v.key1[((uint64_t)b * RX_NXG + (blockIdx.x & (RX_NXG - 1))) * v.cap1 + dst] = key;
+    if (dst < v.cap1) v.key1[((uint64_t)b * RX_NREG + (blockIdx.x & (RX_NREG - 1))) * v.cap1 + dst] = key;
     else { t.stats[ST_SPILLED] = 1; table_add1(t, (uint64_t)rx_unmix(v, key), 1u); }
   }
 }
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(RX2_THREADS) void rx2_kernel(int tiles_per_sub, RxV
   const int tid = threadIdx.x;
   const uint32_t nb1 = 1u << v.b1;
   const uint32_t xg = blockIdx.x & (RX_NXG - 1), seq = blockIdx.x / RX_NXG;
-  const uint32_t per_bin = (uint32_t)RX_NXG * (uint32_t)tiles_per_sub;
+  const uint32_t per_bin = (uint32_t)RX_NREG * (uint32_t)tiles_per_sub;
   // bins are dealt to the 8 workgroup-id groups round robin (nb1 may be smaller than 8)
   const uint32_t bins_per_group = (nb1 + RX_NXG - 1) / RX_NXG;
   const uint32_t bl = seq / per_bin;
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(RX2_THREADS) void rx2_kernel(int tiles_per_sub, RxV
   if (bin1 >= nb1) return;
   const uint32_t sub = (seq % per_bin) / (uint32_t)tiles_per_sub;
   const uint32_t tile = (seq % per_bin) % (uint32_t)tiles_per_sub;
-  const uint32_t reg = bin1 * RX_NXG + sub;
+  const uint32_t reg = bin1 * RX_NREG + sub;
   const uint64_t n = min((uint64_t)v.cnt1[reg], v.cap1);
   const uint64_t r0 = (uint64_t)tile * RX2_KEYS;
   if (r0 >= n) return;
@@ -367,9 +369,9 @@ int cfrk_radix_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   v.mul = 0x9E3779B1u;
   v.inv = inv_odd32(v.mul);
   const uint64_t nb1 = 1ull << v.b1, nleaf = 1ull << (v.b1 + v.b2);
-  const uint64_t cap1 = (uint64_t)((double)nN / (double)(nb1 * RX_NXG) * 1.3) + 4096;
+  const uint64_t cap1 = (uint64_t)((double)nN / (double)(nb1 * RX_NREG) * 1.3) + 4096;
   const uint64_t cap2 = (uint64_t)((double)nN / (double)nleaf * 1.5) + 1024;
-  const size_t need = (size_t)nb1 * RX_NXG * cap1 * 4 + (size_t)nleaf * cap2 * 4 + (size_t)ctx->g_cap * 12;
+  const size_t need = (size_t)nb1 * RX_NREG * cap1 * 4 + (size_t)nleaf * cap2 * 4 + (size_t)ctx->g_cap * 12;
   const size_t have = ctx->pool[BUF_MSP_L1].cap + ctx->pool[BUF_MSP_L2].cap + ctx->pool[BUF_MSP_OUTK].cap + ctx->pool[BUF_MSP_OUTC].cap;
   if (need > have) {
     size_t free_b = 0, total_b = 0;
@@ -377,12 +379,12 @@ int cfrk_radix_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
     if (need > have + free_b) return cfrk_fail(ctx, CFRK_ERR_NOMEM, "radix path needs %zu B, %zu B available", need, have + free_b);
   }
   void *p;
-  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L1, (size_t)nb1 * RX_NXG * cap1 * 4, &p))) return rc;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L1, (size_t)nb1 * RX_NREG * cap1 * 4, &p))) return rc;
   v.key1 = (uint32_t *)p; v.cap1 = cap1;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)nleaf * cap2 * 4, &p))) return rc;
   v.key2 = (uint32_t *)p; v.cap2 = cap2;
-  if ((rc = cfrk_pool_get(ctx, BUF_MSP_AUX, (size_t)(nb1 * RX_NXG + nleaf) * 4, &p))) return rc;
-  v.cnt1 = (uint32_t *)p; v.cnt2 = v.cnt1 + nb1 * RX_NXG;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_AUX, (size_t)(nb1 * RX_NREG + nleaf) * 4, &p))) return rc;
+  v.cnt1 = (uint32_t *)p; v.cnt2 = v.cnt1 + nb1 * RX_NREG;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTK, (size_t)ctx->g_cap * 8, &p))) return rc;
   v.out_keys = (uint64_t *)p;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTC, (size_t)ctx->g_cap * 4, &p))) return rc;
@@ -390,7 +392,7 @@ int cfrk_radix_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   v.stats = ctx->g_stats;
   TableView t = cfrk_table_view(ctx);
 
-  HIP_TRY(ctx, hipMemsetAsync(v.cnt1, 0, (size_t)(nb1 * RX_NXG + nleaf) * 4, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(v.cnt1, 0, (size_t)(nb1 * RX_NREG + nleaf) * 4, ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_CURSOR, 0, sizeof(uint64_t), ctx->stream));
   const int64_t tiles = (nN + (int64_t)RX1_KEYS - 1) / RX1_KEYS;
   if (tiles > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
@@ -400,7 +402,7 @@ int cfrk_radix_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   HIP_TRY(ctx, hipGetLastError());
   const int64_t tiles_per_sub = (int64_t)((cap1 + RX2_KEYS - 1) / RX2_KEYS);
   const int64_t bins_per_group = (int64_t)((nb1 + RX_NXG - 1) / RX_NXG);
-  const int64_t g2 = bins_per_group * RX_NXG * RX_NXG * tiles_per_sub;
+  const int64_t g2 = bins_per_group * RX_NXG * RX_NREG * tiles_per_sub;
   if (g2 > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
   hipLaunchKernelGGL(rx2_kernel, dim3((unsigned)g2), dim3(RX2_THREADS), 0, ctx->stream, (int)tiles_per_sub, v, t);
   HIP_TRY(ctx, hipGetLastError());
