@@ -240,32 +240,54 @@ constexpr int NCLS = 2;
 constexpr int NSUB = NCLS * B2;                           // 512 sub-bins of a level-1 bin
 __device__ __forceinline__ uint32_t sub_of(uint32_t w) { return (((w >> 8) & (B2 - 1)) << 1) | ((w >> 6) & 1u); }
 
-__global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int groups_per_sub, int k, int canon,
+__global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int groups_per_bin, int k, int canon,
                                                             MspView v, TableView t) {
   __shared__ uint4 sorted[P2_TILE];
   __shared__ uint32_t hist[NSUB], loff[NSUB], gbase[NSUB];   // hist doubles as the fill cursor
   __shared__ uint32_t wtot[P2_THREADS / 64];
+  __shared__ uint32_t rpre[NXG + 1];             // exclusive prefix of the bin's sub-region sizes
   static_assert(NSUB <= P2_THREADS && NSUB % 64 == 0, "the scan below gives one thread per sub-bin");
+  static_assert(NXG <= 64, "one wave scans the sub-region sizes");
   const int tid = threadIdx.x;
   const uint32_t xg = blockIdx.x & (NXCD - 1), seq = blockIdx.x / NXCD;
-  const uint32_t per_bin = v.nxg * (uint32_t)groups_per_sub;
-  const uint32_t b1 = xg + NXCD * (seq / per_bin);
-  const uint32_t sub = (seq % per_bin) / (uint32_t)groups_per_sub;
-  const uint32_t grp = (seq % per_bin) % (uint32_t)groups_per_sub;
-  const uint32_t reg = b1 * v.nxg + sub;
-  const uint64_t n = min((uint64_t)v.cnt1[reg], v.cap1);
+  const uint32_t b1 = xg + NXCD * (seq / (uint32_t)groups_per_bin);
+  const uint32_t grp = seq % (uint32_t)groups_per_bin;
+  // The bin's sub-regions are read as ONE stream (region after region): tiles are full except the
+  // bin's last one, however many cursors P1 spreads its appends over.
+  if (tid < 64) {
+    const uint32_t c = ((uint32_t)tid < v.nxg) ? (uint32_t)min((uint64_t)v.cnt1[b1 * v.nxg + tid], v.cap1) : 0u;
+    uint32_t incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t y = __shfl_up(incl, d);
+      if (tid >= d) incl += y;
+    }
+    if ((uint32_t)tid < v.nxg) rpre[tid] = incl - c;
+    if (tid == 63) rpre[v.nxg] = incl;
+  }
+  __syncthreads();
+  const uint64_t n = rpre[v.nxg];
   // a workgroup takes P2_GROUP consecutive tiles and asks for the next tile's records before it
   // sorts and writes the current one: the load latency hides under the LDS work
   const uint64_t g0r = (uint64_t)grp * P2_GROUP * P2_TILE;
   if (g0r >= n) return;
-  const uint4 *base = v.rec1 + (uint64_t)reg * v.cap1;
+  const uint4 *bin_base = v.rec1 + (uint64_t)b1 * v.nxg * v.cap1;
+  // record `idx` of the bin's stream: find its sub-region (binary search over <= 64 prefixes)
+  auto fetch = [&](uint64_t idx) {
+    uint32_t lo = 0, hi = v.nxg;               // invariant: rpre[lo] <= idx < rpre[hi]
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (rpre[mid] <= idx) lo = mid; else hi = mid;
+    }
+    return bin_base[(uint64_t)lo * v.cap1 + (idx - rpre[lo])];
+  };
   const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
   uint4 nx[P2_PER];
 #pragma unroll
   for (int i = 0; i < P2_PER; ++i) {
     const uint64_t idx = g0r + (uint64_t)i * P2_THREADS + tid;
     nx[i] = zero4;
-    if (idx < n) nx[i] = base[idx];
+    if (idx < n) nx[i] = fetch(idx);
   }
   for (int tt = 0; tt < P2_GROUP; ++tt) {
     const uint64_t r0 = g0r + (uint64_t)tt * P2_TILE;
@@ -279,7 +301,7 @@ __global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int groups_per_sub, 
       for (int i = 0; i < P2_PER; ++i) {
         const uint64_t idx = r0 + P2_TILE + (uint64_t)i * P2_THREADS + tid;
         nx[i] = zero4;
-        if (idx < n) nx[i] = base[idx];
+        if (idx < n) nx[i] = fetch(idx);
       }
     }
     if (tid < NSUB) hist[tid] = 0;
@@ -819,10 +841,10 @@ static void msp_params(int k, int *W, int *m) {
 }
 
 // Sub-regions (cursors) per level-1 bin, from the expected number of records.  Many cursors keep
-// the chains of returning atomics on one address short and spread the write frontiers of a big
-// batch (msp_dev.h: NXG); a small batch is better off with few, fuller regions (10 M reads:
-// k = 31, 1.8e8 records expected: 5.3 ms with 8, 6.1 ms with 64; k = 21, 3.3e8: 12.4 vs 7.9 ms).
-static int msp_nxg(double expect_records) { return expect_records >= 2.5e8 ? NXG : NXCD; }
+// the chains of returning atomics on one address short and spread the write frontiers (msp_dev.h:
+// NXG); P2 reads a bin's sub-regions as one stream, so they cost it nothing.  Tiny batches keep 8
+// (every sub-region reserves 2048 records of slack).
+static int msp_nxg(double expect_records) { return expect_records >= 2.5e7 ? NXG : NXCD; }
 
 // bytes of pool memory one pipeline pass over `span` base positions needs (the caps below)
 static size_t msp_need(const cfrk_ctx *ctx, int64_t span) {
@@ -854,8 +876,10 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
   // per leaf: complete runs dominate at depth; truncated ones are ~2 per read plus invalid bases
   const uint64_t cap2c = (uint64_t)(expect / NLEAF * 2.1 * slack) + 96;
   const uint64_t cap2t = (uint64_t)(expect / NLEAF * 0.6 * slack) + 96;   // truncated runs: ~15 % of the records
-  const int64_t tiles_per_sub = (int64_t)((cap1 + (uint64_t)P2_TILE * P2_GROUP - 1) / ((uint64_t)P2_TILE * P2_GROUP));   // tile groups
-  if (tiles_per_sub * B1 * nxg > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
+  // P2 reads a bin's sub-regions as one stream: tile groups per BIN, enough for full regions
+  const int64_t tiles_per_sub = (int64_t)(((uint64_t)nxg * cap1 + (uint64_t)P2_TILE * P2_GROUP - 1) /
+                                          ((uint64_t)P2_TILE * P2_GROUP));
+  if (tiles_per_sub * B1 > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
 
   void *p;
   MspView &v = ms->view;
@@ -887,7 +911,7 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
   }
 #undef CFRK_P1_CASE
   HIP_TRY(ctx, hipGetLastError());
-  hipLaunchKernelGGL(msp_p2_kernel, dim3((unsigned)(tiles_per_sub * B1 * nxg)), dim3(P2_THREADS), 0, ctx->stream,
+  hipLaunchKernelGGL(msp_p2_kernel, dim3((unsigned)(tiles_per_sub * B1)), dim3(P2_THREADS), 0, ctx->stream,
                      (int)tiles_per_sub, k, canon, v, t);
   HIP_TRY(ctx, hipGetLastError());
   if (canon) hipLaunchKernelGGL((msp_p3_kernel<true>), dim3(NLEAF), dim3(P3_THREADS), 0, ctx->stream, k, v, t);
