@@ -253,32 +253,52 @@ __global__ __launch_bounds__(Q1_THREADS) void msp2_p1_kernel(const int8_t *__res
 
 // ---------------------------------------------------------------------------------------- Q2
 // msp.hip's P2 on 32-byte records (same header word, same sub-bins, same XCD-affine order)
-__global__ __launch_bounds__(Q2_THREADS) void msp2_p2_kernel(int groups_per_sub, int k, int canon, View2 v,
+__global__ __launch_bounds__(Q2_THREADS) void msp2_p2_kernel(int groups_per_bin, int k, int canon, View2 v,
                                                              TableView t) {
   __shared__ Rec2 sorted[Q2_TILE];
   __shared__ uint32_t hist[NSUB], loff[NSUB], gbase[NSUB];
   __shared__ uint32_t wtot[Q2_THREADS / 64];
+  __shared__ uint32_t rpre[NXG + 1];             // exclusive prefix of the bin's sub-region sizes
   static_assert(NSUB == Q2_THREADS, "one sub-bin per thread");
+  static_assert(NXG <= 64, "one wave scans the sub-region sizes");
   const int tid = threadIdx.x;
   const uint32_t xg = blockIdx.x & (NXCD - 1), seq = blockIdx.x / NXCD;
-  const uint32_t per_bin = (uint32_t)NXG * (uint32_t)groups_per_sub;
-  const uint32_t b1 = xg + NXCD * (seq / per_bin);
-  const uint32_t sub = (seq % per_bin) / (uint32_t)groups_per_sub;
-  const uint32_t grp = (seq % per_bin) % (uint32_t)groups_per_sub;
-  const uint32_t reg = b1 * NXG + sub;
-  const uint64_t n = min((uint64_t)v.cnt1[reg], v.cap1);
+  const uint32_t b1 = xg + NXCD * (seq / (uint32_t)groups_per_bin);
+  const uint32_t grp = seq % (uint32_t)groups_per_bin;
+  // the bin's sub-regions are read as one stream (as in msp.hip's P2)
+  if (tid < 64) {
+    const uint32_t c = (tid < NXG) ? (uint32_t)min((uint64_t)v.cnt1[b1 * NXG + tid], v.cap1) : 0u;
+    uint32_t incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t y = __shfl_up(incl, d);
+      if (tid >= d) incl += y;
+    }
+    if (tid < NXG) rpre[tid] = incl - c;
+    if (tid == 63) rpre[NXG] = incl;
+  }
+  __syncthreads();
+  const uint64_t n = rpre[NXG];
   // Q2_GROUP consecutive tiles per workgroup, the next tile's records requested before the
   // current tile is sorted and written (as in msp.hip's P2)
   const uint64_t g0r = (uint64_t)grp * Q2_GROUP * Q2_TILE;
   if (g0r >= n) return;
-  const Rec2 *base = v.rec1 + (uint64_t)reg * v.cap1;
+  const Rec2 *bin_base = v.rec1 + (uint64_t)b1 * NXG * v.cap1;
+  auto fetch = [&](uint64_t idx) {
+    uint32_t lo = 0, hi = NXG;                 // invariant: rpre[lo] <= idx < rpre[hi]
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (rpre[mid] <= idx) lo = mid; else hi = mid;
+    }
+    return bin_base[(uint64_t)lo * v.cap1 + (idx - rpre[lo])];
+  };
   const Rec2 zrec = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
   Rec2 nx[Q2_PER];
 #pragma unroll
   for (int i = 0; i < Q2_PER; ++i) {
     const uint64_t idx = g0r + (uint64_t)i * Q2_THREADS + tid;
     nx[i] = zrec;
-    if (idx < n) nx[i] = base[idx];
+    if (idx < n) nx[i] = fetch(idx);
   }
   for (int tt = 0; tt < Q2_GROUP; ++tt) {
     const uint64_t r0 = g0r + (uint64_t)tt * Q2_TILE;
@@ -292,7 +312,7 @@ __global__ __launch_bounds__(Q2_THREADS) void msp2_p2_kernel(int groups_per_sub,
       for (int i = 0; i < Q2_PER; ++i) {
         const uint64_t idx = r0 + Q2_TILE + (uint64_t)i * Q2_THREADS + tid;
         nx[i] = zrec;
-        if (idx < n) nx[i] = base[idx];
+        if (idx < n) nx[i] = fetch(idx);
       }
     }
     hist[tid] = 0;
@@ -664,8 +684,8 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
   const uint64_t cap1 = (uint64_t)(expect / (B1 * NXG) * 1.35) + 2048;
   const uint64_t cap2c = (uint64_t)(expect / NLEAF * 2.1) + 96;
   const uint64_t cap2t = (uint64_t)(expect / NLEAF * 0.4) + 96;
-  const int64_t tiles_per_sub = (int64_t)((cap1 + (uint64_t)Q2_TILE * Q2_GROUP - 1) / ((uint64_t)Q2_TILE * Q2_GROUP));   // tile groups
-  if (tiles_per_sub * B1 * NXG > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
+  const int64_t tiles_per_sub = (int64_t)(((uint64_t)NXG * cap1 + (uint64_t)Q2_TILE * Q2_GROUP - 1) / ((uint64_t)Q2_TILE * Q2_GROUP));   // tile groups per bin
+  if (tiles_per_sub * B1 > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
   void *p;
   View2 v;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_L1, (size_t)B1 * NXG * cap1 * sizeof(Rec2), &p))) return rc;
@@ -689,7 +709,7 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
   hipLaunchKernelGGL(msp2_p1_kernel, dim3((unsigned)ntiles), dim3(Q1_THREADS), 0, ctx->stream, d_data, nN, k, m, c,
                      canon, tile0, v, t);
   HIP_TRY(ctx, hipGetLastError());
-  hipLaunchKernelGGL(msp2_p2_kernel, dim3((unsigned)(tiles_per_sub * B1 * NXG)), dim3(Q2_THREADS), 0, ctx->stream,
+  hipLaunchKernelGGL(msp2_p2_kernel, dim3((unsigned)(tiles_per_sub * B1)), dim3(Q2_THREADS), 0, ctx->stream,
                      (int)tiles_per_sub, k, canon, v, t);
   HIP_TRY(ctx, hipGetLastError());
   if (canon) hipLaunchKernelGGL((msp2_p3_kernel<true>), dim3(NLEAF), dim3(Q3_THREADS), 0, ctx->stream, k, v, t);
