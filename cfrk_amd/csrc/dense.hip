@@ -23,6 +23,9 @@ __device__ __forceinline__ int wave_sum(int v) {
   return v;
 }
 
+constexpr int DENSE_SEG = 1024;                    // windows staged per pass (the compat cap)
+constexpr int DENSE_STAGE = DENSE_SEG + 64;        // bytes of LDS per wave: segment + k-1 + alignment slack
+
 template <bool COMPAT, bool LDS_HIST>
 __global__ __launch_bounds__(256) void dense_kernel(const int8_t *__restrict__ data,
                                                     const int64_t *__restrict__ start,
@@ -34,6 +37,10 @@ __global__ __launch_bounds__(256) void dense_kernel(const int8_t *__restrict__ d
   const uint32_t mask = (uint32_t)(fourk - 1);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int32_t *hist = lds + (LDS_HIST ? wave * (int)fourk : 0);
+  // LDS variant: the read's codes are staged in LDS with coalesced dword loads (one load
+  // instruction per 256 bytes of read instead of one byte gather per window base)
+  int32_t *stage_dw = lds + 4 * (int)fourk + wave * (DENSE_STAGE / 4);
+  const int8_t *stage = reinterpret_cast<const int8_t *>(stage_dw);
   if (LDS_HIST)
     for (int b = lane; b < (int)fourk; b += 64) hist[b] = 0;
 
@@ -42,31 +49,67 @@ __global__ __launch_bounds__(256) void dense_kernel(const int8_t *__restrict__ d
     const int L = length[i];
     // compat: threadIdx.x < length-1 with blockDim 1024 (src/kmer_kernel.cu:85); native: every
     // position of the read, validity decides (src/kmer_kernel.cu:61-68)
-    int nwin = COMPAT ? min(max(L - 1, 0), 1024) : max(L, 0);
-    const int per = (nwin + 63) >> 6;
-    const int t0 = lane * per;
-    const int t1 = min(t0 + per, nwin);
+    const int nwin_all = COMPAT ? min(max(L - 1, 0), 1024) : max(L, 0);
     int invalid = 0;
     int32_t *row = freq + i * fourk;
-    if (t0 < t1) {
-      uint32_t val = 0;
-      int run = 0;
-      for (int p = t0; p < t1 + k - 1; ++p) {
-        const int64_t g = st + p;
-        const int c = (g < nN) ? (int)data[g] : -1;
-        if (c < 0 || c > 3) {
-          run = 0;
-        } else {
-          val = ((val << 2) | (uint32_t)c) & mask;
-          ++run;
+    for (int seg0 = 0; seg0 < (LDS_HIST ? nwin_all : 1); seg0 += DENSE_SEG) {
+      const int nwin = LDS_HIST ? min(DENSE_SEG, nwin_all - seg0) : nwin_all;
+      int skew = 0;
+      if (LDS_HIST) {
+        // bytes [A, A + nwin + k - 1) of the buffer, as the aligned dwords that cover them; a dword
+        // that is not wholly inside [data, data + nN) is assembled from guarded byte loads
+        const int64_t A = st + seg0;
+        const int nbytes = nwin + k - 1;
+        const uintptr_t abs0 = reinterpret_cast<uintptr_t>(data) + (uintptr_t)A;
+        skew = (int)(abs0 & 3u);
+        const int ndw = (skew + nbytes + 3) >> 2;
+        for (int d = lane; d < ndw; d += 64) {
+          const int64_t off = A - skew + 4 * (int64_t)d;          // offset of the dword in data
+          int32_t w;
+          if (off >= 0 && off + 4 <= nN) {
+            w = *reinterpret_cast<const int32_t *>(data + off);
+          } else {
+            uint32_t u = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int64_t g = off + j;
+              const uint32_t c = (g >= 0 && g < nN) ? (uint32_t)(uint8_t)data[g] : 0xFFu;
+              u |= c << (8 * j);
+            }
+            w = (int32_t)u;
+          }
+          stage_dw[d] = w;
         }
-        if (p >= t0 + k - 1) {
-          if (run >= k) {
-            if (LDS_HIST) atomicAdd(&hist[val], 1);
-            else atomicAdd(&row[val], 1);
-          } else if (COMPAT) {
-            if (LDS_HIST) ++invalid;
-            else if (i > 0) atomicAdd(&row[-1], 1);   // Freq[fourk*i + (-1)]
+        // (a wave executes in lock step and LDS is in order per wave: no barrier needed)
+      }
+      const int per = (nwin + 63) >> 6;
+      const int t0 = lane * per;
+      const int t1 = min(t0 + per, nwin);
+      if (t0 < t1) {
+        uint32_t val = 0;
+        int run = 0;
+        for (int p = t0; p < t1 + k - 1; ++p) {
+          int c;
+          if (LDS_HIST) {
+            c = (int)stage[skew + p];
+          } else {
+            const int64_t g = st + p;
+            c = (g < nN) ? (int)data[g] : -1;
+          }
+          if (c < 0 || c > 3) {
+            run = 0;
+          } else {
+            val = ((val << 2) | (uint32_t)c) & mask;
+            ++run;
+          }
+          if (p >= t0 + k - 1) {
+            if (run >= k) {
+              if (LDS_HIST) atomicAdd(&hist[val], 1);
+              else atomicAdd(&row[val], 1);
+            } else if (COMPAT) {
+              if (LDS_HIST) ++invalid;
+              else if (i > 0) atomicAdd(&row[-1], 1);   // Freq[fourk*i + (-1)]
+            }
           }
         }
       }
@@ -107,7 +150,10 @@ int cfrk_launch_dense(cfrk_ctx *ctx, const int8_t *d_data, const int64_t *d_star
     void *d_spill = nullptr;
     int rc;
     if (compat && (rc = cfrk_pool_get(ctx, BUF_SPILL, (size_t)nS * 4, &d_spill))) return rc;
-    const size_t lds = 4 * (size_t)fourk * sizeof(int32_t);
+    const size_t lds = 4 * (size_t)fourk * sizeof(int32_t) + 4 * (size_t)DENSE_STAGE;
+    // more than the default 64 KiB of dynamic LDS at k = 6
+    HIP_TRY(ctx, hipFuncSetAttribute(compat ? (const void *)dense_kernel<true, true> : (const void *)dense_kernel<false, true>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (compat) {
       hipLaunchKernelGGL((dense_kernel<true, true>), dim3(grid), dim3(256), lds, ctx->stream, d_data,
                          d_start, d_length, nN, nS, k, d_freq, (int32_t *)d_spill);
