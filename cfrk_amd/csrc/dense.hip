@@ -18,15 +18,21 @@
 
 namespace {
 
-__device__ __forceinline__ int wave_sum(int v) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+// sum over the G consecutive lanes that share a read
+template <int G>
+__device__ __forceinline__ int group_sum(int v) {
+  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
 
 constexpr int DENSE_SEG = 1024;                    // windows staged per pass (the compat cap)
 constexpr int DENSE_STAGE = DENSE_SEG + 64;        // bytes of LDS per wave: segment + k-1 + alignment slack
 
-template <bool COMPAT, bool LDS_HIST>
+// G lanes per read: 64 (one wave per read) or, for the small rows of k <= 4, 16 (four reads per
+// wave: the per-read fixed work -- table lookups, staging, zeroing and writing the row -- is
+// shared by a quarter of the lanes, and a 150-base read keeps 15 of 16 lanes busy instead of 50
+// of 64).
+template <bool COMPAT, bool LDS_HIST, int G>
 __global__ __launch_bounds__(256) void dense_kernel(const int8_t *__restrict__ data,
                                                     const int64_t *__restrict__ start,
                                                     const int32_t *__restrict__ length, int64_t nN,
@@ -35,16 +41,17 @@ __global__ __launch_bounds__(256) void dense_kernel(const int8_t *__restrict__ d
   extern __shared__ int32_t lds[];
   const int64_t fourk = (int64_t)1 << (2 * k);
   const uint32_t mask = (uint32_t)(fourk - 1);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  int32_t *hist = lds + (LDS_HIST ? wave * (int)fourk : 0);
+  constexpr int RPB = 256 / G;                      // reads per workgroup pass
+  const int grp = threadIdx.x / G, lane = threadIdx.x % G;   // `lane` = lane within the read's group
+  int32_t *hist = lds + (LDS_HIST ? grp * (int)fourk : 0);
   // LDS variant: the read's codes are staged in LDS with coalesced dword loads (one load
   // instruction per 256 bytes of read instead of one byte gather per window base)
-  int32_t *stage_dw = lds + 4 * (int)fourk + wave * (DENSE_STAGE / 4);
+  int32_t *stage_dw = lds + RPB * (int)fourk + grp * (DENSE_STAGE / 4);
   const int8_t *stage = reinterpret_cast<const int8_t *>(stage_dw);
   if (LDS_HIST)
-    for (int b = lane; b < (int)fourk; b += 64) hist[b] = 0;
+    for (int b = lane; b < (int)fourk; b += G) hist[b] = 0;
 
-  for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < nS; i += (int64_t)gridDim.x * 4) {
+  for (int64_t i = (int64_t)blockIdx.x * RPB + grp; i < nS; i += (int64_t)gridDim.x * RPB) {
     const int64_t st = start[i];
     const int L = length[i];
     // compat: threadIdx.x < length-1 with blockDim 1024 (src/kmer_kernel.cu:85); native: every
@@ -63,7 +70,7 @@ __global__ __launch_bounds__(256) void dense_kernel(const int8_t *__restrict__ d
         const uintptr_t abs0 = reinterpret_cast<uintptr_t>(data) + (uintptr_t)A;
         skew = (int)(abs0 & 3u);
         const int ndw = (skew + nbytes + 3) >> 2;
-        for (int d = lane; d < ndw; d += 64) {
+        for (int d = lane; d < ndw; d += G) {
           const int64_t off = A - skew + 4 * (int64_t)d;          // offset of the dword in data
           int32_t w;
           if (off >= 0 && off + 4 <= nN) {
@@ -80,9 +87,10 @@ __global__ __launch_bounds__(256) void dense_kernel(const int8_t *__restrict__ d
           }
           stage_dw[d] = w;
         }
-        // (a wave executes in lock step and LDS is in order per wave: no barrier needed)
+        // (the group's lanes sit in one wave, which executes in lock step, and LDS is in order per
+        // wave: no barrier needed)
       }
-      const int per = (nwin + 63) >> 6;
+      const int per = (nwin + G - 1) / G;
       const int t0 = lane * per;
       const int t1 = min(t0 + per, nwin);
       if (t0 < t1) {
@@ -115,12 +123,12 @@ __global__ __launch_bounds__(256) void dense_kernel(const int8_t *__restrict__ d
       }
     }
     if (LDS_HIST) {
-      for (int b = lane; b < (int)fourk; b += 64) {
+      for (int b = lane; b < (int)fourk; b += G) {
         row[b] = hist[b];
         hist[b] = 0;
       }
       if (COMPAT) {
-        invalid = wave_sum(invalid);
+        invalid = group_sum<G>(invalid);
         if (lane == 0) spill[i] = invalid;
       }
     }
@@ -144,33 +152,35 @@ int cfrk_launch_dense(cfrk_ctx *ctx, const int8_t *d_data, const int64_t *d_star
                       int32_t *d_freq) {
   const bool compat = (flags & CFRK_COMPAT) != 0;
   const int64_t fourk = (int64_t)1 << (2 * k);
-  const int64_t want = (nS + 3) / 4;
-  const int grid = (int)std::min<int64_t>(want, (int64_t)ctx->num_cus * 16);
   if (k <= 6) {
     void *d_spill = nullptr;
     int rc;
     if (compat && (rc = cfrk_pool_get(ctx, BUF_SPILL, (size_t)nS * 4, &d_spill))) return rc;
-    const size_t lds = 4 * (size_t)fourk * sizeof(int32_t) + 4 * (size_t)DENSE_STAGE;
+    const int G = (k <= 4) ? 16 : 64;                       // lanes per read
+    const int rpb = 256 / G;
+    const int grid = (int)std::min<int64_t>((nS + rpb - 1) / rpb, (int64_t)ctx->num_cus * 16);
+    const size_t lds = (size_t)rpb * ((size_t)fourk * sizeof(int32_t) + (size_t)DENSE_STAGE);
+    const void *fn = compat ? (G == 16 ? (const void *)dense_kernel<true, true, 16> : (const void *)dense_kernel<true, true, 64>)
+                            : (G == 16 ? (const void *)dense_kernel<false, true, 16> : (const void *)dense_kernel<false, true, 64>);
     // more than the default 64 KiB of dynamic LDS at k = 6
-    HIP_TRY(ctx, hipFuncSetAttribute(compat ? (const void *)dense_kernel<true, true> : (const void *)dense_kernel<false, true>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (compat) {
-      hipLaunchKernelGGL((dense_kernel<true, true>), dim3(grid), dim3(256), lds, ctx->stream, d_data,
-                         d_start, d_length, nN, nS, k, d_freq, (int32_t *)d_spill);
-      if (nS > 1)
-        hipLaunchKernelGGL(dense_spill_kernel, dim3((unsigned)((nS - 1 + 255) / 256)), dim3(256), 0,
-                           ctx->stream, d_freq, (const int32_t *)d_spill, nS, fourk);
-    } else {
-      hipLaunchKernelGGL((dense_kernel<false, true>), dim3(grid), dim3(256), lds, ctx->stream, d_data,
-                         d_start, d_length, nN, nS, k, d_freq, (int32_t *)nullptr);
-    }
+    HIP_TRY(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#define CFRK_DENSE_LAUNCH(C_, G_)                                                                        \
+    hipLaunchKernelGGL((dense_kernel<C_, true, G_>), dim3(grid), dim3(256), lds, ctx->stream, d_data, d_start, \
+                       d_length, nN, nS, k, d_freq, (int32_t *)d_spill)
+    if (compat) { if (G == 16) CFRK_DENSE_LAUNCH(true, 16); else CFRK_DENSE_LAUNCH(true, 64); }
+    else { if (G == 16) CFRK_DENSE_LAUNCH(false, 16); else CFRK_DENSE_LAUNCH(false, 64); }
+#undef CFRK_DENSE_LAUNCH
+    if (compat && nS > 1)
+      hipLaunchKernelGGL(dense_spill_kernel, dim3((unsigned)((nS - 1 + 255) / 256)), dim3(256), 0, ctx->stream,
+                         d_freq, (const int32_t *)d_spill, nS, fourk);
   } else {
+    const int grid = (int)std::min<int64_t>((nS + 3) / 4, (int64_t)ctx->num_cus * 16);
     HIP_TRY(ctx, hipMemsetAsync(d_freq, 0, (size_t)nS * (size_t)fourk * 4, ctx->stream));  // SetMatrix(d_Freq, 0)
     if (compat)
-      hipLaunchKernelGGL((dense_kernel<true, false>), dim3(grid), dim3(256), 0, ctx->stream, d_data,
+      hipLaunchKernelGGL((dense_kernel<true, false, 64>), dim3(grid), dim3(256), 0, ctx->stream, d_data,
                          d_start, d_length, nN, nS, k, d_freq, (int32_t *)nullptr);
     else
-      hipLaunchKernelGGL((dense_kernel<false, false>), dim3(grid), dim3(256), 0, ctx->stream, d_data,
+      hipLaunchKernelGGL((dense_kernel<false, false, 64>), dim3(grid), dim3(256), 0, ctx->stream, d_data,
                          d_start, d_length, nN, nS, k, d_freq, (int32_t *)nullptr);
   }
   HIP_TRY(ctx, hipGetLastError());
