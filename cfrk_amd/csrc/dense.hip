@@ -2,13 +2,14 @@
 // SetMatrix + ComputeIndex + ComputeFreqNew launches (/root/reference/src/kmer_main.cu:107-111,
 // kernels at src/kmer_kernel.cu:6-90).
 //
-// One 64-lane wave per read (the reference uses a 1024-thread block per read with <= L-1 lanes
-// active, src/kmer_main.cu:82-83).  Each lane owns a contiguous run of window starts and rolls
+// One 64-lane wave per read -- 16 lanes for k <= 4, four reads per wave -- (the reference uses a
+// 1024-thread block per read with <= L-1 lanes active, src/kmer_main.cu:82-83).  Each lane owns a contiguous run of window starts and rolls
 // the 2-bit index forward one base at a time (exact integers; the reference recomputes k powf
 // terms per window, src/kmer_kernel.cu:33-46).  No Index[] array is materialised (the
 // reference writes and re-reads 4 B per base).
-//   k <= 6 : row histogram lives in LDS (4^k * 4 B <= 16 KiB per wave), ds_add_u32, then one
-//            coalesced row store -- the row is written exactly once, no memset, no HBM atomics.
+//   k <= 6 : the read's codes are staged in LDS by coalesced dword loads; the row histogram
+//            lives in LDS (4^k * 4 B <= 16 KiB per read), ds_add_u32, then one coalesced row
+//            store -- the row is written exactly once, no memset, no HBM atomics.
 //   k >= 7 : HBM atomics into the zeroed row, as the reference does.
 // CFRK_COMPAT reproduces ComputeFreqNew's missing -1 guard: every invalid window of read i is
 // added to row i-1's last bin (dropped for i == 0, where the reference writes Freq[-1]).
