@@ -124,9 +124,14 @@ __global__ __launch_bounds__(256) void dense_kernel(const int8_t *__restrict__ d
       }
     }
     if (LDS_HIST) {
-      for (int b = lane; b < (int)fourk; b += G) {
-        row[b] = hist[b];
-        hist[b] = 0;
+      // 16 bytes per lane and store (rows are 16-byte aligned: 4^k * 4 bytes each from an aligned base)
+      {
+        int4 *row4 = reinterpret_cast<int4 *>(row);
+        int4 *hist4 = reinterpret_cast<int4 *>(hist);
+        for (int b = lane; b < (int)fourk / 4; b += G) {
+          row4[b] = hist4[b];
+          hist4[b] = make_int4(0, 0, 0, 0);
+        }
       }
       if (COMPAT) {
         invalid = group_sum<G>(invalid);
