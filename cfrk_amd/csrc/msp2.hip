@@ -670,8 +670,9 @@ static size_t msp2_need(const cfrk_ctx *ctx, int64_t span) {
 }
 
 // one pass of Q1 -> Q2 -> Q3 over the Q1 tiles [tile0, tile0 + ntiles)
+// slack >= 1 widens the per-leaf streams beyond what msp2_need() accounts for (memory permitting)
 static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, int64_t nN, int64_t tile0,
-                            int64_t ntiles) {
+                            int64_t ntiles, double slack) {
   int rc;
   const int k = ctx->g_k;
   const int m = (k & 1) ? 14 : 13;                       // k - m + 1 - 18 must be even
@@ -682,8 +683,8 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
   const double dens = 2.0 / (W2 + 1) + 1.0 / 64.0;
   const double expect = (double)span * dens;
   const uint64_t cap1 = (uint64_t)(expect / (B1 * NXG) * 1.35) + 2048;
-  const uint64_t cap2c = (uint64_t)(expect / NLEAF * 2.1) + 96;
-  const uint64_t cap2t = (uint64_t)(expect / NLEAF * 0.4) + 96;
+  const uint64_t cap2c = (uint64_t)(expect / NLEAF * 2.1 * slack) + 96;
+  const uint64_t cap2t = (uint64_t)(expect / NLEAF * 0.4 * slack) + 96;
   const int64_t tiles_per_sub = (int64_t)(((uint64_t)NXG * cap1 + (uint64_t)Q2_TILE * Q2_GROUP - 1) / ((uint64_t)Q2_TILE * Q2_GROUP));   // tile groups per bin
   if (tiles_per_sub * B1 > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
   void *p;
@@ -758,7 +759,19 @@ int cfrk_msp2_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   const int passes = (int)((ntiles + per - 1) / per);
   ctx->last_passes = passes;
   if (ms->pending && (rc = cfrk_msp_flush_to_table(ctx))) return rc;
-  if (passes == 1) return msp2_count_tiles(ctx, ms, d_data, nN, 0, ntiles);
+  if (passes == 1) {
+    // lumpy leaves (small genomes): up to twice the stream room when memory is plentiful (msp.hip)
+    double slack = 1.0;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      const double l2 = (double)(nN + 32) * (2.0 / (W2 + 1) + 1.0 / 64.0) * 3.3 * 32;
+      size_t budget = have + free_b;
+      if (ctx->mem_budget) budget = std::min(budget, ctx->mem_budget);
+      const double room = 0.5 * (double)budget - (double)msp2_need(ctx, nN + 32);
+      if (room > 0 && l2 > 0) slack = std::min(2.0, 1.0 + room / l2);
+    }
+    return msp2_count_tiles(ctx, ms, d_data, nN, 0, ntiles, slack);
+  }
 
   // several passes over tile ranges: keep every pass's per-leaf list, add them leaf by leaf in
   // LDS at the end (as msp.hip does)
@@ -775,7 +788,7 @@ int cfrk_msp2_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   uint64_t acc_n = 0;
   int pass = 0;
   for (int64_t t0 = 0; t0 < ntiles; t0 += per, ++pass) {
-    if ((rc = msp2_count_tiles(ctx, ms, d_data, nN, t0, std::min(per, ntiles - t0)))) {
+    if ((rc = msp2_count_tiles(ctx, ms, d_data, nN, t0, std::min(per, ntiles - t0), 1.0))) {
       // a refusal after the first pass must not reach the caller's fallback (it would count
       // the finished passes twice)
       if (t0 > 0 && rc == CFRK_ERR_NOMEM) return cfrk_fail(ctx, CFRK_ERR_STATE, "out of device memory in pass %d of a multi-pass add", pass);
