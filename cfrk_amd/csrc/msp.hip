@@ -471,10 +471,12 @@ static_assert(TL_CAP <= (1 << 14), "list positions are 14 bits");
 static_assert(RT == P3_THREADS, "phase 2 lists the record table with one slot per thread");
 constexpr uint32_t RT_LOCK = 0xFFFFFFFFu;
 
+// (rotations decorrelate the three base words, one multiply spreads them into the top bits: the
+// bases of a record are sequence, already close to uniform)
 __device__ __forceinline__ uint32_t rtab_slot(uint4 rec) {
-  uint32_t h = (rec.x * 0x9E3779B1u) ^ (rec.y * 0x85EBCA77u) ^ (rec.z * 0xC2B2AE3Du) ^ ((rec.w & 63u) * 0x27D4EB2Fu);
-  h = (h ^ (h >> 15)) * 0x2C1B3C6Du;
-  return h >> (32 - RT_LOG);
+  const uint32_t t = rec.x ^ __builtin_amdgcn_alignbit(rec.y, rec.y, 11) ^ __builtin_amdgcn_alignbit(rec.z, rec.z, 21) ^
+                     ((rec.w & 63u) << 26);
+  return (t * 0x9E3779B1u) >> (32 - RT_LOG);
 }
 
 // Every instruction -- vector or scalar -- costs an issue slot here, so the probe step is written
