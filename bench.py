@@ -77,6 +77,8 @@ def measured_traffic(R, L, k, canonical):
 
 def main():
     args = parse()
+    # the host driver only supports dmabuf IPC (RCCL / CUDA-tensor sharing across processes)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     import cfrk_amd
@@ -87,6 +89,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.same_gpu:
         local_rank = 0
+    torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":
