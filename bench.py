@@ -119,7 +119,7 @@ def main():
     ctx.synth_reads_device(r0, Rl, L, glen, d_data.data_ptr(), d_start.data_ptr(), d_length.data_ptr())
     torch.cuda.synchronize()
 
-    hint = min(glen, R * (L - k + 1)) + 1024
+    hint = min(glen, R * max(L - k + 1, 0)) + 1024
     owner_ctx = cfrk_amd.Context(local_rank, stream) if world > 1 else None
 
     class Engine:
@@ -213,7 +213,7 @@ def main():
     if world > 1:
         digest = sharded.merge_digests(digest, "cpu" if wire else dev)
 
-    kmers_total = R * (L - k + 1)
+    kmers_total = R * max(L - k + 1, 0)
     D = digest[0]
     ok = digest[1] == kmers_total
     if rank == 0:
