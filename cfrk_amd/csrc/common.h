@@ -16,12 +16,16 @@ enum {  // pool slots
   BUF_DATA = 0, BUF_START, BUF_LENGTH, BUF_FREQ, BUF_SPILL, BUF_EXPORT_LO, BUF_EXPORT_HI,
   BUF_EXPORT_CNT, BUF_SCRATCH, BUF_MSP_L1, BUF_MSP_L2, BUF_MSP_OUTK, BUF_MSP_OUTC, BUF_MSP_AUX, BUF_MSP_OUTH,
   BUF_MSP_ACCK, BUF_MSP_ACCH, BUF_MSP_ACCC,   // lists of the passes of a multi-pass add, merged per leaf at the end
+  BUF_MSP_LAYOUT,                             // exact second-level layout (stream bases and sizes)
+  BUF_MSP_OVF,                                // records that did not fit their leaf stream (a few)
   BUF_NSLOTS
 };
 
 enum {  // device stats words (uint64 each)
   ST_OVERFLOW = 0, ST_ONES, ST_CURSOR, ST_DIG0, ST_DIG1, ST_DIG2, ST_DIG3, ST_SPILLED, ST_AUX0,
-  ST_AUX1, ST_NWORDS = 16
+  ST_AUX1, ST_L2OVF /* leaf streams were too small by a lot: the second level is redone with exact sizes */,
+  ST_OVFN /* records parked in the overflow buffer (leaf streams too small by a little) */,
+  ST_NWORDS = 16
 };
 
 struct cfrk_buf { void *p; size_t cap; };

@@ -354,10 +354,21 @@ __global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int groups_per_bin, 
       const uint32_t dst = gbase[sb] + (p - loff[sb]);
       const uint64_t leaf = ((uint64_t)b1 * NSUB + sb) >> 1;
       const uint32_t cls = sb & 1u;
-      const uint64_t cap = cls ? v.cap2c : v.cap2t;
-      const uint64_t at = leaf * (v.cap2c + v.cap2t) + (cls ? 0 : v.cap2c);
+      uint64_t cap = cls ? v.cap2c : v.cap2t;
+      uint64_t at = leaf * (v.cap2c + v.cap2t) + (cls ? 0 : v.cap2c);
+      if (v.exact) { cap = v.lcap[b1 * NSUB + sb]; at = v.lbase[b1 * NSUB + sb]; }
       if (dst < cap) v.rec2[at + dst] = rec;
-      else spill_record(rec, k, canon != 0, t);
+      else if (v.exact) spill_record(rec, k, canon != 0, t);      // cannot happen: cap is the exact count
+      else {
+        // too small by a little: park the record (the host counts the parked ones through the
+        // HBM table); by a lot: the cursors keep counting and the host redoes P2 with exact sizes
+        // (once the flag is up nobody takes a number any more: 10^7 atomics on one word are slow)
+        if (*(volatile uint64_t *)&v.stats[ST_L2OVF] == 0) {
+          const unsigned long long o = atomicAdd((unsigned long long *)&v.stats[ST_OVFN], 1ull);
+          if (o < v.ovf_cap) v.ovf[o] = rec;
+          else v.stats[ST_L2OVF] = 1;
+        }
+      }
     }
     __syncthreads();                                       // sorted/loff/gbase are reused by the next tile
   }
@@ -534,9 +545,9 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
   __shared__ unsigned long long wg_base;
   const int tid = threadIdx.x, lane = tid & 63;
   const uint32_t leaf = blockIdx.x;
-  const uint64_t nt = min((uint64_t)v.cnt2[NCLS * leaf + 0], v.cap2t);     // truncated runs
-  const uint64_t n1 = min((uint64_t)v.cnt2[NCLS * leaf + 1], v.cap2c);     // complete runs
-  const uint4 *leaf_rec = v.rec2 + (uint64_t)leaf * (v.cap2c + v.cap2t);
+  const uint64_t nt = min((uint64_t)v.cnt2[NCLS * leaf + 0], v.exact ? (uint64_t)v.lcap[NCLS * leaf + 0] : v.cap2t);  // truncated runs
+  const uint64_t n1 = min((uint64_t)v.cnt2[NCLS * leaf + 1], v.exact ? (uint64_t)v.lcap[NCLS * leaf + 1] : v.cap2c);  // complete runs
+  const uint4 *leaf_rec = v.exact ? v.rec2 + v.lbase[NCLS * leaf + 1] : v.rec2 + (uint64_t)leaf * (v.cap2c + v.cap2t);
   if (nt + n1 == 0) return;
   for (int s = tid; s < TS; s += P3_THREADS) { keys[s] = CFRK_EMPTY_KEY; cnts[s] = 0; }
   for (int s = tid; s < RT; s += P3_THREADS) rtab[s] = make_uint4(0u, 0u, 0u, RT_EMPTY);
@@ -547,7 +558,7 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
   const uint64_t kmask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1ull);
   const int rcsh = 2 * k - 2;
   // truncated runs that go through the length-sorted list: as many as fit
-  const uint4 *trunc = leaf_rec + v.cap2c;
+  const uint4 *trunc = v.exact ? v.rec2 + v.lbase[NCLS * leaf + 0] : leaf_rec + v.cap2c;
   const uint32_t tl = (uint32_t)min(nt, (uint64_t)TL_CAP);
 
   // ---- phase 1a: complete runs, one record-table update per record.  Most records find their
@@ -779,6 +790,38 @@ __global__ __launch_bounds__(P3_THREADS) void msp_merge_kernel(const uint64_t *_
   }
 }
 
+// exact layout of the second level from the demand the first attempt counted: lbase = exclusive
+// prefix sum of cnt2 over the NCLS * NLEAF streams, lcap = cnt2 (single workgroup, 1024 threads)
+__global__ __launch_bounds__(1024) void msp_layout_kernel(const uint32_t *__restrict__ cnt2, uint64_t *__restrict__ lbase,
+                                                          uint32_t *__restrict__ lcap) {
+  __shared__ unsigned long long part[1024];
+  constexpr int N = NCLS * NLEAF, PER = N / 1024;
+  const int tid = threadIdx.x;
+  unsigned long long s = 0;
+  for (int i = 0; i < PER; ++i) s += cnt2[tid * PER + i];
+  part[tid] = s;
+  __syncthreads();
+  if (tid == 0) {
+    unsigned long long run = 0;
+    for (int i = 0; i < 1024; ++i) { const unsigned long long x = part[i]; part[i] = run; run += x; }
+  }
+  __syncthreads();
+  unsigned long long run = part[tid];
+  for (int i = 0; i < PER; ++i) {
+    const uint32_t c = cnt2[tid * PER + i];
+    lbase[tid * PER + i] = run;
+    lcap[tid * PER + i] = c;
+    run += c;
+  }
+}
+
+// the few records that did not fit their leaf stream: counted k-mer by k-mer in the HBM table
+__global__ __launch_bounds__(256) void msp_spill_list_kernel(const uint4 *__restrict__ recs, uint32_t n, int k,
+                                                             int canon, TableView t) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n) spill_record(recs[i], k, canon != 0, t);
+}
+
 __global__ void msp_info_kernel(MspView v, uint64_t *out) {
   // diagnostics: record totals / maxima per level (single block)
   __shared__ unsigned long long tot1, max1, tot2, max2;
@@ -913,9 +956,45 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
   }
 #undef CFRK_P1_CASE
   HIP_TRY(ctx, hipGetLastError());
+  v.exact = 0; v.lbase = nullptr; v.lcap = nullptr;
+  constexpr uint32_t OVF_CAP = 1u << 20;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_OVF, (size_t)OVF_CAP * sizeof(uint4), &p))) return rc;
+  // "a few" = under 0.4 % of the expected records (and what the buffer holds)
+  v.ovf = (uint4 *)p; v.ovf_cap = (uint32_t)std::min<double>((double)OVF_CAP, expect / 256.0);
+  HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_L2OVF, 0, 2 * sizeof(uint64_t), ctx->stream));   // ST_L2OVF, ST_OVFN
   hipLaunchKernelGGL(msp_p2_kernel, dim3((unsigned)(tiles_per_sub * B1)), dim3(P2_THREADS), 0, ctx->stream,
                      (int)tiles_per_sub, k, canon, v, t);
   HIP_TRY(ctx, hipGetLastError());
+  {
+    // Did every leaf stream fit its fixed stride?  (Deep coverage of a small genome puts tens of
+    // thousands of records into a handful of leaves.)  If not, the cursors hold the exact demand:
+    // lay the streams out back to back with exactly that much room -- all records together never
+    // exceed what the level-2 buffer already holds -- and run P2 again.  One word D2H + a stream
+    // sync per add; the alternative was 10^7 records counted k-mer by k-mer with HBM atomics.
+    uint64_t ovf[2] = {0, 0};                              // ST_L2OVF, ST_OVFN
+    HIP_TRY(ctx, hipMemcpyAsync(ovf, ctx->g_stats + ST_L2OVF, sizeof ovf, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ovf[0] && ovf[1]) {
+      // a few records (lumpy leaves): count them in the HBM table, keep everything else
+      const uint32_t n = (uint32_t)ovf[1];
+      hipLaunchKernelGGL(msp_spill_list_kernel, dim3((n + 255u) / 256u), dim3(256), 0, ctx->stream, (const uint4 *)v.ovf, n, k,
+                         canon, t);
+      HIP_TRY(ctx, hipGetLastError());
+    }
+    if (ovf[0]) {
+      if ((rc = cfrk_pool_get(ctx, BUF_MSP_LAYOUT, (size_t)NCLS * NLEAF * (sizeof(uint64_t) + 2 * sizeof(uint32_t)), &p))) return rc;
+      uint64_t *lbase = (uint64_t *)p;
+      uint32_t *lcap = (uint32_t *)(lbase + NCLS * NLEAF);
+      hipLaunchKernelGGL(msp_layout_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)v.cnt2, lbase, lcap);
+      HIP_TRY(ctx, hipGetLastError());
+      HIP_TRY(ctx, hipMemsetAsync(v.cnt2, 0, (size_t)NCLS * NLEAF * sizeof(uint32_t), ctx->stream));
+      HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_L2OVF, 0, 2 * sizeof(uint64_t), ctx->stream));
+      v.exact = 1; v.lbase = lbase; v.lcap = lcap;
+      hipLaunchKernelGGL(msp_p2_kernel, dim3((unsigned)(tiles_per_sub * B1)), dim3(P2_THREADS), 0, ctx->stream,
+                         (int)tiles_per_sub, k, canon, v, t);
+      HIP_TRY(ctx, hipGetLastError());
+    }
+  }
   if (canon) hipLaunchKernelGGL((msp_p3_kernel<true>), dim3(NLEAF), dim3(P3_THREADS), 0, ctx->stream, k, v, t);
   else hipLaunchKernelGGL((msp_p3_kernel<false>), dim3(NLEAF), dim3(P3_THREADS), 0, ctx->stream, k, v, t);
   HIP_TRY(ctx, hipGetLastError());
