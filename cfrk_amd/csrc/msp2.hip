@@ -40,6 +40,10 @@ struct View2 {
   Rec2 *rec2; uint32_t *cnt2; uint64_t cap2c, cap2t;    // per leaf: complete stream, 3 truncated classes
   uint64_t *out_lo, *out_hi; uint32_t *out_cnt; uint64_t out_cap;
   uint64_t *leaf_off; uint32_t *leaf_n;                  // where each leaf's entries sit in the result list
+  // exact layout after leaf streams overflowed the fixed stride (see msp.hip): stream (leaf, class)
+  // starts at record lbase[NCLS * leaf + class] and holds exactly lcap[...] records
+  const uint64_t *lbase; const uint32_t *lcap; uint32_t exact;
+  Rec2 *ovf; uint32_t ovf_cap;                           // parking for a few overflowing records
   uint64_t *stats;
 };
 
@@ -358,10 +362,17 @@ __global__ __launch_bounds__(Q2_THREADS) void msp2_p2_kernel(int groups_per_bin,
       const uint32_t dst = gbase[sb] + (p - loff[sb]);
       const uint64_t leaf = ((uint64_t)b1 * NSUB + sb) >> 2;
       const uint32_t cls = sb & 3u;
-      const uint64_t cap = (cls == 3u) ? v.cap2c : v.cap2t;
-      const uint64_t at = leaf * (v.cap2c + 3 * v.cap2t) + ((cls == 3u) ? 0 : v.cap2c + cls * v.cap2t);
+      uint64_t cap = (cls == 3u) ? v.cap2c : v.cap2t;
+      uint64_t at = leaf * (v.cap2c + 3 * v.cap2t) + ((cls == 3u) ? 0 : v.cap2c + cls * v.cap2t);
+      if (v.exact) { cap = v.lcap[b1 * NSUB + sb]; at = v.lbase[b1 * NSUB + sb]; }
       if (dst < cap) v.rec2[at + dst] = rec;
-      else spill_record2(rec, k, canon != 0, t);
+      else if (v.exact) spill_record2(rec, k, canon != 0, t);    // cannot happen: cap is the exact count
+      else if (*(volatile uint64_t *)&v.stats[ST_L2OVF] == 0) {
+        // too small by a little: park the record; by a lot: the host redoes Q2 with exact sizes
+        const unsigned long long o = atomicAdd((unsigned long long *)&v.stats[ST_OVFN], 1ull);
+        if (o < v.ovf_cap) v.ovf[o] = rec;
+        else v.stats[ST_L2OVF] = 1;
+      }
     }
     __syncthreads();                                       // the LDS buffers are reused by the next tile
   }
@@ -491,7 +502,8 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
   uint64_t total = 0;
 #pragma unroll
   for (int cl = 0; cl < NCLS; ++cl) {
-    ns[cl] = min((uint64_t)v.cnt2[NCLS * leaf + cl], cl == 3 ? v.cap2c : v.cap2t);
+    ns[cl] = min((uint64_t)v.cnt2[NCLS * leaf + cl],
+                 v.exact ? (uint64_t)v.lcap[NCLS * leaf + cl] : (cl == 3 ? v.cap2c : v.cap2t));
     total += ns[cl];
   }
   if (total == 0) return;
@@ -505,7 +517,7 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
   if (tid < 32) nhist[tid] = 0;
   __syncthreads();
 
-  const Rec2 *leaf_rec = v.rec2 + (uint64_t)leaf * (v.cap2c + 3 * v.cap2t);
+  const Rec2 *leaf_rec = v.exact ? v.rec2 + v.lbase[NCLS * leaf + 3] : v.rec2 + (uint64_t)leaf * (v.cap2c + 3 * v.cap2t);
   const Rec2 zrec = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
   // ---- phase 1: complete runs, one record-table update per record; a record that finds no
   //      room is expanded on the spot
@@ -549,7 +561,7 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
     count_record2<CANON>(keys, cnts, rec, rec.b.w >> 6, valid, k, t);
   }
   for (int cl = 2; cl >= 0; --cl) {
-    const Rec2 *src = leaf_rec + v.cap2c + (uint64_t)cl * v.cap2t;
+    const Rec2 *src = v.exact ? v.rec2 + v.lbase[NCLS * leaf + cl] : leaf_rec + v.cap2c + (uint64_t)cl * v.cap2t;
     for (uint64_t r = tid; r < ((ns[cl] + 63) & ~63ull); r += Q3_THREADS) {
       const bool valid = r < ns[cl];
       Rec2 rec = zrec;
@@ -589,6 +601,37 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
       else v.stats[ST_OVERFLOW] = 1;
     }
   }
+}
+
+// exact layout of the second level from the demand the first attempt counted (see msp.hip)
+__global__ __launch_bounds__(1024) void msp2_layout_kernel(const uint32_t *__restrict__ cnt2, uint64_t *__restrict__ lbase,
+                                                           uint32_t *__restrict__ lcap) {
+  __shared__ unsigned long long part[1024];
+  constexpr int N = NCLS * NLEAF, PER = N / 1024;
+  const int tid = threadIdx.x;
+  unsigned long long s = 0;
+  for (int i = 0; i < PER; ++i) s += cnt2[tid * PER + i];
+  part[tid] = s;
+  __syncthreads();
+  if (tid == 0) {
+    unsigned long long run = 0;
+    for (int i = 0; i < 1024; ++i) { const unsigned long long x = part[i]; part[i] = run; run += x; }
+  }
+  __syncthreads();
+  unsigned long long run = part[tid];
+  for (int i = 0; i < PER; ++i) {
+    const uint32_t c = cnt2[tid * PER + i];
+    lbase[tid * PER + i] = run;
+    lcap[tid * PER + i] = c;
+    run += c;
+  }
+}
+
+// the few records that did not fit their leaf stream: counted k-mer by k-mer in the HBM table
+__global__ __launch_bounds__(256) void msp2_spill_list_kernel(const Rec2 *__restrict__ recs, uint32_t n, int k,
+                                                              int canon, TableView t) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n) spill_record2(recs[i], k, canon != 0, t);
 }
 
 // One workgroup per leaf: add the `parts` lists of that leaf (the passes of a multi-pass add) in
@@ -710,9 +753,41 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
   hipLaunchKernelGGL(msp2_p1_kernel, dim3((unsigned)ntiles), dim3(Q1_THREADS), 0, ctx->stream, d_data, nN, k, m, c,
                      canon, tile0, v, t);
   HIP_TRY(ctx, hipGetLastError());
+  v.exact = 0; v.lbase = nullptr; v.lcap = nullptr;
+  constexpr uint32_t OVF_CAP = 1u << 19;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_OVF, (size_t)OVF_CAP * sizeof(Rec2), &p))) return rc;
+  v.ovf = (Rec2 *)p; v.ovf_cap = (uint32_t)std::min<double>((double)OVF_CAP, expect / 256.0);
+  HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_L2OVF, 0, 2 * sizeof(uint64_t), ctx->stream));   // ST_L2OVF, ST_OVFN
   hipLaunchKernelGGL(msp2_p2_kernel, dim3((unsigned)(tiles_per_sub * B1)), dim3(Q2_THREADS), 0, ctx->stream,
                      (int)tiles_per_sub, k, canon, v, t);
   HIP_TRY(ctx, hipGetLastError());
+  {
+    // leaf streams too small (deep coverage of a small genome)?  As in msp.hip: a few records are
+    // parked and counted through the HBM table, many make the host lay the streams out again
+    // with the exact sizes the cursors counted and rerun Q2.
+    uint64_t ovf[2] = {0, 0};                              // ST_L2OVF, ST_OVFN
+    HIP_TRY(ctx, hipMemcpyAsync(ovf, ctx->g_stats + ST_L2OVF, sizeof ovf, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ovf[0] && ovf[1]) {
+      const uint32_t n = (uint32_t)ovf[1];
+      hipLaunchKernelGGL(msp2_spill_list_kernel, dim3((n + 255u) / 256u), dim3(256), 0, ctx->stream, (const Rec2 *)v.ovf, n,
+                         k, canon, t);
+      HIP_TRY(ctx, hipGetLastError());
+    }
+    if (ovf[0]) {
+      if ((rc = cfrk_pool_get(ctx, BUF_MSP_LAYOUT, (size_t)NCLS * NLEAF * (sizeof(uint64_t) + 2 * sizeof(uint32_t)), &p))) return rc;
+      uint64_t *lbase = (uint64_t *)p;
+      uint32_t *lcap = (uint32_t *)(lbase + NCLS * NLEAF);
+      hipLaunchKernelGGL(msp2_layout_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)v.cnt2, lbase, lcap);
+      HIP_TRY(ctx, hipGetLastError());
+      HIP_TRY(ctx, hipMemsetAsync(v.cnt2, 0, (size_t)NCLS * NLEAF * sizeof(uint32_t), ctx->stream));
+      HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_L2OVF, 0, 2 * sizeof(uint64_t), ctx->stream));
+      v.exact = 1; v.lbase = lbase; v.lcap = lcap;
+      hipLaunchKernelGGL(msp2_p2_kernel, dim3((unsigned)(tiles_per_sub * B1)), dim3(Q2_THREADS), 0, ctx->stream,
+                         (int)tiles_per_sub, k, canon, v, t);
+      HIP_TRY(ctx, hipGetLastError());
+    }
+  }
   if (canon) hipLaunchKernelGGL((msp2_p3_kernel<true>), dim3(NLEAF), dim3(Q3_THREADS), 0, ctx->stream, k, v, t);
   else hipLaunchKernelGGL((msp2_p3_kernel<false>), dim3(NLEAF), dim3(Q3_THREADS), 0, ctx->stream, k, v, t);
   HIP_TRY(ctx, hipGetLastError());
@@ -734,6 +809,7 @@ int cfrk_msp2_merge_lists(cfrk_ctx *ctx, const uint64_t *d_lo, const uint64_t *d
   v.rec1 = nullptr; v.cnt1 = nullptr; v.cap1 = 0; v.rec2 = nullptr; v.cnt2 = nullptr; v.cap2c = v.cap2t = 0;
   v.out_lo = ms->view.out_keys; v.out_hi = ms->view.out_hi; v.out_cnt = ms->view.out_cnt; v.out_cap = ms->view.out_cap;
   v.leaf_off = nullptr; v.leaf_n = nullptr; v.stats = ctx->g_stats;
+  v.exact = 0; v.lbase = nullptr; v.lcap = nullptr; v.ovf = nullptr; v.ovf_cap = 0;
   hipLaunchKernelGGL(msp2_merge_kernel, dim3(leaves_per_part), dim3(Q3_THREADS), 0, ctx->stream, d_lo, d_hi, d_cnt,
                      d_seg_off, d_seg_n, parts, leaves_per_part, v, cfrk_table_view(ctx));
   HIP_TRY(ctx, hipGetLastError());
