@@ -34,6 +34,9 @@ constexpr int RX_IDX_MAX = 13;
 struct RxView {
   uint32_t *key1; uint32_t *cnt1; uint64_t cap1;      // 2^b1 x RX_NXG regions
   uint32_t *key2; uint32_t *cnt2; uint64_t cap2;      // 2^(b1+b2) leaves
+  // exact layout after a leaf stream overflowed the fixed stride (few distinct keys, each seen
+  // very often): leaf l starts at key lbase[l] and holds exactly lcap[l] keys
+  const uint64_t *lbase; const uint32_t *lcap; uint32_t exact;
   uint64_t *out_keys; uint32_t *out_cnt; uint64_t out_cap;
   uint64_t *stats;
   int k, b1, b2, idx;
@@ -192,8 +195,36 @@ __global__ __launch_bounds__(RX2_THREADS) void rx2_kernel(int tiles_per_sub, RxV
     const uint32_t b = (key >> v.idx) & m2;
     const uint32_t dst = gbase[b] + (p - loff[b]);
     const uint64_t leaf = ((uint64_t)bin1 << v.b2) + b;
-    if (dst < v.cap2) v.key2[leaf * v.cap2 + dst] = key;
-    else { t.stats[ST_SPILLED] = 1; table_add1(t, (uint64_t)rx_unmix(v, key), 1u); }
+    if (v.exact) {
+      if (dst < v.lcap[leaf]) v.key2[v.lbase[leaf] + dst] = key;
+      else { t.stats[ST_SPILLED] = 1; table_add1(t, (uint64_t)rx_unmix(v, key), 1u); }   // cannot happen
+    } else if (dst < v.cap2) {
+      v.key2[leaf * v.cap2 + dst] = key;
+    } else {
+      v.stats[ST_L2OVF] = 1;       // the cursor keeps counting: the host redoes RX2 with exact sizes
+    }
+  }
+}
+
+// exact leaf layout from the demand the first attempt counted (single workgroup)
+__global__ __launch_bounds__(1024) void rx_layout_kernel(const uint32_t *__restrict__ cnt2, uint32_t nleaf,
+                                                         uint64_t *__restrict__ lbase, uint32_t *__restrict__ lcap) {
+  __shared__ unsigned long long part[1024];
+  const uint32_t per = (nleaf + 1023u) / 1024u;
+  const uint32_t tid = threadIdx.x;
+  unsigned long long s = 0;
+  for (uint32_t i = 0; i < per; ++i) { const uint32_t l = tid * per + i; if (l < nleaf) s += cnt2[l]; }
+  part[tid] = s;
+  __syncthreads();
+  if (tid == 0) {
+    unsigned long long run = 0;
+    for (int i = 0; i < 1024; ++i) { const unsigned long long x = part[i]; part[i] = run; run += x; }
+  }
+  __syncthreads();
+  unsigned long long run = part[tid];
+  for (uint32_t i = 0; i < per; ++i) {
+    const uint32_t l = tid * per + i;
+    if (l < nleaf) { const uint32_t c = cnt2[l]; lbase[l] = run; lcap[l] = c; run += c; }
   }
 }
 
@@ -204,7 +235,7 @@ __global__ __launch_bounds__(RX3_THREADS) void rx3_kernel(RxView v) {
   __shared__ unsigned long long wg_base;
   const int tid = threadIdx.x, lane = tid & 63;
   const uint32_t leaf = blockIdx.x;
-  const uint64_t n = min((uint64_t)v.cnt2[leaf], v.cap2);
+  const uint64_t n = min((uint64_t)v.cnt2[leaf], v.exact ? (uint64_t)v.lcap[leaf] : v.cap2);
   if (n == 0) return;
   const uint32_t nidx = 1u << v.idx, imask = nidx - 1u;
   // few counters per leaf (small k): every thread group gets its own replica, or all 256 threads
@@ -214,7 +245,7 @@ __global__ __launch_bounds__(RX3_THREADS) void rx3_kernel(RxView v) {
   for (uint32_t s = tid; s < (nidx << rlog); s += RX3_THREADS) cnt[s] = 0;
   if (tid == 0) wg_total = 0;
   __syncthreads();
-  const uint32_t *src = v.key2 + (uint64_t)leaf * v.cap2;
+  const uint32_t *src = v.exact ? v.key2 + v.lbase[leaf] : v.key2 + (uint64_t)leaf * v.cap2;
   for (uint64_t i = tid; i < n; i += RX3_THREADS)
     atomicAdd(&cnt[((src[i] & imask) << rlog) | ((uint32_t)tid & rmask)], 1u);
   __syncthreads();
@@ -404,8 +435,30 @@ int cfrk_radix_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   const int64_t bins_per_group = (int64_t)((nb1 + RX_NXG - 1) / RX_NXG);
   const int64_t g2 = bins_per_group * RX_NXG * RX_NREG * tiles_per_sub;
   if (g2 > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
+  v.exact = 0; v.lbase = nullptr; v.lcap = nullptr;
+  HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_L2OVF, 0, sizeof(uint64_t), ctx->stream));
   hipLaunchKernelGGL(rx2_kernel, dim3((unsigned)g2), dim3(RX2_THREADS), 0, ctx->stream, (int)tiles_per_sub, v, t);
   HIP_TRY(ctx, hipGetLastError());
+  {
+    // few distinct keys, each seen very often (deep coverage of a small genome): their leaves
+    // overflow the fixed stride.  The cursors counted the exact demand: lay the leaves out back
+    // to back (all keys together never exceed the buffer) and run RX2 again (see msp.hip).
+    uint64_t ovf = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&ovf, ctx->g_stats + ST_L2OVF, sizeof ovf, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ovf) {
+      if ((rc = cfrk_pool_get(ctx, BUF_MSP_LAYOUT, (size_t)nleaf * (sizeof(uint64_t) + sizeof(uint32_t)), &p))) return rc;
+      uint64_t *lbase = (uint64_t *)p;
+      uint32_t *lcap = (uint32_t *)(lbase + nleaf);
+      hipLaunchKernelGGL(rx_layout_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)v.cnt2, (uint32_t)nleaf, lbase, lcap);
+      HIP_TRY(ctx, hipGetLastError());
+      HIP_TRY(ctx, hipMemsetAsync(v.cnt2, 0, (size_t)nleaf * sizeof(uint32_t), ctx->stream));
+      HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_L2OVF, 0, sizeof(uint64_t), ctx->stream));
+      v.exact = 1; v.lbase = lbase; v.lcap = lcap;
+      hipLaunchKernelGGL(rx2_kernel, dim3((unsigned)g2), dim3(RX2_THREADS), 0, ctx->stream, (int)tiles_per_sub, v, t);
+      HIP_TRY(ctx, hipGetLastError());
+    }
+  }
   hipLaunchKernelGGL(rx3_kernel, dim3((unsigned)nleaf), dim3(RX3_THREADS), 0, ctx->stream, v);
   HIP_TRY(ctx, hipGetLastError());
   // the result list lives where msp.hip keeps its own: digest / export / fold are shared
