@@ -90,6 +90,15 @@ int cfrk_result_export(cfrk_ctx *ctx, const ResultSrc *src, uint64_t *d_lo, uint
 // ---- device helpers -----------------------------------------------------------------------
 #ifdef __HIPCC__
 
+// Diagnostics counter bumped by many lanes at once: the active lanes elect one that adds their
+// number (10^9 atomics on ONE word take seconds: they serialise at the L2).  Counts events.
+__device__ __forceinline__ void dev_count_event(uint64_t *word) {
+  const unsigned long long m = __ballot(1);
+  const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  if (lane == (unsigned)__ffsll((long long)m) - 1u)
+    atomicAdd((unsigned long long *)word, (unsigned long long)__popcll(m));
+}
+
 // Neighbour-lane reads as DPP wave shifts (one VALU instruction; __shfl_down(x, 1) compiles to
 // ds_bpermute + address arithmetic).  The lane without a neighbour reads 0.
 __device__ __forceinline__ uint32_t dev_lane_next(uint32_t x) {       // value of lane + 1

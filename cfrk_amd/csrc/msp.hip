@@ -54,7 +54,7 @@ constexpr int TS_LOG = 12, TS = 1 << TS_LOG;   // LDS table slots per leaf
 // count every k-mer of a record straight into the global HBM table
 __device__ __noinline__ void spill_record(uint4 rec, int k, bool canon, const TableView &t) {
   t.stats[ST_SPILLED] = 1;
-  atomicAdd((unsigned long long *)&t.stats[ST_AUX0], 1ull);
+  dev_count_event(&t.stats[ST_AUX0]);
   const int nk = (int)(rec.w & 63u) + 1;
   const uint64_t hi = ((uint64_t)rec.x << 32) | rec.y;
   const uint64_t lo = (uint64_t)rec.z << 32;
@@ -382,7 +382,7 @@ __device__ __noinline__ void spill_kmer(const TableView &t, uint64_t key, uint32
     return;
   }
   t.stats[ST_SPILLED] = 1;
-  atomicAdd((unsigned long long *)&t.stats[ST_AUX1], (unsigned long long)add);
+  dev_count_event(&t.stats[ST_AUX1]);
   table_add1(t, key, add);
 }
 

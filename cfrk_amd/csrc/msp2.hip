@@ -96,7 +96,7 @@ struct Roll2 {
 
 __device__ __noinline__ void spill_record2(const Rec2 &rec, int k, bool canon, const TableView &t) {
   t.stats[ST_SPILLED] = 1;
-  atomicAdd((unsigned long long *)&t.stats[ST_AUX0], 1ull);
+  dev_count_event(&t.stats[ST_AUX0]);
   const int nk = (int)(rec.b.w & 63u) + 1;
   Roll2 r;
   r.init(rec, k);
@@ -430,7 +430,7 @@ __device__ __forceinline__ void count_record2(ulonglong2 *keys, uint32_t *cnts, 
     for (int it = 0; it < T2_TRIPS && __ballot((int32_t)h >= 0); ++it) t2_step(keys, cnts, lo, hi, add, h);
     if ((int32_t)h >= 0) {
       t.stats[ST_SPILLED] = 1;
-      atomicAdd((unsigned long long *)&t.stats[ST_AUX1], (unsigned long long)add);
+      dev_count_event(&t.stats[ST_AUX1]);
       table_add2(t, lo, hi, add);
     }
     roll.next();
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_merge_kernel(const uint64_t *
       for (int it = 0; it < T2_TRIPS && __ballot((int32_t)h >= 0); ++it) t2_step(keys, cnts, lo, hi, c, h);
       if ((int32_t)h >= 0) {
         t.stats[ST_SPILLED] = 1;
-        atomicAdd((unsigned long long *)&t.stats[ST_AUX1], (unsigned long long)c);
+        dev_count_event(&t.stats[ST_AUX1]);
         table_add2(t, lo, hi, c);
       }
     }
