@@ -25,6 +25,7 @@ enum {  // device stats words (uint64 each)
   ST_OVERFLOW = 0, ST_ONES, ST_CURSOR, ST_DIG0, ST_DIG1, ST_DIG2, ST_DIG3, ST_SPILLED, ST_AUX0,
   ST_AUX1, ST_L2OVF /* leaf streams were too small by a lot: the second level is redone with exact sizes */,
   ST_OVFN /* records parked in the overflow buffer (leaf streams too small by a little) */,
+  ST_MULTISEG /* a leaf was counted in several key-subset passes: its list entries are not contiguous */,
   ST_NWORDS = 16
 };
 

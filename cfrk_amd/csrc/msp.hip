@@ -434,11 +434,24 @@ __device__ __forceinline__ void kt_count(unsigned long long *keys, uint32_t *cnt
   if ((int32_t)b >= 0) spill_kmer(t, key, add);
 }
 
-// expand one record per lane (valid lanes), two k-mers per step; every lane of the wave must call
+// Subset of a leaf's key space (a leaf with more distinct k-mers than its LDS table holds is
+// counted in several passes, each over the keys whose selector bits equal `val`): the selector
+// comes from the same product as the bucket index, but from bits the bucket does not use.
+struct KeySubset { uint32_t mask, val; };
+__device__ __forceinline__ bool in_subset(uint64_t key, KeySubset ss) {
+  return (((((uint32_t)key ^ (uint32_t)(key >> 32)) * 0x9E3779B1u) >> 8) & ss.mask) == ss.val;
+}
+
+// expand one record per lane (valid lanes), two k-mers per step; every lane of the wave must call.
+// Only keys of subset `ss` are counted.  A key that finds no room is counted in the HBM table when
+// ovf == nullptr; otherwise *ovf (an LDS flag) is raised and the caller redoes the subset in
+// halves -- and waves that see the flag up stop working on a pass that is lost anyway.
 template <bool CANON>
 __device__ __forceinline__ void count_record_v2(unsigned long long *keys, uint32_t *cnts, uint4 rec, uint32_t add,
                                                 bool valid, int k, uint64_t kmask, int rcsh,
-                                                const TableView &t) {
+                                                const TableView &t, KeySubset ss = KeySubset{0u, 0u},
+                                                uint32_t *ovf = nullptr) {
+  if (ovf && *(volatile uint32_t *)ovf) return;
   const int nk = valid ? (int)(rec.w & 63u) + 1 : 0;
   const uint64_t hi = ((uint64_t)rec.x << 32) | rec.y;
   const uint64_t lo = (uint64_t)rec.z << 32;
@@ -456,7 +469,7 @@ __device__ __forceinline__ void count_record_v2(unsigned long long *keys, uint32
     T <<= 2;
     fwd = ((fwd << 2) | nb) & kmask;
     if (CANON) rc = (rc >> 2) | ((uint64_t)(3u - nb) << rcsh);
-    bool p0 = j < nk, p1 = j + 1 < nk;
+    bool p0 = j < nk && in_subset(key0, ss), p1 = j + 1 < nk && in_subset(key1, ss);
     if (!CANON && k == 32) {
       // forward-strand all-T 32-mer collides with the EMPTY marker: side counter
       if (p0 && key0 == CFRK_EMPTY_KEY) { spill_kmer(t, key0, add); p0 = false; }
@@ -467,8 +480,12 @@ __device__ __forceinline__ void count_record_v2(unsigned long long *keys, uint32
       kt_try(keys, cnts, key0, b0, add);
       kt_try(keys, cnts, key1, b1, add);
     }
-    if ((int32_t)b0 >= 0) spill_kmer(t, key0, add);
-    if ((int32_t)b1 >= 0) spill_kmer(t, key1, add);
+    if (ovf) {
+      if ((int32_t)(b0 & b1) >= 0) *ovf = 1u;
+    } else {
+      if ((int32_t)b0 >= 0) spill_kmer(t, key0, add);
+      if ((int32_t)b1 >= 0) spill_kmer(t, key1, add);
+    }
   }
 }
 
@@ -543,6 +560,11 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
   __shared__ uint32_t nocc;
   __shared__ uint32_t wg_total;
   __shared__ unsigned long long wg_base;
+  __shared__ uint32_t rt_fail;                   // the record table ran out of room: count from the streams
+  __shared__ uint32_t kovf;                      // the k-mer table ran out of room in this pass
+  __shared__ uint32_t stk[40];                   // key subsets still to count: bits << 16 | value
+  __shared__ int sp;
+  __shared__ uint32_t leaf_total, nseg;
   const int tid = threadIdx.x, lane = tid & 63;
   const uint32_t leaf = blockIdx.x;
   const uint64_t nt = min((uint64_t)v.cnt2[NCLS * leaf + 0], v.exact ? (uint64_t)v.lcap[NCLS * leaf + 0] : v.cap2t);  // truncated runs
@@ -551,7 +573,7 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
   if (nt + n1 == 0) return;
   for (int s = tid; s < TS; s += P3_THREADS) { keys[s] = CFRK_EMPTY_KEY; cnts[s] = 0; }
   for (int s = tid; s < RT; s += P3_THREADS) rtab[s] = make_uint4(0u, 0u, 0u, RT_EMPTY);
-  if (tid == 0) { wg_total = 0; nocc = 0; }
+  if (tid == 0) { wg_total = 0; nocc = 0; rt_fail = 0; kovf = 0; sp = 0; leaf_total = 0; nseg = 0; }
   if (tid < 32) { nhist[tid] = 0; thist[tid] = 0; }
   __syncthreads();
 
@@ -577,8 +599,9 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     auto drain = [&](int cnt) {
       uint32_t h = Lh | ((lane < cnt) ? 0u : RT_DONE);
       rtab_insert_loop(rtab, L, h);
-      // no room in the record table (a leaf with more distinct runs than it holds): expand now
-      if (__ballot((int32_t)h >= 0)) count_record_v2<CANON>(keys, cnts, L, 1u, (int32_t)h >= 0, k, kmask, rcsh, t);
+      // no room in the record table: a leaf with more distinct runs than it holds (low coverage
+      // of a large genome).  Dedupe is pointless there: the whole leaf is counted from its streams.
+      if ((int32_t)h >= 0) rt_fail = 1u;
     };
     auto home = [&](const uint4 rec, bool valid) {
       const uint32_t h = rtab_slot(rec);
@@ -617,10 +640,11 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
   //      its multiplicity) and the truncated runs (weight 1).  Both are first listed SORTED BY
   //      LENGTH (counting sort of 16-bit indices in LDS): a wave expands 64 records in lock-step
   //      for as many steps as its longest one, so equal lengths keep every lane busy.
+  const bool big = rt_fail != 0u;                // (read after the barrier above: uniform)
   {
-    // (a) record table: occupied slots, longest first
+    // (a) record table: occupied slots, longest first (not when the leaf is counted from its streams)
     const uint4 e = rtab[tid];                       // RT == P3_THREADS
-    const bool occ = e.w != RT_EMPTY;
+    const bool occ = !big && e.w != RT_EMPTY;
     uint32_t rank = 0;
     if (occ) rank = atomicAdd(&nhist[e.w & 31u], 1u);
     // (b) truncated runs: the first TL_CAP of the stream, by position
@@ -652,62 +676,111 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
 #pragma unroll
     for (int i = 0; i < TL_PER; ++i)
       if (tw[i] != 0xFFFFFFFFu) tlist[thist[tw[i]] + trank[i]] = (uint16_t)(i * P3_THREADS + tid);
-  }
-  __syncthreads();
-  {
-    const uint32_t nlist = nocc;
-    for (uint32_t i = tid; i < ((nlist + 63u) & ~63u); i += P3_THREADS) {
-      const bool valid = i < nlist;
-      uint4 rec = make_uint4(0u, 0u, 0u, 0u);
-      if (valid) rec = rtab[occ_list[i]];
-      count_record_v2<CANON>(keys, cnts, rec, rec.w >> 6, valid, k, kmask, rcsh, t);
-    }
-    for (uint32_t i = tid; i < ((tl + 63u) & ~63u); i += P3_THREADS) {
-      const bool valid = i < tl;
-      uint4 rec = make_uint4(0u, 0u, 0u, 0u);
-      if (valid) rec = trunc[tlist[i]];
-      count_record_v2<CANON>(keys, cnts, rec, 1u, valid, k, kmask, rcsh, t);
-    }
-    // truncated runs beyond the sorted list (very large leaves): in stream order
-    for (uint64_t i = (uint64_t)tl + tid; i < ((nt + 63) & ~63ull) && tl < nt; i += P3_THREADS) {
-      const bool valid = i < nt;
-      uint4 rec = make_uint4(0u, 0u, 0u, 0u);
-      if (valid) rec = trunc[i];
-      count_record_v2<CANON>(keys, cnts, rec, 1u, valid, k, kmask, rcsh, t);
+    // Key subsets to count: the whole leaf in one pass -- or, when the record table overflowed (it
+    // then held ~10^3 distinct runs, i.e. twice as many distinct k-mers as the k-mer table takes),
+    // four quarters to begin with.
+    if (tid == 0) {
+      if (big) { stk[0] = (2u << 16) | 0u; stk[1] = (2u << 16) | 1u; stk[2] = (2u << 16) | 2u; stk[3] = (2u << 16) | 3u; sp = 4; }
+      else { stk[0] = 0u; sp = 1; }
     }
   }
   __syncthreads();
+  constexpr uint32_t SUBSET_BITS_MAX = 8;        // 256 passes at most; beyond: the HBM table
+  bool first_pass = true;
+  while (true) {
+    const int depth = sp;                        // (every thread reads the same value: barriers around)
+    if (depth == 0) break;
+    const uint32_t item = stk[depth - 1];
+    __syncthreads();
+    if (tid == 0) { sp = depth - 1; kovf = 0; wg_total = 0; }
+    const uint32_t bits = item >> 16;
+    const KeySubset ss{(1u << bits) - 1u, item & 0xFFFFu};
+    uint32_t *ovf = (bits < SUBSET_BITS_MAX) ? &kovf : nullptr;
+    if (!first_pass)
+      for (int s = tid; s < TS; s += P3_THREADS) { keys[s] = CFRK_EMPTY_KEY; cnts[s] = 0; }
+    first_pass = false;
+    __syncthreads();
+    {
+      if (!big) {
+        const uint32_t nlist = nocc;
+        for (uint32_t i = tid; i < ((nlist + 63u) & ~63u); i += P3_THREADS) {
+          const bool valid = i < nlist;
+          uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+          if (valid) rec = rtab[occ_list[i]];
+          count_record_v2<CANON>(keys, cnts, rec, rec.w >> 6, valid, k, kmask, rcsh, t, ss, ovf);
+        }
+      } else {
+        // the complete runs straight from their stream, weight 1 each
+        for (uint64_t i = tid; i < ((n1 + 63) & ~63ull); i += P3_THREADS) {
+          const bool valid = i < n1;
+          uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+          if (valid) rec = leaf_rec[i];
+          count_record_v2<CANON>(keys, cnts, rec, 1u, valid, k, kmask, rcsh, t, ss, ovf);
+        }
+      }
+      for (uint32_t i = tid; i < ((tl + 63u) & ~63u); i += P3_THREADS) {
+        const bool valid = i < tl;
+        uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+        if (valid) rec = trunc[tlist[i]];
+        count_record_v2<CANON>(keys, cnts, rec, 1u, valid, k, kmask, rcsh, t, ss, ovf);
+      }
+      // truncated runs beyond the sorted list (very large leaves): in stream order
+      for (uint64_t i = (uint64_t)tl + tid; i < ((nt + 63) & ~63ull) && tl < nt; i += P3_THREADS) {
+        const bool valid = i < nt;
+        uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+        if (valid) rec = trunc[i];
+        count_record_v2<CANON>(keys, cnts, rec, 1u, valid, k, kmask, rcsh, t, ss, ovf);
+      }
+    }
+    __syncthreads();
+    if (kovf) {
+      // this subset does not fit the table either: its two halves replace it (the table is discarded)
+      if (tid == 0) {
+        const int d0 = sp;
+        stk[d0] = ((bits + 1u) << 16) | ss.val;
+        stk[d0 + 1] = ((bits + 1u) << 16) | ss.val | (1u << bits);
+        sp = d0 + 2;
+      }
+      __syncthreads();
+      continue;
+    }
 
-  // ---- compact occupied slots to the output list: ONE cursor atomic per workgroup (a global
-  //      atomic per wave on the single cursor word serialises the whole grid)
-  constexpr int NIT = TS / P3_THREADS;
-  uint32_t wbase[NIT];
+    // ---- compact occupied slots to the output list: ONE cursor atomic per workgroup and pass (a
+    //      global atomic per wave on the single cursor word serialises the whole grid)
+    constexpr int NIT = TS / P3_THREADS;
+    uint32_t wbase[NIT];
 #pragma unroll
-  for (int i = 0; i < NIT; ++i) {
-    const unsigned long long m = __ballot(keys[i * P3_THREADS + tid] != CFRK_EMPTY_KEY);
-    uint32_t b = 0;
-    if (lane == 0 && m) b = atomicAdd(&wg_total, (uint32_t)__popcll(m));
-    wbase[i] = __shfl(b, 0);
-  }
-  __syncthreads();
-  if (tid == 0) {
-    wg_base = atomicAdd((unsigned long long *)&v.stats[ST_CURSOR], (unsigned long long)wg_total);
-    v.leaf_off[leaf] = wg_base;
-    v.leaf_n[leaf] = wg_total;
-  }
-  __syncthreads();
-  const unsigned long long gb = wg_base;
-#pragma unroll
-  for (int i = 0; i < NIT; ++i) {
-    const int s = i * P3_THREADS + tid;
-    const unsigned long long key = keys[s];
-    const bool occ = key != CFRK_EMPTY_KEY;
-    const unsigned long long m = __ballot(occ);
-    if (occ) {
-      const unsigned long long dst = gb + wbase[i] + __popcll(m & ((1ull << lane) - 1ull));
-      if (dst < v.out_cap) { v.out_keys[dst] = key; v.out_cnt[dst] = cnts[s]; }
-      else v.stats[ST_OVERFLOW] = 1;
+    for (int i = 0; i < NIT; ++i) {
+      const unsigned long long m = __ballot(keys[i * P3_THREADS + tid] != CFRK_EMPTY_KEY);
+      uint32_t b = 0;
+      if (lane == 0 && m) b = atomicAdd(&wg_total, (uint32_t)__popcll(m));
+      wbase[i] = __shfl(b, 0);
     }
+    __syncthreads();
+    if (tid == 0) {
+      wg_base = atomicAdd((unsigned long long *)&v.stats[ST_CURSOR], (unsigned long long)wg_total);
+      // a leaf counted in several passes has several segments in the list: no per-leaf index then
+      if (nseg == 0) v.leaf_off[leaf] = wg_base;
+      else if (wg_total) v.stats[ST_MULTISEG] = 1;
+      if (wg_total) nseg = nseg + 1;
+      leaf_total += wg_total;
+      v.leaf_n[leaf] = leaf_total;
+    }
+    __syncthreads();
+    const unsigned long long gb = wg_base;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int s = i * P3_THREADS + tid;
+      const unsigned long long key = keys[s];
+      const bool occ = key != CFRK_EMPTY_KEY;
+      const unsigned long long m = __ballot(occ);
+      if (occ) {
+        const unsigned long long dst = gb + wbase[i] + __popcll(m & ((1ull << lane) - 1ull));
+        if (dst < v.out_cap) { v.out_keys[dst] = key; v.out_cnt[dst] = cnts[s]; }
+        else v.stats[ST_OVERFLOW] = 1;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -1088,6 +1161,14 @@ int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
     if ((rc = cfrk_msp_sync_stats(ctx, st))) return rc;
     if (st[ST_OVERFLOW]) return cfrk_fail(ctx, CFRK_ERR_TABLE_FULL, "result list of %llu entries overflowed", (unsigned long long)ms->view.out_cap);
     const uint64_t n = st[ST_CURSOR];
+    if (st[ST_MULTISEG]) {
+      // leaves counted in several key-subset passes have no per-leaf index: this pass's list goes
+      // through the HBM table instead of the per-leaf merge
+      for (int l = 0; l < NLEAF; ++l) { so[(size_t)pass * NLEAF + l] = acc_n; sn[(size_t)pass * NLEAF + l] = 0; }
+      if ((rc = cfrk_msp_flush_to_table(ctx))) return rc;
+      HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_MULTISEG, 0, sizeof(uint64_t), ctx->stream));
+      continue;
+    }
     HIP_TRY(ctx, hipMemcpyAsync(acc_k + acc_n, ms->view.out_keys, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(acc_c + acc_n, ms->view.out_cnt, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(lo1.data(), ms->view.leaf_off, NLEAF * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -1197,6 +1278,7 @@ extern "C" int cfrk_global_export_leaves_device(cfrk_ctx *ctx, uint64_t *d_keys,
   if (rc) return rc;
   if (st[ST_OVERFLOW]) return cfrk_fail(ctx, CFRK_ERR_TABLE_FULL, "result list overflowed");
   if (st[ST_SPILLED] || st[ST_ONES]) return cfrk_fail(ctx, CFRK_ERR_STATE, "part of the result lives in the HBM table");
+  if (st[ST_MULTISEG]) return cfrk_fail(ctx, CFRK_ERR_STATE, "leaves were counted in several passes: no per-leaf index");
   const int lpp = (NLEAF + parts - 1) / parts;           // leaves per part (owner p: leaves p, p+parts, ...)
   std::vector<uint32_t> ln(NLEAF), ordered((size_t)parts * lpp, 0u);
   std::vector<uint64_t> doff(NLEAF);

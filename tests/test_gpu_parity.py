@@ -380,12 +380,14 @@ def test_msp_low_complexity_and_many_invalid(ctx):
 
 
 def test_msp_leaf_table_overflow_spills_to_hbm_table(ctx):
-    """all-distinct input with far more distinct k-mers per leaf than an LDS table holds: the
-    excess is counted in the HBM table and the result is still exact"""
+    """all-distinct input with more distinct k-mers per leaf (5500) than an LDS table holds: the
+    leaf is counted in several passes over subsets of its key space (earlier: the excess went to
+    the HBM table) and the result is exact"""
     import cfrk_amd
     data, _, _ = orc.synth_reads(0, 3_000_000, 150, 0, uniform=True)   # 3.6e8 k-mers, ~all distinct
     g = cfrk_amd.GlobalCounter(ctx, 31, cfrk_amd.CFRK_CANONICAL, 400_000_000)
     g.add(data)
+    assert g.msp_info()["spilled_kmers"] == 0
     d = g.digest()
     assert d[1] == 3_000_000 * 120
     g2 = cfrk_amd.GlobalCounter(ctx, 31, cfrk_amd.CFRK_CANONICAL | cfrk_amd.CFRK_FORCE_HASH, 400_000_000)
