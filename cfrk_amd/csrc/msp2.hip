@@ -415,23 +415,37 @@ __device__ __forceinline__ void t2_step(ulonglong2 *keys, uint32_t *cnts, uint64
   h = (p && !match && won == 0u) ? nh : (h | T2_DONE);
 }
 
+// key subsets as in msp.hip: selector bits from the slot hash's unused bits
+struct KeySubset2 { uint32_t mask, val; };
+__device__ __forceinline__ bool in_subset2(uint64_t lo, uint64_t hi, KeySubset2 ss) {
+  const uint32_t x = (uint32_t)lo ^ (uint32_t)(lo >> 32) ^ ((uint32_t)hi * 0x85EBCA77u) ^ (uint32_t)(hi >> 32);
+  return (((x * 0x9E3779B1u) >> 6) & ss.mask) == ss.val;
+}
+
 // expand one record per lane (valid lanes), every k-mer counted `add` times; every lane of the
-// wave must call
+// wave must call.  Only keys of subset `ss`; a key without room goes to the HBM table when
+// ovf == nullptr, else raises the LDS flag *ovf (the caller then redoes the subset in halves).
 template <bool CANON>
 __device__ __forceinline__ void count_record2(ulonglong2 *keys, uint32_t *cnts, const Rec2 &rec, uint32_t add,
-                                              bool valid, int k, const TableView &t) {
+                                              bool valid, int k, const TableView &t,
+                                              KeySubset2 ss = KeySubset2{0u, 0u}, uint32_t *ovf = nullptr) {
+  if (ovf && *(volatile uint32_t *)ovf) return;
   const int nk = valid ? (int)(rec.b.w & 63u) + 1 : 0;
   Roll2 roll;
   roll.init(rec, k);
   for (int j = 0; __ballot(j < nk); ++j) {
     const u128 key = (CANON && roll.rc < roll.fwd) ? roll.rc : roll.fwd;
     const uint64_t lo = (uint64_t)key, hi = (uint64_t)(key >> 64);
-    uint32_t h = t2_slot(lo, hi) | ((j < nk) ? 0u : T2_DONE);
+    uint32_t h = t2_slot(lo, hi) | ((j < nk && in_subset2(lo, hi, ss)) ? 0u : T2_DONE);
     for (int it = 0; it < T2_TRIPS && __ballot((int32_t)h >= 0); ++it) t2_step(keys, cnts, lo, hi, add, h);
     if ((int32_t)h >= 0) {
-      t.stats[ST_SPILLED] = 1;
-      dev_count_event(&t.stats[ST_AUX1]);
-      table_add2(t, lo, hi, add);
+      if (ovf) {
+        *ovf = 1u;
+      } else {
+        t.stats[ST_SPILLED] = 1;
+        dev_count_event(&t.stats[ST_AUX1]);
+        table_add2(t, lo, hi, add);
+      }
     }
     roll.next();
   }
@@ -496,6 +510,10 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
   __shared__ uint32_t nocc;
   __shared__ uint32_t wg_total;
   __shared__ unsigned long long wg_base;
+  __shared__ uint32_t rt_fail, kovf;             // record table / k-mer table ran out of room (msp.hip)
+  __shared__ uint32_t stk[40];                   // key subsets still to count: bits << 16 | value
+  __shared__ int sp;
+  __shared__ uint32_t leaf_total, nseg;
   const int tid = threadIdx.x, lane = tid & 63;
   const uint32_t leaf = blockIdx.x;
   uint64_t ns[NCLS];
@@ -513,29 +531,31 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
     z.a = make_uint4(0u, 0u, 0u, 0u); z.b = make_uint4(0u, 0u, 0u, R2_EMPTY);
     rtab[tid] = z;
   }
-  if (tid == 0) { wg_total = 0; nocc = 0; }
+  if (tid == 0) { wg_total = 0; nocc = 0; rt_fail = 0; kovf = 0; sp = 0; leaf_total = 0; nseg = 0; }
   if (tid < 32) nhist[tid] = 0;
   __syncthreads();
 
   const Rec2 *leaf_rec = v.exact ? v.rec2 + v.lbase[NCLS * leaf + 3] : v.rec2 + (uint64_t)leaf * (v.cap2c + 3 * v.cap2t);
   const Rec2 zrec = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
-  // ---- phase 1: complete runs, one record-table update per record; a record that finds no
-  //      room is expanded on the spot
+  // ---- phase 1: complete runs, one record-table update per record; when the table runs out of
+  //      room (more distinct runs than it holds: low coverage of a large genome) the dedupe is
+  //      dropped and the whole leaf is counted from its streams
   for (uint64_t r = tid; r < ((ns[3] + 63) & ~63ull); r += Q3_THREADS) {
     const bool valid = r < ns[3];
     Rec2 rec = zrec;
     if (valid) rec = leaf_rec[r];
     uint32_t h = r2_slot(rec) | (valid ? 0u : R2_DONE);
     r2_insert_loop(rtab, rec, h);
-    if (__ballot((int32_t)h >= 0)) count_record2<CANON>(keys, cnts, rec, 1u, (int32_t)h >= 0, k, t);
+    if ((int32_t)h >= 0) rt_fail = 1u;
   }
   __syncthreads();
+  const bool big = rt_fail != 0u;
   // ---- phase 2: every distinct complete record once (weight = multiplicity), listed longest
   //      first (a wave expands 64 records in lock-step for as many steps as its longest one),
   //      then the truncated runs by length class, long ones first
   {
     const uint32_t st = rtab[tid].b.w;
-    const bool occ = st != R2_EMPTY;
+    const bool occ = !big && st != R2_EMPTY;
     uint32_t rank = 0;
     if (occ) rank = atomicAdd(&nhist[st & 31u], 1u);
     __syncthreads();
@@ -552,54 +572,97 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
     }
     __syncthreads();
     if (occ) occ_list[nhist[st & 31u] + rank] = (uint16_t)tid;
-  }
-  __syncthreads();
-  for (uint32_t i = tid; i < ((nocc + 63u) & ~63u); i += Q3_THREADS) {
-    const bool valid = i < nocc;
-    Rec2 rec = zrec;
-    if (valid) rec = rtab[occ_list[i]];
-    count_record2<CANON>(keys, cnts, rec, rec.b.w >> 6, valid, k, t);
-  }
-  for (int cl = 2; cl >= 0; --cl) {
-    const Rec2 *src = v.exact ? v.rec2 + v.lbase[NCLS * leaf + cl] : leaf_rec + v.cap2c + (uint64_t)cl * v.cap2t;
-    for (uint64_t r = tid; r < ((ns[cl] + 63) & ~63ull); r += Q3_THREADS) {
-      const bool valid = r < ns[cl];
-      Rec2 rec = zrec;
-      if (valid) rec = src[r];
-      count_record2<CANON>(keys, cnts, rec, 1u, valid, k, t);
+    if (tid == 0) {
+      if (big) { stk[0] = (2u << 16) | 0u; stk[1] = (2u << 16) | 1u; stk[2] = (2u << 16) | 2u; stk[3] = (2u << 16) | 3u; sp = 4; }
+      else { stk[0] = 0u; sp = 1; }
     }
   }
   __syncthreads();
+  constexpr uint32_t SUBSET_BITS_MAX = 8;
+  bool first_pass = true;
+  while (true) {
+    const int depth = sp;
+    if (depth == 0) break;
+    const uint32_t item = stk[depth - 1];
+    __syncthreads();
+    if (tid == 0) { sp = depth - 1; kovf = 0; wg_total = 0; }
+    const uint32_t bits = item >> 16;
+    const KeySubset2 ss{(1u << bits) - 1u, item & 0xFFFFu};
+    uint32_t *ovf = (bits < SUBSET_BITS_MAX) ? &kovf : nullptr;
+    if (!first_pass)
+      for (int s = tid; s < T2; s += Q3_THREADS) cnts[s] = 0;
+    first_pass = false;
+    __syncthreads();
+    if (!big) {
+      for (uint32_t i = tid; i < ((nocc + 63u) & ~63u); i += Q3_THREADS) {
+        const bool valid = i < nocc;
+        Rec2 rec = zrec;
+        if (valid) rec = rtab[occ_list[i]];
+        count_record2<CANON>(keys, cnts, rec, rec.b.w >> 6, valid, k, t, ss, ovf);
+      }
+    } else {
+      for (uint64_t r = tid; r < ((ns[3] + 63) & ~63ull); r += Q3_THREADS) {
+        const bool valid = r < ns[3];
+        Rec2 rec = zrec;
+        if (valid) rec = leaf_rec[r];
+        count_record2<CANON>(keys, cnts, rec, 1u, valid, k, t, ss, ovf);
+      }
+    }
+    for (int cl = 2; cl >= 0; --cl) {
+      const Rec2 *src = v.exact ? v.rec2 + v.lbase[NCLS * leaf + cl] : leaf_rec + v.cap2c + (uint64_t)cl * v.cap2t;
+      for (uint64_t r = tid; r < ((ns[cl] + 63) & ~63ull); r += Q3_THREADS) {
+        const bool valid = r < ns[cl];
+        Rec2 rec = zrec;
+        if (valid) rec = src[r];
+        count_record2<CANON>(keys, cnts, rec, 1u, valid, k, t, ss, ovf);
+      }
+    }
+    __syncthreads();
+    if (kovf) {
+      if (tid == 0) {
+        const int d0 = sp;
+        stk[d0] = ((bits + 1u) << 16) | ss.val;
+        stk[d0 + 1] = ((bits + 1u) << 16) | ss.val | (1u << bits);
+        sp = d0 + 2;
+      }
+      __syncthreads();
+      continue;
+    }
 
-  // compaction to the two-word result list: one cursor atomic per workgroup
-  constexpr int NIT = T2 / Q3_THREADS;
-  uint32_t wbase[NIT];
+    // compaction to the two-word result list: one cursor atomic per workgroup and pass
+    constexpr int NIT = T2 / Q3_THREADS;
+    uint32_t wbase[NIT];
 #pragma unroll
-  for (int i = 0; i < NIT; ++i) {
-    const unsigned long long mm = __ballot(cnts[i * Q3_THREADS + tid] != 0u);
-    uint32_t b = 0;
-    if (lane == 0 && mm) b = atomicAdd(&wg_total, (uint32_t)__popcll(mm));
-    wbase[i] = __shfl(b, 0);
-  }
-  __syncthreads();
-  if (tid == 0) {
-    wg_base = atomicAdd((unsigned long long *)&v.stats[ST_CURSOR], (unsigned long long)wg_total);
-    v.leaf_off[leaf] = wg_base;
-    v.leaf_n[leaf] = wg_total;
-  }
-  __syncthreads();
-  const unsigned long long gb = wg_base;
-#pragma unroll
-  for (int i = 0; i < NIT; ++i) {
-    const int s = i * Q3_THREADS + tid;
-    const uint32_t cval = cnts[s];
-    const bool occ = cval != 0u;
-    const unsigned long long mm = __ballot(occ);
-    if (occ) {
-      const unsigned long long dst = gb + wbase[i] + __popcll(mm & ((1ull << lane) - 1ull));
-      if (dst < v.out_cap) { v.out_lo[dst] = keys[s].x; v.out_hi[dst] = keys[s].y; v.out_cnt[dst] = cval; }
-      else v.stats[ST_OVERFLOW] = 1;
+    for (int i = 0; i < NIT; ++i) {
+      const unsigned long long mm = __ballot(cnts[i * Q3_THREADS + tid] != 0u);
+      uint32_t b = 0;
+      if (lane == 0 && mm) b = atomicAdd(&wg_total, (uint32_t)__popcll(mm));
+      wbase[i] = __shfl(b, 0);
     }
+    __syncthreads();
+    if (tid == 0) {
+      wg_base = atomicAdd((unsigned long long *)&v.stats[ST_CURSOR], (unsigned long long)wg_total);
+      if (nseg == 0) v.leaf_off[leaf] = wg_base;
+      else if (wg_total) v.stats[ST_MULTISEG] = 1;
+      if (wg_total) nseg = nseg + 1;
+      leaf_total += wg_total;
+      v.leaf_n[leaf] = leaf_total;
+    }
+    __syncthreads();
+    const unsigned long long gb = wg_base;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int s = i * Q3_THREADS + tid;
+      const uint32_t cval = cnts[s];
+      const bool occ = cval != 0u;
+      const unsigned long long mm = __ballot(occ);
+      if (occ) {
+        const unsigned long long dst = gb + wbase[i] + __popcll(mm & ((1ull << lane) - 1ull));
+        if (dst < v.out_cap) { v.out_lo[dst] = keys[s].x; v.out_hi[dst] = keys[s].y; v.out_cnt[dst] = cval; }
+        else v.stats[ST_OVERFLOW] = 1;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -874,6 +937,13 @@ int cfrk_msp2_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
     if ((rc = cfrk_msp_sync_stats(ctx, st))) return rc;
     if (st[ST_OVERFLOW]) return cfrk_fail(ctx, CFRK_ERR_TABLE_FULL, "result list of %llu entries overflowed", (unsigned long long)ms->view.out_cap);
     const uint64_t n = st[ST_CURSOR];
+    if (st[ST_MULTISEG]) {
+      // leaves counted in several key-subset passes have no per-leaf index: through the HBM table
+      for (int l = 0; l < NLEAF; ++l) { so[(size_t)pass * NLEAF + l] = acc_n; sn[(size_t)pass * NLEAF + l] = 0; }
+      if ((rc = cfrk_msp_flush_to_table(ctx))) return rc;
+      HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_MULTISEG, 0, sizeof(uint64_t), ctx->stream));
+      continue;
+    }
     HIP_TRY(ctx, hipMemcpyAsync(acc_lo + acc_n, ms->view.out_keys, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(acc_hi + acc_n, ms->view.out_hi, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(acc_c + acc_n, ms->view.out_cnt, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
