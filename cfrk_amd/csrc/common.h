@@ -18,6 +18,7 @@ enum {  // pool slots
   BUF_MSP_ACCK, BUF_MSP_ACCH, BUF_MSP_ACCC,   // lists of the passes of a multi-pass add, merged per leaf at the end
   BUF_MSP_LAYOUT,                             // exact second-level layout (stream bases and sizes)
   BUF_MSP_OVF,                                // records that did not fit their leaf stream (a few)
+  BUF_MSP_OVF1, BUF_MSP_LAYOUT1,              // the same for the level-1 regions
   BUF_NSLOTS
 };
 
@@ -26,6 +27,8 @@ enum {  // device stats words (uint64 each)
   ST_AUX1, ST_L2OVF /* leaf streams were too small by a lot: the second level is redone with exact sizes */,
   ST_OVFN /* records parked in the overflow buffer (leaf streams too small by a little) */,
   ST_MULTISEG /* a leaf was counted in several key-subset passes: its list entries are not contiguous */,
+  ST_L1OVF /* level-1 regions were too small by a lot: the first level is redone with exact sizes */,
+  ST_OVFN1 /* records parked because their level-1 region was full (a few) */,
   ST_NWORDS = 16
 };
 

@@ -77,6 +77,23 @@ __device__ __noinline__ void spill_record(uint4 rec, int k, bool canon, const Ta
 constexpr int P1_OWN = 61;                       // owner lanes per wave
 constexpr int P1_WAVES = P1_THREADS / 64;
 
+// write record `rec` as entry `dst` of level-1 region `reg`; a full region parks a few records and
+// beyond that raises ST_L1OVF (the cursors keep counting: the host redoes P1 with exact sizes)
+__device__ __forceinline__ void l1_put(const MspView &v, uint32_t reg, uint32_t dst, uint4 rec, int k, bool canon,
+                                       const TableView &t) {
+  const uint64_t cap = v.exact1 ? (uint64_t)v.rcap[reg] : v.cap1;
+  const uint64_t at = v.exact1 ? v.rbase[reg] : (uint64_t)reg * v.cap1;
+  if (dst < cap) {
+    v.rec1[at + dst] = rec;
+  } else if (v.exact1) {
+    spill_record(rec, k, canon, t);                      // cannot happen: cap is the exact count
+  } else if (*(volatile uint64_t *)&v.stats[ST_L1OVF] == 0) {
+    const unsigned long long o = atomicAdd((unsigned long long *)&v.stats[ST_OVFN1], 1ull);
+    if (o < v.ovf1_cap) v.ovf1[o] = rec;
+    else v.stats[ST_L1OVF] = 1;
+  }
+}
+
 template <int W>
 __global__ __launch_bounds__(P1_THREADS, 6) void msp_p1_kernel(const int8_t *__restrict__ data,
                                                             int64_t nN, int k, int m, int canon,
@@ -191,8 +208,7 @@ __global__ __launch_bounds__(P1_THREADS, 6) void msp_p1_kernel(const int8_t *__r
       // LDS staging full (pathological tile): append directly
       const uint32_t reg = bin1 * v.nxg + (blockIdx.x & (v.nxg - 1));
       const uint32_t dst = atomicAdd(&v.cnt1[reg], 1u);
-      if (dst < v.cap1) v.rec1[(uint64_t)reg * v.cap1 + dst] = rec;
-      else spill_record(rec, k, canon != 0, t);
+      l1_put(v, reg, dst, rec, k, canon != 0, t);
     }
     ++slot;
   }
@@ -221,8 +237,7 @@ __global__ __launch_bounds__(P1_THREADS, 6) void msp_p1_kernel(const int8_t *__r
     const uint32_t b = bin_tmp[s];
     const uint32_t dst = gbase[b] + (p - loff[b]);
     const uint4 rec = rec_tmp[s];
-    if (dst < v.cap1) v.rec1[((uint64_t)b * v.nxg + (blockIdx.x & (v.nxg - 1))) * v.cap1 + dst] = rec;
-    else spill_record(rec, k, canon != 0, t);
+    l1_put(v, b * v.nxg + (blockIdx.x & (v.nxg - 1)), dst, rec, k, canon != 0, t);
   }
 }
 
@@ -255,7 +270,8 @@ __global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int groups_per_bin, 
   // The bin's sub-regions are read as ONE stream (region after region): tiles are full except the
   // bin's last one, however many cursors P1 spreads its appends over.
   if (tid < 64) {
-    const uint32_t c = ((uint32_t)tid < v.nxg) ? (uint32_t)min((uint64_t)v.cnt1[b1 * v.nxg + tid], v.cap1) : 0u;
+    const uint32_t c = ((uint32_t)tid < v.nxg) ? (uint32_t)min((uint64_t)v.cnt1[b1 * v.nxg + tid],
+                                                               v.exact1 ? (uint64_t)v.rcap[b1 * v.nxg + tid] : v.cap1) : 0u;
     uint32_t incl = c;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -279,6 +295,7 @@ __global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int groups_per_bin, 
       const uint32_t mid = (lo + hi) >> 1;
       if (rpre[mid] <= idx) lo = mid; else hi = mid;
     }
+    if (v.exact1) return v.rec1[v.rbase[b1 * v.nxg + lo] + (idx - rpre[lo])];
     return bin_base[(uint64_t)lo * v.cap1 + (idx - rpre[lo])];
   };
   const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
@@ -863,15 +880,15 @@ __global__ __launch_bounds__(P3_THREADS) void msp_merge_kernel(const uint64_t *_
   }
 }
 
-// exact layout of the second level from the demand the first attempt counted: lbase = exclusive
-// prefix sum of cnt2 over the NCLS * NLEAF streams, lcap = cnt2 (single workgroup, 1024 threads)
-__global__ __launch_bounds__(1024) void msp_layout_kernel(const uint32_t *__restrict__ cnt2, uint64_t *__restrict__ lbase,
-                                                          uint32_t *__restrict__ lcap) {
+// exact layout of a level from the demand the first attempt counted: base = exclusive prefix sum
+// of the n cursors, cap = the cursors themselves (single workgroup, 1024 threads)
+__global__ __launch_bounds__(1024) void msp_layout_kernel(const uint32_t *__restrict__ cnt, uint32_t n,
+                                                          uint64_t *__restrict__ base, uint32_t *__restrict__ cap) {
   __shared__ unsigned long long part[1024];
-  constexpr int N = NCLS * NLEAF, PER = N / 1024;
-  const int tid = threadIdx.x;
+  const uint32_t per = (n + 1023u) / 1024u;
+  const uint32_t tid = threadIdx.x;
   unsigned long long s = 0;
-  for (int i = 0; i < PER; ++i) s += cnt2[tid * PER + i];
+  for (uint32_t i = 0; i < per; ++i) { const uint32_t l = tid * per + i; if (l < n) s += cnt[l]; }
   part[tid] = s;
   __syncthreads();
   if (tid == 0) {
@@ -880,11 +897,9 @@ __global__ __launch_bounds__(1024) void msp_layout_kernel(const uint32_t *__rest
   }
   __syncthreads();
   unsigned long long run = part[tid];
-  for (int i = 0; i < PER; ++i) {
-    const uint32_t c = cnt2[tid * PER + i];
-    lbase[tid * PER + i] = run;
-    lcap[tid * PER + i] = c;
-    run += c;
+  for (uint32_t i = 0; i < per; ++i) {
+    const uint32_t l = tid * per + i;
+    if (l < n) { const uint32_t c = cnt[l]; base[l] = run; cap[l] = c; run += c; }
   }
 }
 
@@ -1018,55 +1033,97 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
   HIP_TRY(ctx, hipMemsetAsync(v.cnt1, 0, (size_t)(B1 * nxg + (NCLS + 1) * NLEAF) * sizeof(uint32_t), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_CURSOR, 0, sizeof(uint64_t), ctx->stream));
 
-  const dim3 g1((unsigned)ntiles), b1(P1_THREADS);
-#define CFRK_P1_CASE(WW) \
-  case WW: hipLaunchKernelGGL((msp_p1_kernel<WW>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, tile0, v, t); break;
-  switch (W) {
-    CFRK_P1_CASE(4) CFRK_P1_CASE(5) CFRK_P1_CASE(6) CFRK_P1_CASE(7) CFRK_P1_CASE(8) CFRK_P1_CASE(9)
-    CFRK_P1_CASE(10) CFRK_P1_CASE(11) CFRK_P1_CASE(12) CFRK_P1_CASE(13) CFRK_P1_CASE(14)
-    CFRK_P1_CASE(15) CFRK_P1_CASE(16) CFRK_P1_CASE(17) CFRK_P1_CASE(18)
-    default: return cfrk_fail(ctx, CFRK_ERR_ARG, "no partition kernel for W=%d", W);
-  }
-#undef CFRK_P1_CASE
-  HIP_TRY(ctx, hipGetLastError());
-  v.exact = 0; v.lbase = nullptr; v.lcap = nullptr;
+  // Both levels are laid out for an input that spreads evenly over the minimizer space.  One that
+  // does not -- deep coverage of a small genome puts tens of thousands of records into a handful of
+  // leaves, a single amplicon into a handful of level-1 bins -- overflows its regions; the cursors
+  // keep counting past the capacity, so after P2 the host knows the exact demand of both levels
+  // (one 40-byte D2H + stream sync per add).  A few overflowing records (lumpy leaves) were
+  // parked in a small buffer and are counted through the HBM table; more than that and the
+  // level is laid out again back to back with exactly the room each region needs -- all records
+  // together never exceed what the buffers already hold -- and its kernel runs again.
   constexpr uint32_t OVF_CAP = 1u << 20;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_OVF, (size_t)OVF_CAP * sizeof(uint4), &p))) return rc;
-  // "a few" = under 0.4 % of the expected records (and what the buffer holds)
-  v.ovf = (uint4 *)p; v.ovf_cap = (uint32_t)std::min<double>((double)OVF_CAP, expect / 256.0);
-  HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_L2OVF, 0, 2 * sizeof(uint64_t), ctx->stream));   // ST_L2OVF, ST_OVFN
-  hipLaunchKernelGGL(msp_p2_kernel, dim3((unsigned)(tiles_per_sub * B1)), dim3(P2_THREADS), 0, ctx->stream,
-                     (int)tiles_per_sub, k, canon, v, t);
-  HIP_TRY(ctx, hipGetLastError());
-  {
-    // Did every leaf stream fit its fixed stride?  (Deep coverage of a small genome puts tens of
-    // thousands of records into a handful of leaves.)  If not, the cursors hold the exact demand:
-    // lay the streams out back to back with exactly that much room -- all records together never
-    // exceed what the level-2 buffer already holds -- and run P2 again.  One word D2H + a stream
-    // sync per add; the alternative was 10^7 records counted k-mer by k-mer with HBM atomics.
-    uint64_t ovf[2] = {0, 0};                              // ST_L2OVF, ST_OVFN
-    HIP_TRY(ctx, hipMemcpyAsync(ovf, ctx->g_stats + ST_L2OVF, sizeof ovf, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (!ovf[0] && ovf[1]) {
-      // a few records (lumpy leaves): count them in the HBM table, keep everything else
-      const uint32_t n = (uint32_t)ovf[1];
-      hipLaunchKernelGGL(msp_spill_list_kernel, dim3((n + 255u) / 256u), dim3(256), 0, ctx->stream, (const uint4 *)v.ovf, n, k,
-                         canon, t);
+  v.ovf = (uint4 *)p; v.ovf_cap = (uint32_t)std::min<double>((double)OVF_CAP, expect / 256.0);   // "a few": < 0.4 %
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_OVF1, (size_t)OVF_CAP * sizeof(uint4), &p))) return rc;
+  v.ovf1 = (uint4 *)p; v.ovf1_cap = v.ovf_cap;
+  v.exact = 0; v.lbase = nullptr; v.lcap = nullptr;
+  v.exact1 = 0; v.rbase = nullptr; v.rcap = nullptr;
+  const size_t nreg = (size_t)B1 * nxg;
+  int64_t p2_groups = tiles_per_sub;             // tile groups per bin P2 is launched with
+  bool run_p1 = true;
+  uint64_t parked1 = 0, parked2 = 0;
+  for (int attempt = 0; attempt < 4; ++attempt) {
+    if (run_p1) {
+      HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_L1OVF, 0, 2 * sizeof(uint64_t), ctx->stream));   // ST_L1OVF, ST_OVFN1
+      const dim3 g1((unsigned)ntiles), b1(P1_THREADS);
+#define CFRK_P1_CASE(WW) \
+      case WW: hipLaunchKernelGGL((msp_p1_kernel<WW>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, tile0, v, t); break;
+      switch (W) {
+        CFRK_P1_CASE(4) CFRK_P1_CASE(5) CFRK_P1_CASE(6) CFRK_P1_CASE(7) CFRK_P1_CASE(8) CFRK_P1_CASE(9)
+        CFRK_P1_CASE(10) CFRK_P1_CASE(11) CFRK_P1_CASE(12) CFRK_P1_CASE(13) CFRK_P1_CASE(14)
+        CFRK_P1_CASE(15) CFRK_P1_CASE(16) CFRK_P1_CASE(17) CFRK_P1_CASE(18)
+        default: return cfrk_fail(ctx, CFRK_ERR_ARG, "no partition kernel for W=%d", W);
+      }
+#undef CFRK_P1_CASE
       HIP_TRY(ctx, hipGetLastError());
     }
-    if (ovf[0]) {
-      if ((rc = cfrk_pool_get(ctx, BUF_MSP_LAYOUT, (size_t)NCLS * NLEAF * (sizeof(uint64_t) + 2 * sizeof(uint32_t)), &p))) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_L2OVF, 0, 2 * sizeof(uint64_t), ctx->stream));   // ST_L2OVF, ST_OVFN
+    hipLaunchKernelGGL(msp_p2_kernel, dim3((unsigned)(p2_groups * B1)), dim3(P2_THREADS), 0, ctx->stream,
+                       (int)p2_groups, k, canon, v, t);
+    HIP_TRY(ctx, hipGetLastError());
+    uint64_t st[ST_NWORDS];
+    HIP_TRY(ctx, hipMemcpyAsync(st, ctx->g_stats, sizeof st, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (st[ST_L1OVF]) {
+      // exact level-1 layout; P2 ran on an incomplete level 1 and is redone as well
+      if ((rc = cfrk_pool_get(ctx, BUF_MSP_LAYOUT1, nreg * (sizeof(uint64_t) + sizeof(uint32_t)), &p))) return rc;
+      uint64_t *rbase = (uint64_t *)p;
+      uint32_t *rcap = (uint32_t *)(rbase + nreg);
+      hipLaunchKernelGGL(msp_layout_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)v.cnt1, (uint32_t)nreg, rbase, rcap);
+      HIP_TRY(ctx, hipGetLastError());
+      {
+        // the heaviest bin decides how many tile groups per bin P2 needs from now on
+        std::vector<uint32_t> c1(nreg);
+        HIP_TRY(ctx, hipMemcpyAsync(c1.data(), v.cnt1, nreg * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        uint64_t maxbin = 0;
+        for (int b = 0; b < B1; ++b) {
+          uint64_t sum = 0;
+          for (int r = 0; r < nxg; ++r) sum += c1[(size_t)b * nxg + r];
+          maxbin = std::max(maxbin, sum);
+        }
+        p2_groups = (int64_t)((maxbin + (uint64_t)P2_TILE * P2_GROUP - 1) / ((uint64_t)P2_TILE * P2_GROUP)) + 1;
+        if (p2_groups * B1 > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
+      }
+      HIP_TRY(ctx, hipMemsetAsync(v.cnt1, 0, (nreg + (size_t)NCLS * NLEAF) * sizeof(uint32_t), ctx->stream));   // cnt1 and cnt2
+      v.exact1 = 1; v.rbase = rbase; v.rcap = rcap;
+      run_p1 = true;
+      continue;
+    }
+    parked1 = st[ST_OVFN1];
+    if (st[ST_L2OVF]) {
+      if ((rc = cfrk_pool_get(ctx, BUF_MSP_LAYOUT, (size_t)NCLS * NLEAF * (sizeof(uint64_t) + sizeof(uint32_t)), &p))) return rc;
       uint64_t *lbase = (uint64_t *)p;
       uint32_t *lcap = (uint32_t *)(lbase + NCLS * NLEAF);
-      hipLaunchKernelGGL(msp_layout_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)v.cnt2, lbase, lcap);
+      hipLaunchKernelGGL(msp_layout_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)v.cnt2, (uint32_t)(NCLS * NLEAF), lbase, lcap);
       HIP_TRY(ctx, hipGetLastError());
       HIP_TRY(ctx, hipMemsetAsync(v.cnt2, 0, (size_t)NCLS * NLEAF * sizeof(uint32_t), ctx->stream));
-      HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_L2OVF, 0, 2 * sizeof(uint64_t), ctx->stream));
       v.exact = 1; v.lbase = lbase; v.lcap = lcap;
-      hipLaunchKernelGGL(msp_p2_kernel, dim3((unsigned)(tiles_per_sub * B1)), dim3(P2_THREADS), 0, ctx->stream,
-                         (int)tiles_per_sub, k, canon, v, t);
-      HIP_TRY(ctx, hipGetLastError());
+      run_p1 = false;
+      continue;
     }
+    parked2 = st[ST_OVFN];
+    break;
+  }
+  if (parked1) {
+    const uint32_t n = (uint32_t)std::min<uint64_t>(parked1, v.ovf1_cap);
+    hipLaunchKernelGGL(msp_spill_list_kernel, dim3((n + 255u) / 256u), dim3(256), 0, ctx->stream, (const uint4 *)v.ovf1, n, k, canon, t);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  if (parked2) {
+    const uint32_t n = (uint32_t)std::min<uint64_t>(parked2, v.ovf_cap);
+    hipLaunchKernelGGL(msp_spill_list_kernel, dim3((n + 255u) / 256u), dim3(256), 0, ctx->stream, (const uint4 *)v.ovf, n, k, canon, t);
+    HIP_TRY(ctx, hipGetLastError());
   }
   if (canon) hipLaunchKernelGGL((msp_p3_kernel<true>), dim3(NLEAF), dim3(P3_THREADS), 0, ctx->stream, k, v, t);
   else hipLaunchKernelGGL((msp_p3_kernel<false>), dim3(NLEAF), dim3(P3_THREADS), 0, ctx->stream, k, v, t);
