@@ -77,6 +77,12 @@ __device__ __noinline__ void spill_record(uint4 rec, int k, bool canon, const Ta
 constexpr int P1_OWN = 61;                       // owner lanes per wave
 constexpr int P1_WAVES = P1_THREADS / 64;
 
+// Level-1 region (and cursor) of bin `bin`, sub-region `xg`: sub-region major.  Global atomics
+// execute at the memory side, one 64-byte request per touched 64 bytes: with the cursors of the
+// 256 bins of one sub-region side by side, a workgroup's 256 reservations are 16 requests instead
+// of 256.
+__host__ __device__ __forceinline__ uint32_t l1_reg(uint32_t bin, uint32_t xg) { return xg * (uint32_t)B1 + bin; }
+
 // write record `rec` as entry `dst` of level-1 region `reg`; a full region parks a few records and
 // beyond that raises ST_L1OVF (the cursors keep counting: the host redoes P1 with exact sizes)
 __device__ __forceinline__ void l1_put(const MspView &v, uint32_t reg, uint32_t dst, uint4 rec, int k, bool canon,
@@ -206,7 +212,7 @@ __global__ __launch_bounds__(P1_THREADS, 6) void msp_p1_kernel(const int8_t *__r
       atomicAdd(&hist[bin1], 1u);
     } else {
       // LDS staging full (pathological tile): append directly
-      const uint32_t reg = bin1 * v.nxg + (blockIdx.x & (v.nxg - 1));
+      const uint32_t reg = l1_reg(bin1, blockIdx.x & (v.nxg - 1));
       const uint32_t dst = atomicAdd(&v.cnt1[reg], 1u);
       l1_put(v, reg, dst, rec, k, canon != 0, t);
     }
@@ -220,7 +226,7 @@ __global__ __launch_bounds__(P1_THREADS, 6) void msp_p1_kernel(const int8_t *__r
   uint32_t my_base = 0;
   if (tid < B1) {
     const uint32_t c = hist[tid];
-    if (c) my_base = atomicAdd(&v.cnt1[tid * v.nxg + (blockIdx.x & (v.nxg - 1))], c);
+    if (c) my_base = atomicAdd(&v.cnt1[l1_reg(tid, blockIdx.x & (v.nxg - 1))], c);
   }
   block_scan<B1>(hist, loff, wtot);
   const uint32_t nrec = min(nrec_s, (uint32_t)P1_RCAP);
@@ -237,7 +243,212 @@ __global__ __launch_bounds__(P1_THREADS, 6) void msp_p1_kernel(const int8_t *__r
     const uint32_t b = bin_tmp[s];
     const uint32_t dst = gbase[b] + (p - loff[b]);
     const uint4 rec = rec_tmp[s];
-    l1_put(v, b * v.nxg + (blockIdx.x & (v.nxg - 1)), dst, rec, k, canon != 0, t);
+    l1_put(v, l1_reg(b, blockIdx.x & (v.nxg - 1)), dst, rec, k, canon != 0, t);
+  }
+}
+
+// ---------------------------------------------------------------------------------------- P1b
+// P1 for W >= 16 (k = 28..32) with a wave-balanced emission phase.  In msp_p1_kernel a lane builds
+// the records of ITS runs in a divergent loop: the wave pays max-over-lanes trips (5..6 at W = 18
+// for 2.8 runs per lane on average) of a ~75-instruction body.  Here a lane only lists its run
+// starts (position descriptors, a few instructions per trip); everything a record is made of is
+// staged per wave in LDS -- the wave's 2-bit base string, run terminators, validity, the leaf id of
+// every position -- and then lane i builds the wave's i-th record: ceil(runs / 64) trips with all
+// lanes busy.  Records stay in registers until the workgroup's bin histogram is scanned and go to
+// LDS directly in bin order (rank from the histogram atomic), so the staging area and the sorted
+// records share one allocation and the permutation pass of msp_p1_kernel is gone.
+constexpr int P1B_TR = 4;                        // balanced trips held in registers (256 runs per wave)
+constexpr int P1B_STAGE = 4096 + 3 * 512 + P1B_TR * 128;     // bytes of staging per wave
+constexpr int P1B_RCAP = P1_WAVES * P1B_STAGE / 16;          // sorted records share the staging bytes
+
+template <int W>
+__global__ __launch_bounds__(P1_THREADS, 6) void msp_p1b_kernel(const int8_t *__restrict__ data,
+                                                             int64_t nN, int k, int m, int canon,
+                                                             int64_t tile0, MspView v, TableView t) {
+  constexpr int NH = 32 + W - 1;
+  __shared__ uint4 arena[P1B_RCAP];              // per-wave staging, later the bin-sorted records
+  __shared__ uint32_t hist[B1], loff[B1], gbase[B1];
+  __shared__ uint32_t wtot[4];
+  __shared__ uint32_t nrec_s;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nkmax = min(48 - k + 1, 32);
+  uint8_t *const stage = reinterpret_cast<uint8_t *>(arena) + wave * P1B_STAGE;
+  uint16_t *const s_leaf = reinterpret_cast<uint16_t *>(stage);               // [64 lanes][32 positions]
+  uint32_t *const s_str = reinterpret_cast<uint32_t *>(stage + 4096);         // 128 dwords of bases
+  uint64_t *const s_E = reinterpret_cast<uint64_t *>(stage + 4096 + 512);     // run terminators
+  uint64_t *const s_W = reinterpret_cast<uint64_t *>(stage + 4096 + 1024);    // validity of position p-1
+  uint16_t *const s_dsc = reinterpret_cast<uint16_t *>(stage + 4096 + 1536);  // (lane << 5) | position
+
+  if (tid < B1) hist[tid] = 0;
+  __syncthreads();
+
+  // ---- A: as msp_p1_kernel ----
+  const int64_t wave_g = (tile0 + blockIdx.x) * P1_WAVES + wave;
+  const int64_t chunk = wave_g * P1_OWN + lane - 1;
+  const int64_t off = chunk * 32;
+  uint32_t b0 = 0, b1 = 0, bad = 0xFFFFFFFFu;
+  if (chunk >= 0) dev_load_chunk32(data, off, nN, b0, b1, bad);
+  const uint32_t n0 = dev_lane_next(b0), n1 = dev_lane_next(b1);
+  const uint32_t nbad = dev_lane_next(bad), nnbad = dev_lane_next(dev_lane_next(bad));
+  const uint64_t hi = ((uint64_t)b0 << 32) | b1;
+  const uint64_t mid = ((uint64_t)n0 << 32) | n1;
+  const uint64_t lo = (uint64_t)dev_lane_next(n0) << 32;       // only the overflow path below reads it
+  uint64_t Yh = ((uint64_t)bad << 32) | nbad, Yl = (uint64_t)nnbad << 32;
+  {
+    int w = 1;
+#pragma unroll
+    for (int st = 0; st < 5; ++st) {
+      if (2 * w <= k) {
+        Yh |= (Yh << w) | (Yl >> (64 - w));
+        Yl |= Yl << w;
+        w *= 2;
+      }
+    }
+    if (k > w) {
+      Yh |= (Yh << (k - w)) | (Yl >> (64 - (k - w)));
+      Yl |= Yl << (k - w);
+    }
+  }
+  const uint64_t Vx = ~Yh;
+  const uint32_t V = (uint32_t)(Vx >> 32);
+  const uint32_t prevV = dev_lane_prev(V) & 1u;
+
+  uint32_t H[NH];
+  const uint64_t Cx = msp_minimizers<W>(hi, mid, chunk, m, H);
+  const uint64_t E = Cx | ~Vx | (1ull << (63 - NH));
+  const uint32_t Vprev = (V >> 1) | (prevV << 31);
+  uint32_t S = V & ((uint32_t)(Cx >> 32) | ~Vprev);
+  const bool owner = lane >= 1 && lane <= P1_OWN && off < nN;
+  if (!owner) S = 0;
+
+  // ---- B1: stage what records are made of; list the run starts ----
+  {
+    const LeafPack LP = leaf_pack(H);
+    uint4 *lp = reinterpret_cast<uint4 *>(s_leaf + lane * 32);
+    lp[0] = make_uint4(LP.w[0], LP.w[1], LP.w[2], LP.w[3]);
+    lp[1] = make_uint4(LP.w[4], LP.w[5], LP.w[6], LP.w[7]);
+    lp[2] = make_uint4(LP.w[8], LP.w[9], LP.w[10], LP.w[11]);
+    lp[3] = make_uint4(LP.w[12], LP.w[13], LP.w[14], LP.w[15]);
+    reinterpret_cast<uint2 *>(s_str)[lane] = make_uint2(b0, b1);
+    s_E[lane] = E;
+    s_W[lane] = (Vx >> 1) | ((uint64_t)prevV << 63);
+  }
+  uint32_t cnt_w;
+  {
+    const uint32_t mine = (uint32_t)__popc(S);
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t y = __shfl_up(incl, d);
+      if (lane >= d) incl += y;
+    }
+    cnt_w = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    uint32_t widx = incl - mine;
+    const uint32_t tag = (uint32_t)lane << 5;
+    while (S) {
+      const int a = __clz(S);
+      S &= ~(0x80000000u >> a);
+      if (widx < (uint32_t)(P1B_TR * 64)) {
+        s_dsc[widx] = (uint16_t)(tag | (uint32_t)a);
+      } else {
+        // more runs in this wave than the balanced phase holds (pathological input): build the
+        // record here and append it directly
+        const uint64_t rest = E << (a + 1);
+        const int n = min(__clzll(rest) + 1, nkmax);
+        const uint32_t pv = a ? ((V >> (32 - a)) & 1u) : prevV;
+        const uint32_t complete = (pv & (uint32_t)(Vx >> (63 - (a + n))) & 1u) << 6;
+        const uint32_t leaf = s_leaf[lane * 32 + a];
+        uint4 rec;
+        const uint64_t r01 = a ? ((hi << (2 * a)) | (mid >> (64 - 2 * a))) : hi;
+        const uint64_t r23 = a ? ((mid << (2 * a)) | (lo >> (64 - 2 * a))) : mid;
+        rec.x = (uint32_t)(r01 >> 32);
+        const int z = 2 * (48 - (n + k - 1));
+        uint64_t r12 = ((uint64_t)(uint32_t)r01 << 32) | (uint32_t)(r23 >> 32);
+        r12 = (z >= 64) ? 0ull : ((r12 >> z) << z);
+        rec.y = (uint32_t)(r12 >> 32);
+        rec.z = (uint32_t)r12;
+        rec.w = (leaf << 8) | complete | (uint32_t)(n - 1);
+        const uint32_t reg = l1_reg(leaf >> B2_LOG, blockIdx.x & (v.nxg - 1));
+        const uint32_t dst = atomicAdd(&v.cnt1[reg], 1u);
+        l1_put(v, reg, dst, rec, k, canon != 0, t);
+      }
+      ++widx;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+  // ---- B2: lane i builds the wave's i-th record ----
+  uint4 rc[P1B_TR];
+  uint32_t rk[P1B_TR];                           // rank inside the record's bin; ~0: no record
+  cnt_w = min(cnt_w, (uint32_t)(P1B_TR * 64));
+#pragma unroll
+  for (int tr = 0; tr < P1B_TR; ++tr) {
+    rk[tr] = 0xFFFFFFFFu;
+    rc[tr] = make_uint4(0, 0, 0, 0);
+    const uint32_t i = (uint32_t)(tr * 64 + lane);
+    if (i < cnt_w) {
+      const uint32_t d = s_dsc[i];               // 32 * lane + position: also the index of the leaf id
+      const uint32_t L = d >> 5, a = d & 31u;
+      const uint64_t Es = s_E[L], Ws = s_W[L];
+      const uint32_t leaf = s_leaf[d];
+      // 96 bits of the wave's base string from bit 2d: dwords idx0..idx0+3, funnel-shifted
+      const uint32_t P = 2u * d - 2u, idx0 = P >> 5, sh = 30u - (P & 31u);
+      const uint32_t D0 = s_str[idx0], D1 = s_str[idx0 + 1], D2 = s_str[idx0 + 2], D3 = s_str[idx0 + 3];
+      const uint64_t rest = Es << (a + 1);
+      const int n = min(__clzll(rest) + 1, nkmax);
+      const uint32_t complete = ((uint32_t)(Ws >> (63 - a)) & (uint32_t)(Ws >> (62 - a - n)) & 1u) << 6;
+      uint4 rec;
+      rec.x = __builtin_amdgcn_alignbit(D0, D1, sh);
+      // bases after the run's last k-mer are cleared: equal runs -> byte-identical records
+      const int z = 2 * (48 - (n + k - 1));      // < 64: k >= 28 on this path
+      uint64_t r12 = ((uint64_t)__builtin_amdgcn_alignbit(D1, D2, sh) << 32) | __builtin_amdgcn_alignbit(D2, D3, sh);
+      r12 = (r12 >> z) << z;
+      rec.y = (uint32_t)(r12 >> 32);
+      rec.z = (uint32_t)r12;
+      rec.w = (leaf << 8) | complete | (uint32_t)(n - 1);
+      rc[tr] = rec;
+      rk[tr] = atomicAdd(&hist[leaf >> B2_LOG], 1u);
+    }
+  }
+  __syncthreads();
+
+  // ---- C: one global reservation per non-empty bin; bin offsets ----
+  uint32_t my_base = 0;
+  if (tid < B1) {
+    const uint32_t c = hist[tid];
+    if (c) my_base = atomicAdd(&v.cnt1[l1_reg(tid, blockIdx.x & (v.nxg - 1))], c);
+  }
+  block_scan<B1>(hist, loff, wtot);              // ends with a barrier: the staging area is dead
+  if (tid == B1 - 1) nrec_s = loff[tid] + hist[tid];
+#pragma unroll
+  for (int tr = 0; tr < P1B_TR; ++tr) {
+    if (rk[tr] != 0xFFFFFFFFu) {
+      const uint32_t pos = loff[rc[tr].w >> 16] + rk[tr];
+      if (pos < (uint32_t)P1B_RCAP) arena[pos] = rc[tr];
+    }
+  }
+  if (tid < B1) gbase[tid] = my_base;
+  __syncthreads();
+
+  // ---- D: copy out in bin order ----
+  const uint32_t nrec = min(nrec_s, (uint32_t)P1B_RCAP);
+  for (uint32_t p = tid; p < nrec; p += P1_THREADS) {
+    const uint4 rec = arena[p];
+    const uint32_t b = rec.w >> 16;
+    l1_put(v, l1_reg(b, blockIdx.x & (v.nxg - 1)), gbase[b] + (p - loff[b]), rec, k, canon != 0, t);
+  }
+  if (nrec_s > (uint32_t)P1B_RCAP) {             // records beyond the LDS arena go to their reserved places
+#pragma unroll
+    for (int tr = 0; tr < P1B_TR; ++tr) {
+      if (rk[tr] != 0xFFFFFFFFu) {
+        const uint32_t b = rc[tr].w >> 16;
+        if (loff[b] + rk[tr] >= (uint32_t)P1B_RCAP)
+          l1_put(v, l1_reg(b, blockIdx.x & (v.nxg - 1)), gbase[b] + rk[tr], rc[tr], k, canon != 0, t);
+      }
+    }
   }
 }
 
@@ -270,8 +481,8 @@ __global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int groups_per_bin, 
   // The bin's sub-regions are read as ONE stream (region after region): tiles are full except the
   // bin's last one, however many cursors P1 spreads its appends over.
   if (tid < 64) {
-    const uint32_t c = ((uint32_t)tid < v.nxg) ? (uint32_t)min((uint64_t)v.cnt1[b1 * v.nxg + tid],
-                                                               v.exact1 ? (uint64_t)v.rcap[b1 * v.nxg + tid] : v.cap1) : 0u;
+    const uint32_t c = ((uint32_t)tid < v.nxg) ? (uint32_t)min((uint64_t)v.cnt1[l1_reg(b1, tid)],
+                                                               v.exact1 ? (uint64_t)v.rcap[l1_reg(b1, tid)] : v.cap1) : 0u;
     uint32_t incl = c;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -287,7 +498,6 @@ __global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int groups_per_bin, 
   // sorts and writes the current one: the load latency hides under the LDS work
   const uint64_t g0r = (uint64_t)grp * P2_GROUP * P2_TILE;
   if (g0r >= n) return;
-  const uint4 *bin_base = v.rec1 + (uint64_t)b1 * v.nxg * v.cap1;
   // record `idx` of the bin's stream: find its sub-region (binary search over <= 64 prefixes)
   auto fetch = [&](uint64_t idx) {
     uint32_t lo = 0, hi = v.nxg;               // invariant: rpre[lo] <= idx < rpre[hi]
@@ -295,8 +505,8 @@ __global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int groups_per_bin, 
       const uint32_t mid = (lo + hi) >> 1;
       if (rpre[mid] <= idx) lo = mid; else hi = mid;
     }
-    if (v.exact1) return v.rec1[v.rbase[b1 * v.nxg + lo] + (idx - rpre[lo])];
-    return bin_base[(uint64_t)lo * v.cap1 + (idx - rpre[lo])];
+    if (v.exact1) return v.rec1[v.rbase[l1_reg(b1, lo)] + (idx - rpre[lo])];
+    return v.rec1[(uint64_t)l1_reg(b1, lo) * v.cap1 + (idx - rpre[lo])];
   };
   const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
   uint4 nx[P2_PER];
@@ -1058,13 +1268,16 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
       const dim3 g1((unsigned)ntiles), b1(P1_THREADS);
 #define CFRK_P1_CASE(WW) \
       case WW: hipLaunchKernelGGL((msp_p1_kernel<WW>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, tile0, v, t); break;
+#define CFRK_P1B_CASE(WW) \
+      case WW: hipLaunchKernelGGL((msp_p1b_kernel<WW>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, tile0, v, t); break;
       switch (W) {
         CFRK_P1_CASE(4) CFRK_P1_CASE(5) CFRK_P1_CASE(6) CFRK_P1_CASE(7) CFRK_P1_CASE(8) CFRK_P1_CASE(9)
         CFRK_P1_CASE(10) CFRK_P1_CASE(11) CFRK_P1_CASE(12) CFRK_P1_CASE(13) CFRK_P1_CASE(14)
-        CFRK_P1_CASE(15) CFRK_P1_CASE(16) CFRK_P1_CASE(17) CFRK_P1_CASE(18)
+        CFRK_P1_CASE(15) CFRK_P1B_CASE(16) CFRK_P1B_CASE(17) CFRK_P1B_CASE(18)
         default: return cfrk_fail(ctx, CFRK_ERR_ARG, "no partition kernel for W=%d", W);
       }
 #undef CFRK_P1_CASE
+#undef CFRK_P1B_CASE
       HIP_TRY(ctx, hipGetLastError());
     }
     HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_L2OVF, 0, 2 * sizeof(uint64_t), ctx->stream));   // ST_L2OVF, ST_OVFN
@@ -1089,7 +1302,7 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
         uint64_t maxbin = 0;
         for (int b = 0; b < B1; ++b) {
           uint64_t sum = 0;
-          for (int r = 0; r < nxg; ++r) sum += c1[(size_t)b * nxg + r];
+          for (int r = 0; r < nxg; ++r) sum += c1[l1_reg((uint32_t)b, (uint32_t)r)];
           maxbin = std::max(maxbin, sum);
         }
         p2_groups = (int64_t)((maxbin + (uint64_t)P2_TILE * P2_GROUP - 1) / ((uint64_t)P2_TILE * P2_GROUP)) + 1;

@@ -108,6 +108,9 @@ __device__ __noinline__ void spill_record2(const Rec2 &rec, int k, bool canon, c
 }
 
 // ---------------------------------------------------------------------------------------- Q1
+// level-1 region / cursor of (bin, sub-region): sub-region major, so that a workgroup's 256
+// reservations (memory-side atomics, one request per touched 64 bytes) are 16 requests (msp.hip: l1_reg)
+__device__ __forceinline__ uint32_t q1_reg(uint32_t bin, uint32_t xg) { return xg * (uint32_t)B1 + bin; }
 __global__ __launch_bounds__(Q1_THREADS) void msp2_p1_kernel(const int8_t *__restrict__ data, int64_t nN,
                                                              int k, int m, int c, int canon, int64_t tile0,
                                                              View2 v, TableView t) {
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(Q1_THREADS) void msp2_p1_kernel(const int8_t *__res
       bin_tmp[slot] = (uint8_t)bin1;
       atomicAdd(&hist[bin1], 1u);
     } else {
-      const uint32_t reg = bin1 * NXG + (blockIdx.x & (NXG - 1));
+      const uint32_t reg = q1_reg(bin1, blockIdx.x & (NXG - 1));
       const uint32_t dst = atomicAdd(&v.cnt1[reg], 1u);
       if (dst < v.cap1) v.rec1[(uint64_t)reg * v.cap1 + dst] = rec;
       else spill_record2(rec, k, canon != 0, t);
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(Q1_THREADS) void msp2_p1_kernel(const int8_t *__res
   uint32_t my_base = 0;
   if (tid < B1) {
     const uint32_t cnum = hist[tid];
-    if (cnum) my_base = atomicAdd(&v.cnt1[tid * NXG + (blockIdx.x & (NXG - 1))], cnum);
+    if (cnum) my_base = atomicAdd(&v.cnt1[q1_reg(tid, blockIdx.x & (NXG - 1))], cnum);
   }
   block_scan<B1>(hist, loff, wtot);
   const uint32_t nrec = min(nrec_s, (uint32_t)Q1_RCAP);
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(Q1_THREADS) void msp2_p1_kernel(const int8_t *__res
     const uint32_t b = bin_tmp[s];
     const uint32_t dst = gbase[b] + (p - loff[b]);
     const Rec2 rec = rec_tmp[s];
-    if (dst < v.cap1) v.rec1[((uint64_t)b * NXG + (blockIdx.x & (NXG - 1))) * v.cap1 + dst] = rec;
+    if (dst < v.cap1) v.rec1[(uint64_t)q1_reg(b, blockIdx.x & (NXG - 1)) * v.cap1 + dst] = rec;
     else spill_record2(rec, k, canon != 0, t);
   }
 }
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(Q2_THREADS) void msp2_p2_kernel(int groups_per_bin,
   const uint32_t grp = seq % (uint32_t)groups_per_bin;
   // the bin's sub-regions are read as one stream (as in msp.hip's P2)
   if (tid < 64) {
-    const uint32_t c = (tid < NXG) ? (uint32_t)min((uint64_t)v.cnt1[b1 * NXG + tid], v.cap1) : 0u;
+    const uint32_t c = (tid < NXG) ? (uint32_t)min((uint64_t)v.cnt1[q1_reg(b1, tid)], v.cap1) : 0u;
     uint32_t incl = c;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -287,14 +290,13 @@ __global__ __launch_bounds__(Q2_THREADS) void msp2_p2_kernel(int groups_per_bin,
   // current tile is sorted and written (as in msp.hip's P2)
   const uint64_t g0r = (uint64_t)grp * Q2_GROUP * Q2_TILE;
   if (g0r >= n) return;
-  const Rec2 *bin_base = v.rec1 + (uint64_t)b1 * NXG * v.cap1;
   auto fetch = [&](uint64_t idx) {
     uint32_t lo = 0, hi = NXG;                 // invariant: rpre[lo] <= idx < rpre[hi]
     while (hi - lo > 1) {
       const uint32_t mid = (lo + hi) >> 1;
       if (rpre[mid] <= idx) lo = mid; else hi = mid;
     }
-    return bin_base[(uint64_t)lo * v.cap1 + (idx - rpre[lo])];
+    return v.rec1[(uint64_t)q1_reg(b1, lo) * v.cap1 + (idx - rpre[lo])];
   };
   const Rec2 zrec = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
   Rec2 nx[Q2_PER];

@@ -43,6 +43,9 @@ struct RxView {
   uint32_t mul, inv, kmask;                           // scramble: x * mul mod 4^k, x ^= x >> k
 };
 
+// level-1 region / cursor of (bin, sub-region): sub-region major -- the cursors a workgroup reserves
+// from lie side by side (memory-side atomics: one request per touched 64 bytes, see msp.hip l1_reg)
+__device__ __forceinline__ uint32_t rx_reg(const RxView &v, uint32_t bin, uint32_t sub) { return (sub << v.b1) | bin; }
 __device__ __forceinline__ uint32_t rx_mix(const RxView &v, uint32_t key) {
   uint32_t x = (key * v.mul) & v.kmask;
   return x ^ (x >> v.k);
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(RX1_THREADS) void rx1_kernel(const int8_t *__restri
   uint32_t my_base = 0;
   {
     const uint32_t c = hist[tid];
-    if (c) my_base = atomicAdd(&v.cnt1[tid * RX_NREG + (blockIdx.x & (RX_NREG - 1))], c);
+    if (c) my_base = atomicAdd(&v.cnt1[rx_reg(v, tid, blockIdx.x & (RX_NREG - 1))], c);
   }
   rx_scan<256>(hist, loff, wtot);
 #pragma unroll
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(RX1_THREADS) void rx1_kernel(const int8_t *__restri
     const uint32_t key = sorted[p];
     const uint32_t b = key >> sh1;
     const uint32_t dst = gbase[b] + (p - loff[b]);
-    if (dst < v.cap1) v.key1[((uint64_t)b * RX_NREG + (blockIdx.x & (RX_NREG - 1))) * v.cap1 + dst] = key;
+    if (dst < v.cap1) v.key1[(uint64_t)rx_reg(v, b, blockIdx.x & (RX_NREG - 1)) * v.cap1 + dst] = key;
     else { t.stats[ST_SPILLED] = 1; table_add1(t, (uint64_t)rx_unmix(v, key), 1u); }
   }
 }
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(RX2_THREADS) void rx2_kernel(int tiles_per_sub, RxV
   if (bin1 >= nb1) return;
   const uint32_t sub = (seq % per_bin) / (uint32_t)tiles_per_sub;
   const uint32_t tile = (seq % per_bin) % (uint32_t)tiles_per_sub;
-  const uint32_t reg = bin1 * RX_NREG + sub;
+  const uint32_t reg = rx_reg(v, bin1, sub);
   const uint64_t n = min((uint64_t)v.cnt1[reg], v.cap1);
   const uint64_t r0 = (uint64_t)tile * RX2_KEYS;
   if (r0 >= n) return;

@@ -29,6 +29,9 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, uint32_t seed) {
       if (OP == 11) a[i] = __builtin_amdgcn_ubfe(a[i] ^ c, 5, 13) + a[i];      // bfe
       if (OP == 12) a[i] = __popc(a[i]) + a[i] * 3u;                  // popc + mul small const
       if (OP == 13) a[i] = __brev(a[i]) ^ c;                          // brev
+      if (OP == 14) a[i] = (a[i] * c) ^ a[(i + 1) & 7];               // v_mul_lo_u32 + v_xor (not foldable)
+      if (OP == 15) a[i] = (a[i] * 0x9E3779B1u) ^ a[(i + 1) & 7];     // v_mul_lo_u32 by a literal + v_xor
+      if (OP == 16) a[i] = __umulhi(a[i] & 0x80808080u, 0x10080402u) ^ a[(i + 1) & 7];  // and + mul_hi + xor
     }
   }
   uint32_t r = 0;
@@ -60,5 +63,6 @@ int main() {
   run<4>("xor+min", d); run<5>("shl64|shr64", d); run<6>("cmp_u64+sel", d); run<7>("alignbit", d);
   run<8>("shfl_down 1", d); run<9>("add_u64", d); run<10>("and,shr,or", d); run<11>("xor,bfe,add", d);
   run<12>("popc + mul3", d); run<13>("brev,xor", d);
+  run<14>("mul_lo,xor", d); run<15>("mul_lo literal,xor", d); run<16>("and,mul_hi,xor", d);
   return 0;
 }
