@@ -52,7 +52,9 @@ constexpr int P3_THREADS = 1024;
 constexpr int TS_LOG = 12, TS = 1 << TS_LOG;   // LDS table slots per leaf
 
 // count every k-mer of a record straight into the global HBM table
-__device__ __noinline__ void spill_record(uint4 rec, int k, bool canon, const TableView &t) {
+// (the table view by value: a reference makes every thread of the calling kernel store the view
+// to scratch memory at kernel entry -- 48 bytes per thread that reach HBM)
+__device__ __noinline__ void spill_record(uint4 rec, int k, bool canon, TableView t) {
   t.stats[ST_SPILLED] = 1;
   dev_count_event(&t.stats[ST_AUX0]);
   const int nk = (int)(rec.w & 63u) + 1;
@@ -293,7 +295,6 @@ __global__ __launch_bounds__(P1_THREADS, 6) void msp_p1b_kernel(const int8_t *__
   const uint32_t nbad = dev_lane_next(bad), nnbad = dev_lane_next(dev_lane_next(bad));
   const uint64_t hi = ((uint64_t)b0 << 32) | b1;
   const uint64_t mid = ((uint64_t)n0 << 32) | n1;
-  const uint64_t lo = (uint64_t)dev_lane_next(n0) << 32;       // only the overflow path below reads it
   uint64_t Yh = ((uint64_t)bad << 32) | nbad, Yl = (uint64_t)nnbad << 32;
   {
     int w = 1;
@@ -335,6 +336,7 @@ __global__ __launch_bounds__(P1_THREADS, 6) void msp_p1b_kernel(const int8_t *__
     s_W[lane] = (Vx >> 1) | ((uint64_t)prevV << 63);
   }
   uint32_t cnt_w;
+  uint32_t S2 = 0;                               // run starts beyond the balanced phase's capacity
   {
     const uint32_t mine = (uint32_t)__popc(S);
     uint32_t incl = mine;
@@ -348,37 +350,51 @@ __global__ __launch_bounds__(P1_THREADS, 6) void msp_p1b_kernel(const int8_t *__
     const uint32_t tag = (uint32_t)lane << 5;
     while (S) {
       const int a = __clz(S);
-      S &= ~(0x80000000u >> a);
-      if (widx < (uint32_t)(P1B_TR * 64)) {
-        s_dsc[widx] = (uint16_t)(tag | (uint32_t)a);
-      } else {
-        // more runs in this wave than the balanced phase holds (pathological input): build the
-        // record here and append it directly
-        const uint64_t rest = E << (a + 1);
-        const int n = min(__clzll(rest) + 1, nkmax);
-        const uint32_t pv = a ? ((V >> (32 - a)) & 1u) : prevV;
-        const uint32_t complete = (pv & (uint32_t)(Vx >> (63 - (a + n))) & 1u) << 6;
-        const uint32_t leaf = s_leaf[lane * 32 + a];
-        uint4 rec;
-        const uint64_t r01 = a ? ((hi << (2 * a)) | (mid >> (64 - 2 * a))) : hi;
-        const uint64_t r23 = a ? ((mid << (2 * a)) | (lo >> (64 - 2 * a))) : mid;
-        rec.x = (uint32_t)(r01 >> 32);
-        const int z = 2 * (48 - (n + k - 1));
-        uint64_t r12 = ((uint64_t)(uint32_t)r01 << 32) | (uint32_t)(r23 >> 32);
-        r12 = (z >= 64) ? 0ull : ((r12 >> z) << z);
-        rec.y = (uint32_t)(r12 >> 32);
-        rec.z = (uint32_t)r12;
-        rec.w = (leaf << 8) | complete | (uint32_t)(n - 1);
-        const uint32_t reg = l1_reg(leaf >> B2_LOG, blockIdx.x & (v.nxg - 1));
-        const uint32_t dst = atomicAdd(&v.cnt1[reg], 1u);
-        l1_put(v, reg, dst, rec, k, canon != 0, t);
-      }
+      const uint32_t bit = 0x80000000u >> a;
+      S &= ~bit;
+      if (widx < (uint32_t)(P1B_TR * 64)) s_dsc[widx] = (uint16_t)(tag | (uint32_t)a);
+      else S2 |= bit;
       ++widx;
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+  // record of the run that starts at position d & 31 of lane d >> 5 (d is also the index of its leaf id)
+  auto build = [&](uint32_t d) {
+    const uint32_t L = d >> 5, a = d & 31u;
+    const uint64_t Es = s_E[L], Ws = s_W[L];
+    const uint32_t leaf = s_leaf[d];
+    // 96 bits of the wave's base string from bit 2d: dwords idx0..idx0+3, funnel-shifted
+    const uint32_t P = 2u * d - 2u, idx0 = P >> 5, sh = 30u - (P & 31u);
+    const uint32_t D0 = s_str[idx0], D1 = s_str[idx0 + 1], D2 = s_str[idx0 + 2], D3 = s_str[idx0 + 3];
+    const uint64_t rest = Es << (a + 1);
+    const int n = min(__clzll(rest) + 1, nkmax);
+    // "complete": both ends are minimizer changes between valid k-mers, so every read covering
+    // this locus emits the same record
+    const uint32_t complete = ((uint32_t)(Ws >> (63 - a)) & (uint32_t)(Ws >> (62 - a - n)) & 1u) << 6;
+    uint4 rec;
+    rec.x = __builtin_amdgcn_alignbit(D0, D1, sh);
+    // bases after the run's last k-mer are cleared: equal runs -> byte-identical records
+    const int z = 2 * (48 - (n + k - 1));        // < 64: k >= 28 on this path
+    uint64_t r12 = ((uint64_t)__builtin_amdgcn_alignbit(D1, D2, sh) << 32) | __builtin_amdgcn_alignbit(D2, D3, sh);
+    r12 = (r12 >> z) << z;
+    rec.y = (uint32_t)(r12 >> 32);
+    rec.z = (uint32_t)r12;
+    rec.w = (leaf << 8) | complete | (uint32_t)(n - 1);
+    return rec;
+  };
+
+  // more runs in this wave than the balanced phase holds (pathological input): append directly
+  while (S2) {
+    const int a = __clz(S2);
+    S2 &= ~(0x80000000u >> a);
+    const uint4 rec = build(((uint32_t)lane << 5) | (uint32_t)a);
+    const uint32_t reg = l1_reg(rec.w >> 16, blockIdx.x & (v.nxg - 1));
+    const uint32_t dst = atomicAdd(&v.cnt1[reg], 1u);
+    l1_put(v, reg, dst, rec, k, canon != 0, t);
+  }
 
   // ---- B2: lane i builds the wave's i-th record ----
   uint4 rc[P1B_TR];
@@ -390,27 +406,8 @@ __global__ __launch_bounds__(P1_THREADS, 6) void msp_p1b_kernel(const int8_t *__
     rc[tr] = make_uint4(0, 0, 0, 0);
     const uint32_t i = (uint32_t)(tr * 64 + lane);
     if (i < cnt_w) {
-      const uint32_t d = s_dsc[i];               // 32 * lane + position: also the index of the leaf id
-      const uint32_t L = d >> 5, a = d & 31u;
-      const uint64_t Es = s_E[L], Ws = s_W[L];
-      const uint32_t leaf = s_leaf[d];
-      // 96 bits of the wave's base string from bit 2d: dwords idx0..idx0+3, funnel-shifted
-      const uint32_t P = 2u * d - 2u, idx0 = P >> 5, sh = 30u - (P & 31u);
-      const uint32_t D0 = s_str[idx0], D1 = s_str[idx0 + 1], D2 = s_str[idx0 + 2], D3 = s_str[idx0 + 3];
-      const uint64_t rest = Es << (a + 1);
-      const int n = min(__clzll(rest) + 1, nkmax);
-      const uint32_t complete = ((uint32_t)(Ws >> (63 - a)) & (uint32_t)(Ws >> (62 - a - n)) & 1u) << 6;
-      uint4 rec;
-      rec.x = __builtin_amdgcn_alignbit(D0, D1, sh);
-      // bases after the run's last k-mer are cleared: equal runs -> byte-identical records
-      const int z = 2 * (48 - (n + k - 1));      // < 64: k >= 28 on this path
-      uint64_t r12 = ((uint64_t)__builtin_amdgcn_alignbit(D1, D2, sh) << 32) | __builtin_amdgcn_alignbit(D2, D3, sh);
-      r12 = (r12 >> z) << z;
-      rec.y = (uint32_t)(r12 >> 32);
-      rec.z = (uint32_t)r12;
-      rec.w = (leaf << 8) | complete | (uint32_t)(n - 1);
-      rc[tr] = rec;
-      rk[tr] = atomicAdd(&hist[leaf >> B2_LOG], 1u);
+      rc[tr] = build(s_dsc[i]);
+      rk[tr] = atomicAdd(&hist[rc[tr].w >> 16], 1u);
     }
   }
   __syncthreads();
@@ -603,7 +600,7 @@ __global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int groups_per_bin, 
 
 // ---------------------------------------------------------------------------------------- P3
 // rare path, kept out of line so that the hot loop stays small
-__device__ __noinline__ void spill_kmer(const TableView &t, uint64_t key, uint32_t add) {
+__device__ __noinline__ void spill_kmer(TableView t, uint64_t key, uint32_t add) {
   if (key == CFRK_EMPTY_KEY) {   // k = 32, all T, forward strand
     atomicAdd((unsigned long long *)&t.stats[ST_ONES], (unsigned long long)add);
     return;

@@ -26,7 +26,7 @@ namespace {
 constexpr int W2 = 18;
 constexpr int Q1_THREADS = 512, Q1_WAVES = Q1_THREADS / 64;
 constexpr int Q1_OWN = 60;                 // owner lanes 1..60; lane 0 and lanes 61..63 are halo lanes
-constexpr int Q1_RCAP = 2048;              // 32-byte records staged in LDS per workgroup
+constexpr int Q1_RCAP = 1536;              // 32-byte records staged in LDS per workgroup (48 KB: three workgroups per CU)
 constexpr int Q2_THREADS = 1024, Q2_PER = 2, Q2_TILE = Q2_THREADS * Q2_PER;
 constexpr int Q2_GROUP = 4;                      // consecutive tiles per workgroup (next tile prefetched)
 constexpr int Q3_THREADS = 1024;
@@ -94,7 +94,9 @@ struct Roll2 {
   }
 };
 
-__device__ __noinline__ void spill_record2(const Rec2 &rec, int k, bool canon, const TableView &t) {
+// (record and table view by value: references pin the caller's copies to scratch memory)
+__device__ __noinline__ void spill_record2(uint4 ra, uint4 rb, int k, bool canon, TableView t) {
+  const Rec2 rec = {ra, rb};
   t.stats[ST_SPILLED] = 1;
   dev_count_event(&t.stats[ST_AUX0]);
   const int nk = (int)(rec.b.w & 63u) + 1;
@@ -111,39 +113,78 @@ __device__ __noinline__ void spill_record2(const Rec2 &rec, int k, bool canon, c
 // level-1 region / cursor of (bin, sub-region): sub-region major, so that a workgroup's 256
 // reservations (memory-side atomics, one request per touched 64 bytes) are 16 requests (msp.hip: l1_reg)
 __device__ __forceinline__ uint32_t q1_reg(uint32_t bin, uint32_t xg) { return xg * (uint32_t)B1 + bin; }
-__global__ __launch_bounds__(Q1_THREADS) void msp2_p1_kernel(const int8_t *__restrict__ data, int64_t nN,
+// Emission is wave-balanced as in msp.hip's msp_p1b_kernel: a lane lists its run starts, the wave
+// stages its base string, run terminators, validity and the leaf id of every position in LDS, and
+// lane i builds the wave's i-th record; records wait in registers for the bin offsets and go to
+// LDS in bin order (the staging bytes are reused).
+constexpr int Q1_TR = 3;                           // balanced trips held in registers (192 runs per wave; ~131 expected at k = 63, ~170 at k = 33)
+constexpr int Q1_STAGE = 4096 + 3 * 512 + Q1_TR * 128;        // staging bytes per wave
+static_assert(Q1_WAVES * Q1_STAGE <= Q1_RCAP * 32, "staging fits the record arena");
+
+struct Stage2 {
+  const uint16_t *leaf; const uint32_t *str; const uint64_t *E, *Wv;
+};
+// record of the run that starts at window position d & 31 of lane d >> 5
+__device__ __forceinline__ Rec2 q1_build(const Stage2 &st, uint32_t d, int k, int c) {
+  const uint32_t L = d >> 5, a = d & 31u;
+  const uint64_t Es = st.E[L], Ws = st.Wv[L];
+  const uint32_t leaf = st.leaf[d];
+  // 192 bits of the wave's base string from base d - c: dwords idx0 .. idx0+6, funnel-shifted
+  const uint32_t P = 2u * (d - (uint32_t)c) - 2u, idx0 = P >> 5, sh = 30u - (P & 31u);
+  uint32_t D[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) D[i] = st.str[idx0 + i];
+  const uint64_t rest = Es << (a + 1);
+  const int n = min(__clzll(rest) + 1, W2);
+  const uint32_t complete = ((uint32_t)(Ws >> (63 - a)) & (uint32_t)(Ws >> (62 - a - n)) & 1u) << 6;
+  const int nb = n + k - 1;                                     // bases that belong to the run
+  uint32_t T[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    uint32_t x = __builtin_amdgcn_alignbit(D[i], D[i + 1], sh);
+    const int keep = 2 * nb - 32 * i;                           // bits of this dword inside the run
+    x = (keep >= 32) ? x : ((keep <= 0) ? 0u : (x & (~0u << (32 - keep))));
+    T[i] = x;
+  }
+  Rec2 rec;
+  rec.a = make_uint4(T[0], T[1], T[2], T[3]);
+  rec.b = make_uint4(T[4], T[5], 0u, (leaf << 8) | complete | (uint32_t)(n - 1));
+  return rec;
+}
+
+__global__ __launch_bounds__(Q1_THREADS, 6) void msp2_p1_kernel(const int8_t *__restrict__ data, int64_t nN,
                                                              int k, int m, int c, int canon, int64_t tile0,
                                                              View2 v, TableView t) {
   constexpr int NH = 32 + W2 - 1;
-  __shared__ Rec2 rec_tmp[Q1_RCAP];
-  __shared__ uint16_t perm[Q1_RCAP];
-  __shared__ uint8_t bin_tmp[Q1_RCAP];
-  __shared__ uint32_t hist[B1], loff[B1], gbase[B1], fill[B1];
+  __shared__ Rec2 arena[Q1_RCAP];                  // per-wave staging, later the bin-sorted records
+  __shared__ uint32_t hist[B1], loff[B1], gbase[B1];
   __shared__ uint32_t wtot[4];
   __shared__ uint32_t nrec_s;
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint8_t *const stage = reinterpret_cast<uint8_t *>(arena) + wave * Q1_STAGE;
+  uint16_t *const s_leaf = reinterpret_cast<uint16_t *>(stage);               // [64 lanes][32 positions]
+  uint32_t *const s_str = reinterpret_cast<uint32_t *>(stage + 4096);         // 128 dwords of bases
+  uint64_t *const s_E = reinterpret_cast<uint64_t *>(stage + 4096 + 512);     // run terminators
+  uint64_t *const s_W = reinterpret_cast<uint64_t *>(stage + 4096 + 1024);    // validity of position p-1
+  uint16_t *const s_dsc = reinterpret_cast<uint16_t *>(stage + 4096 + 1536);  // (lane << 5) | position
 
-  if (tid < B1) { hist[tid] = 0; fill[tid] = 0; }
-  if (tid == 0) nrec_s = 0;
+  if (tid < B1) hist[tid] = 0;
   __syncthreads();
 
-  // ---- A: own chunk, the previous one and the next three (by shuffle) ----
-  const int64_t wave_g = (tile0 + blockIdx.x) * Q1_WAVES + (tid >> 6);
+  // ---- A: own chunk and its neighbours (by shuffle) ----
+  const int64_t wave_g = (tile0 + blockIdx.x) * Q1_WAVES + wave;
   const int64_t chunk = wave_g * Q1_OWN + lane - 1;
   const int64_t off = chunk * 32;
-  uint32_t R[10], bd[5];                       // bases / invalid masks of chunks -1, 0, 1, 2, 3
-  R[2] = 0; R[3] = 0; bd[1] = 0xFFFFFFFFu;
-  if (chunk >= 0) dev_load_chunk32(data, off, nN, R[2], R[3], bd[1]);
-  R[0] = dev_lane_prev(R[2]); R[1] = dev_lane_prev(R[3]); bd[0] = dev_lane_prev(bd[1]);
-  R[4] = dev_lane_next(R[2]); R[5] = dev_lane_next(R[3]); bd[2] = dev_lane_next(bd[1]);
-  R[6] = dev_lane_next(dev_lane_next(R[2])); R[7] = dev_lane_next(dev_lane_next(R[3])); bd[3] = dev_lane_next(dev_lane_next(bd[1]));
-  R[8] = dev_lane_next(dev_lane_next(dev_lane_next(R[2]))); R[9] = dev_lane_next(dev_lane_next(dev_lane_next(R[3]))); bd[4] = dev_lane_next(dev_lane_next(dev_lane_next(bd[1])));
-  const uint64_t hi = ((uint64_t)R[2] << 32) | R[3];
-  const uint64_t mid = ((uint64_t)R[4] << 32) | R[5];
+  uint32_t b0 = 0, b1 = 0, bd1 = 0xFFFFFFFFu;
+  if (chunk >= 0) dev_load_chunk32(data, off, nN, b0, b1, bd1);
+  const uint32_t bd0 = dev_lane_prev(bd1), bd2 = dev_lane_next(bd1);
+  const uint32_t bd3 = dev_lane_next(bd2), bd4 = dev_lane_next(bd3);
+  const uint64_t hi = ((uint64_t)b0 << 32) | b1;
+  const uint64_t mid = ((uint64_t)dev_lane_next(b0) << 32) | dev_lane_next(b1);
 
   // validity of the k-mer that belongs to window position y: bases y-c .. y-c+k-1.  I = invalid
   // mask with origin at base -32; smear over the k following bases, then read at offset 32-c.
-  uint64_t I0 = ((uint64_t)bd[0] << 32) | bd[1], I1 = ((uint64_t)bd[2] << 32) | bd[3], I2 = (uint64_t)bd[4] << 32;
+  uint64_t I0 = ((uint64_t)bd0 << 32) | bd1, I1 = ((uint64_t)bd2 << 32) | bd3, I2 = (uint64_t)bd4 << 32;
   {
     int w = 1;
 #pragma unroll
@@ -174,8 +215,21 @@ __global__ __launch_bounds__(Q1_THREADS) void msp2_p1_kernel(const int8_t *__res
   const bool owner = lane >= 1 && lane <= Q1_OWN && off < nN + 32;   // a k-mer may START in the previous chunk
   if (!owner) S = 0;
 
-  // ---- B: one 32-byte record per run, staged in LDS ----
-  uint32_t slot;
+  // ---- B1: stage what records are made of; list the run starts ----
+  {
+    const LeafPack LP = leaf_pack(H);
+    uint4 *lp = reinterpret_cast<uint4 *>(s_leaf + lane * 32);
+    lp[0] = make_uint4(LP.w[0], LP.w[1], LP.w[2], LP.w[3]);
+    lp[1] = make_uint4(LP.w[4], LP.w[5], LP.w[6], LP.w[7]);
+    lp[2] = make_uint4(LP.w[8], LP.w[9], LP.w[10], LP.w[11]);
+    lp[3] = make_uint4(LP.w[12], LP.w[13], LP.w[14], LP.w[15]);
+    reinterpret_cast<uint2 *>(s_str)[lane] = make_uint2(b0, b1);
+    s_E[lane] = E;
+    s_W[lane] = (Vx >> 1) | ((uint64_t)prevV << 63);
+  }
+  const Stage2 st = {s_leaf, s_str, s_E, s_W};
+  uint32_t cnt_w;
+  uint32_t widx, S2 = 0;                           // S2: run starts beyond the balanced phase's capacity
   {
     const uint32_t mine = (uint32_t)__popc(S);
     uint32_t incl = mine;
@@ -184,77 +238,95 @@ __global__ __launch_bounds__(Q1_THREADS) void msp2_p1_kernel(const int8_t *__res
       const uint32_t y = __shfl_up(incl, d);
       if (lane >= d) incl += y;
     }
-    uint32_t wbase = 0;
-    if (lane == 63 && incl) wbase = atomicAdd(&nrec_s, incl);
-    slot = __shfl(wbase, 63) + incl - mine;
+    cnt_w = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    widx = incl - mine;
+    const uint32_t tag = (uint32_t)lane << 5;
+    while (S) {
+      const int a = __clz(S);
+      const uint32_t bit = 0x80000000u >> a;
+      S &= ~bit;
+      if (widx < (uint32_t)(Q1_TR * 64)) s_dsc[widx] = (uint16_t)(tag | (uint32_t)a);
+      else S2 |= bit;
+      ++widx;
+    }
   }
-  const LeafPack LP = leaf_pack(H);
-  while (S) {
-    const int a = __clz(S);
-    S &= ~(0x80000000u >> a);
-    const uint64_t rest = E << (a + 1);
-    const int n = min(__clzll(rest) + 1, W2);
-    const uint32_t pv = a ? ((V >> (32 - a)) & 1u) : prevV;
-    const uint32_t complete = (pv & (uint32_t)(Vx >> (63 - (a + n))) & 1u) << 6;
-    const uint32_t leaf = leaf_pick(LP, a);
-    const uint32_t bin1 = leaf >> B2_LOG;
-    // bases of the run: 96 bases from string offset 32 + a - c (origin = chunk -1)
-    const int o2 = 32 + a - c;                                  // 15..63
-    const int q = o2 >> 4, sb = 2 * (o2 & 15);
-    uint32_t T[7];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+  // more runs in this wave than the balanced phase holds (pathological input): append directly
+  while (S2) {
+    const int a = __clz(S2);
+    S2 &= ~(0x80000000u >> a);
+    const Rec2 rec = q1_build(st, ((uint32_t)lane << 5) | (uint32_t)a, k, c);
+    const uint32_t reg = q1_reg(rec.b.w >> 16, blockIdx.x & (NXG - 1));
+    const uint32_t dst = atomicAdd(&v.cnt1[reg], 1u);
+    if (dst < v.cap1) v.rec1[(uint64_t)reg * v.cap1 + dst] = rec;
+    else spill_record2(rec.a, rec.b, k, canon != 0, t);
+  }
+
+  // ---- B2: lane i builds the wave's i-th record ----
+  Rec2 rc[Q1_TR];
+  uint32_t rk[Q1_TR];                              // rank inside the record's bin; ~0: no record
+  cnt_w = min(cnt_w, (uint32_t)(Q1_TR * 64));
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      const uint32_t x0 = R[i], x1 = R[i + 1], x2 = R[i + 2], x3 = R[i + 3];
-      const uint32_t lo_ = (q & 1) ? x1 : x0, hi_ = (q & 1) ? x3 : x2;
-      T[i] = (q & 2) ? hi_ : lo_;
+  for (int tr = 0; tr < Q1_TR; ++tr) {
+    rk[tr] = 0xFFFFFFFFu;
+    rc[tr].a = make_uint4(0, 0, 0, 0);
+    rc[tr].b = make_uint4(0, 0, 0, 0);
+    const uint32_t i = (uint32_t)(tr * 64 + lane);
+    if (i < cnt_w) {
+      rc[tr] = q1_build(st, s_dsc[i], k, c);
+      rk[tr] = atomicAdd(&hist[rc[tr].b.w >> 16], 1u);
     }
-    uint32_t D[6];
-    const int nb = n + k - 1;                                   // bases that belong to the run
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      uint32_t d = sb ? ((T[i] << sb) | (T[i + 1] >> (32 - sb))) : T[i];
-      const int keep = 2 * nb - 32 * i;                         // bits of this dword inside the run
-      d = (keep >= 32) ? d : ((keep <= 0) ? 0u : (d & (~0u << (32 - keep))));
-      D[i] = d;
-    }
-    Rec2 rec;
-    rec.a = make_uint4(D[0], D[1], D[2], D[3]);
-    rec.b = make_uint4(D[4], D[5], 0u, (leaf << 8) | complete | (uint32_t)(n - 1));
-    if (slot < (uint32_t)Q1_RCAP) {
-      rec_tmp[slot] = rec;
-      bin_tmp[slot] = (uint8_t)bin1;
-      atomicAdd(&hist[bin1], 1u);
-    } else {
-      const uint32_t reg = q1_reg(bin1, blockIdx.x & (NXG - 1));
-      const uint32_t dst = atomicAdd(&v.cnt1[reg], 1u);
-      if (dst < v.cap1) v.rec1[(uint64_t)reg * v.cap1 + dst] = rec;
-      else spill_record2(rec, k, canon != 0, t);
-    }
-    ++slot;
+    __builtin_amdgcn_sched_barrier(0);             // one trip at a time: interleaved trips spill registers
   }
   __syncthreads();
 
-  // ---- C / D: reservation, bin-ordered copy-out (as msp.hip) ----
+  // ---- C: one global reservation per non-empty bin; bin offsets ----
   uint32_t my_base = 0;
   if (tid < B1) {
     const uint32_t cnum = hist[tid];
     if (cnum) my_base = atomicAdd(&v.cnt1[q1_reg(tid, blockIdx.x & (NXG - 1))], cnum);
   }
-  block_scan<B1>(hist, loff, wtot);
-  const uint32_t nrec = min(nrec_s, (uint32_t)Q1_RCAP);
-  for (uint32_t s = tid; s < nrec; s += Q1_THREADS) {
-    const uint32_t b = bin_tmp[s];
-    perm[loff[b] + atomicAdd(&fill[b], 1u)] = (uint16_t)s;
+  block_scan<B1>(hist, loff, wtot);                // ends with a barrier: the staging area is dead
+  if (tid == B1 - 1) nrec_s = loff[tid] + hist[tid];
+#pragma unroll
+  for (int tr = 0; tr < Q1_TR; ++tr) {
+    if (rk[tr] != 0xFFFFFFFFu) {
+      const uint32_t pos = loff[rc[tr].b.w >> 16] + rk[tr];
+      if (pos < (uint32_t)Q1_RCAP) arena[pos] = rc[tr];
+    }
   }
   if (tid < B1) gbase[tid] = my_base;
   __syncthreads();
-  for (uint32_t p = tid; p < nrec; p += Q1_THREADS) {
-    const uint32_t s = perm[p];
-    const uint32_t b = bin_tmp[s];
-    const uint32_t dst = gbase[b] + (p - loff[b]);
-    const Rec2 rec = rec_tmp[s];
+
+  // ---- D: copy out in bin order ----
+  auto put = [&](uint32_t b, uint32_t dst, const Rec2 &rec) {
     if (dst < v.cap1) v.rec1[(uint64_t)q1_reg(b, blockIdx.x & (NXG - 1)) * v.cap1 + dst] = rec;
-    else spill_record2(rec, k, canon != 0, t);
+    else spill_record2(rec.a, rec.b, k, canon != 0, t);
+  };
+  if (nrec_s > (uint32_t)Q1_RCAP) {                // records beyond the LDS arena go to their reserved places
+#pragma unroll
+    for (int tr = 0; tr < Q1_TR; ++tr) {
+      if (rk[tr] != 0xFFFFFFFFu) {
+        const uint32_t b = rc[tr].b.w >> 16;
+        if (loff[b] + rk[tr] >= (uint32_t)Q1_RCAP) put(b, gbase[b] + rk[tr], rc[tr]);
+      }
+    }
+  }
+  // consecutive lanes write consecutive 16-byte HALVES of consecutive records: every store
+  // instruction fills whole 32-byte sectors (a record written as two strided halves leaves every
+  // sector half-written by the first store: the L2 then fetches the line to merge, and writes it twice)
+  const uint32_t nrec = min(nrec_s, (uint32_t)Q1_RCAP);
+  const uint4 *arena4 = reinterpret_cast<const uint4 *>(arena);
+  uint4 *out4 = reinterpret_cast<uint4 *>(v.rec1);
+  for (uint32_t q = tid; q < 2 * nrec; q += Q1_THREADS) {
+    const uint32_t p = q >> 1;
+    const uint32_t b = arena[p].b.w >> 16;
+    const uint32_t dst = gbase[b] + (p - loff[b]);
+    if (dst < v.cap1) out4[((uint64_t)q1_reg(b, blockIdx.x & (NXG - 1)) * v.cap1 + dst) * 2 + (q & 1u)] = arena4[q];
+    else if (!(q & 1u)) spill_record2(arena[p].a, arena[p].b, k, canon != 0, t);
   }
 }
 
@@ -368,7 +440,7 @@ __global__ __launch_bounds__(Q2_THREADS) void msp2_p2_kernel(int groups_per_bin,
       uint64_t at = leaf * (v.cap2c + 3 * v.cap2t) + ((cls == 3u) ? 0 : v.cap2c + cls * v.cap2t);
       if (v.exact) { cap = v.lcap[b1 * NSUB + sb]; at = v.lbase[b1 * NSUB + sb]; }
       if (dst < cap) v.rec2[at + dst] = rec;
-      else if (v.exact) spill_record2(rec, k, canon != 0, t);    // cannot happen: cap is the exact count
+      else if (v.exact) spill_record2(rec.a, rec.b, k, canon != 0, t);    // cannot happen: cap is the exact count
       else if (*(volatile uint64_t *)&v.stats[ST_L2OVF] == 0) {
         // too small by a little: park the record; by a lot: the host redoes Q2 with exact sizes
         const unsigned long long o = atomicAdd((unsigned long long *)&v.stats[ST_OVFN], 1ull);
@@ -696,7 +768,7 @@ __global__ __launch_bounds__(1024) void msp2_layout_kernel(const uint32_t *__res
 __global__ __launch_bounds__(256) void msp2_spill_list_kernel(const Rec2 *__restrict__ recs, uint32_t n, int k,
                                                               int canon, TableView t) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i < n) spill_record2(recs[i], k, canon != 0, t);
+  if (i < n) spill_record2(recs[i].a, recs[i].b, k, canon != 0, t);
 }
 
 // One workgroup per leaf: add the `parts` lists of that leaf (the passes of a multi-pass add) in
