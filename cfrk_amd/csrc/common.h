@@ -133,11 +133,11 @@ __device__ __forceinline__ uint32_t dev_pack4(uint32_t w) {
 }
 // 4 code bytes -> 4 bits, bit 3 = first base; set where the byte is not in 0..3
 __device__ __forceinline__ uint32_t dev_bad4(uint32_t w) {
-  uint32_t b = w & 0xFCFCFCFCu;
-  uint32_t t = b | (b >> 4);
-  t |= t >> 2;
-  t |= t >> 1;
-  return ((t & 0x01010101u) * 0x08040201u) >> 24;
+  // bit 7 of a byte <- (bits 2..6 nonzero) | bit 7: the add cannot carry out of a byte (0x7C + 0x7F)
+  const uint32_t f = (((w & 0x7C7C7C7Cu) + 0x7F7F7F7Fu) | w) & 0x80808080u;
+  // the flags at bits 7, 15, 23, 31 land on bits 35, 34, 33, 32 of the product (every partial
+  // product hits its own bit: no carries); bits 4.. of the high word hold other partial products
+  return __umulhi(f, 0x10080402u) & 15u;
 }
 __device__ __forceinline__ void dev_pack16(uint4 v, uint32_t &bases, uint32_t &bad) {
   bases = (dev_pack4(v.x) << 24) | (dev_pack4(v.y) << 16) | (dev_pack4(v.z) << 8) | dev_pack4(v.w);

@@ -45,7 +45,7 @@ namespace {
 constexpr int P1_THREADS = 512;
 constexpr int P1_RCAP = 2304;              // records staged in LDS per workgroup (expected ~1800 at W=18); 3 workgroups per CU
 
-constexpr int P2_THREADS = 1024, P2_PER = 4, P2_TILE = P2_THREADS * P2_PER;
+constexpr int P2_THREADS = 512, P2_PER = 8, P2_TILE = P2_THREADS * P2_PER;
 constexpr int P2_GROUP = 4;                      // consecutive tiles per workgroup (next tile prefetched)
 
 constexpr int P3_THREADS = 1024;
