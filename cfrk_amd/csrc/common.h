@@ -60,6 +60,7 @@ struct cfrk_ctx {
   // minimizer-partitioned fast path (msp.hip)
   struct cfrk_msp *msp;
   int last_passes;       // passes the most recent add took on a partitioned path (1 unless memory was short)
+  uint32_t dbg_flags;    // cfrk_debug_set_flags
   size_t mem_budget;     // 0 = what the device has free; else a cap on the partitioned paths' buffers (diagnostics)
 };
 

@@ -34,6 +34,7 @@ struct MspView {
   uint4 *ovf; uint32_t ovf_cap;                // parking for records that overflow a leaf stream
   // the same one level up: exact level-1 layout (region r starts at record rbase[r], holds rcap[r])
   const uint64_t *rbase; const uint32_t *rcap; uint32_t exact1;
+  uint32_t dbg;                                  // cfrk_debug_set_flags
   uint4 *ovf1; uint32_t ovf1_cap;
   uint64_t *stats;
 };

@@ -725,10 +725,10 @@ constexpr uint32_t RT_LOCK = 0xFFFFFFFFu;
 
 // (rotations decorrelate the three base words, one multiply spreads them into the top bits: the
 // bases of a record are sequence, already close to uniform)
-__device__ __forceinline__ uint32_t rtab_slot(uint4 rec) {
+__device__ __forceinline__ uint32_t rtab_slot(uint4 rec, int log_slots = RT_LOG) {
   const uint32_t t = rec.x ^ __builtin_amdgcn_alignbit(rec.y, rec.y, 11) ^ __builtin_amdgcn_alignbit(rec.z, rec.z, 21) ^
                      ((rec.w & 63u) << 26);
-  return (t * 0x9E3779B1u) >> (32 - RT_LOG);
+  return (t * 0x9E3779B1u) >> (32 - log_slots);
 }
 
 // Every instruction -- vector or scalar -- costs an issue slot here, so the probe step is written
@@ -746,12 +746,13 @@ __device__ __forceinline__ uint32_t rtab_diff(uint4 e, uint4 rec) {
 // the record is placed (lanes without a record start that way).  On return lanes still without
 // RT_DONE found no place.
 constexpr uint32_t RT_DONE = 0x80000000u;
-__device__ __forceinline__ void rtab_insert_loop(uint4 *rtab, uint4 rec, uint32_t &h) {
+__device__ __forceinline__ void rtab_insert_loop(uint4 *rtab, uint4 rec, uint32_t &h, uint32_t mask = RT - 1,
+                                                 int trips = RT_TRIPS) {
   uint32_t *rmeta = reinterpret_cast<uint32_t *>(rtab);
   const uint32_t nm1 = rec.w & 63u;
-  for (int it = 0; it < RT_TRIPS && __ballot((int32_t)h >= 0); ++it) {
+  for (int it = 0; it < trips && __ballot((int32_t)h >= 0); ++it) {
     const bool p = (int32_t)h >= 0;
-    const uint32_t hh = h & (RT - 1);
+    const uint32_t hh = h & mask;
     const uint4 e = rtab[hh];
     const bool match = rtab_diff(e, rec) == 0u;
     const bool empty = e.w == RT_EMPTY;
@@ -768,23 +769,93 @@ __device__ __forceinline__ void rtab_insert_loop(uint4 *rtab, uint4 rec, uint32_
     // an empty slot lost to another lane, or a locked one, is read again; a slot holding another
     // record sends the lane on
     const bool stay = match || empty || e.w == RT_LOCK;
-    const uint32_t nh = stay ? hh : ((hh + 1) & (RT - 1));
+    const uint32_t nh = stay ? hh : ((hh + 1) & mask);
     h = (p && !match && won == 0u) ? nh : (h | RT_DONE);
   }
 }
 
+// Second chance for a leaf whose complete runs do not fit the record table (a small k has short
+// windows, hence ~2/(W+1) distinct runs per locus and strand: ~600 per leaf at k = 21 where k = 31
+// has ~300, and heavy leaves several times that).  Before phase 2 the k-mer table is still empty,
+// so the whole LDS pool (k-mer table + record table, 64 KB) serves as one 4096-slot record table;
+// the distinct runs with their multiplicities then overwrite the head of the leaf's complete-run
+// stream in HBM -- this workgroup is its only reader and has read all of it -- and phase 2 expands
+// them from there.  Returns the number of distinct runs, or ~0 if even that table is too small
+// (the leaf is then counted k-mer by k-mer from its streams).  Out of line: a rare path that would
+// otherwise cost the hot path registers.
+constexpr int BT_LOG = 12, BT = 1 << BT_LOG, BT_TRIPS = 192;
+// occupied slots of the pool-wide record table -> head of the stream; returns their number
+__device__ __noinline__ uint32_t p3_compact(uint4 *pool, uint4 *stream, uint32_t *wsum) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t *meta = reinterpret_cast<const uint32_t *>(pool);
+  // a thread owns BT / P3_THREADS consecutive slots (two passes over LDS: an array of entries
+  // would live in scratch memory)
+  constexpr int PER = BT / P3_THREADS;
+  uint32_t mine = 0;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) mine += (meta[4 * (PER * tid + i) + 3] != RT_EMPTY) ? 1u : 0u;
+  uint32_t incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t y = __shfl_up(incl, d);
+    if (lane >= d) incl += y;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  uint32_t base = 0, total = 0;
+  for (int w = 0; w < P3_THREADS / 64; ++w) {
+    const uint32_t x = wsum[w];
+    base += (w < wave) ? x : 0u;
+    total += x;
+  }
+  uint32_t at = base + incl - mine;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const uint4 e = pool[PER * tid + i];
+    if (e.w != RT_EMPTY) stream[at++] = e;
+  }
+  // the list is read back by the waves of this workgroup only: workgroup scope (one CU, whose
+  // vector cache its own stores keep current) -- an agent-scope release would write back the L2
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  return total;
+}
+__device__ __noinline__ uint32_t p3_big_dedupe(uint4 *pool, uint4 *stream, uint64_t n1, uint32_t *wsum, uint32_t *fail) {
+  const int tid = threadIdx.x;
+  __syncthreads();                               // every thread has read *fail (that is why we are here)
+  for (int s = tid; s < BT; s += P3_THREADS) pool[s] = make_uint4(0u, 0u, 0u, RT_EMPTY);
+  if (tid == 0) *fail = 0u;
+  __syncthreads();
+  for (uint64_t r = tid; r < ((n1 + 63) & ~63ull); r += P3_THREADS) {
+    const bool valid = r < n1;
+    uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+    if (valid) rec = stream[r];
+    uint32_t h = valid ? rtab_slot(rec, BT_LOG) : RT_DONE;
+    rtab_insert_loop(pool, rec, h, BT - 1, BT_TRIPS);
+    if ((int32_t)h >= 0) *fail = 1u;
+  }
+  __syncthreads();
+  if (*fail) return 0xFFFFFFFFu;
+  return p3_compact(pool, stream, wsum);
+}
+
 template <bool CANON>
 __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void msp_p3_kernel(int k, MspView v, TableView t) {
-  __shared__ unsigned long long keys[TS];
-  __shared__ uint32_t cnts[TS];
-  __shared__ uint4 rtab[RT];
+  // k-mer table (keys, counts) and record table in one allocation: p3_big_dedupe uses all of it
+  __shared__ uint4 pool[BT];
+  static_assert(BT * 16 == TS * 12 + RT * 16, "the pool is exactly the k-mer table plus the record table");
+  unsigned long long *const keys = reinterpret_cast<unsigned long long *>(pool);
+  uint32_t *const cnts = reinterpret_cast<uint32_t *>(pool + TS / 2);
+  uint4 *const rtab = pool + TS / 2 + TS / 4;
   __shared__ uint16_t occ_list[RT];
   __shared__ uint16_t tlist[TL_CAP];
   __shared__ uint32_t nhist[32], thist[32];
+  __shared__ uint32_t wsum[P3_THREADS / 64];
   __shared__ uint32_t nocc;
   __shared__ uint32_t wg_total;
   __shared__ unsigned long long wg_base;
-  __shared__ uint32_t rt_fail;                   // the record table ran out of room: count from the streams
+  __shared__ uint32_t rt_fail;                   // the record table ran out of room: second chance, then count from the streams
   __shared__ uint32_t kovf;                      // the k-mer table ran out of room in this pass
   __shared__ uint32_t stk[40];                   // key subsets still to count: bits << 16 | value
   __shared__ int sp;
@@ -795,8 +866,20 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
   const uint64_t n1 = min((uint64_t)v.cnt2[NCLS * leaf + 1], v.exact ? (uint64_t)v.lcap[NCLS * leaf + 1] : v.cap2c);  // complete runs
   const uint4 *leaf_rec = v.exact ? v.rec2 + v.lbase[NCLS * leaf + 1] : v.rec2 + (uint64_t)leaf * (v.cap2c + v.cap2t);
   if (nt + n1 == 0) return;
-  for (int s = tid; s < TS; s += P3_THREADS) { keys[s] = CFRK_EMPTY_KEY; cnts[s] = 0; }
-  for (int s = tid; s < RT; s += P3_THREADS) rtab[s] = make_uint4(0u, 0u, 0u, RT_EMPTY);
+  // Short windows (k < 28) mean more distinct runs per leaf than the record table holds (~600 at
+  // k = 21, heavy leaves several times that): the complete runs are then deduplicated in a table
+  // over the whole pool right away and listed in the stream (see p3_big_dedupe / p3_compact).
+  const bool big_first = k < 28;
+  uint4 *const tab = big_first ? pool : rtab;
+  const int tab_log = big_first ? BT_LOG : RT_LOG;
+  const uint32_t tab_mask = (1u << tab_log) - 1u;
+  const int tab_trips = big_first ? BT_TRIPS : RT_TRIPS;
+  if (big_first) {
+    for (int s = tid; s < BT; s += P3_THREADS) pool[s] = make_uint4(0u, 0u, 0u, RT_EMPTY);
+  } else {
+    for (int s = tid; s < TS; s += P3_THREADS) { keys[s] = CFRK_EMPTY_KEY; cnts[s] = 0; }
+    for (int s = tid; s < RT; s += P3_THREADS) rtab[s] = make_uint4(0u, 0u, 0u, RT_EMPTY);
+  }
   if (tid == 0) { wg_total = 0; nocc = 0; rt_fail = 0; kovf = 0; sp = 0; leaf_total = 0; nseg = 0; }
   if (tid < 32) { nhist[tid] = 0; thist[tid] = 0; }
   __syncthreads();
@@ -816,20 +899,20 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     const uint4 *src = leaf_rec;
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
     const uint64_t n1a = n1;
-    uint32_t *rmeta = reinterpret_cast<uint32_t *>(rtab);
+    uint32_t *rmeta = reinterpret_cast<uint32_t *>(tab);
     uint4 L = zero4;                 // leftover records, lanes [0, c)
     uint32_t Lh = 0;
     int c = 0;                       // wave-uniform
     auto drain = [&](int cnt) {
       uint32_t h = Lh | ((lane < cnt) ? 0u : RT_DONE);
-      rtab_insert_loop(rtab, L, h);
+      rtab_insert_loop(tab, L, h, tab_mask, tab_trips);
       // no room in the record table: a leaf with more distinct runs than it holds (low coverage
       // of a large genome).  Dedupe is pointless there: the whole leaf is counted from its streams.
       if ((int32_t)h >= 0) rt_fail = 1u;
     };
     auto home = [&](const uint4 rec, bool valid) {
-      const uint32_t h = rtab_slot(rec);
-      const uint4 e = rtab[h];
+      const uint32_t h = rtab_slot(rec, tab_log);
+      const uint4 e = tab[h];
       const bool match = valid && rtab_diff(e, rec) == 0u;
       if (match) atomicAdd(&rmeta[4 * h + 3], 1u << 6);
       const bool left = valid && !match;
@@ -858,13 +941,24 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
       home(rec1, v1);
     }
     if (c) drain(c);
+    if ((v.dbg & CFRK_DEBUG_FORCE_RT_OVERFLOW) && !big_first) rt_fail = 1u;
   }
   __syncthreads();
   // ---- phase 2: k-mer by k-mer -- every distinct complete record of the record table (weight =
   //      its multiplicity) and the truncated runs (weight 1).  Both are first listed SORTED BY
   //      LENGTH (counting sort of 16-bit indices in LDS): a wave expands 64 records in lock-step
   //      for as many steps as its longest one, so equal lengths keep every lane busy.
-  const bool big = rt_fail != 0u;                // (read after the barrier above: uniform)
+  uint32_t nd = 0xFFFFFFFFu;                     // distinct runs listed in the stream (second chance), ~0: none
+  if (big_first || rt_fail != 0u) {              // (rt_fail read after the barrier above: uniform)
+    if (!big_first) nd = p3_big_dedupe(pool, const_cast<uint4 *>(leaf_rec), n1, wsum, &rt_fail);
+    else if (rt_fail == 0u) nd = p3_compact(pool, const_cast<uint4 *>(leaf_rec), wsum);
+    else __syncthreads();                        // (the pool is cleared below: everybody has read rt_fail and the table)
+    for (int s = tid; s < TS; s += P3_THREADS) { keys[s] = CFRK_EMPTY_KEY; cnts[s] = 0; }
+    for (int s = tid; s < RT; s += P3_THREADS) rtab[s] = make_uint4(0u, 0u, 0u, RT_EMPTY);
+    __syncthreads();
+  }
+  const bool listed = nd != 0xFFFFFFFFu;
+  const bool big = !listed && rt_fail != 0u;
   {
     // (a) record table: occupied slots, longest first (not when the leaf is counted from its streams)
     const uint4 e = rtab[tid];                       // RT == P3_THREADS
@@ -925,7 +1019,15 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     first_pass = false;
     __syncthreads();
     {
-      if (!big) {
+      if (listed) {
+        // distinct complete runs with their multiplicities, from the head of the stream
+        for (uint32_t i = tid; i < ((nd + 63u) & ~63u); i += P3_THREADS) {
+          const bool valid = i < nd;
+          uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+          if (valid) rec = leaf_rec[i];
+          count_record_v2<CANON>(keys, cnts, rec, rec.w >> 6, valid, k, kmask, rcsh, t, ss, ovf);
+        }
+      } else if (!big) {
         const uint32_t nlist = nocc;
         for (uint32_t i = tid; i < ((nlist + 63u) & ~63u); i += P3_THREADS) {
           const bool valid = i < nlist;
@@ -1224,7 +1326,7 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
   void *p;
   MspView &v = ms->view;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_L1, (size_t)B1 * nxg * cap1 * sizeof(uint4), &p))) return rc;
-  v.rec1 = (uint4 *)p; v.cap1 = cap1; v.nxg = (uint32_t)nxg;
+  v.rec1 = (uint4 *)p; v.cap1 = cap1; v.nxg = (uint32_t)nxg; v.dbg = ctx->dbg_flags;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)NLEAF * (cap2c + cap2t) * sizeof(uint4), &p))) return rc;
   v.rec2 = (uint4 *)p; v.cap2c = cap2c; v.cap2t = cap2t;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_AUX, (size_t)NLEAF * 8 + (size_t)(B1 * nxg + (NCLS + 1) * NLEAF) * sizeof(uint32_t), &p))) return rc;
@@ -1500,6 +1602,12 @@ int cfrk_msp_resolve(cfrk_ctx *ctx, ResultSrc *src, bool *use_list) {
 extern "C" int cfrk_debug_set_mem_budget(cfrk_ctx *ctx, uint64_t bytes) {
   if (!ctx) return CFRK_ERR_ARG;
   ctx->mem_budget = (size_t)bytes;
+  return CFRK_OK;
+}
+
+extern "C" int cfrk_debug_set_flags(cfrk_ctx *ctx, uint32_t flags) {
+  if (!ctx) return CFRK_ERR_ARG;
+  ctx->dbg_flags = flags;
   return CFRK_OK;
 }
 

@@ -13,6 +13,7 @@ import numpy as np
 CFRK_COMPAT = 0x1
 CFRK_CANONICAL = 0x2
 CFRK_FORCE_HASH = 0x4
+CFRK_DEBUG_FORCE_RT_OVERFLOW = 0x1   # cfrk_debug_set_flags
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libcfrk_hip.so")
@@ -77,6 +78,7 @@ def load_library():
         "cfrk_global_merge_leaves_device": ([vp, vp, vp, vp, C.POINTER(u64), vp, C.c_int], C.c_int),
         "cfrk_debug_msp_info": ([vp, C.POINTER(u64)], C.c_int),
         "cfrk_debug_set_mem_budget": ([vp, u64], C.c_int),
+        "cfrk_debug_set_flags": ([vp, C.c_uint32], C.c_int),
         "cfrk_debug_last_add_passes": ([vp, C.POINTER(C.c_int)], C.c_int),
         "cfrk_synth_reads_device": ([vp, i64, i64, i32, i64, u64, u64, u64, i32, vp, vp, vp], C.c_int),
     }
@@ -233,6 +235,9 @@ class GlobalCounter:
 
     def set_mem_budget(self, nbytes):
         self.ctx.check(self._L.cfrk_debug_set_mem_budget(self.ctx._h, int(nbytes)), "cfrk_debug_set_mem_budget")
+
+    def set_debug_flags(self, flags):
+        self.ctx.check(self._L.cfrk_debug_set_flags(self.ctx._h, int(flags)), "cfrk_debug_set_flags")
 
     def last_add_passes(self):
         n = C.c_int()

@@ -175,6 +175,12 @@ int cfrk_debug_msp_info(cfrk_ctx *ctx, uint64_t out[9]);
 int cfrk_debug_set_mem_budget(cfrk_ctx *ctx, uint64_t bytes);
 int cfrk_debug_last_add_passes(cfrk_ctx *ctx, int *out_passes);
 
+/* Test switches for rarely taken device paths (0 = normal operation).  Bit 0: every leaf of the
+ * one-word partitioned path (16 <= k <= 32) is treated as if its complete runs had overflowed the
+ * record table, i.e. takes the second-chance deduplication over the whole LDS pool. */
+#define CFRK_DEBUG_FORCE_RT_OVERFLOW 0x1
+int cfrk_debug_set_flags(cfrk_ctx *ctx, uint32_t flags);
+
 /* ---- synthetic reads, generated on device ----------------------------------- */
 
 /* Reads [r0, r0+R) of the deterministic generator, struct-read layout: d_data R*(L+1) bytes,

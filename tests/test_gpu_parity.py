@@ -395,6 +395,39 @@ def test_msp_leaf_table_overflow_spills_to_hbm_table(ctx):
     assert g2.digest() == d
 
 
+@pytest.mark.parametrize("k", [28, 31, 32])
+def test_msp_record_table_overflow_second_chance(ctx, k):
+    """k >= 28 deduplicates a leaf's complete runs in a 1024-slot LDS table; a leaf with more
+    distinct runs takes a second pass with a table over the whole LDS pool, whose entries replace
+    the head of the leaf's stream in HBM.  The debug switch sends EVERY leaf down that path
+    (k < 28 always deduplicates that way: covered by every other test of those k)."""
+    import cfrk_amd
+    rng = np.random.default_rng(900 + k)
+    genome = rng.integers(0, 4, 30_000).astype(np.int8)
+    reads = []
+    for _ in range(6000):                                   # ~30x coverage, both strands
+        p = int(rng.integers(0, len(genome) - 150))
+        r = genome[p:p + 150].copy()
+        if rng.random() < 0.5:
+            r = (3 - r[::-1]).astype(np.int8)
+        if rng.random() < 0.1:
+            r[int(rng.integers(0, 150))] = -1
+        reads.append(r)
+    data, _, _ = refsem.flatten(reads)
+    for canonical in (False, True):
+        flags = cfrk_amd.CFRK_CANONICAL if canonical else 0
+        g = cfrk_amd.GlobalCounter(ctx, k, flags, 0)
+        g.set_debug_flags(cfrk_amd.CFRK_DEBUG_FORCE_RT_OVERFLOW)
+        try:
+            g.add(data)
+        finally:
+            g.set_debug_flags(0)
+        assert g.msp_info()["spilled_kmers"] == 0
+        lo, hi, cnt = g.export()
+        wlo, whi, wcnt = orc.global_count(data, k, orc.ORC_CANONICAL if canonical else 0)
+        assert len(lo) == len(wlo) and (lo == wlo).all() and (cnt.astype(np.uint64) == wcnt).all()
+
+
 def test_msp_then_merge_and_second_add(ctx):
     """the leaf-output list is folded into the table when a later add / merge needs it"""
     import cfrk_amd
