@@ -259,17 +259,17 @@ __global__ __launch_bounds__(P1_THREADS, 6) void msp_p1_kernel(const int8_t *__r
 // lanes busy.  Records stay in registers until the workgroup's bin histogram is scanned and go to
 // LDS directly in bin order (rank from the histogram atomic), so the staging area and the sorted
 // records share one allocation and the permutation pass of msp_p1_kernel is gone.
-constexpr int P1B_TR = 4;                        // balanced trips held in registers (256 runs per wave)
-constexpr int P1B_STAGE = 4096 + 3 * 512 + P1B_TR * 128;     // bytes of staging per wave
-constexpr int P1B_RCAP = P1_WAVES * P1B_STAGE / 16;          // sorted records share the staging bytes
-
-template <int W>
+// P1B_TR = balanced trips held in registers (64 runs per wave each)
+template <int W, int P1B_TR>
 __global__ __launch_bounds__(P1_THREADS, 6) void msp_p1b_kernel(const int8_t *__restrict__ data,
                                                              int64_t nN, int k, int m, int canon,
                                                              int64_t tile0, MspView v, TableView t) {
   constexpr int NH = 32 + W - 1;
+  constexpr int P1B_STAGE = 4096 + 3 * 512 + P1B_TR * 128;     // bytes of staging per wave
+  constexpr int P1B_RCAP = P1_WAVES * P1B_STAGE / 16;          // sorted records share the staging bytes
   __shared__ uint4 arena[P1B_RCAP];              // per-wave staging, later the bin-sorted records
-  __shared__ uint32_t hist[B1], loff[B1], gbase[B1];
+  __shared__ uint32_t hist[B1], loff[B1];
+  uint32_t *const gbase = hist;                  // the global bases take the histogram's place once it is scanned
   __shared__ uint32_t wtot[4];
   __shared__ uint32_t nrec_s;
 
@@ -377,9 +377,9 @@ __global__ __launch_bounds__(P1_THREADS, 6) void msp_p1b_kernel(const int8_t *__
     uint4 rec;
     rec.x = __builtin_amdgcn_alignbit(D0, D1, sh);
     // bases after the run's last k-mer are cleared: equal runs -> byte-identical records
-    const int z = 2 * (48 - (n + k - 1));        // < 64: k >= 28 on this path
+    const int z = 2 * (48 - (n + k - 1));        // < 64 for k >= 17
     uint64_t r12 = ((uint64_t)__builtin_amdgcn_alignbit(D1, D2, sh) << 32) | __builtin_amdgcn_alignbit(D2, D3, sh);
-    r12 = (r12 >> z) << z;
+    r12 = (W < 8 && z >= 64) ? 0ull : ((r12 >> z) << z);
     rec.y = (uint32_t)(r12 >> 32);
     rec.z = (uint32_t)r12;
     rec.w = (leaf << 8) | complete | (uint32_t)(n - 1);
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(P1_THREADS, 6) void msp_p1b_kernel(const int8_t *__
     if (c) my_base = atomicAdd(&v.cnt1[l1_reg(tid, blockIdx.x & (v.nxg - 1))], c);
   }
   block_scan<B1>(hist, loff, wtot);              // ends with a barrier: the staging area is dead
-  if (tid == B1 - 1) nrec_s = loff[tid] + hist[tid];
+  if (tid == B1 - 1) nrec_s = loff[tid] + hist[tid];   // (before this thread overwrites hist[tid] below)
 #pragma unroll
   for (int tr = 0; tr < P1B_TR; ++tr) {
     if (rk[tr] != 0xFFFFFFFFu) {
@@ -1368,11 +1368,11 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
 #define CFRK_P1_CASE(WW) \
       case WW: hipLaunchKernelGGL((msp_p1_kernel<WW>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, tile0, v, t); break;
 #define CFRK_P1B_CASE(WW) \
-      case WW: hipLaunchKernelGGL((msp_p1b_kernel<WW>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, tile0, v, t); break;
+      case WW: hipLaunchKernelGGL((msp_p1b_kernel<WW, (WW >= 16 ? 4 : WW >= 12 ? 6 : 8)>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, tile0, v, t); break;
       switch (W) {
-        CFRK_P1_CASE(4) CFRK_P1_CASE(5) CFRK_P1_CASE(6) CFRK_P1_CASE(7) CFRK_P1_CASE(8) CFRK_P1_CASE(9)
-        CFRK_P1_CASE(10) CFRK_P1_CASE(11) CFRK_P1_CASE(12) CFRK_P1_CASE(13) CFRK_P1_CASE(14)
-        CFRK_P1_CASE(15) CFRK_P1B_CASE(16) CFRK_P1B_CASE(17) CFRK_P1B_CASE(18)
+        CFRK_P1_CASE(4) CFRK_P1_CASE(5) CFRK_P1_CASE(6) CFRK_P1_CASE(7) CFRK_P1_CASE(8) CFRK_P1B_CASE(9)
+        CFRK_P1B_CASE(10) CFRK_P1B_CASE(11) CFRK_P1B_CASE(12) CFRK_P1B_CASE(13) CFRK_P1B_CASE(14)
+        CFRK_P1B_CASE(15) CFRK_P1B_CASE(16) CFRK_P1B_CASE(17) CFRK_P1B_CASE(18)
         default: return cfrk_fail(ctx, CFRK_ERR_ARG, "no partition kernel for W=%d", W);
       }
 #undef CFRK_P1_CASE
