@@ -249,8 +249,33 @@ __global__ __launch_bounds__(RX3_THREADS) void rx3_kernel(RxView v) {
   if (tid == 0) wg_total = 0;
   __syncthreads();
   const uint32_t *src = v.exact ? v.key2 + v.lbase[leaf] : v.key2 + (uint64_t)leaf * v.cap2;
-  for (uint64_t i = tid; i < n; i += RX3_THREADS)
-    atomicAdd(&cnt[((src[i] & imask) << rlog) | ((uint32_t)tid & rmask)], 1u);
+  {
+    // 16-byte loads, four of them in flight per thread (a key per load and iteration left the
+    // workgroup waiting for HBM ~40 times per leaf): the stream is read as uint4 from the
+    // 16-byte boundary below its first key, elements outside [0, n) are skipped
+    const uint32_t head = (uint32_t)((reinterpret_cast<uintptr_t>(src) >> 2) & 3u);
+    const uint4 *src4 = reinterpret_cast<const uint4 *>(src - head);
+    const uint64_t n4 = (head + n + 3) >> 2;                 // uint4 elements that hold keys
+    const uint64_t lo = head, hi = head + n;                 // valid element range in the aligned view
+    constexpr int INFL = 4;
+    for (uint64_t q0 = 0; q0 < n4; q0 += (uint64_t)INFL * RX3_THREADS) {
+      uint4 x[INFL];
+#pragma unroll
+      for (int u = 0; u < INFL; ++u) {
+        const uint64_t q = q0 + (uint64_t)u * RX3_THREADS + tid;
+        x[u] = make_uint4(0u, 0u, 0u, 0u);
+        if (q < n4) x[u] = src4[q];
+      }
+#pragma unroll
+      for (int u = 0; u < INFL; ++u) {
+        const uint64_t e = 4 * (q0 + (uint64_t)u * RX3_THREADS + tid);
+        const uint32_t w[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (e + c >= lo && e + c < hi) atomicAdd(&cnt[((w[c] & imask) << rlog) | ((uint32_t)tid & rmask)], 1u);
+      }
+    }
+  }
   __syncthreads();
   if (rlog) {                       // fold the replicas into replica 0
     for (uint32_t s = tid; s < nidx; s += RX3_THREADS) {
