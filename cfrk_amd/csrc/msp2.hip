@@ -614,13 +614,20 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
   // ---- phase 1: complete runs, one record-table update per record; when the table runs out of
   //      room (more distinct runs than it holds: low coverage of a large genome) the dedupe is
   //      dropped and the whole leaf is counted from its streams
-  for (uint64_t r = tid; r < ((ns[3] + 63) & ~63ull); r += Q3_THREADS) {
-    const bool valid = r < ns[3];
-    Rec2 rec = zrec;
-    if (valid) rec = leaf_rec[r];
-    uint32_t h = r2_slot(rec) | (valid ? 0u : R2_DONE);
-    r2_insert_loop(rtab, rec, h);
-    if ((int32_t)h >= 0) rt_fail = 1u;
+  //      (the next record is asked for before the current one is inserted: one workgroup per CU,
+  //      nothing else hides the load)
+  {
+    Rec2 nxt = zrec;
+    if ((uint64_t)tid < ns[3]) nxt = leaf_rec[tid];
+    for (uint64_t r = tid; r < ((ns[3] + 63) & ~63ull); r += Q3_THREADS) {
+      const bool valid = r < ns[3];
+      const Rec2 rec = nxt;
+      nxt = zrec;
+      if (r + Q3_THREADS < ns[3]) nxt = leaf_rec[r + Q3_THREADS];
+      uint32_t h = r2_slot(rec) | (valid ? 0u : R2_DONE);
+      r2_insert_loop(rtab, rec, h);
+      if ((int32_t)h >= 0) rt_fail = 1u;
+    }
   }
   __syncthreads();
   const bool big = rt_fail != 0u;
@@ -684,10 +691,13 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
     }
     for (int cl = 2; cl >= 0; --cl) {
       const Rec2 *src = v.exact ? v.rec2 + v.lbase[NCLS * leaf + cl] : leaf_rec + v.cap2c + (uint64_t)cl * v.cap2t;
+      Rec2 nxt = zrec;
+      if ((uint64_t)tid < ns[cl]) nxt = src[tid];
       for (uint64_t r = tid; r < ((ns[cl] + 63) & ~63ull); r += Q3_THREADS) {
         const bool valid = r < ns[cl];
-        Rec2 rec = zrec;
-        if (valid) rec = src[r];
+        const Rec2 rec = nxt;
+        nxt = zrec;
+        if (r + Q3_THREADS < ns[cl]) nxt = src[r + Q3_THREADS];
         count_record2<CANON>(keys, cnts, rec, 1u, valid, k, t, ss, ovf);
       }
     }
