@@ -64,9 +64,16 @@ struct Roll2 {
   u128 fwd, rc, kmask;
   uint64_t t0, t1, t2;     // bases not yet consumed, first one in the top bits of t0
   int rcsh;
-  __device__ __forceinline__ void init(const Rec2 &r, int k) {
-    const uint64_t s0 = ((uint64_t)r.a.x << 32) | r.a.y, s1 = ((uint64_t)r.a.z << 32) | r.a.w;
-    const uint64_t s2 = ((uint64_t)r.b.x << 32) | r.b.y;
+  // j0: first k-mer to produce (the record's base string is shifted left by j0 bases first)
+  __device__ __forceinline__ void init(const Rec2 &r, int k, int j0 = 0) {
+    uint64_t s0 = ((uint64_t)r.a.x << 32) | r.a.y, s1 = ((uint64_t)r.a.z << 32) | r.a.w;
+    uint64_t s2 = ((uint64_t)r.b.x << 32) | r.b.y;
+    if (j0) {                                        // 1 <= j0 <= 31
+      const int sh = 2 * j0;
+      s0 = (s0 << sh) | (s1 >> (64 - sh));
+      s1 = (s1 << sh) | (s2 >> (64 - sh));
+      s2 <<= sh;
+    }
     kmask = (k == 64) ? ~(u128)0 : ((((u128)1) << (2 * k)) - 1);
     rcsh = 2 * k - 2;
     const u128 top = ((u128)s0 << 64) | s1;            // bases 0..63
@@ -502,12 +509,17 @@ __device__ __forceinline__ bool in_subset2(uint64_t lo, uint64_t hi, KeySubset2 
 template <bool CANON>
 __device__ __forceinline__ void count_record2(ulonglong2 *keys, uint32_t *cnts, const Rec2 &rec, uint32_t add,
                                               bool valid, int k, const TableView &t,
-                                              KeySubset2 ss = KeySubset2{0u, 0u}, uint32_t *ovf = nullptr) {
+                                              KeySubset2 ss = KeySubset2{0u, 0u}, uint32_t *ovf = nullptr,
+                                              int part = 0, int parts = 1) {
   if (ovf && *(volatile uint32_t *)ovf) return;
-  const int nk = valid ? (int)(rec.b.w & 63u) + 1 : 0;
+  // a record may be shared by `parts` lanes, each expanding a contiguous share of its k-mers
+  const int nall = valid ? (int)(rec.b.w & 63u) + 1 : 0;
+  const int per = (parts == 1) ? nall : (parts == 2) ? ((nall + 1) >> 1) : (parts == 3) ? ((nall + 2) / 3) : ((nall + 3) >> 2);
+  const int j0 = part * per;
+  const int nk = min(nall, j0 + per);
   Roll2 roll;
-  roll.init(rec, k);
-  for (int j = 0; __ballot(j < nk); ++j) {
+  roll.init(rec, k, j0);
+  for (int j = j0; __ballot(j < nk); ++j) {
     const u128 key = (CANON && roll.rc < roll.fwd) ? roll.rc : roll.fwd;
     const uint64_t lo = (uint64_t)key, hi = (uint64_t)(key >> 64);
     uint32_t h = t2_slot(lo, hi) | ((j < nk && in_subset2(lo, hi, ss)) ? 0u : T2_DONE);
@@ -675,11 +687,18 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
     first_pass = false;
     __syncthreads();
     if (!big) {
-      for (uint32_t i = tid; i < ((nocc + 63u) & ~63u); i += Q3_THREADS) {
-        const bool valid = i < nocc;
+      // few distinct runs (~320) for 1024 lanes, and a wave works for as many steps as its longest
+      // run has k-mers: up to four lanes share a record, each expanding a quarter of its k-mers
+      const uint32_t nocc_ = nocc;
+      const int parts = (nocc_ * 4u <= (uint32_t)Q3_THREADS) ? 4 : (nocc_ * 3u <= (uint32_t)Q3_THREADS) ? 3
+                        : (nocc_ * 2u <= (uint32_t)Q3_THREADS) ? 2 : 1;
+      const uint32_t nitems = nocc_ * (uint32_t)parts;
+      for (uint32_t i = tid; i < ((nitems + 63u) & ~63u); i += Q3_THREADS) {
+        const bool valid = i < nitems;
+        const uint32_t ri = (parts == 1) ? i : (parts == 2) ? (i >> 1) : (parts == 3) ? (i / 3u) : (i >> 2);
         Rec2 rec = zrec;
-        if (valid) rec = rtab[occ_list[i]];
-        count_record2<CANON>(keys, cnts, rec, rec.b.w >> 6, valid, k, t, ss, ovf);
+        if (valid) rec = rtab[occ_list[ri]];
+        count_record2<CANON>(keys, cnts, rec, rec.b.w >> 6, valid, k, t, ss, ovf, (int)(i - ri * (uint32_t)parts), parts);
       }
     } else {
       for (uint64_t r = tid; r < ((ns[3] + 63) & ~63ull); r += Q3_THREADS) {
