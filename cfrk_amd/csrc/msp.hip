@@ -674,11 +674,19 @@ template <bool CANON>
 __device__ __forceinline__ void count_record_v2(unsigned long long *keys, uint32_t *cnts, uint4 rec, uint32_t add,
                                                 bool valid, int k, uint64_t kmask, int rcsh,
                                                 const TableView &t, KeySubset ss = KeySubset{0u, 0u},
-                                                uint32_t *ovf = nullptr) {
+                                                uint32_t *ovf = nullptr, int part = 0, int parts = 1) {
   if (ovf && *(volatile uint32_t *)ovf) return;
-  const int nk = valid ? (int)(rec.w & 63u) + 1 : 0;
-  const uint64_t hi = ((uint64_t)rec.x << 32) | rec.y;
-  const uint64_t lo = (uint64_t)rec.z << 32;
+  // a record may be shared by `parts` lanes, each expanding a contiguous share of its k-mers
+  const int nall = valid ? (int)(rec.w & 63u) + 1 : 0;
+  const int per = (parts == 1) ? nall : (parts == 2) ? ((nall + 1) >> 1) : ((nall + 2) / 3);
+  const int j0 = part * per;
+  const int nk = max(min(nall, j0 + per) - j0, 0);
+  uint64_t hi = ((uint64_t)rec.x << 32) | rec.y;
+  uint64_t lo = (uint64_t)rec.z << 32;
+  if (parts != 1 && j0) {                          // start at k-mer j0: 1 <= j0 <= 31
+    hi = (hi << (2 * j0)) | (lo >> (64 - 2 * j0));
+    lo <<= 2 * j0;
+  }
   uint64_t fwd = hi >> (64 - 2 * k);
   uint64_t rc = CANON ? dev_revcomp64(fwd, k) : 0;
   uint64_t T = (k == 32) ? lo : ((hi << (2 * k)) | (lo >> (64 - 2 * k)));
@@ -1028,12 +1036,18 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
           count_record_v2<CANON>(keys, cnts, rec, rec.w >> 6, valid, k, kmask, rcsh, t, ss, ovf);
         }
       } else if (!big) {
+        // ~320 distinct runs for 1024 lanes, and a wave works for as many steps as its longest run
+        // has k-mers: up to three lanes share a record, each expanding a share of its k-mers
         const uint32_t nlist = nocc;
-        for (uint32_t i = tid; i < ((nlist + 63u) & ~63u); i += P3_THREADS) {
-          const bool valid = i < nlist;
+        const int parts = (nlist * 3u <= (uint32_t)P3_THREADS) ? 3 : (nlist * 2u <= (uint32_t)P3_THREADS) ? 2 : 1;
+        const uint32_t nitems = nlist * (uint32_t)parts;
+        for (uint32_t i = tid; i < ((nitems + 63u) & ~63u); i += P3_THREADS) {
+          const bool valid = i < nitems;
+          const uint32_t ri = (parts == 1) ? i : (parts == 2) ? (i >> 1) : (i / 3u);
           uint4 rec = make_uint4(0u, 0u, 0u, 0u);
-          if (valid) rec = rtab[occ_list[i]];
-          count_record_v2<CANON>(keys, cnts, rec, rec.w >> 6, valid, k, kmask, rcsh, t, ss, ovf);
+          if (valid) rec = rtab[occ_list[ri]];
+          count_record_v2<CANON>(keys, cnts, rec, rec.w >> 6, valid, k, kmask, rcsh, t, ss, ovf,
+                                 (int)(i - ri * (uint32_t)parts), parts);
         }
       } else {
         // the complete runs straight from their stream, weight 1 each
