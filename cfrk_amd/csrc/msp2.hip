@@ -626,9 +626,46 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
   // ---- phase 1: complete runs, one record-table update per record; when the table runs out of
   //      room (more distinct runs than it holds: low coverage of a large genome) the dedupe is
   //      dropped and the whole leaf is counted from its streams
-  //      (the next record is asked for before the current one is inserted: one workgroup per CU,
-  //      nothing else hides the load)
+  //      Most records find their twin in the home slot (two LDS reads, an XOR/OR reduction, one
+  //      LDS add, every lane busy); the rest are compacted across the wave into a 64-lane leftover
+  //      set and only a full set runs the probe loop (as in msp.hip).  The next record is asked
+  //      for before the current one is inserted: one workgroup per CU, nothing else hides the load.
   {
+    uint32_t *words = reinterpret_cast<uint32_t *>(rtab);
+    Rec2 Lr = zrec;                    // leftover records, lanes [0, c)
+    uint32_t Lh = 0;
+    int c = 0;                         // wave-uniform
+    auto drain = [&](int cnt) {
+      uint32_t h = Lh | ((lane < cnt) ? 0u : R2_DONE);
+      r2_insert_loop(rtab, Lr, h);
+      if ((int32_t)h >= 0) rt_fail = 1u;
+    };
+    auto home = [&](const Rec2 &rec, bool valid) {
+      const uint32_t h = r2_slot(rec);
+      const uint4 eb = rtab[h].b;                              // state word + bases 64..95
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // bases 0..63 only after the state
+      const uint4 ea = rtab[h].a;
+      const bool match = valid && ((((eb.w ^ rec.b.w) & 63u) | (eb.x ^ rec.b.x) | (eb.y ^ rec.b.y) | (ea.x ^ rec.a.x) |
+                                    (ea.y ^ rec.a.y) | (ea.z ^ rec.a.z) | (ea.w ^ rec.a.w)) == 0u);
+      if (match) atomicAdd(&words[8 * h + 7], 1u << 6);
+      const bool left = valid && !match;
+      const unsigned long long mask = __ballot(left);
+      if (mask == 0ull) return;
+      const int n = __popcll(mask);
+      if (c + n > 64) { drain(c); c = 0; }
+      const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+      const int dst = left ? (c + rank) : ((c + n) & 63);      // the others aim at a lane nobody keeps
+      const int da = dst << 2;
+      const uint32_t p0 = __builtin_amdgcn_ds_permute(da, rec.a.x), p1 = __builtin_amdgcn_ds_permute(da, rec.a.y);
+      const uint32_t p2 = __builtin_amdgcn_ds_permute(da, rec.a.z), p3 = __builtin_amdgcn_ds_permute(da, rec.a.w);
+      const uint32_t p4 = __builtin_amdgcn_ds_permute(da, rec.b.x), p5 = __builtin_amdgcn_ds_permute(da, rec.b.y);
+      const uint32_t p7 = __builtin_amdgcn_ds_permute(da, rec.b.w), ph = __builtin_amdgcn_ds_permute(da, h);
+      const bool take = lane >= c && lane < c + n;
+      Lr.a.x = take ? p0 : Lr.a.x; Lr.a.y = take ? p1 : Lr.a.y; Lr.a.z = take ? p2 : Lr.a.z; Lr.a.w = take ? p3 : Lr.a.w;
+      Lr.b.x = take ? p4 : Lr.b.x; Lr.b.y = take ? p5 : Lr.b.y; Lr.b.w = take ? p7 : Lr.b.w;
+      Lh = take ? ph : Lh;
+      c += n;
+    };
     Rec2 nxt = zrec;
     if ((uint64_t)tid < ns[3]) nxt = leaf_rec[tid];
     for (uint64_t r = tid; r < ((ns[3] + 63) & ~63ull); r += Q3_THREADS) {
@@ -636,10 +673,9 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
       const Rec2 rec = nxt;
       nxt = zrec;
       if (r + Q3_THREADS < ns[3]) nxt = leaf_rec[r + Q3_THREADS];
-      uint32_t h = r2_slot(rec) | (valid ? 0u : R2_DONE);
-      r2_insert_loop(rtab, rec, h);
-      if ((int32_t)h >= 0) rt_fail = 1u;
+      home(rec, valid);
     }
+    if (c) drain(c);
   }
   __syncthreads();
   const bool big = rt_fail != 0u;
