@@ -337,6 +337,8 @@ __global__ __launch_bounds__(P1_THREADS, 6) void msp_p1b_kernel(const int8_t *__
   }
   uint32_t cnt_w;
   uint32_t S2 = 0;                               // run starts beyond the balanced phase's capacity
+  // (CFRK_DEBUG_SMALL_WAVE_CAP: one trip's worth, so that tests reach the direct-append path)
+  const uint32_t wcap = (v.dbg & CFRK_DEBUG_SMALL_WAVE_CAP) ? 64u : (uint32_t)(P1B_TR * 64);
   {
     const uint32_t mine = (uint32_t)__popc(S);
     uint32_t incl = mine;
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(P1_THREADS, 6) void msp_p1b_kernel(const int8_t *__
       const int a = __clz(S);
       const uint32_t bit = 0x80000000u >> a;
       S &= ~bit;
-      if (widx < (uint32_t)(P1B_TR * 64)) s_dsc[widx] = (uint16_t)(tag | (uint32_t)a);
+      if (widx < wcap) s_dsc[widx] = (uint16_t)(tag | (uint32_t)a);
       else S2 |= bit;
       ++widx;
     }
@@ -399,7 +401,7 @@ __global__ __launch_bounds__(P1_THREADS, 6) void msp_p1b_kernel(const int8_t *__
   // ---- B2: lane i builds the wave's i-th record ----
   uint4 rc[P1B_TR];
   uint32_t rk[P1B_TR];                           // rank inside the record's bin; ~0: no record
-  cnt_w = min(cnt_w, (uint32_t)(P1B_TR * 64));
+  cnt_w = min(cnt_w, wcap);
 #pragma unroll
   for (int tr = 0; tr < P1B_TR; ++tr) {
     rk[tr] = 0xFFFFFFFFu;

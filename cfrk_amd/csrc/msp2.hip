@@ -44,6 +44,7 @@ struct View2 {
   // starts at record lbase[NCLS * leaf + class] and holds exactly lcap[...] records
   const uint64_t *lbase; const uint32_t *lcap; uint32_t exact;
   Rec2 *ovf; uint32_t ovf_cap;                           // parking for a few overflowing records
+  uint32_t dbg;                                          // cfrk_debug_set_flags
   uint64_t *stats;
 };
 
@@ -237,6 +238,7 @@ __global__ __launch_bounds__(Q1_THREADS, 6) void msp2_p1_kernel(const int8_t *__
   const Stage2 st = {s_leaf, s_str, s_E, s_W};
   uint32_t cnt_w;
   uint32_t widx, S2 = 0;                           // S2: run starts beyond the balanced phase's capacity
+  const uint32_t wcap = (v.dbg & CFRK_DEBUG_SMALL_WAVE_CAP) ? 64u : (uint32_t)(Q1_TR * 64);
   {
     const uint32_t mine = (uint32_t)__popc(S);
     uint32_t incl = mine;
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(Q1_THREADS, 6) void msp2_p1_kernel(const int8_t *__
       const int a = __clz(S);
       const uint32_t bit = 0x80000000u >> a;
       S &= ~bit;
-      if (widx < (uint32_t)(Q1_TR * 64)) s_dsc[widx] = (uint16_t)(tag | (uint32_t)a);
+      if (widx < wcap) s_dsc[widx] = (uint16_t)(tag | (uint32_t)a);
       else S2 |= bit;
       ++widx;
     }
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(Q1_THREADS, 6) void msp2_p1_kernel(const int8_t *__
   // ---- B2: lane i builds the wave's i-th record ----
   Rec2 rc[Q1_TR];
   uint32_t rk[Q1_TR];                              // rank inside the record's bin; ~0: no record
-  cnt_w = min(cnt_w, (uint32_t)(Q1_TR * 64));
+  cnt_w = min(cnt_w, wcap);
 #pragma unroll
   for (int tr = 0; tr < Q1_TR; ++tr) {
     rk[tr] = 0xFFFFFFFFu;
@@ -947,7 +949,7 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
   v.out_hi = (uint64_t *)p;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTC, (size_t)ctx->g_cap * 4, &p))) return rc;
   v.out_cnt = (uint32_t *)p; v.out_cap = ctx->g_cap;
-  v.stats = ctx->g_stats;
+  v.stats = ctx->g_stats; v.dbg = ctx->dbg_flags;
   TableView t = cfrk_table_view(ctx);
 
   HIP_TRY(ctx, hipMemsetAsync(v.cnt1, 0, (size_t)(B1 * NXG + (NCLS + 1) * NLEAF) * sizeof(uint32_t), ctx->stream));

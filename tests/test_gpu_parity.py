@@ -428,6 +428,28 @@ def test_msp_record_table_overflow_second_chance(ctx, k):
         assert len(lo) == len(wlo) and (lo == wlo).all() and (cnt.astype(np.uint64) == wcnt).all()
 
 
+@pytest.mark.parametrize("k", [21, 24, 27, 28, 31, 32, 33, 48, 63])
+def test_partition_kernel_direct_append_path(ctx, k):
+    """the first partition kernel keeps a wave's runs in registers (4..8 trips of 64); runs beyond
+    that are built and appended one by one.  Real inputs never get there; the debug switch cuts
+    the capacity to one trip so that most records of this input do."""
+    import cfrk_amd
+    rng = np.random.default_rng(1200 + k)
+    reads = _random_reads(rng, 3000, 20, 400, 0.01)
+    data, _, _ = refsem.flatten(reads)
+    for canonical in (False, True):
+        flags = cfrk_amd.CFRK_CANONICAL if canonical else 0
+        g = cfrk_amd.GlobalCounter(ctx, k, flags, 0)
+        g.set_debug_flags(cfrk_amd.CFRK_DEBUG_SMALL_WAVE_CAP)
+        try:
+            g.add(data)
+        finally:
+            g.set_debug_flags(0)
+        lo, hi, cnt = g.export()
+        wlo, whi, wcnt = orc.global_count(data, k, orc.ORC_CANONICAL if canonical else 0)
+        assert len(lo) == len(wlo) and (lo == wlo).all() and (hi == whi).all() and (cnt.astype(np.uint64) == wcnt).all()
+
+
 def test_msp_then_merge_and_second_add(ctx):
     """the leaf-output list is folded into the table when a later add / merge needs it"""
     import cfrk_amd
