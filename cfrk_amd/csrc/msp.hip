@@ -794,6 +794,7 @@ __device__ __forceinline__ void rtab_insert_loop(uint4 *rtab, uint4 rec, uint32_
 // (the leaf is then counted k-mer by k-mer from its streams).  Out of line: a rare path that would
 // otherwise cost the hot path registers.
 constexpr int BT_LOG = 12, BT = 1 << BT_LOG, BT_TRIPS = 192;
+constexpr int BT_MIN_RUNS = 2 * BT;
 // occupied slots of the pool-wide record table -> head of the stream; returns their number
 __device__ __noinline__ uint32_t p3_compact(uint4 *pool, uint4 *stream, uint32_t *wsum) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -879,7 +880,10 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
   // Short windows (k < 28) mean more distinct runs per leaf than the record table holds (~600 at
   // k = 21, heavy leaves several times that): the complete runs are then deduplicated in a table
   // over the whole pool right away and listed in the stream (see p3_big_dedupe / p3_compact).
-  const bool big_first = k < 28;
+  // Both uses of the pool-wide table need duplicates to pay for the extra pass: a leaf with
+  // fewer than BT_MIN_RUNS complete runs cannot hold many copies of more than ~10^3 distinct ones
+  // (low coverage of a large genome: the stream path is the better fallback there).
+  const bool big_first = k < 28 && n1 >= (uint64_t)BT_MIN_RUNS;
   uint4 *const tab = big_first ? pool : rtab;
   const int tab_log = big_first ? BT_LOG : RT_LOG;
   const uint32_t tab_mask = (1u << tab_log) - 1u;
@@ -960,7 +964,8 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
   //      for as many steps as its longest one, so equal lengths keep every lane busy.
   uint32_t nd = 0xFFFFFFFFu;                     // distinct runs listed in the stream (second chance), ~0: none
   if (big_first || rt_fail != 0u) {              // (rt_fail read after the barrier above: uniform)
-    if (!big_first) nd = p3_big_dedupe(pool, const_cast<uint4 *>(leaf_rec), n1, wsum, &rt_fail);
+    if (!big_first && (n1 >= (uint64_t)BT_MIN_RUNS || (v.dbg & CFRK_DEBUG_FORCE_RT_OVERFLOW))) nd = p3_big_dedupe(pool, const_cast<uint4 *>(leaf_rec), n1, wsum, &rt_fail);
+    else if (!big_first) __syncthreads();        // (as below)
     else if (rt_fail == 0u) nd = p3_compact(pool, const_cast<uint4 *>(leaf_rec), wsum);
     else __syncthreads();                        // (the pool is cleared below: everybody has read rt_fail and the table)
     for (int s = tid; s < TS; s += P3_THREADS) { keys[s] = CFRK_EMPTY_KEY; cnts[s] = 0; }

@@ -19,11 +19,10 @@ constexpr int NXG = 64;
 constexpr int NLEAF = B1 * B2;
 
 
-// ordering hash of a canonical m-mer (bijective: odd multiplier, xorshift)
-__device__ __forceinline__ uint32_t hash_mmer(uint32_t c) {
-  uint32_t h = c * 0x9E3779B1u;
-  return h ^ (h >> 16);
-}
+// ordering hash of a canonical m-mer (bijective: odd multiplier).  No xorshift on top: the window
+// minimum looks at the product's top bits, which already mix every bit of c, and the leaf id is
+// bits 8..23 -- folding the top half down would only add the winner's (small, skewed) top bits.
+__device__ __forceinline__ uint32_t hash_mmer(uint32_t c) { return c * 0x9E3779B1u; }
 // minimizer -> leaf id (16 bits).  The window minimum is skewed low in its TOP bits only (that is
 // what the comparison looks at); bits 8..23 of the winning hash stay uniform (simulated: same
 // leaf balance as a full re-mix), and the low bits hold the position tag.  Byte-aligned so that
