@@ -58,16 +58,19 @@ def exchange_by_leaf(engine, world, device, wire_device=None):
     engine.export_leaves(parts) -> (keys, keys_hi_or_None, counts, part_counts, leaf_counts) or None."""
     wire = torch.device(wire_device) if wire_device is not None else torch.device(device)
     exp = engine.export_leaves(world)
-    ok = torch.tensor([1 if exp is not None else 0], dtype=torch.int32, device=wire)
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    if int(ok.item()) == 0:
-        return None
-    keys, hi, cnt, part_counts, leaf_counts = exp
-    send = torch.tensor(part_counts, dtype=torch.int64, device=wire)
+    # one small all-to-all carries the segment sizes AND every rank's "I can export by leaf" vote
+    # (each rank tells every other): one collective and one host sync instead of two
+    part_counts = exp[3] if exp is not None else [0] * world
+    mine = 1 if exp is not None else 0
+    send = torch.tensor([[int(c), mine] for c in part_counts], dtype=torch.int64, device=wire)
     recv = torch.empty_like(send)
     dist.all_to_all_single(recv, send)
+    got = recv.cpu().tolist()
+    if mine == 0 or min(int(g[1]) for g in got) == 0:
+        return None
+    keys, hi, cnt, part_counts, leaf_counts = exp
     send_l = [int(x) for x in part_counts]
-    recv_l = [int(x) for x in recv.cpu().tolist()]
+    recv_l = [int(g[0]) for g in got]
     n_send, n_recv = sum(send_l), sum(recv_l)
 
     def a2a(t):

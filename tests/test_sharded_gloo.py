@@ -34,6 +34,21 @@ class OracleEngine:
     def export_leaves(self, parts):
         return None                     # the oracle has no leaf form: exercises the fallback vote
 
+    NL = 16                             # "leaves" of the stand-in: splitmix(key) % NL
+
+    def export_leaves_fake(self, parts):
+        """leaf form of the same table: part = leaf % parts, lists ordered by (part, leaf)"""
+        leaf = np.array([self.orc.splitmix64(int(x)) % self.NL for x in self.lo], np.int64)
+        lpp = self.NL // parts
+        order = np.lexsort((self.lo, leaf // parts, leaf % parts))
+        pc = [int((leaf % parts == p).sum()) for p in range(parts)]
+        lc = np.zeros((parts, lpp), np.int32)
+        for lf in leaf:
+            lc[lf % parts, lf // parts] += 1
+        lo = torch.from_numpy(self.lo[order].view(np.int64).copy())
+        cnt = torch.from_numpy(self.cnt[order].astype(np.uint32).view(np.int32).copy())
+        return lo, None, cnt, pc, torch.from_numpy(lc.reshape(-1).copy())
+
     def merge(self, lo, hi, cnt):
         for k_, c in zip(lo.numpy().view(np.uint64), cnt.numpy().view(np.uint32)):
             self.merged[int(k_)] = self.merged.get(int(k_), 0) + int(c)
@@ -55,6 +70,15 @@ def _worker(rank, world, port, q):
     data, _, _ = orc.synth_reads(r0, r1 - r0, L, G)
     eng = OracleEngine(data, K)
     assert sharded.exchange_by_leaf(eng, world, torch.device("cpu")) is None   # all ranks agree
+    # one rank cannot export by leaf: every rank must fall back
+    eng.export_leaves = (lambda parts: None) if rank == 1 else eng.export_leaves_fake
+    assert sharded.exchange_by_leaf(eng, world, torch.device("cpu")) is None
+    # all can: segment sizes and the vote travel in one collective
+    eng.export_leaves = eng.export_leaves_fake
+    rkeys, rhi_, rcnt_, recv_l, rlc = sharded.exchange_by_leaf(eng, world, torch.device("cpu"))
+    assert rhi_ is None and sum(recv_l) == len(rkeys) == len(rcnt_) == int(rlc.sum())
+    assert all(orc.splitmix64(int(x)) % OracleEngine.NL % world == rank for x in rkeys.numpy().view(np.uint64))
+    eng.export_leaves = lambda parts: None
     rlo, rhi, rcnt = sharded.exchange_by_owner(eng, world, torch.device("cpu"))
     eng.merge(rlo, rhi, rcnt)
     # every received key must be owned by this rank
