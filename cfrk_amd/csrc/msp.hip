@@ -12,7 +12,8 @@
 //                      {48 bases, leaf id, complete flag, n} to level-1 bin = leaf >> 8.  A
 //                      workgroup stages its records in LDS, reserves space with ONE global
 //                      atomic per non-empty bin per 15.6 KB of input, then copies out in bin
-//                      order (coalesced).
+//                      order (coalesced).  msp_p1b_kernel (k >= 21) is the same kernel with a
+//                      wave-balanced emission phase: lane i builds the wave's i-th record.
 //   P2  msp_p2_kernel  stream every level-1 region, split it 512 ways: leaf low byte x
 //                      {truncated run, complete run} (LDS counting sort of 4096-record tiles,
 //                      one global atomic per stream per tile, coalesced copy-out).
@@ -22,6 +23,9 @@
 //                      truncated runs with weight 1, into a bucketized k-mer table
 //                      (ds_cmpst_b64 to claim, ds_add_u32 to count); the occupied slots are
 //                      compacted to the output list with one cursor atomic per workgroup.
+//                      Leaves with more distinct runs than the record table holds (and every
+//                      leaf for k < 28) deduplicate in a table over the whole LDS pool first
+//                      and list the distinct runs at the head of their own stream.
 //   multi-GPU          leaves are disjoint in key space on every rank, so lists are exchanged
 //                      and added per leaf, again in LDS (msp_gather_kernel, msp_merge_kernel).
 //
