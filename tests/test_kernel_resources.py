@@ -1,0 +1,71 @@
+"""The counting kernels must not touch scratch (private) memory.
+
+Found the hard way: a `const TableView &` parameter on a rarely called
+`__noinline__` helper made every thread of the calling kernel store the 44-byte view to scratch at
+kernel entry -- 32 GB per benchmark step that reached HBM -- and a by-reference record kept a
+kernel's records there.  Neither shows up in a functional test.  This one cross-compiles the device
+code to assembly (no GPU needed) and reads the ISA: `scratch_` instructions per kernel / function
+and the ScratchSize the metadata reports.
+"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "cfrk_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+# (file, {symbol fragment: allowed scratch instructions}); everything else must have none.
+# msp_p3_kernel<true> spills one dword once per workgroup (64 VGPRs at 8 waves/SIMD);
+# p3_big_dedupe is the out-of-line second-chance path and saves a callee-saved pair.
+FILES = [("msp.hip", {"msp_p3_kernelILb1E": 2, "p3_big_dedupe": 2}),
+         ("msp2.hip", {}),
+         ("radix.hip", {}),
+         ("dense.hip", {}),
+         ("global_hash.hip", {})]
+
+
+def _functions(asm):
+    """yield (symbol, scratch instruction count, ScratchSize or None) per device function"""
+    lines = asm.split("\n")
+    i = 0
+    while i < len(lines):
+        m = re.match(r"^(_Z\S+):", lines[i])
+        if m and "@function" in "".join(lines[max(0, i - 4):i]):
+            name, j, ops = m.group(1), i, 0
+            while j < len(lines) and not lines[j].startswith(".Lfunc_end"):
+                ops += "scratch_" in lines[j]
+                j += 1
+            size = None
+            for l in lines[j:j + 80]:
+                mm = re.match(r"^; ScratchSize: ?(\d+)", l)
+                if mm:
+                    size = int(mm.group(1))
+                    break
+            yield name, ops, size
+            i = j
+        i += 1
+
+
+@pytest.mark.parametrize("src,allowed", FILES, ids=[f for f, _ in FILES])
+def test_no_scratch_traffic_in_device_code(src, allowed, tmp_path):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out = tmp_path / (src + ".s")
+    cmd = [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only",
+           "-I" + CSRC, "-I" + os.path.join(ROOT, "include"), os.path.join(CSRC, src), "-o", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    seen = 0
+    for name, ops, size in _functions(out.read_text()):
+        if "rocprim" in name or "hipcub" in name:
+            continue
+        seen += 1
+        limit = max([v for k, v in allowed.items() if k in name] or [0])
+        assert ops <= limit, f"{src}: {name} has {ops} scratch instructions (allowed {limit})"
+        if size is not None:
+            assert size <= 32, f"{src}: {name} reserves {size} bytes of scratch per thread"
+    assert seen > 0
