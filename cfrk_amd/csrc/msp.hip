@@ -12,7 +12,7 @@
 //                      {48 bases, leaf id, complete flag, n} to level-1 bin = leaf >> 8.  A
 //                      workgroup stages its records in LDS, reserves space with ONE global
 //                      atomic per non-empty bin per 15.6 KB of input, then copies out in bin
-//                      order (coalesced).  msp_p1b_kernel (k >= 21) is the same kernel with a
+//                      order (coalesced).  msp_p1b_kernel (k >= 20) is the same kernel with a
 //                      wave-balanced emission phase: lane i builds the wave's i-th record.
 //   P2  msp_p2_kernel  stream every level-1 region, split it 512 ways: leaf low byte x
 //                      {truncated run, complete run} (LDS counting sort of 4096-record tiles,
@@ -1395,7 +1395,7 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
 #define CFRK_P1B_CASE(WW) \
       case WW: hipLaunchKernelGGL((msp_p1b_kernel<WW, (WW >= 16 ? 4 : WW >= 12 ? 6 : 8)>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, tile0, v, t); break;
       switch (W) {
-        CFRK_P1_CASE(4) CFRK_P1_CASE(5) CFRK_P1_CASE(6) CFRK_P1_CASE(7) CFRK_P1_CASE(8) CFRK_P1B_CASE(9)
+        CFRK_P1_CASE(4) CFRK_P1_CASE(5) CFRK_P1_CASE(6) CFRK_P1_CASE(7) CFRK_P1B_CASE(8) CFRK_P1B_CASE(9)
         CFRK_P1B_CASE(10) CFRK_P1B_CASE(11) CFRK_P1B_CASE(12) CFRK_P1B_CASE(13) CFRK_P1B_CASE(14)
         CFRK_P1B_CASE(15) CFRK_P1B_CASE(16) CFRK_P1B_CASE(17) CFRK_P1B_CASE(18)
         default: return cfrk_fail(ctx, CFRK_ERR_ARG, "no partition kernel for W=%d", W);
