@@ -4,7 +4,7 @@
 // rate (~2e10/s), two orders of magnitude under what HBM bandwidth allows.  Here HBM only sees
 // streams, and every occurrence is counted with LDS atomics:
 //
-//   P1  msp_p1_kernel  read the flat code buffer once (2 x dwordx4 per lane, 2-bit packing in
+//   P1  msp_p1b_kernel read the flat code buffer once (2 x dwordx4 per lane, 2-bit packing in
 //                      registers), compute for every k-mer the minimum hash over its W = k-m+1
 //                      canonical m-mers (its minimizer), cut the k-mers into runs that share one
 //                      minimizer occurrence ("super-k-mers"; content-defined, they may cross into
@@ -12,8 +12,8 @@
 //                      {48 bases, leaf id, complete flag, n} to level-1 bin = leaf >> 8.  A
 //                      workgroup stages its records in LDS, reserves space with ONE global
 //                      atomic per non-empty bin per 15.6 KB of input, then copies out in bin
-//                      order (coalesced).  msp_p1b_kernel (k >= 20) is the same kernel with a
-//                      wave-balanced emission phase: lane i builds the wave's i-th record.
+//                      order (coalesced).  Emission is wave-balanced: lane i builds the wave's
+//                      i-th record.
 //   P2  msp_p2_kernel  stream every level-1 region, split it 512 ways: leaf low byte x
 //                      {truncated run, complete run} (LDS counting sort of 4096-record tiles,
 //                      one global atomic per stream per tile, coalesced copy-out).
@@ -47,7 +47,6 @@
 namespace {
 
 constexpr int P1_THREADS = 512;
-constexpr int P1_RCAP = 2304;              // records staged in LDS per workgroup (expected ~1800 at W=18); 3 workgroups per CU
 
 constexpr int P2_THREADS = 512, P2_PER = 8, P2_TILE = P2_THREADS * P2_PER;
 constexpr int P2_GROUP = 4;                      // consecutive tiles per workgroup (next tile prefetched)
@@ -106,166 +105,20 @@ __device__ __forceinline__ void l1_put(const MspView &v, uint32_t reg, uint32_t 
   }
 }
 
-template <int W>
-__global__ __launch_bounds__(P1_THREADS, 6) void msp_p1_kernel(const int8_t *__restrict__ data,
-                                                            int64_t nN, int k, int m, int canon,
-                                                            int64_t tile0, MspView v, TableView t) {
-  constexpr int NH = 32 + W - 1;                 // positions a lane looks at: its own 32 + W-1 ahead
-  __shared__ uint4 rec_tmp[P1_RCAP];
-  __shared__ uint16_t perm[P1_RCAP];
-  __shared__ uint8_t bin_tmp[P1_RCAP];
-  __shared__ uint32_t hist[B1], loff[B1], gbase[B1], fill[B1];
-  __shared__ uint32_t wtot[4];
-  __shared__ uint32_t nrec_s;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int nkmax = min(48 - k + 1, 32);         // >= W for every (k, W) class
-
-  if (tid < B1) { hist[tid] = 0; fill[tid] = 0; }
-  if (tid == 0) nrec_s = 0;
-  __syncthreads();
-
-  // ---- A: this lane's chunk, packed 2 bits per base; neighbours' chunks by shuffle ----
-  const int64_t wave_g = (tile0 + blockIdx.x) * P1_WAVES + (tid >> 6);
-  const int64_t chunk = wave_g * P1_OWN + lane - 1;          // lane 0 of wave 0: chunk -1
-  const int64_t off = chunk * 32;
-  uint32_t b0 = 0, b1 = 0, bad = 0xFFFFFFFFu;
-  if (chunk >= 0) dev_load_chunk32(data, off, nN, b0, b1, bad);
-  const uint32_t n0 = dev_lane_next(b0), n1 = dev_lane_next(b1), nn0 = dev_lane_next(dev_lane_next(b0));
-  const uint32_t nbad = dev_lane_next(bad), nnbad = dev_lane_next(dev_lane_next(bad));
-  const uint64_t hi = ((uint64_t)b0 << 32) | b1;              // bases 0..31
-  const uint64_t mid = ((uint64_t)n0 << 32) | n1;             // bases 32..63
-  const uint64_t lo = (uint64_t)nn0 << 32;                    // bases 64..79
-
-  // Vx bit(63-p): the k-mer starting at position p (0..63 relative to this chunk) has k valid
-  // bases; only p <= 31 + W - 1 is used
-  uint64_t Yh = ((uint64_t)bad << 32) | nbad, Yl = (uint64_t)nnbad << 32;
-  {
-    // OR over the k bases starting at each position: doubling, then one closing step
-    int w = 1;
-#pragma unroll
-    for (int st = 0; st < 5; ++st) {
-      if (2 * w <= k) {
-        Yh |= (Yh << w) | (Yl >> (64 - w));
-        Yl |= Yl << w;
-        w *= 2;
-      }
-    }
-    if (k > w) {
-      Yh |= (Yh << (k - w)) | (Yl >> (64 - (k - w)));
-      Yl |= Yl << (k - w);
-    }
-  }
-  const uint64_t Vx = ~Yh;
-  const uint32_t V = (uint32_t)(Vx >> 32);
-  const uint32_t prevV = dev_lane_prev(V) & 1u;                // validity of position -1
-
-  // minimizers of the own k-mers (+ W-1 of the next lane) and the change mask
-  uint32_t H[NH];
-  const uint64_t Cx = msp_minimizers<W>(hi, mid, chunk, m, H);
-  // terminators: change, invalid, or the end of what this lane can see (never reached: runs <= W)
-  const uint64_t E = Cx | ~Vx | (1ull << (63 - NH));
-  const uint32_t Vprev = (V >> 1) | (prevV << 31);
-  uint32_t S = V & ((uint32_t)(Cx >> 32) | ~Vprev);             // run starts among own positions
-  const bool owner = lane >= 1 && lane <= P1_OWN && off < nN;
-  if (!owner) S = 0;
-
-  // ---- B: one 16-byte record per run, staged in LDS ----
-  // Staging slots: the lane's run count is known (popcount of S), so one wave-level prefix sum
-  // and ONE LDS atomic per wave hand out all slots (an atomic per loop trip would put an LDS
-  // round trip on the critical path of every trip).
-  uint32_t slot;
-  {
-    const uint32_t mine = (uint32_t)__popc(S);
-    uint32_t incl = mine;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t y = __shfl_up(incl, d);
-      if (lane >= d) incl += y;
-    }
-    uint32_t wbase = 0;
-    if (lane == 63 && incl) wbase = atomicAdd(&nrec_s, incl);
-    slot = __shfl(wbase, 63) + incl - mine;
-  }
-  const LeafPack LP = leaf_pack(H);
-  while (S) {
-    const int a = __clz(S);
-    S &= ~(0x80000000u >> a);
-    const uint64_t rest = E << (a + 1);
-    int n = __clzll(rest) + 1;
-    if (n > nkmax) n = nkmax;                                   // cannot happen (W <= nkmax)
-    // "complete": both ends are minimizer changes between valid k-mers, so every read covering
-    // this locus emits the same record
-    const uint32_t pv = a ? ((V >> (32 - a)) & 1u) : prevV;
-    const uint32_t complete = (pv & (uint32_t)(Vx >> (63 - (a + n))) & 1u) << 6;
-    const uint32_t leaf = leaf_pick(LP, a);
-    const uint32_t bin1 = leaf >> B2_LOG;
-    uint4 rec;
-    const uint64_t r01 = a ? ((hi << (2 * a)) | (mid >> (64 - 2 * a))) : hi;
-    const uint64_t r23 = a ? ((mid << (2 * a)) | (lo >> (64 - 2 * a))) : mid;
-    rec.x = (uint32_t)(r01 >> 32);
-    // bases after the run's last k-mer are cleared: equal runs -> byte-identical records
-    const int z = 2 * (48 - (n + k - 1));
-    uint64_t r12 = ((uint64_t)(uint32_t)r01 << 32) | (uint32_t)(r23 >> 32);
-    r12 = (z >= 64) ? 0ull : ((r12 >> z) << z);
-    rec.y = (uint32_t)(r12 >> 32);
-    rec.z = (uint32_t)r12;
-    rec.w = (leaf << 8) | complete | (uint32_t)(n - 1);
-
-    if (slot < (uint32_t)P1_RCAP) {
-      rec_tmp[slot] = rec;
-      bin_tmp[slot] = (uint8_t)bin1;
-      atomicAdd(&hist[bin1], 1u);
-    } else {
-      // LDS staging full (pathological tile): append directly
-      const uint32_t reg = l1_reg(bin1, blockIdx.x & (v.nxg - 1));
-      const uint32_t dst = atomicAdd(&v.cnt1[reg], 1u);
-      l1_put(v, reg, dst, rec, k, canon != 0, t);
-    }
-    ++slot;
-  }
-  __syncthreads();
-
-  // ---- C: one global reservation per non-empty bin; LDS offsets for a bin-sorted order ----
-  // The returning atomics are issued first and consumed last: their latency (microseconds under
-  // load) flies under the scan and the LDS permutation.
-  uint32_t my_base = 0;
-  if (tid < B1) {
-    const uint32_t c = hist[tid];
-    if (c) my_base = atomicAdd(&v.cnt1[l1_reg(tid, blockIdx.x & (v.nxg - 1))], c);
-  }
-  block_scan<B1>(hist, loff, wtot);
-  const uint32_t nrec = min(nrec_s, (uint32_t)P1_RCAP);
-  for (uint32_t s = tid; s < nrec; s += P1_THREADS) {
-    const uint32_t b = bin_tmp[s];
-    perm[loff[b] + atomicAdd(&fill[b], 1u)] = (uint16_t)s;
-  }
-  if (tid < B1) gbase[tid] = my_base;
-  __syncthreads();
-
-  // ---- D: copy out in bin order: consecutive lanes write consecutive 16-byte records ----
-  for (uint32_t p = tid; p < nrec; p += P1_THREADS) {
-    const uint32_t s = perm[p];
-    const uint32_t b = bin_tmp[s];
-    const uint32_t dst = gbase[b] + (p - loff[b]);
-    const uint4 rec = rec_tmp[s];
-    l1_put(v, l1_reg(b, blockIdx.x & (v.nxg - 1)), dst, rec, k, canon != 0, t);
-  }
-}
-
-// ---------------------------------------------------------------------------------------- P1b
-// P1 for W >= 16 (k = 28..32) with a wave-balanced emission phase.  In msp_p1_kernel a lane builds
-// the records of ITS runs in a divergent loop: the wave pays max-over-lanes trips (5..6 at W = 18
-// for 2.8 runs per lane on average) of a ~75-instruction body.  Here a lane only lists its run
-// starts (position descriptors, a few instructions per trip); everything a record is made of is
-// staged per wave in LDS -- the wave's 2-bit base string, run terminators, validity, the leaf id of
-// every position -- and then lane i builds the wave's i-th record: ceil(runs / 64) trips with all
-// lanes busy.  Records stay in registers until the workgroup's bin histogram is scanned and go to
-// LDS directly in bin order (rank from the histogram atomic), so the staging area and the sorted
-// records share one allocation and the permutation pass of msp_p1_kernel is gone.
+// ---------------------------------------------------------------------------------------- P1
+// Emission is wave-balanced.  Building a lane's records in a loop over ITS runs (first version)
+// costs the wave max-over-lanes trips (5..6 at W = 18 for 2.8 runs per lane on average, 18 at
+// W = 4) of a ~75-instruction body.  Here a lane only lists its run starts (position descriptors,
+// a few instructions per trip); everything a record is made of is staged per wave in LDS -- the
+// wave's 2-bit base string, run terminators, validity, the leaf id of every position -- and then
+// lane i builds the wave's i-th record: ceil(runs / 64) trips with all lanes busy.  Records stay
+// in registers until the workgroup's bin histogram is scanned and go to LDS directly in bin order
+// (rank from the histogram atomic), so the staging area and the sorted records share one
+// allocation.  Runs per wave grow as 2/(W+1): the trips held in registers are a template
+// parameter (4 for W >= 16 ... 12 for W = 4), and so are registers and workgroups per CU.
 // P1B_TR = balanced trips held in registers (64 runs per wave each)
 template <int W, int P1B_TR>
-__global__ __launch_bounds__(P1_THREADS, 6) void msp_p1b_kernel(const int8_t *__restrict__ data,
+__global__ __launch_bounds__(P1_THREADS, (P1B_TR <= 6 ? 6 : 4)) void msp_p1b_kernel(const int8_t *__restrict__ data,
                                                              int64_t nN, int k, int m, int canon,
                                                              int64_t tile0, MspView v, TableView t) {
   constexpr int NH = 32 + W - 1;
@@ -289,7 +142,7 @@ __global__ __launch_bounds__(P1_THREADS, 6) void msp_p1b_kernel(const int8_t *__
   if (tid < B1) hist[tid] = 0;
   __syncthreads();
 
-  // ---- A: as msp_p1_kernel ----
+  // ---- A: this lane's chunk, packed 2 bits per base; neighbours' chunks by shuffle ----
   const int64_t wave_g = (tile0 + blockIdx.x) * P1_WAVES + wave;
   const int64_t chunk = wave_g * P1_OWN + lane - 1;
   const int64_t off = chunk * 32;
@@ -1390,17 +1243,14 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
     if (run_p1) {
       HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_L1OVF, 0, 2 * sizeof(uint64_t), ctx->stream));   // ST_L1OVF, ST_OVFN1
       const dim3 g1((unsigned)ntiles), b1(P1_THREADS);
-#define CFRK_P1_CASE(WW) \
-      case WW: hipLaunchKernelGGL((msp_p1_kernel<WW>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, tile0, v, t); break;
 #define CFRK_P1B_CASE(WW) \
-      case WW: hipLaunchKernelGGL((msp_p1b_kernel<WW, (WW >= 16 ? 4 : WW >= 12 ? 6 : 8)>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, tile0, v, t); break;
+      case WW: hipLaunchKernelGGL((msp_p1b_kernel<WW, (WW >= 16 ? 4 : WW >= 12 ? 6 : WW >= 8 ? 8 : WW >= 6 ? 10 : 12)>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, tile0, v, t); break;
       switch (W) {
-        CFRK_P1_CASE(4) CFRK_P1_CASE(5) CFRK_P1_CASE(6) CFRK_P1_CASE(7) CFRK_P1B_CASE(8) CFRK_P1B_CASE(9)
+        CFRK_P1B_CASE(4) CFRK_P1B_CASE(5) CFRK_P1B_CASE(6) CFRK_P1B_CASE(7) CFRK_P1B_CASE(8) CFRK_P1B_CASE(9)
         CFRK_P1B_CASE(10) CFRK_P1B_CASE(11) CFRK_P1B_CASE(12) CFRK_P1B_CASE(13) CFRK_P1B_CASE(14)
         CFRK_P1B_CASE(15) CFRK_P1B_CASE(16) CFRK_P1B_CASE(17) CFRK_P1B_CASE(18)
         default: return cfrk_fail(ctx, CFRK_ERR_ARG, "no partition kernel for W=%d", W);
       }
-#undef CFRK_P1_CASE
 #undef CFRK_P1B_CASE
       HIP_TRY(ctx, hipGetLastError());
     }

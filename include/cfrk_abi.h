@@ -179,7 +179,7 @@ int cfrk_debug_last_add_passes(cfrk_ctx *ctx, int *out_passes);
  * one-word partitioned path (16 <= k <= 32) is treated as if its complete runs had overflowed the
  * record table, i.e. takes the second-chance deduplication over the whole LDS pool. */
 #define CFRK_DEBUG_FORCE_RT_OVERFLOW 0x1
-/* Bit 1: the first partition kernel (k >= 20) holds one trip's worth (64) of a wave's runs in
+/* Bit 1: the first partition kernel (k >= 16) holds one trip's worth (64) of a wave's runs in
  * registers instead of 4..8: the rest takes the direct-append path meant for pathological waves. */
 #define CFRK_DEBUG_SMALL_WAVE_CAP 0x2
 int cfrk_debug_set_flags(cfrk_ctx *ctx, uint32_t flags);
