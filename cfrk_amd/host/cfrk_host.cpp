@@ -49,34 +49,79 @@ int cfrk_host_parse_fasta(const char *buf, size_t len, int flags, cfrk_batch *ou
   if (!out || (!buf && len)) return -4;
   memset(out, 0, sizeof *out);
   const bool compat = (flags & CFRK_INGEST_COMPAT) != 0;
-  // pass 1: record extents (sequence bytes as the reference would strcat them)
+  // pass 1: record extents (sequence bytes as the reference would strcat them).  Large inputs are
+  // scanned by several threads, each over a range of whole lines; a sequence line that precedes
+  // the first header of its range belongs to the last record of the ranges before it.
   struct Rec { size_t first_line; size_t seq_chars; };
   std::vector<Rec> recs;
   std::vector<std::pair<size_t, size_t>> lines;     // (begin, end incl. newline) of sequence lines
-  std::vector<size_t> line_rec;
-  size_t pos = 0;
-  while (pos < len) {
-    const char *nl = (const char *)memchr(buf + pos, '\n', len - pos);
-    size_t end = nl ? (size_t)(nl - buf) + 1 : len;
-    if (buf[pos] == '>') {
-      recs.push_back(Rec{lines.size(), 0});
-    } else {
-      if (recs.empty()) return -2;
-      lines.push_back({pos, end});
-      line_rec.push_back(recs.size() - 1);
+  unsigned nthr = std::thread::hardware_concurrency();
+  if (nthr > 16) nthr = 16;
+  if (nthr < 2 || len < ((size_t)8 << 20)) nthr = 1;
+  {
+    struct Part { std::vector<size_t> rec_first; std::vector<std::pair<size_t, size_t>> lines; };
+    std::vector<Part> parts(nthr);
+    std::vector<size_t> cut(nthr + 1, len);
+    cut[0] = 0;
+    for (unsigned t = 1; t < nthr; ++t) {            // cuts at line starts
+      size_t c = len / nthr * t;
+      if (c < cut[t - 1]) c = cut[t - 1];
+      const char *nl = (c < len) ? (const char *)memchr(buf + c, '\n', len - c) : nullptr;
+      cut[t] = nl ? (size_t)(nl - buf) + 1 : len;
     }
-    pos = end;
+    auto scan = [&](unsigned t) {
+      Part &pt = parts[t];
+      size_t pos = cut[t];
+      const size_t stop = cut[t + 1];
+      while (pos < stop) {
+        const char *nl = (const char *)memchr(buf + pos, '\n', stop - pos);
+        const size_t end = nl ? (size_t)(nl - buf) + 1 : stop;
+        if (buf[pos] == '>') pt.rec_first.push_back(pt.lines.size());
+        else pt.lines.push_back({pos, end});
+        pos = end;
+      }
+    };
+    if (nthr == 1) {
+      scan(0);
+    } else {
+      std::vector<std::thread> pool;
+      for (unsigned t = 0; t < nthr; ++t) pool.emplace_back(scan, t);
+      for (auto &th : pool) th.join();
+    }
+    size_t nrec = 0, nline = 0;
+    for (auto &pt : parts) { nrec += pt.rec_first.size(); nline += pt.lines.size(); }
+    recs.reserve(nrec);
+    lines.reserve(nline);
+    for (auto &pt : parts) {
+      // (a sequence line before any header at all: the reference would dereference garbage)
+      if (recs.empty() && pt.rec_first.empty() && !pt.lines.empty()) return -2;
+      if (recs.empty() && !pt.rec_first.empty() && pt.rec_first[0] != 0) return -2;
+      const size_t base = lines.size();
+      for (size_t f : pt.rec_first) recs.push_back(Rec{base + f, 0});
+      lines.insert(lines.end(), pt.lines.begin(), pt.lines.end());
+    }
   }
   // per-record code counts
   std::vector<int64_t> rlen(recs.size(), 0);
-  for (size_t li = 0; li < lines.size(); ++li) {
-    size_t b = lines[li].first, e = lines[li].second;
-    if (compat) {
-      rlen[line_rec[li]] += (int64_t)(e - b);
-    } else {
-      while (e > b && (buf[e - 1] == '\n' || buf[e - 1] == '\r')) --e;
-      rlen[line_rec[li]] += (int64_t)(e - b);
+  auto count = [&](size_t r0, size_t r1) {
+    for (size_t r = r0; r < r1; ++r) {
+      const size_t l1 = (r + 1 < recs.size()) ? recs[r + 1].first_line : lines.size();
+      int64_t n = 0;
+      for (size_t li = recs[r].first_line; li < l1; ++li) {
+        size_t b = lines[li].first, e = lines[li].second;
+        if (!compat) while (e > b && (buf[e - 1] == '\n' || buf[e - 1] == '\r')) --e;
+        n += (int64_t)(e - b);
+      }
+      rlen[r] = n;
     }
+  };
+  if (nthr == 1) {
+    count(0, recs.size());
+  } else {
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nthr; ++t)
+      pool.emplace_back(count, recs.size() * t / nthr, recs.size() * (t + 1) / nthr);
+    for (auto &th : pool) th.join();
   }
   int64_t nN = 0;
   for (size_t r = 0; r < recs.size(); ++r) {
@@ -93,19 +138,44 @@ int cfrk_host_parse_fasta(const char *buf, size_t len, int flags, cfrk_batch *ou
   out->length = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nS > 0 ? nS : 1));
   if (!out->data || !out->start || !out->length) { cfrk_host_free_batch(out); return -4; }
   out->nN = nN; out->nS = nS;
-  // pass 2: encode (ProcessData, src/fastaIO.h:74-102: codes, then one -1 terminator)
-  int64_t w = 0;
-  size_t li = 0;
-  for (int64_t r = 0; r < nS; ++r) {
-    out->start[r] = w;
-    out->length[r] = (int32_t)rlen[r];
-    int64_t left = rlen[r];
-    for (; li < lines.size() && line_rec[li] == (size_t)r; ++li) {
-      size_t b = lines[li].first, e = lines[li].second;
-      if (!compat) while (e > b && (buf[e - 1] == '\n' || buf[e - 1] == '\r')) --e;
-      for (size_t p = b; p < e && left > 0; ++p, --left) out->data[w++] = kCodes.t[(unsigned char)buf[p]];
+  // pass 2: encode (ProcessData, src/fastaIO.h:74-102: codes, then one -1 terminator).  Records
+  // are independent once their offsets are known: large batches are encoded by several threads.
+  {
+    int64_t w = 0;
+    for (int64_t r = 0; r < nS; ++r) {
+      out->start[r] = w;
+      out->length[r] = (int32_t)rlen[r];
+      w += rlen[r] + 1;
     }
-    out->data[w++] = -1;
+  }
+  auto encode = [&](int64_t r0, int64_t r1) {
+    for (int64_t r = r0; r < r1; ++r) {
+      int64_t w = out->start[r];
+      int64_t left = rlen[r];
+      const size_t l1 = (r + 1 < nS) ? recs[(size_t)r + 1].first_line : lines.size();
+      for (size_t li = recs[(size_t)r].first_line; li < l1; ++li) {
+        size_t b = lines[li].first, e = lines[li].second;
+        if (!compat) while (e > b && (buf[e - 1] == '\n' || buf[e - 1] == '\r')) --e;
+        for (size_t p = b; p < e && left > 0; ++p, --left) out->data[w++] = kCodes.t[(unsigned char)buf[p]];
+      }
+      out->data[w] = -1;
+    }
+  };
+  if (nthr < 2 || nN < (int64_t)(8 << 20)) {
+    encode(0, nS);
+  } else {
+    // split by bytes, not by records: reads may differ in length by orders of magnitude
+    std::vector<std::thread> pool;
+    int64_t r0 = 0;
+    for (unsigned t = 0; t < nthr; ++t) {
+      const int64_t target = nN / nthr * (t + 1);
+      int64_t r1 = r0;
+      if (t + 1 == nthr) r1 = nS;
+      else while (r1 < nS && out->start[r1] < target) ++r1;
+      if (r1 > r0) pool.emplace_back(encode, r0, r1);
+      r0 = r1;
+    }
+    for (auto &th : pool) th.join();
   }
   return 0;
 }

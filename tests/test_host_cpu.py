@@ -74,6 +74,34 @@ def test_native_ingest_joins_lines_and_keeps_last_base(host):
     assert list(data) == [0, 1, 2, 3, -1, 3, 3, 3, 3, -1]
 
 
+def test_large_batch_is_encoded_by_several_threads_identically(host):
+    """batches of >= 8 MB of codes are encoded by a thread pool (records split by bytes): ragged
+    multi-line records, lower case and N, checked against the one-record-at-a-time reference"""
+    rng = np.random.default_rng(77)
+    alphabet = np.frombuffer(b"ACGTacgtN", np.uint8)
+    parts = []
+    reads = []
+    for i in range(1500):
+        n = int(rng.integers(1, 20000)) if i % 7 else int(rng.integers(1, 400000))
+        seq = alphabet[rng.integers(0, len(alphabet), n)]
+        reads.append(seq)
+        parts.append(b">r%d\n" % i)
+        w = int(rng.integers(20, 200))
+        for o in range(0, n, w):
+            parts.append(seq[o:o + w].tobytes() + b"\n")
+    raw = b"".join(parts)
+    rc, (data, start, length) = _parse(host, raw, 0)
+    assert rc == 0 and len(data) >= (8 << 20)
+    lut = np.full(256, -1, np.int8)
+    for ch, v in zip(b"ACGT", range(4)):
+        lut[ch] = v
+        lut[ch + 32] = v
+    want = np.concatenate([np.concatenate([lut[r], np.array([-1], np.int8)]) for r in reads])
+    assert list(length) == [len(r) for r in reads]
+    assert (start == np.concatenate([[0], np.cumsum([len(r) + 1 for r in reads])[:-1]])).all()
+    assert data.shape == want.shape and (data == want).all()
+
+
 def test_ingest_errors(host):
     assert _parse(host, b"ACGT\n>a\nAC\n", 1)[0] == -2
     assert _parse(host, b">a\n>b\nAC\n", 1)[0] == -3          # UB in the reference: rejected
