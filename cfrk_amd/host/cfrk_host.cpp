@@ -183,10 +183,20 @@ int cfrk_host_parse_fasta(const char *buf, size_t len, int flags, cfrk_batch *ou
 int cfrk_host_read_fasta(const char *path, int flags, cfrk_batch *out) {
   FILE *f = fopen(path, "rb");
   if (!f) return -1;                                // the reference exits (src/fastaIO.h:36)
+  // a regular file is read in one piece into a buffer of its size (no growth copies); anything
+  // that cannot be sized (a pipe) is appended chunk by chunk
   std::string buf;
+  long size = -1;
+  if (fseek(f, 0, SEEK_END) == 0) { size = ftell(f); if (fseek(f, 0, SEEK_SET) != 0) size = -1; }
+  if (size > 0) {
+    buf.resize((size_t)size);
+    size_t got = 0, n;
+    while (got < (size_t)size && (n = fread(&buf[got], 1, (size_t)size - got, f)) > 0) got += n;
+    buf.resize(got);
+  }
   char tmp[1 << 16];
   size_t n;
-  while ((n = fread(tmp, 1, sizeof tmp, f)) > 0) buf.append(tmp, n);
+  while ((n = fread(tmp, 1, sizeof tmp, f)) > 0) buf.append(tmp, n);   // growing file / pipe
   fclose(f);
   return cfrk_host_parse_fasta(buf.data(), buf.size(), flags, out);
 }

@@ -111,6 +111,25 @@ def test_ingest_errors(host):
     assert rc == 0 and len(data) == 0 and len(length) == 0
 
 
+def test_read_fasta_from_a_file_equals_parsing_its_bytes(host, tmp_path):
+    raw = b">a\nACGTACGTAC\n>b\nAAAANAAAA\nCC\n>c\nTTTTT\n" * 500
+    path = tmp_path / "x.fasta"
+    path.write_bytes(raw)
+    for flags in (0, 1):
+        b = Batch()
+        assert host.cfrk_host_read_fasta(str(path).encode(), flags, C.byref(b)) == 0
+        data = np.ctypeslib.as_array(b.data, (b.nN,)).copy()
+        length = np.ctypeslib.as_array(b.length, (b.nS,)).copy()
+        host.cfrk_host_free_batch(C.byref(b))
+        rc, (wdata, _, wlength) = _parse(host, raw, flags)
+        assert rc == 0 and (data == wdata).all() and (length == wlength).all()
+    empty = tmp_path / "empty.fasta"
+    empty.write_bytes(b"")
+    b = Batch()
+    assert host.cfrk_host_read_fasta(str(empty).encode(), 0, C.byref(b)) == 0 and b.nS == 0
+    host.cfrk_host_free_batch(C.byref(b))
+
+
 @pytest.mark.parametrize("name", ["seq1", "seq2"])
 def test_golden_through_host_ingest_and_writer(host, derived_fasta, name):
     """reference goldens: C++ ingest -> oracle counts -> C++ writer == golden bytes"""
