@@ -5,6 +5,14 @@
 struct ResultSrc;
 struct TableView;
 
+// Timing ablations (cfrk_debug_set_flags, internal bits): the kernel skips one of its phases, so the
+// counts are WRONG -- only for measuring what a phase costs (tools/ablate.sh).
+#define CFRK_ABL_P3_NO_TRUNC 0x100u   // leaf kernel: truncated runs are not expanded
+#define CFRK_ABL_P3_NO_CEXP  0x200u   // leaf kernel: distinct complete runs are not expanded
+#define CFRK_ABL_P3_NO_RTAB  0x400u   // leaf kernel: complete runs are not read / deduplicated
+#define CFRK_ABL_P3_NO_OUT   0x800u   // leaf kernel: no compaction to the result list
+#define CFRK_ABL_P1_NO_EMIT  0x1000u  // partition kernel: front end only, no records built
+
 bool cfrk_msp_usable(const cfrk_ctx *ctx);                 // fast path applies to this begin()?
 int  cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN);
 // Where does the result live?  *use_list = true and *src filled when it is the compact list the

@@ -192,6 +192,10 @@ __global__ __launch_bounds__(P1_THREADS, (P1B_TR <= 6 ? 6 : 4)) void msp_p1b_ker
     s_E[lane] = E;
     s_W[lane] = (Vx >> 1) | ((uint64_t)prevV << 63);
   }
+  if (v.dbg & CFRK_ABL_P1_NO_EMIT) {             // timing ablation: keep the front end alive, emit nothing
+    if (S == 0x12345678u && (uint32_t)E == 0x9ABCDEFu) v.stats[ST_AUX0] = 1;
+    return;
+  }
   uint32_t cnt_w;
   uint32_t S2 = 0;                               // run starts beyond the balanced phase's capacity
   // (CFRK_DEBUG_SMALL_WAVE_CAP: one trip's worth, so that tests reach the direct-append path)
@@ -802,7 +806,7 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
       Lh = take ? ph : Lh;
       c += n;
     };
-    for (uint64_t r = tid; r < ((n1a + 63) & ~63ull); r += 2ull * P3_THREADS) {
+    for (uint64_t r = tid; r < ((n1a + 63) & ~63ull) && !(v.dbg & CFRK_ABL_P3_NO_RTAB); r += 2ull * P3_THREADS) {
       const uint64_t r1 = r + P3_THREADS;
       const bool v0 = r < n1a, v1 = r1 < n1a;
       uint4 rec0 = zero4, rec1 = zero4;
@@ -902,7 +906,7 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
       } else if (!big) {
         // ~320 distinct runs for 1024 lanes, and a wave works for as many steps as its longest run
         // has k-mers: up to three lanes share a record, each expanding a share of its k-mers
-        const uint32_t nlist = nocc;
+        const uint32_t nlist = (v.dbg & CFRK_ABL_P3_NO_CEXP) ? 0u : nocc;
         const int parts = (nlist * 3u <= (uint32_t)P3_THREADS) ? 3 : (nlist * 2u <= (uint32_t)P3_THREADS) ? 2 : 1;
         const uint32_t nitems = nlist * (uint32_t)parts;
         for (uint32_t i = tid; i < ((nitems + 63u) & ~63u); i += P3_THREADS) {
@@ -922,7 +926,7 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
           count_record_v2<CANON>(keys, cnts, rec, 1u, valid, k, kmask, rcsh, t, ss, ovf);
         }
       }
-      for (uint32_t i = tid; i < ((tl + 63u) & ~63u); i += P3_THREADS) {
+      for (uint32_t i = tid; i < ((tl + 63u) & ~63u) && !(v.dbg & CFRK_ABL_P3_NO_TRUNC); i += P3_THREADS) {
         const bool valid = i < tl;
         uint4 rec = make_uint4(0u, 0u, 0u, 0u);
         if (valid) rec = trunc[tlist[i]];
@@ -953,6 +957,7 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     //      global atomic per wave on the single cursor word serialises the whole grid)
     constexpr int NIT = TS / P3_THREADS;
     uint32_t wbase[NIT];
+    if (v.dbg & CFRK_ABL_P3_NO_OUT) continue;
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
       const unsigned long long m = __ballot(keys[i * P3_THREADS + tid] != CFRK_EMPTY_KEY);

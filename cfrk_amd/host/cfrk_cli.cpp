@@ -2,24 +2,39 @@
 // (/root/reference/src/main.cu:232-309), counting done by libcfrk_hip.so.
 //
 //   cfrk dataset.fasta out.cfrk k [threads] [chunkSize] [options]
+//   cfrk --batch N dataset_prefix out_prefix k [threads] [chunkSize] [options]
 //
 // Default = byte-exact reference behaviour: compat ingest (src/fastaIO.h quirks), chunks of
 // chunkSize reads (default 8192, src/main.cu:235), ComputeFreqNew semantics, and ONLY the last
 // partial chunk in the file -- the reference's second PrintFreq re-opens the file with "w"
 // (src/main.cu:303-305), so a read count that is a multiple of chunkSize gives an empty file.
+// chunkSize is narrowed to unsigned short where the reference narrows it (SelectChunkRemain's
+// `ushort chunkSize, ushort it`, src/main.cu:110): the chunk that reaches the file starts at read
+// (chunkSize mod 65536) * (nChunk mod 65536) and holds gnS - nChunk * chunkSize reads.
 // Options:
 //   --all-chunks     write every chunk (what the reference evidently meant to do)
 //   --native         guarded per-read counting (src/kmer_kernel.cu:52-70) + clean FASTA parsing
 //   --global         one sparse table over all reads ("key:count" lines), k up to 32
 //   --canonical      (global) count min(kmer, reverse complement)
-//   --device N       GPU ordinal (the reference picks the GPU with most memory, src/main.cu:83-108)
-// The threads argument is accepted and ignored (the reference uses it for host memcpy only,
-// src/main.cu:137,186); like the reference, with 5 positional arguments the 5th is chunkSize and
-// the 4th is not parsed (src/main.cu:246-249).
+//   --device N       first GPU ordinal (the reference picks the GPU with most memory, src/main.cu:83-108)
+//   --gpus N         chunks (per-read modes) or files (--batch) are dealt round-robin to N devices,
+//                    one cfrk_ctx pair per device; replaces the reference's pthread fan-out, whose
+//                    threads all use the same device (src/main.cu:208-230,277-295)
+//   --batch N        the Swift/T workflow's loop (swift/cfrk.swf:15-20) in one process: for i < N
+//                    count <dataset_prefix>_<i>.fasta into <out_prefix>_<i>.cfrk
+// Chunk pipeline: every device runs two contexts (two HIP streams), each on a host thread of its
+// own, so the H2D copy of chunk c+1 overlaps the kernel / D2H / text formatting of chunk c; the
+// main thread writes the formatted chunks in order.
+// The threads argument is the number of host threads that format the .cfrk text (the reference
+// uses it for host memcpy only, src/main.cu:137,186); like the reference, with 5 positional
+// arguments the 5th is chunkSize and the 4th is not parsed (src/main.cu:246-249).
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -27,21 +42,166 @@
 #include "../../include/cfrk_abi.h"
 #include "cfrk_host.h"
 
-static int die(cfrk_ctx *ctx, int rc, const char *what) {
+namespace {
+
+struct Options {
+  int k = 0, threads = 12;
+  long chunk_size = 8192;
+  bool all_chunks = false, native = false, global = false, canonical = false, same_device = false;
+  int device = 0, gpus = 1;
+};
+
+struct Worker {            // one context (= one HIP stream + buffer pool) on one device
+  cfrk_ctx *ctx = nullptr;
+  int device = 0;
+};
+
+int die(cfrk_ctx *ctx, int rc, const char *what) {
   fprintf(stderr, "cfrk: %s: %s (%s)\n", what, cfrk_strerror(rc), ctx ? cfrk_last_error(ctx) : "");
   return 2;
 }
 
+struct ChunkRange { int64_t first, count; };
+
+// which reads reach the file, in which chunks (src/main.cu:270-305)
+std::vector<ChunkRange> plan_chunks(const Options &o, int64_t nS) {
+  std::vector<ChunkRange> v;
+  const int64_t C = o.chunk_size;
+  const int64_t n_full = nS / C;                     // nChunk = floor(gnS/chunkSize), src/main.cu:270
+  if (o.all_chunks) {
+    for (int64_t c = 0; c <= n_full; ++c) {
+      const int64_t first = c * C, count = (c < n_full) ? C : nS - first;
+      if (count > 0) v.push_back({first, count});
+    }
+    return v;
+  }
+  if (o.native) {                                    // the remainder chunk, where it really is
+    if (nS - n_full * C > 0) v.push_back({n_full * C, nS - n_full * C});
+    return v;
+  }
+  // compat: only SelectChunkRemain's chunk is written, located with the narrowed arguments
+  const int64_t count = nS - n_full * C;             // chunkRemain, src/main.cu:297
+  const int64_t first = (int64_t)(uint16_t)C * (int64_t)(uint16_t)n_full;
+  if (count > 0 && first + count <= nS) v.push_back({first, count});
+  return v;
+}
+
+// per-read modes: the chunks of one batch through `workers` (any number of devices), text in order
+int run_per_read(const Options &o, const cfrk_batch &batch, std::vector<Worker> &workers, FILE *out) {
+  const std::vector<ChunkRange> chunks = plan_chunks(o, batch.nS);
+  const int flags = o.native ? 0 : CFRK_COMPAT;
+  const size_t fourk = (size_t)1 << (2 * (o.k > 0 && o.k < 16 ? o.k : 1));
+  const size_t n = chunks.size();
+  std::vector<std::string> text(n);
+  std::vector<char> ready(n, 0);
+  std::mutex mu;
+  std::condition_variable cv;
+  std::atomic<size_t> next{0};
+  size_t written = 0;                                // guarded by mu
+  int failed = 0;                                    // guarded by mu
+  const size_t window = 2 * workers.size() + 2;      // formatted chunks that may wait for the writer
+  const int fmt_threads = std::max(1, o.threads / (int)workers.size());
+
+  auto work = [&](Worker &w) {
+    std::vector<int64_t> start;
+    std::vector<int32_t> freq;
+    for (;;) {
+      const size_t c = next.fetch_add(1);
+      if (c >= n) return;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return failed || c < written + window; });
+        if (failed) return;
+      }
+      const int8_t *data; const int32_t *length; int64_t nN;
+      start.resize((size_t)chunks[c].count);
+      cfrk_host_chunk(&batch, chunks[c].first, chunks[c].count, &data, start.data(), &length, &nN);
+      freq.resize((size_t)chunks[c].count * fourk);
+      const int rc = cfrk_per_read_dense(w.ctx, data, start.data(), length, nN, chunks[c].count, o.k, flags, freq.data());
+      std::string t;
+      if (!rc) {
+        t.resize(cfrk_host_format_dense_mt(freq.data(), chunks[c].count, o.k, nullptr, 0, fmt_threads));
+        cfrk_host_format_dense_mt(freq.data(), chunks[c].count, o.k, &t[0], t.size(), fmt_threads);
+      }
+      std::lock_guard<std::mutex> lk(mu);
+      if (rc && !failed) failed = die(w.ctx, rc, "cfrk_per_read_dense");
+      text[c].swap(t);
+      ready[c] = 1;
+      cv.notify_all();
+    }
+  };
+  std::vector<std::thread> th;
+  for (size_t i = 1; i < workers.size() && i < n; ++i) th.emplace_back(work, std::ref(workers[i]));
+  std::thread first_worker;
+  if (n) first_worker = std::thread(work, std::ref(workers[0]));
+  for (size_t c = 0; c < n; ++c) {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return failed || ready[c]; });
+    if (failed) break;
+    std::string t;
+    t.swap(text[c]);
+    lk.unlock();
+    if (c) fputc('\n', out);
+    fwrite(t.data(), 1, t.size(), out);
+    lk.lock();
+    written = c + 1;
+    cv.notify_all();
+  }
+  if (first_worker.joinable()) first_worker.join();
+  for (auto &t : th) t.join();
+  return failed;
+}
+
+int run_global(const Options &o, const cfrk_batch &batch, Worker &w, FILE *out) {
+  int rc;
+  cfrk_ctx *ctx = w.ctx;
+  // distinct k-mers cannot exceed the number of window starts; the hint sizes the result list
+  // and the spill table (12 B per slot at load 0.5), so it is capped at 2^31 keys
+  uint64_t hint = (uint64_t)(batch.nN > 0 ? batch.nN : 1);
+  if (hint < (1ull << 20)) hint = 1ull << 20;
+  if (hint > (1ull << 31)) hint = 1ull << 31;
+  if (o.k > 32) { fprintf(stderr, "cfrk: --global text output supports k <= 32\n"); return 1; }
+  if ((rc = cfrk_global_begin(ctx, o.k, o.canonical ? CFRK_CANONICAL : 0, hint))) return die(ctx, rc, "cfrk_global_begin");
+  if ((rc = cfrk_global_add(ctx, batch.data, batch.start, batch.length, batch.nN, batch.nS))) return die(ctx, rc, "cfrk_global_add");
+  uint64_t n = 0;
+  if ((rc = cfrk_global_finish(ctx, &n))) return die(ctx, rc, "cfrk_global_finish");
+  std::vector<uint64_t> keys(n), hi(n);
+  std::vector<uint32_t> cnt(n);
+  if ((rc = cfrk_global_export(ctx, keys.data(), hi.data(), cnt.data(), n, &n))) return die(ctx, rc, "cfrk_global_export");
+  std::string buf(cfrk_host_format_sparse(keys.data(), cnt.data(), n, nullptr, 0), '\0');
+  cfrk_host_format_sparse(keys.data(), cnt.data(), n, &buf[0], buf.size());
+  fwrite(buf.data(), 1, buf.size(), out);
+  return 0;
+}
+
+// one FASTA file -> one .cfrk file on the given workers
+int run_file(const Options &o, const char *in, const char *outp, std::vector<Worker> &workers) {
+  cfrk_batch batch;
+  int rc = cfrk_host_read_fasta(in, (o.native || o.global) ? 0 : CFRK_INGEST_COMPAT, &batch);
+  if (rc) { fprintf(stderr, "cfrk: cannot read %s (error %d)\n", in, rc); return 1; }
+  FILE *out = fopen(outp, "wb");                      // PrintFreq opens with "w" even when empty
+  if (!out) { fprintf(stderr, "cfrk: cannot write %s\n", outp); cfrk_host_free_batch(&batch); return 1; }
+  rc = o.global ? run_global(o, batch, workers[0], out) : run_per_read(o, batch, workers, out);
+  fclose(out);
+  cfrk_host_free_batch(&batch);
+  return rc;
+}
+
+}  // namespace
+
 int main(int argc, char **argv) {
   std::vector<const char *> pos;
-  bool all_chunks = false, native = false, global = false, canonical = false;
-  int device = 0;
+  Options o;
+  int batch_n = -1;
   for (int i = 1; i < argc; ++i) {
-    if (!strcmp(argv[i], "--all-chunks")) all_chunks = true;
-    else if (!strcmp(argv[i], "--native")) native = true;
-    else if (!strcmp(argv[i], "--global")) global = true;
-    else if (!strcmp(argv[i], "--canonical")) canonical = true;
-    else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
+    if (!strcmp(argv[i], "--all-chunks")) o.all_chunks = true;
+    else if (!strcmp(argv[i], "--native")) o.native = true;
+    else if (!strcmp(argv[i], "--global")) o.global = true;
+    else if (!strcmp(argv[i], "--canonical")) o.canonical = true;
+    else if (!strcmp(argv[i], "--same-device")) o.same_device = true;   // rehearsal: every "device" is --device
+    else if (!strcmp(argv[i], "--device") && i + 1 < argc) o.device = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) o.gpus = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--batch") && i + 1 < argc) batch_n = atoi(argv[++i]);
     else pos.push_back(argv[i]);
   }
   if (pos.size() < 3) {
@@ -49,71 +209,53 @@ int main(int argc, char **argv) {
     printf("Usage: ./cfrk [dataset.fasta] [file_out.cfrk] [k] <number of threads: Default 12> <chunkSize: Default 8192>");
     return 1;
   }
-  const int k = atoi(pos[2]);
-  // <number of threads>: the reference spreads chunks over pthreads; here it is the number of host
-  // threads that format the .cfrk text (the GPU side needs none)
-  int threads = 12;
-  if (pos.size() >= 4) threads = atoi(pos[3]);
-  if (threads < 1) threads = 1;
-  { const unsigned hw = std::thread::hardware_concurrency(); if (hw && (unsigned)threads > hw) threads = (int)hw; }
-  long chunk_size = 8192;
-  if (pos.size() == 5) chunk_size = atol(pos[4]);     // argc == 6 in the reference
-  if (chunk_size <= 0) { fprintf(stderr, "cfrk: chunkSize must be positive\n"); return 1; }
+  o.k = atoi(pos[2]);
+  if (pos.size() >= 4) o.threads = atoi(pos[3]);
+  if (o.threads < 1) o.threads = 1;
+  { const unsigned hw = std::thread::hardware_concurrency(); if (hw && (unsigned)o.threads > hw) o.threads = (int)hw; }
+  if (pos.size() == 5) o.chunk_size = atol(pos[4]);     // argc == 6 in the reference
+  if (o.chunk_size <= 0) { fprintf(stderr, "cfrk: chunkSize must be positive\n"); return 1; }
+  if (o.gpus < 1) { fprintf(stderr, "cfrk: --gpus must be positive\n"); return 1; }
+  if (batch_n == 0 || batch_n < -1) { fprintf(stderr, "cfrk: --batch needs a positive file count\n"); return 1; }
 
-  cfrk_batch batch;
-  int rc = cfrk_host_read_fasta(pos[0], (native || global) ? 0 : CFRK_INGEST_COMPAT, &batch);
-  if (rc) { fprintf(stderr, "cfrk: cannot read %s (error %d)\n", pos[0], rc); return 1; }
-
-  cfrk_ctx *ctx = nullptr;
-  if ((rc = cfrk_ctx_create(device, nullptr, &ctx))) return die(nullptr, rc, "cfrk_ctx_create");
-
-  FILE *out = fopen(pos[1], "wb");                    // PrintFreq opens with "w" even when empty
-  if (!out) { fprintf(stderr, "cfrk: cannot write %s\n", pos[1]); return 1; }
-
-  if (global) {
-    // distinct k-mers cannot exceed the number of window starts; the hint sizes the result list
-    // and the spill table (12 B per slot at load 0.5), so it is capped at 2^31 keys
-    uint64_t hint = (uint64_t)(batch.nN > 0 ? batch.nN : 1);
-    if (hint < (1ull << 20)) hint = 1ull << 20;
-    if (hint > (1ull << 31)) hint = 1ull << 31;
-    if ((rc = cfrk_global_begin(ctx, k, canonical ? CFRK_CANONICAL : 0, hint))) return die(ctx, rc, "cfrk_global_begin");
-    if ((rc = cfrk_global_add(ctx, batch.data, batch.start, batch.length, batch.nN, batch.nS))) return die(ctx, rc, "cfrk_global_add");
-    uint64_t n = 0;
-    if ((rc = cfrk_global_finish(ctx, &n))) return die(ctx, rc, "cfrk_global_finish");
-    std::vector<uint64_t> keys(n), hi(n);
-    std::vector<uint32_t> cnt(n);
-    if ((rc = cfrk_global_export(ctx, keys.data(), hi.data(), cnt.data(), n, &n))) return die(ctx, rc, "cfrk_global_export");
-    if (k > 32) { fprintf(stderr, "cfrk: --global text output supports k <= 32\n"); return 1; }
-    std::string buf(cfrk_host_format_sparse(keys.data(), cnt.data(), n, nullptr, 0), '\0');
-    cfrk_host_format_sparse(keys.data(), cnt.data(), n, &buf[0], buf.size());
-    fwrite(buf.data(), 1, buf.size(), out);
-  } else {
-    const int64_t n_full = batch.nS / chunk_size;     // nChunk = floor(gnS/chunkSize), src/main.cu:270
-    const int64_t first_written = all_chunks ? 0 : n_full;
-    const int flags = native ? 0 : CFRK_COMPAT;
-    const size_t fourk = (size_t)1 << (2 * (k > 0 && k < 16 ? k : 1));
-    std::vector<int64_t> start((size_t)chunk_size);
-    std::vector<int32_t> freq;
-    std::string text;
-    bool first_row = true;
-    for (int64_t c = first_written; c <= n_full; ++c) {
-      const int64_t first = c * chunk_size;
-      const int64_t count = (c < n_full) ? chunk_size : batch.nS - first;   // remainder chunk last
-      if (count == 0) break;
-      const int8_t *data; const int32_t *length; int64_t nN;
-      cfrk_host_chunk(&batch, first, count, &data, start.data(), &length, &nN);
-      freq.resize((size_t)count * fourk);
-      if ((rc = cfrk_per_read_dense(ctx, data, start.data(), length, nN, count, k, flags, freq.data())))
-        return die(ctx, rc, "cfrk_per_read_dense");
-      text.resize(cfrk_host_format_dense_mt(freq.data(), count, k, nullptr, 0, threads));
-      cfrk_host_format_dense_mt(freq.data(), count, k, &text[0], text.size(), threads);
-      if (!first_row) fputc('\n', out);
-      fwrite(text.data(), 1, text.size(), out);
-      first_row = false;
-    }
+  int ndev = 0, rc;
+  if ((rc = cfrk_device_count(&ndev))) return die(nullptr, rc, "cfrk_device_count");
+  if (!o.same_device && o.device + o.gpus > ndev) {
+    fprintf(stderr, "cfrk: --device %d --gpus %d but %d device(s) present\n", o.device, o.gpus, ndev);
+    return 1;
   }
-  fclose(out);
-  cfrk_ctx_destroy(ctx);
-  cfrk_host_free_batch(&batch);
-  return 0;
+  // two contexts (streams) per device: chunk c+1 is copied in while chunk c is counted / copied out / formatted
+  std::vector<std::vector<Worker>> per_dev((size_t)o.gpus);
+  for (int g = 0; g < o.gpus; ++g)
+    for (int s = 0; s < 2; ++s) {
+      Worker w;
+      w.device = o.same_device ? o.device : o.device + g;
+      if ((rc = cfrk_ctx_create(w.device, nullptr, &w.ctx))) return die(nullptr, rc, "cfrk_ctx_create");
+      per_dev[(size_t)g].push_back(w);
+    }
+
+  int status = 0;
+  if (batch_n < 0) {
+    std::vector<Worker> all;
+    for (int s = 0; s < 2; ++s)                       // device-major would put both streams of a device first
+      for (int g = 0; g < o.gpus; ++g) all.push_back(per_dev[(size_t)g][(size_t)s]);
+    status = run_file(o, pos[0], pos[1], all);
+  } else {
+    // file i goes to device i % gpus (swift/cfrk.swf:15-20 starts one cfrk process per file)
+    std::vector<int> st((size_t)o.gpus, 0);
+    std::vector<std::thread> th;
+    for (int g = 0; g < o.gpus; ++g)
+      th.emplace_back([&, g] {
+        for (int i = g; i < batch_n; i += o.gpus) {
+          const std::string in = std::string(pos[0]) + "_" + std::to_string(i) + ".fasta";
+          const std::string outp = std::string(pos[1]) + "_" + std::to_string(i) + ".cfrk";
+          const int r = run_file(o, in.c_str(), outp.c_str(), per_dev[(size_t)g]);
+          if (r && !st[(size_t)g]) st[(size_t)g] = r;
+        }
+      });
+    for (auto &t : th) t.join();
+    for (int r : st) if (r && !status) status = r;
+  }
+  for (auto &d : per_dev) for (auto &w : d) cfrk_ctx_destroy(w.ctx);
+  return status;
 }

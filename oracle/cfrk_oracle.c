@@ -230,72 +230,253 @@ int64_t orc_global_count(const int8_t *data, int64_t nN, int k, int flags,
 
 void orc_free(void *p) { free(p); }
 
-/* ---- multi-threaded variant (bench.py cpu_baseline) ---- */
+/* ---- partition + radix-sort variant (large parity cases, bench.py cpu_baseline) ----
+ * Same result as orc_global_count (tests/test_oracle.py compares the two), any k <= 64, any
+ * thread count: (1) every thread scans its share of the window starts twice -- count per
+ * partition (top bits of the key), then write the keys to their exact places; (2) partitions
+ * are sorted (LSD radix on the remaining bits) and run-length encoded, one partition at a
+ * time from a shared queue; (3) partitions are in key order, so concatenation is the sorted
+ * (hi, lo) list.  The semantics are scan_range's: src/kmer_kernel.cu:36-46 window validity,
+ * the guarded ComputeFreq of src/kmer_kernel.cu:52-70 summed over reads. */
+
+typedef struct { uint64_t hi, lo; } key2;
 
 typedef struct {
-    const int8_t *data; int64_t nN, s0, s1; int k, canonical;
-    orc_table tab;
-} mt_scan_arg;
+    const int8_t *data; int64_t nN; int k, canonical, two, pbits, nthreads, nparts;
+    int64_t *s0, *s1;             /* per thread: window starts [s0, s1) */
+    uint64_t *tcnt;               /* [nthreads][nparts] counts, then write cursors */
+    uint64_t *pstart;             /* [nparts + 1] first key of every partition */
+    uint64_t *k1; key2 *k2;       /* the keys (one-word / two-word) */
+    uint32_t *rle;                /* run lengths, at the compacted positions */
+    uint64_t *pdist;              /* [nparts] distinct keys per partition */
+    uint64_t *ostart;             /* [nparts + 1] output offsets */
+    uint64_t *out_lo, *out_hi, *out_cnt;
+    volatile int64_t next;        /* partition queue */
+    uint64_t maxpart;
+    int phase, oom;
+    pthread_barrier_t bar;
+} ps_job;
 
-static void *mt_scan(void *p)
+typedef struct { ps_job *j; int t; } ps_arg;
+
+static inline uint32_t ps_part(const ps_job *j, u128 key)
 {
-    mt_scan_arg *a = (mt_scan_arg *)p;
-    scan_range(a->data, a->nN, a->s0, a->s1, a->k, a->canonical, &a->tab);
-    return NULL;
+    const int sh = 2 * j->k - j->pbits;
+    return (uint32_t)(key >> sh);
 }
 
-typedef struct { mt_scan_arg *parts; int nparts, me; orc_table out; } mt_merge_arg;
-
-static void *mt_merge(void *p)
+/* windows that start in [s0, s1): pass 0 counts per partition, pass 1 writes the keys
+ * (one-word arithmetic for k <= 32, the same loop on 128-bit values above) */
+static void ps_scan(ps_job *j, int t, int pass)
 {
-    mt_merge_arg *a = (mt_merge_arg *)p;
-    for (int s = 0; s < a->nparts; s++) {
-        orc_table *t = &a->parts[s].tab;
-        for (uint64_t i = 0; i < t->cap; i++)
-            if (t->used[i] && (int)((key_hash(t->lo[i], 0) >> 40) % (uint64_t)a->nparts) == a->me)
-                tab_add(&a->out, t->lo[i], 0, t->cnt[i]);
+    const int k = j->k;
+    uint64_t *cur = j->tcnt + (size_t)t * j->nparts;
+    const int64_t s0 = j->s0[t], s1 = j->s1[t];
+    const int sh = 2 * k - j->pbits;
+    const int canonical = j->canonical;
+    int run = 0;
+    int64_t end = s1 + k - 1;
+    if (end > j->nN) end = j->nN;
+    /* a window starts in [s0, s1) iff it ENDS in [s0 + k - 1, s1 + k - 1) */
+    if (!j->two) {
+        const uint64_t mask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
+        uint64_t fwd = 0, rc = 0;
+        uint64_t *out = j->k1;
+        for (int64_t p = s0; p < end; p++) {
+            int8_t c = j->data[p];
+            if (c < 0 || c > 3) { run = 0; fwd = 0; rc = 0; continue; }
+            fwd = ((fwd << 2) | (uint64_t)c) & mask;
+            rc = (rc >> 2) | ((uint64_t)(3 - c) << (2 * (k - 1)));
+            if (++run >= k) {
+                uint64_t key = (canonical && rc < fwd) ? rc : fwd;
+                uint32_t q = (uint32_t)(key >> sh);
+                if (pass == 0) cur[q]++;
+                else out[cur[q]++] = key;
+            }
+        }
+        return;
+    }
+    const u128 mask = (k == 64) ? ~(u128)0 : (((u128)1 << (2 * k)) - 1);
+    u128 fwd = 0, rc = 0;
+    for (int64_t p = s0; p < end; p++) {
+        int8_t c = j->data[p];
+        if (c < 0 || c > 3) { run = 0; fwd = 0; rc = 0; continue; }
+        fwd = ((fwd << 2) | (u128)c) & mask;
+        rc = (rc >> 2) | ((u128)(3 - c) << (2 * (k - 1)));
+        if (++run >= k) {
+            u128 key = (canonical && rc < fwd) ? rc : fwd;
+            uint32_t q = ps_part(j, key);
+            if (pass == 0) cur[q]++;
+            else { key2 v; v.hi = (uint64_t)(key >> 64); v.lo = (uint64_t)key; j->k2[cur[q]++] = v; }
+        }
+    }
+}
+
+#define PS_RB 11
+static void ps_sort1(uint64_t *a, uint64_t *tmp, uint64_t n, int bits)
+{
+    if (n < 2) return;
+    if (n <= 32) {
+        for (uint64_t i = 1; i < n; i++) { uint64_t x = a[i]; uint64_t q = i; while (q && a[q - 1] > x) { a[q] = a[q - 1]; q--; } a[q] = x; }
+        return;
+    }
+    uint64_t *src = a, *dst = tmp;
+    for (int sh = 0; sh < bits; sh += PS_RB) {
+        uint64_t h[1 << PS_RB] = {0};
+        const uint64_t dm = (1u << PS_RB) - 1;
+        for (uint64_t i = 0; i < n; i++) h[(src[i] >> sh) & dm]++;
+        int single = 0;
+        for (int b = 0; b < (1 << PS_RB); b++) if (h[b] == n) single = 1;
+        if (single) continue;
+        uint64_t run = 0;
+        for (int b = 0; b < (1 << PS_RB); b++) { uint64_t x = h[b]; h[b] = run; run += x; }
+        for (uint64_t i = 0; i < n; i++) dst[h[(src[i] >> sh) & dm]++] = src[i];
+        uint64_t *sw = src; src = dst; dst = sw;
+    }
+    if (src != a) memcpy(a, src, n * 8);
+}
+
+static inline int key2_gt(key2 x, key2 y) { return x.hi != y.hi ? x.hi > y.hi : x.lo > y.lo; }
+
+static void ps_sort2(key2 *a, key2 *tmp, uint64_t n, int bits)
+{
+    if (n < 2) return;
+    if (n <= 32) {
+        for (uint64_t i = 1; i < n; i++) { key2 x = a[i]; uint64_t q = i; while (q && key2_gt(a[q - 1], x)) { a[q] = a[q - 1]; q--; } a[q] = x; }
+        return;
+    }
+    key2 *src = a, *dst = tmp;
+    for (int sh = 0; sh < bits; sh += 8) {
+        uint64_t h[256] = {0};
+#define PS_DIG(v) ((sh < 64 ? ((v).lo >> sh) | (sh > 56 ? (v).hi << (64 - sh) : 0) : (v).hi >> (sh - 64)) & 255)
+        for (uint64_t i = 0; i < n; i++) h[PS_DIG(src[i])]++;
+        int single = 0;
+        for (int b = 0; b < 256; b++) if (h[b] == n) single = 1;
+        if (single) continue;
+        uint64_t run = 0;
+        for (int b = 0; b < 256; b++) { uint64_t x = h[b]; h[b] = run; run += x; }
+        for (uint64_t i = 0; i < n; i++) dst[h[PS_DIG(src[i])]++] = src[i];
+#undef PS_DIG
+        key2 *sw = src; src = dst; dst = sw;
+    }
+    if (src != a) memcpy(a, src, n * sizeof(key2));
+}
+
+static void *ps_worker(void *p)
+{
+    ps_arg *a = (ps_arg *)p;
+    ps_job *j = a->j;
+    const int t = a->t, P = j->nparts, T = j->nthreads;
+    ps_scan(j, t, 0);
+    pthread_barrier_wait(&j->bar);
+    if (t == 0) {
+        /* partition starts; thread cursors inside a partition in thread order */
+        uint64_t run = 0, mx = 0;
+        for (int q = 0; q < P; q++) {
+            j->pstart[q] = run;
+            for (int u = 0; u < T; u++) { uint64_t c = j->tcnt[(size_t)u * P + q]; j->tcnt[(size_t)u * P + q] = run; run += c; }
+            if (run - j->pstart[q] > mx) mx = run - j->pstart[q];
+        }
+        j->pstart[P] = run;
+        j->maxpart = mx;
+        if (j->two) j->k2 = (key2 *)malloc((run ? run : 1) * sizeof(key2));
+        else j->k1 = (uint64_t *)malloc((run ? run : 1) * 8);
+        j->rle = (uint32_t *)malloc((run ? run : 1) * 4);
+        if ((!j->k1 && !j->k2) || !j->rle) j->oom = 1;
+    }
+    pthread_barrier_wait(&j->bar);
+    if (j->oom) return NULL;
+    ps_scan(j, t, 1);
+    pthread_barrier_wait(&j->bar);
+    {
+        void *tmp = malloc((j->maxpart ? j->maxpart : 1) * (j->two ? sizeof(key2) : 8));
+        if (!tmp) j->oom = 1;
+        const int bits = 2 * j->k - j->pbits;
+        for (;;) {
+            int64_t q = __sync_fetch_and_add(&j->next, 1);
+            if (q >= P || !tmp) break;
+            const uint64_t b = j->pstart[q], n = j->pstart[q + 1] - b;
+            uint64_t d = 0;
+            if (j->two) {
+                key2 *v = j->k2 + b;
+                ps_sort2(v, (key2 *)tmp, n, bits);
+                for (uint64_t i = 0; i < n;) {
+                    uint64_t e = i + 1;
+                    while (e < n && v[e].hi == v[i].hi && v[e].lo == v[i].lo) e++;
+                    v[d] = v[i]; j->rle[b + d] = (uint32_t)(e - i); d++; i = e;
+                }
+            } else {
+                uint64_t *v = j->k1 + b;
+                ps_sort1(v, (uint64_t *)tmp, n, bits);
+                for (uint64_t i = 0; i < n;) {
+                    uint64_t e = i + 1;
+                    while (e < n && v[e] == v[i]) e++;
+                    v[d] = v[i]; j->rle[b + d] = (uint32_t)(e - i); d++; i = e;
+                }
+            }
+            j->pdist[q] = d;
+        }
+        free(tmp);
+    }
+    pthread_barrier_wait(&j->bar);
+    if (t == 0 && !j->oom) {
+        uint64_t run = 0;
+        for (int q = 0; q < P; q++) { j->ostart[q] = run; run += j->pdist[q]; }
+        j->ostart[P] = run;
+        j->out_lo = (uint64_t *)malloc((run ? run : 1) * 8);
+        j->out_hi = (uint64_t *)calloc(run ? run : 1, 8);
+        j->out_cnt = (uint64_t *)malloc((run ? run : 1) * 8);
+        if (!j->out_lo || !j->out_hi || !j->out_cnt) j->oom = 1;
+    }
+    pthread_barrier_wait(&j->bar);
+    if (j->oom) return NULL;
+    for (int q = t; q < P; q += T) {
+        const uint64_t b = j->pstart[q], o = j->ostart[q], d = j->pdist[q];
+        for (uint64_t i = 0; i < d; i++) {
+            if (j->two) { j->out_lo[o + i] = j->k2[b + i].lo; j->out_hi[o + i] = j->k2[b + i].hi; }
+            else j->out_lo[o + i] = j->k1[b + i];
+            j->out_cnt[o + i] = j->rle[b + i];
+        }
     }
     return NULL;
 }
 
-int64_t orc_global_count_mt(const int8_t *data, int64_t nN, int k, int flags, int nthreads,
-                            uint64_t **keys_lo, uint64_t **counts)
+int64_t orc_global_count_sorted(const int8_t *data, int64_t nN, int k, int flags, int nthreads,
+                                uint64_t **keys_lo, uint64_t **keys_hi, uint64_t **counts)
 {
-    if (k < 1 || k > 32) return -1;
+    if (k < 1 || k > 64) return -1;
     if (nthreads < 1) nthreads = 1;
-    mt_scan_arg *sa = (mt_scan_arg *)calloc((size_t)nthreads, sizeof(*sa));
-    mt_merge_arg *ma = (mt_merge_arg *)calloc((size_t)nthreads, sizeof(*ma));
-    pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof(*th));
+    if (nthreads > 256) nthreads = 256;
+    ps_job j;
+    memset(&j, 0, sizeof j);
+    j.data = data; j.nN = nN; j.k = k; j.canonical = (flags & ORC_CANONICAL) != 0; j.two = k > 32;
+    j.pbits = 2 * k < 12 ? 2 * k : 12;
+    j.nparts = 1 << j.pbits;
+    j.nthreads = nthreads;
+    j.s0 = (int64_t *)malloc(sizeof(int64_t) * (size_t)nthreads);
+    j.s1 = (int64_t *)malloc(sizeof(int64_t) * (size_t)nthreads);
+    j.tcnt = (uint64_t *)calloc((size_t)nthreads * j.nparts, 8);
+    j.pstart = (uint64_t *)calloc((size_t)j.nparts + 1, 8);
+    j.pdist = (uint64_t *)calloc((size_t)j.nparts, 8);
+    j.ostart = (uint64_t *)calloc((size_t)j.nparts + 1, 8);
+    ps_arg *args = (ps_arg *)calloc((size_t)nthreads, sizeof(ps_arg));
+    pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
+    if (!j.s0 || !j.s1 || !j.tcnt || !j.pstart || !j.pdist || !j.ostart || !args || !th) return -2;
+    pthread_barrier_init(&j.bar, NULL, (unsigned)nthreads);
     for (int t = 0; t < nthreads; t++) {
-        sa[t].data = data; sa[t].nN = nN; sa[t].k = k; sa[t].canonical = (flags & ORC_CANONICAL) != 0;
-        sa[t].s0 = nN * t / nthreads; sa[t].s1 = nN * (t + 1) / nthreads;
-        if (tab_init(&sa[t].tab, 1 << 16, 0)) return -2;
-        pthread_create(&th[t], NULL, mt_scan, &sa[t]);
+        j.s0[t] = nN * t / nthreads; j.s1[t] = nN * (t + 1) / nthreads;
+        args[t].j = &j; args[t].t = t;
+        pthread_create(&th[t], NULL, ps_worker, &args[t]);
     }
     for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
-    for (int t = 0; t < nthreads; t++) {
-        ma[t].parts = sa; ma[t].nparts = nthreads; ma[t].me = t;
-        if (tab_init(&ma[t].out, 1 << 16, 0)) return -2;
-        pthread_create(&th[t], NULL, mt_merge, &ma[t]);
-    }
-    for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
-    uint64_t n = 0;
-    for (int t = 0; t < nthreads; t++) n += ma[t].out.n;
-    orc_ent *e = (orc_ent *)malloc((n ? n : 1) * sizeof(orc_ent));
-    uint64_t j = 0;
-    for (int t = 0; t < nthreads; t++) {
-        orc_table *o = &ma[t].out;
-        for (uint64_t i = 0; i < o->cap; i++)
-            if (o->used[i]) { e[j].lo = o->lo[i]; e[j].hi = 0; e[j].cnt = o->cnt[i]; j++; }
-        tab_free(o);
-        tab_free(&sa[t].tab);
-    }
-    qsort(e, n, sizeof(orc_ent), ent_cmp);
-    *keys_lo = (uint64_t *)malloc((n ? n : 1) * 8);
-    *counts = (uint64_t *)malloc((n ? n : 1) * 8);
-    for (uint64_t i = 0; i < n; i++) { (*keys_lo)[i] = e[i].lo; (*counts)[i] = e[i].cnt; }
-    free(e); free(sa); free(ma); free(th);
-    return (int64_t)n;
+    pthread_barrier_destroy(&j.bar);
+    int64_t n = j.oom ? -2 : (int64_t)j.ostart[j.nparts];
+    free(j.k1); free(j.k2); free(j.rle);
+    free(j.s0); free(j.s1); free(j.tcnt); free(j.pstart); free(j.pdist); free(j.ostart); free(args); free(th);
+    if (n < 0) { free(j.out_lo); free(j.out_hi); free(j.out_cnt); return n; }
+    *keys_lo = j.out_lo; *counts = j.out_cnt;
+    if (keys_hi) *keys_hi = j.out_hi; else free(j.out_hi);
+    return n;
 }
 
 /* ------------------------------------------------------------------ digest */

@@ -55,10 +55,10 @@ int64_t orc_global_count(const int8_t *data, int64_t nN, int k, int flags,
                          uint64_t **keys_lo, uint64_t **keys_hi, uint64_t **counts);
 void orc_free(void *p);
 
-/* Multi-threaded (pthreads) variant used as bench.py's cpu_baseline: same result as
- * orc_global_count, reads split across nthreads, per-thread tables merged. k <= 32 only. */
-int64_t orc_global_count_mt(const int8_t *data, int64_t nN, int k, int flags, int nthreads,
-                            uint64_t **keys_lo, uint64_t **counts);
+/* Partition + radix-sort variant for large inputs (the big parity cases and bench.py's
+ * cpu_baseline): same output as orc_global_count, any 1 <= k <= 64, reads split across nthreads. */
+int64_t orc_global_count_sorted(const int8_t *data, int64_t nN, int k, int flags, int nthreads,
+                                uint64_t **keys_lo, uint64_t **keys_hi, uint64_t **counts);
 
 /* Order-independent digest (SURVEY 8d "Parity at scale").
  * out[0]=D, out[1]=sum count, out[2]=sum count*splitmix64(kh), out[3]=xor splitmix64(kh ^ count)

@@ -41,9 +41,9 @@ def lib():
         L.orc_global_count.argtypes = [p8, C.c_int64, C.c_int, C.c_int, C.POINTER(pu64),
                                        C.POINTER(pu64), C.POINTER(pu64)]
         L.orc_global_count.restype = C.c_int64
-        L.orc_global_count_mt.argtypes = [p8, C.c_int64, C.c_int, C.c_int, C.c_int,
-                                          C.POINTER(pu64), C.POINTER(pu64)]
-        L.orc_global_count_mt.restype = C.c_int64
+        L.orc_global_count_sorted.argtypes = [p8, C.c_int64, C.c_int, C.c_int, C.c_int, C.POINTER(pu64),
+                                              C.POINTER(pu64), C.POINTER(pu64)]
+        L.orc_global_count_sorted.restype = C.c_int64
         L.orc_free.argtypes = [C.c_void_p]
         L.orc_digest.argtypes = [pu64, pu64, pu64, C.c_int64, C.c_int, pu64]
         L.orc_splitmix64.argtypes = [C.c_uint64]
@@ -83,12 +83,14 @@ def compute_index(data, k, float_index=False):
 
 
 def global_count(data, k, flags=0, threads=0):
-    """-> (keys_lo, keys_hi, counts) sorted by (hi, lo); keys_hi is zeros for k <= 32."""
+    """-> (keys_lo, keys_hi, counts) sorted by (hi, lo); keys_hi is zeros for k <= 32.
+    threads = 0: the plain hash-table restatement; threads > 0: the partition + radix-sort
+    variant on that many threads (same result, for the large cases)."""
     data = np.ascontiguousarray(data, np.int8)
     lo, hi, cnt = (C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint64)())
     if threads > 0:
-        n = lib().orc_global_count_mt(_p(data, C.c_int8), len(data), k, flags, threads,
-                                      C.byref(lo), C.byref(cnt))
+        n = lib().orc_global_count_sorted(_p(data, C.c_int8), len(data), k, flags, threads,
+                                          C.byref(lo), C.byref(hi), C.byref(cnt))
     else:
         n = lib().orc_global_count(_p(data, C.c_int8), len(data), k, flags,
                                    C.byref(lo), C.byref(hi), C.byref(cnt))
@@ -96,11 +98,8 @@ def global_count(data, k, flags=0, threads=0):
         raise ValueError(f"orc_global_count rc={n}")
     klo = np.ctypeslib.as_array(lo, (max(n, 1),))[:n].copy()
     kc = np.ctypeslib.as_array(cnt, (max(n, 1),))[:n].copy()
-    if threads > 0:
-        khi = np.zeros(n, np.uint64)
-    else:
-        khi = np.ctypeslib.as_array(hi, (max(n, 1),))[:n].copy()
-        lib().orc_free(hi)
+    khi = np.ctypeslib.as_array(hi, (max(n, 1),))[:n].copy()
+    lib().orc_free(hi)
     lib().orc_free(lo)
     lib().orc_free(cnt)
     return klo, khi, kc

@@ -57,9 +57,12 @@ def flatten(reads):
 
 
 def remainder_chunk(reads, chunk_size=8192):
-    """main.cu:270-305: only the last partial chunk (gnS % chunkSize reads) reaches the file."""
+    """main.cu:270-305: only the last partial chunk (gnS % chunkSize reads) reaches the file.
+    SelectChunkRemain takes `ushort chunkSize, ushort it` (main.cu:110), so the chunk starts at read
+    (chunkSize mod 2^16) * (nChunk mod 2^16) and holds gnS - nChunk*chunkSize reads."""
     n_full = len(reads) // chunk_size
-    return reads[n_full * chunk_size:]
+    first = (chunk_size & 0xFFFF) * (n_full & 0xFFFF)
+    return reads[first:first + len(reads) - n_full * chunk_size]
 
 
 def reference_cfrk_bytes(raw: bytes, k: int, chunk_size=8192):

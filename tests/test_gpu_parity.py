@@ -222,15 +222,122 @@ def test_c3_shape_properties_k31(ctx):
     d2 = g.digest()
     assert d2[0] == d1[0] and d2[1] == 2 * d1[1]
     assert d2[2] == (2 * d1[2]) % (1 << 64)
-    # prefix equality against the oracle on the first 100k reads
+    # SURVEY 8d "parity at scale": full (key, count) equality on the first 10^6 reads
     g2 = cfrk_amd.GlobalCounter(ctx, k, cfrk_amd.CFRK_CANONICAL, 2 * G)
-    n1 = 100_000 * (L + 1)
+    n1 = 1_000_000 * (L + 1)
     g2.add_device(d, n1)
     host = np.empty(n1, np.int8)
     ctx.d2h(host, d)
+    lo, hi, cnt = g2.export()
     wlo, whi, wcnt = orc.global_count(host, k, orc.ORC_CANONICAL, threads=8)
+    assert len(lo) == len(wlo) and (lo == wlo).all() and (cnt.astype(np.uint64) == wcnt).all()
     assert g2.digest() == orc.digest(wlo, whi, wcnt)
     ctx.free(d)
+
+
+def test_c3_generator_prefix_1m_reads_full_equality(ctx):
+    """the first 10^6 reads of configs[2]'s own generator (genome 10^8: ~1.5x coverage, nearly
+    every k-mer distinct -- the opposite regime of the test above), full equality"""
+    import cfrk_amd
+    R, L, G, k = 1_000_000, 150, 100_000_000, 31
+    nN = R * (L + 1)
+    d = ctx.alloc(nN)
+    ctx.synth_reads_device(0, R, L, G, d)
+    g = cfrk_amd.GlobalCounter(ctx, k, cfrk_amd.CFRK_CANONICAL, R * (L - k + 1))
+    g.add_device(d, nN)
+    lo, hi, cnt = g.export()
+    host = np.empty(nN, np.int8)
+    ctx.d2h(host, d)
+    ctx.free(d)
+    wlo, whi, wcnt = orc.global_count(host, k, orc.ORC_CANONICAL, threads=8)
+    assert len(lo) == len(wlo) and (lo == wlo).all() and (cnt.astype(np.uint64) == wcnt).all()
+    assert int(wcnt.sum()) == R * (L - k + 1)
+
+
+@pytest.mark.parametrize("variant", ["high_collision", "all_distinct"])
+def test_c5_shape_1m_reads_250bp_k63_full_equality(ctx, variant):
+    """BASELINE configs[4]'s read shape (250 bp, k=63, two-word keys) at 10^6 reads, both stress
+    variants of SURVEY 8d: Glen = 10^6 (every key hit ~190 times, both strands) and uniform random
+    reads (every k-mer distinct: D = K = 1.88e8) -- full (key, count) equality with the oracle"""
+    import cfrk_amd
+    R, L, k = 1_000_000, 250, 63
+    G = 1_000_000
+    uniform = variant == "all_distinct"
+    nN = R * (L + 1)
+    K = R * (L - k + 1)
+    d = ctx.alloc(nN)
+    ctx.synth_reads_device(0, R, L, 0 if uniform else G, d, uniform=uniform)
+    g = cfrk_amd.GlobalCounter(ctx, k, cfrk_amd.CFRK_CANONICAL, K if uniform else 2 * G)
+    g.add_device(d, nN)
+    dg = g.digest()
+    assert dg[1] == K
+    lo, hi, cnt = g.export()
+    host = np.empty(nN, np.int8)
+    ctx.d2h(host, d)
+    ctx.free(d)
+    del g
+    wlo, whi, wcnt = orc.global_count(host, k, orc.ORC_CANONICAL, threads=8)
+    del host
+    assert len(lo) == len(wlo)
+    assert (lo == wlo).all() and (hi == whi).all() and (cnt.astype(np.uint64) == wcnt).all()
+    assert dg == orc.digest(wlo, whi, wcnt, two_word=True)
+    if uniform:
+        assert len(lo) > 0.999 * K
+    else:
+        assert len(lo) <= 2 * G and int(wcnt.max()) > 100
+
+
+@pytest.mark.parametrize("k", [2, 5, 8, 10])
+def test_global_equals_column_sum_of_per_read_dense_on_gpu(ctx, k):
+    """Ties the benchmarked global path to kmer_main's semantics ON THE GPU: the column sum of
+    cfrk_per_read_dense's native rows (the guarded ComputeFreq, src/kmer_kernel.cu:52-70) equals
+    cfrk_global_* (forward strand) on ragged reads with invalid bases."""
+    import cfrk_amd
+    rng = np.random.default_rng(900 + k)
+    reads = _random_reads(rng, 150 if k == 10 else 600, 1, 400, 0.02)
+    reads.append(np.zeros(0, np.int8))
+    reads.append(np.full(300, 3, np.int8))
+    data, start, length = refsem.flatten(reads)
+    dense = ctx.per_read_dense(data, start, length, k, 0).astype(np.int64).sum(axis=0)
+    g = cfrk_amd.GlobalCounter(ctx, k, 0, 4 ** k)
+    g.add(data, start, length)
+    lo, hi, cnt = g.export()
+    col = np.zeros(4 ** k, np.int64)
+    col[lo.astype(np.int64)] = cnt.astype(np.int64)
+    assert (hi == 0).all() and (col == dense).all()
+    assert int(dense.sum()) > 0
+
+
+def _bench_line(args, timeout=600):
+    """run bench.py as a child process (it starts its own ranks for --gpus N) and parse its line"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for v in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(v, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True,
+                       text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_self_launches_two_ranks_and_matches_the_one_gpu_digest():
+    """`bench.py --gpus 2` from a bare shell (no torchrun): the parent starts the ranks itself;
+    strong scaling of the same 2 M reads gives the 1-GPU digest (rehearsal: both ranks on
+    cuda:0, collectives over gloo)"""
+    common = ["--steps", "1", "--warmup", "0", "--reads", "2000000", "--cpu-reads", "0"]
+    one = _bench_line(["--gpus", "1"] + common)
+    two = _bench_line(["--gpus", "2", "--same-gpu", "--dist-backend", "gloo", "--scaling", "strong"] + common)
+    assert one["sum_count_ok"] and two["sum_count_ok"]
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong"
+    assert two["digest"] == one["digest"]
+    both = _bench_line(["--gpus", "2", "--same-gpu", "--dist-backend", "gloo"] + common)
+    assert both["scaling"] == "strong" and both["digest"] == one["digest"]
+    assert both["weak"]["config"]["reads"] == 4_000_000 and both["weak"]["sum_count_ok"]
 
 
 @pytest.mark.parametrize("k", [15, 21, 31, 63])
@@ -557,3 +664,62 @@ def test_cli_chunking_quirks_and_modes(tmp_path):
     # usage
     r = subprocess.run([cli, str(fa)], capture_output=True)
     assert r.returncode == 1 and r.stdout.startswith(b"Usage: ./cfrk")
+
+
+def test_cli_chunksize_is_narrowed_to_ushort_like_the_reference(tmp_path):
+    """src/main.cu:110,160: chunkSize > 65535 wraps inside SelectChunk*: with chunkSize 65537 and
+    70 000 reads nChunk = 1 and the chunk that reaches the file starts at read (65537 mod 65536) * 1
+    = 1, not at read 65537; 65536 narrows to 0, i.e. the chunk starts at read 0"""
+    import subprocess
+    cli = _cli()
+    rng = np.random.default_rng(11)
+    n = 70_000
+    seqs = ["".join("ACGT"[c] for c in rng.integers(0, 4, int(L))) for L in rng.integers(8, 14, n)]
+    raw = "".join(f">r{i}\n{s}\n" for i, s in enumerate(seqs)).encode()
+    fa = tmp_path / "many.fasta"
+    fa.write_bytes(raw)
+    out = tmp_path / "o.cfrk"
+    for cs in (65537, 65536, 69999):
+        subprocess.check_call([cli, str(fa), str(out), "2", "12", str(cs)])
+        want = refsem.reference_cfrk_bytes(raw, 2, cs)
+        assert out.read_bytes() == want
+        assert want.count(b"\n") + 1 == n - cs
+    reads = refsem.read_fasta_compat(raw)
+    assert refsem.remainder_chunk(reads, 65537)[0] is reads[1]
+    assert refsem.remainder_chunk(reads, 65536)[0] is reads[0]
+
+
+def test_cli_pipeline_over_two_contexts_per_device_and_batch_mode(tmp_path):
+    """--all-chunks through the double-buffered pipeline (two contexts per device, `--gpus 2` rehearsed
+    on one device) gives the bytes of the sequential definition; --batch N counts <prefix>_<i>.fasta
+    into <out>_<i>.cfrk like the Swift/T loop (swift/cfrk.swf:15-20)"""
+    import subprocess
+    cli = _cli()
+    rng = np.random.default_rng(12)
+    files = []
+    for f in range(3):
+        seqs = ["".join("ACGTN"[c] for c in rng.choice(5, int(L), p=[.245, .245, .245, .245, .02]))
+                for L in rng.integers(30, 200, 700 + 100 * f)]
+        raw = "".join(f">r{i}\n{s}\n" for i, s in enumerate(seqs)).encode()
+        (tmp_path / f"ds_{f}.fasta").write_bytes(raw)
+        files.append(raw)
+
+    def want_all(raw, k, cs):
+        reads = refsem.read_fasta_compat(raw)
+        rows = []
+        for c in range(0, len(reads), cs):
+            d, s, l = refsem.flatten(reads[c:c + cs])
+            rows.append(orc.format_cfrk(orc.per_read_dense(d, s, l, k, orc.ORC_COMPAT), k))
+        return b"\n".join(rows)
+
+    out = tmp_path / "o.cfrk"
+    for extra in ([], ["--gpus", "2", "--same-device"]):
+        subprocess.check_call([cli, str(tmp_path / "ds_0.fasta"), str(out), "3", "4", "64", "--all-chunks"] + extra)
+        assert out.read_bytes() == want_all(files[0], 3, 64)
+    subprocess.check_call([cli, "--batch", "3", str(tmp_path / "ds"), str(tmp_path / "res"), "2", "4", "256",
+                           "--gpus", "2", "--same-device"])
+    for f in range(3):
+        assert (tmp_path / f"res_{f}.cfrk").read_bytes() == refsem.reference_cfrk_bytes(files[f], 2, 256)
+    subprocess.check_call([cli, "--batch", "2", str(tmp_path / "ds"), str(tmp_path / "all"), "2", "4", "256", "--all-chunks"])
+    for f in range(2):
+        assert (tmp_path / f"all_{f}.cfrk").read_bytes() == want_all(files[f], 2, 256)

@@ -128,9 +128,10 @@ def test_global_count_vs_python(k, canonical):
     assert got == want
     keys = [(int(h), int(l)) for l, h in zip(klo, khi)]
     assert keys == sorted(keys)
-    if k <= 32:
-        l2, _, c2 = orc.global_count(data, k, orc.ORC_CANONICAL if canonical else 0, threads=3)
-        assert (l2 == klo).all() and (c2 == cnt).all()
+    # the partition + radix-sort variant (large cases, cpu_baseline) gives the identical list
+    for threads in (1, 3):
+        l2, h2, c2 = orc.global_count(data, k, orc.ORC_CANONICAL if canonical else 0, threads=threads)
+        assert (l2 == klo).all() and (h2 == khi).all() and (c2 == cnt).all()
 
 
 def test_synth_reads_deterministic_and_strand():
@@ -175,3 +176,36 @@ def test_no_final_newline_drops_last_base():
     """fastaIO.h:53: len = strlen - 1 drops the last base when the file lacks a final newline"""
     reads = refsem.read_fasta_compat(b">a\nACGT")
     assert [len(r) for r in reads] == [3]
+
+
+@pytest.mark.parametrize("k", [5, 15, 31, 32, 33, 63, 64])
+def test_sorted_variant_equals_hash_variant_on_synthetic_reads(k):
+    """orc_global_count_sorted (threads > 0) against orc_global_count on reads with deep coverage,
+    invalid bases and both strands: same keys, same counts, same digest"""
+    data, _, _ = orc.synth_reads(0, 4000, 150, 20000)
+    data = data.copy()
+    data[::991] = -1
+    a = orc.global_count(data, k, orc.ORC_CANONICAL)
+    b = orc.global_count(data, k, orc.ORC_CANONICAL, threads=5)
+    assert all((x == y).all() for x, y in zip(a, b))
+    assert orc.digest(*a, two_word=k > 32) == orc.digest(*b, two_word=k > 32)
+
+
+@pytest.mark.parametrize("name", ["seq1", "seq2"])
+def test_float_index_equals_exact_index_on_the_golden_preimages_up_to_k12(derived_fasta, name):
+    """The reference accumulates the index through float (src/kmer_kernel.cu:38).  On the inputs
+    that reproduce its goldens the float path and the exact-integer path give identical Index[]
+    arrays and identical compat rows for every k <= 12 -- the range in which the reference is
+    numerically defined -- so the HIP path (exact integers) is checked against the same numbers
+    the reference would produce there."""
+    raw = open(derived_fasta[name], "rb").read()
+    reads = refsem.read_fasta_compat(raw)
+    data, start, length = refsem.flatten(reads)
+    for k in range(1, 13):
+        assert (orc.compute_index(data, k, True) == orc.compute_index(data, k, False)).all(), k
+    sub = slice(0, 64)
+    d2, s2, l2 = refsem.flatten(reads[sub])
+    for k in (2, 6):
+        a = orc.per_read_dense(d2, s2, l2, k, orc.ORC_COMPAT | orc.ORC_FLOAT_INDEX)
+        b = orc.per_read_dense(d2, s2, l2, k, orc.ORC_COMPAT)
+        assert (a == b).all()
