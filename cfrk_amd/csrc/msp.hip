@@ -9,7 +9,7 @@
 //                      canonical m-mers (its minimizer), cut the k-mers into runs that share one
 //                      minimizer occurrence ("super-k-mers"; content-defined, they may cross into
 //                      the next lane's chunk), and append each run as one 16-B record
-//                      {48 bases, leaf id, complete flag, n} to level-1 bin = leaf >> 8.  A
+//                      {48 bases, leaf id, closed-end flags, n} to level-1 bin = leaf >> 8.  A
 //                      workgroup stages its records in LDS, reserves space with ONE global
 //                      atomic per non-empty bin per 15.6 KB of input, then copies out in bin
 //                      order (coalesced).  Emission is wave-balanced: lane i builds the wave's
@@ -234,9 +234,12 @@ __global__ __launch_bounds__(P1_THREADS, (P1B_TR <= 6 ? 6 : 4)) void msp_p1b_ker
     const uint32_t D0 = s_str[idx0], D1 = s_str[idx0 + 1], D2 = s_str[idx0 + 2], D3 = s_str[idx0 + 3];
     const uint64_t rest = Es << (a + 1);
     const int n = min(__clzll(rest) + 1, nkmax);
-    // "complete": both ends are minimizer changes between valid k-mers, so every read covering
-    // this locus emits the same record
-    const uint32_t complete = ((uint32_t)(Ws >> (63 - a)) & (uint32_t)(Ws >> (62 - a - n)) & 1u) << 6;
+    // An end of the run is "closed" when it is a minimizer change between valid k-mers (header
+    // bit 6: left end, bit 7: right end) and open when the read or an invalid base cut it.  Both
+    // closed = a complete run: every read covering this locus emits the same record.  One end
+    // open = a prefix (suffix) of the complete run of its locus, with which it shares its first
+    // (last) k-mer.
+    const uint32_t flags = (((uint32_t)(Ws >> (63 - a)) & 1u) << 6) | (((uint32_t)(Ws >> (62 - a - n)) & 1u) << 7);
     uint4 rec;
     rec.x = __builtin_amdgcn_alignbit(D0, D1, sh);
     // bases after the run's last k-mer are cleared: equal runs -> byte-identical records
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(P1_THREADS, (P1B_TR <= 6 ? 6 : 4)) void msp_p1b_ker
     r12 = (W < 8 && z >= 64) ? 0ull : ((r12 >> z) << z);
     rec.y = (uint32_t)(r12 >> 32);
     rec.z = (uint32_t)r12;
-    rec.w = (leaf << 8) | complete | (uint32_t)(n - 1);
+    rec.w = (leaf << 8) | flags | (uint32_t)(n - 1);
     return rec;
   };
 
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(P1_THREADS, (P1B_TR <= 6 ? 6 : 4)) void msp_p1b_ker
 // sorts records by length itself, so finer classes would only shorten P2's write segments.
 constexpr int NCLS = 2;
 constexpr int NSUB = NCLS * B2;                           // 512 sub-bins of a level-1 bin
-__device__ __forceinline__ uint32_t sub_of(uint32_t w) { return (((w >> 8) & (B2 - 1)) << 1) | ((w >> 6) & 1u); }
+__device__ __forceinline__ uint32_t sub_of(uint32_t w) { return (((w >> 8) & (B2 - 1)) << 1) | ((((w >> 6) & 3u) == 3u) ? 1u : 0u); }
 
 __global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int groups_per_bin, int k, int canon,
                                                             MspView v, TableView t) {
@@ -537,7 +540,10 @@ template <bool CANON>
 __device__ __forceinline__ void count_record_v2(unsigned long long *keys, uint32_t *cnts, uint4 rec, uint32_t add,
                                                 bool valid, int k, uint64_t kmask, int rcsh,
                                                 const TableView &t, KeySubset ss = KeySubset{0u, 0u},
-                                                uint32_t *ovf = nullptr, int part = 0, int parts = 1) {
+                                                uint32_t *ovf = nullptr, int part = 0, int parts = 1,
+                                                const uint8_t *tb = nullptr, uint32_t tb_n = 0u) {
+  // tb[0 .. tb_n): lengths (in k-mers) of the truncated runs that are prefixes of this record: k-mer J
+  // of the record is counted once more for every one of them that is longer than J
   if (ovf && *(volatile uint32_t *)ovf) return;
   // a record may be shared by `parts` lanes, each expanding a contiguous share of its k-mers
   const int nall = valid ? (int)(rec.w & 63u) + 1 : 0;
@@ -554,6 +560,15 @@ __device__ __forceinline__ void count_record_v2(unsigned long long *keys, uint32
   uint64_t rc = CANON ? dev_revcomp64(fwd, k) : 0;
   uint64_t T = (k == 32) ? lo : ((hi << (2 * k)) | (lo >> (64 - 2 * k)));
   for (int j = 0; __ballot(j < nk); j += 2) {
+    uint32_t add0 = add, add1 = add;
+    if (tb) {
+      const uint32_t J = (uint32_t)(j0 + j);
+      for (uint32_t e = 0; __ballot(e < tb_n); ++e) {       // (as many steps as the wave's longest list)
+        const uint32_t tv = (e < tb_n) ? (uint32_t)tb[e] : 0u;
+        add0 += (tv > J) ? 1u : 0u;
+        add1 += (tv > J + 1u) ? 1u : 0u;
+      }
+    }
     const uint64_t key0 = (CANON && rc < fwd) ? rc : fwd;
     uint32_t nb = (uint32_t)(T >> 62);
     T <<= 2;
@@ -567,19 +582,19 @@ __device__ __forceinline__ void count_record_v2(unsigned long long *keys, uint32
     bool p0 = j < nk && in_subset(key0, ss), p1 = j + 1 < nk && in_subset(key1, ss);
     if (!CANON && k == 32) {
       // forward-strand all-T 32-mer collides with the EMPTY marker: side counter
-      if (p0 && key0 == CFRK_EMPTY_KEY) { spill_kmer(t, key0, add); p0 = false; }
-      if (p1 && key1 == CFRK_EMPTY_KEY) { spill_kmer(t, key1, add); p1 = false; }
+      if (p0 && key0 == CFRK_EMPTY_KEY) { spill_kmer(t, key0, add0); p0 = false; }
+      if (p1 && key1 == CFRK_EMPTY_KEY) { spill_kmer(t, key1, add1); p1 = false; }
     }
     uint32_t b0 = lds_bucket(key0) | (p0 ? 0u : KT_DONE), b1 = lds_bucket(key1) | (p1 ? 0u : KT_DONE);
     for (int it = 0; it < KT_TRIPS && __ballot((int32_t)(b0 & b1) >= 0); ++it) {
-      kt_try(keys, cnts, key0, b0, add);
-      kt_try(keys, cnts, key1, b1, add);
+      kt_try(keys, cnts, key0, b0, add0);
+      kt_try(keys, cnts, key1, b1, add1);
     }
     if (ovf) {
       if ((int32_t)(b0 & b1) >= 0) *ovf = 1u;
     } else {
-      if ((int32_t)b0 >= 0) spill_kmer(t, key0, add);
-      if ((int32_t)b1 >= 0) spill_kmer(t, key1, add);
+      if ((int32_t)b0 >= 0) spill_kmer(t, key0, add0);
+      if ((int32_t)b1 >= 0) spill_kmer(t, key1, add1);
     }
   }
 }
@@ -590,6 +605,7 @@ __device__ __forceinline__ void count_record_v2(unsigned long long *keys, uint32
 // bases.
 constexpr int RT_LOG = 10, RT = 1 << RT_LOG;
 constexpr int TL_PER = 4, TL_CAP = TL_PER * 1024;     // length-sorted list of truncated runs (indices)
+constexpr int FL_CAP = 1024;                          // truncated runs without a complete twin, when the others are anchored
 static_assert(TL_CAP <= (1 << 14), "list positions are 14 bits");
 static_assert(RT == P3_THREADS, "phase 2 lists the record table with one slot per thread");
 constexpr uint32_t RT_LOCK = 0xFFFFFFFFu;
@@ -611,6 +627,41 @@ constexpr int RT_TRIPS = 96;
 
 __device__ __forceinline__ uint32_t rtab_diff(uint4 e, uint4 rec) {
   return (e.x ^ rec.x) | (e.y ^ rec.y) | (e.z ^ rec.z) | ((e.w ^ rec.w) & 63u);
+}
+
+// The record table of the ordinary path is keyed by the record's FIRST k-mer: a truncated run that
+// is a prefix of a complete run shares it, so it finds its complete twin by probing from the same
+// slot (a suffix is a prefix of the other strand's twin after a reverse complement).
+__device__ __forceinline__ uint32_t rtab_slot_k(uint4 rec, int k, int log_slots) {
+  const uint32_t y = (k >= 32) ? rec.y : (rec.y & ~(0xFFFFFFFFu >> (2 * k - 32)));   // 16 <= k: the top 2k-32 bits of y
+  const uint32_t t = rec.x ^ __builtin_amdgcn_alignbit(y, y, 11);
+  return (t * 0x9E3779B1u) >> (32 - log_slots);
+}
+// do the first `len` bases (32 <= 2*len <= 96 bits) of two records agree?
+__device__ __forceinline__ bool rec_prefix_equal(uint4 e, uint4 r, int len) {
+  const int rb = 2 * len - 32;                     // bits beyond the first word: 0 .. 64
+  const uint32_t my = (rb >= 32) ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> rb);
+  const uint32_t mz = (rb <= 32) ? 0u : ((rb >= 64) ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> (rb - 32)));
+  return ((e.x ^ r.x) | ((e.y ^ r.y) & my) | ((e.z ^ r.z) & mz)) == 0u;
+}
+// reverse complement of a record's run (len bases, 16 <= len <= 48); header word unchanged
+__device__ __forceinline__ uint4 revcomp_record(uint4 rec, int len) {
+  auto rcw = [](uint32_t x) {                      // reverse the 16 bases of a word and complement them
+    x = __brev(x);
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+    return ~x;
+  };
+  // the 48-base field reversed: the reverse complement preceded by 48 - len complemented pad bases
+  const uint64_t A = ((uint64_t)rcw(rec.z) << 32) | rcw(rec.y);
+  const uint64_t B = (uint64_t)rcw(rec.x) << 32;
+  const int s = 2 * (48 - len);                    // 0 .. 64: shift the pad out at the top
+  uint64_t hi, lo;
+  if (s == 0) { hi = A; lo = B; }
+  else if (s < 64) { hi = (A << s) | (B >> (64 - s)); lo = B << s; }
+  else { hi = B; lo = 0; }
+  uint4 out = rec;
+  out.x = (uint32_t)(hi >> 32); out.y = (uint32_t)hi; out.z = (uint32_t)(lo >> 32);
+  return out;
 }
 
 // insert-or-count one record per lane; the lane's state is its slot h with RT_DONE or-ed in once
@@ -721,7 +772,16 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
   uint32_t *const cnts = reinterpret_cast<uint32_t *>(pool + TS / 2);
   uint4 *const rtab = pool + TS / 2 + TS / 4;
   __shared__ uint16_t occ_list[RT];
-  __shared__ uint16_t tlist[TL_CAP];
+  // truncated runs: either a length-sorted list of stream positions (tlist), or -- with the record
+  // table resident -- their lengths grouped by the complete twin they are a prefix of (th: per
+  // record-table slot the group's start, tbytes: the lengths) plus the few without a twin (flist)
+  __shared__ uint32_t tmem[RT + 1 + TL_CAP / 4 + 2];
+  uint16_t *const tlist = reinterpret_cast<uint16_t *>(tmem);
+  uint32_t *const th = tmem;
+  uint8_t *const tbytes = reinterpret_cast<uint8_t *>(tmem + RT + 1);
+  static_assert(sizeof(uint16_t) * TL_CAP <= sizeof(uint32_t) * (RT + 1 + TL_CAP / 4), "tlist fits the same memory");
+  __shared__ uint16_t flist[FL_CAP];
+  __shared__ uint32_t nfb, nfl;
   __shared__ uint32_t nhist[32], thist[32];
   __shared__ uint32_t wsum[P3_THREADS / 64];
   __shared__ uint32_t nocc;
@@ -755,8 +815,9 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     for (int s = tid; s < TS; s += P3_THREADS) { keys[s] = CFRK_EMPTY_KEY; cnts[s] = 0; }
     for (int s = tid; s < RT; s += P3_THREADS) rtab[s] = make_uint4(0u, 0u, 0u, RT_EMPTY);
   }
-  if (tid == 0) { wg_total = 0; nocc = 0; rt_fail = 0; kovf = 0; sp = 0; leaf_total = 0; nseg = 0; }
+  if (tid == 0) { wg_total = 0; nocc = 0; rt_fail = 0; kovf = 0; sp = 0; leaf_total = 0; nseg = 0; nfb = 0; nfl = 0; }
   if (tid < 32) { nhist[tid] = 0; thist[tid] = 0; }
+  for (int s = tid; s < RT + 1; s += P3_THREADS) th[s] = 0;
   __syncthreads();
 
   const uint64_t kmask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1ull);
@@ -786,7 +847,7 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
       if ((int32_t)h >= 0) rt_fail = 1u;
     };
     auto home = [&](const uint4 rec, bool valid) {
-      const uint32_t h = rtab_slot(rec, tab_log);
+      const uint32_t h = big_first ? rtab_slot(rec, tab_log) : rtab_slot_k(rec, k, tab_log);
       const uint4 e = tab[h];
       const bool match = valid && rtab_diff(e, rec) == 0u;
       if (match) atomicAdd(&rmeta[4 * h + 3], 1u << 6);
@@ -835,6 +896,14 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
   }
   const bool listed = nd != 0xFFFFFFFFu;
   const bool big = !listed && rt_fail != 0u;
+  // Truncated runs (read ends) are most of the leaf's k-mer insertions, one by one with weight 1.
+  // But a run that is cut on ONE side is a prefix -- or, read on the other strand, a suffix -- of
+  // the complete run of its locus, which sits in the record table: it is looked up there by its
+  // first k-mer, and only its LENGTH is noted with its twin.  The twin's expansion then counts its
+  // first t k-mers once more: one table lookup per truncated run instead of one per k-mer.
+  // Runs without a twin (cut on both sides, shallow loci, forward-strand suffixes) stay k-mer by k-mer.
+  const bool anchors_on = !big && !listed && !(v.dbg & CFRK_DEBUG_NO_ANCHORS);
+  bool use_anchors = false;
   {
     // (a) record table: occupied slots, longest first (not when the leaf is counted from its streams)
     const uint4 e = rtab[tid];                       // RT == P3_THREADS
@@ -842,13 +911,54 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     uint32_t rank = 0;
     if (occ) rank = atomicAdd(&nhist[e.w & 31u], 1u);
     // (b) truncated runs: the first TL_CAP of the stream, by position
-    uint32_t tw[TL_PER], trank[TL_PER];
+    constexpr uint32_t TW_NONE = 0xFFFFFFFFu, TW_TWIN = 0x80000000u;
+    uint32_t tw[TL_PER], trank[TL_PER];              // n-1, or TW_TWIN | twin slot << 8 | n
 #pragma unroll
     for (int i = 0; i < TL_PER; ++i) {
       const uint32_t g = (uint32_t)(i * P3_THREADS + tid);
-      tw[i] = 0xFFFFFFFFu; trank[i] = 0u;
-      if (g < tl) {
-        tw[i] = trunc[g].w & 31u;
+      const bool valid = g < tl;
+      tw[i] = TW_NONE; trank[i] = 0u;
+      uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+      if (valid) rec = trunc[g];
+      const uint32_t nm1 = rec.w & 31u;
+      if (valid) tw[i] = nm1;
+      if (anchors_on && __ballot(valid)) {
+        const bool lc = (rec.w & 64u) != 0u, rc_ = (rec.w & 128u) != 0u;
+        const bool suf = CANON && valid && !lc && rc_;
+        if (suf) rec = revcomp_record(rec, (int)nm1 + k);
+        const bool anchored = suf || (valid && lc && !rc_);
+        uint32_t h = anchored ? rtab_slot_k(rec, k, RT_LOG) : RT_DONE;
+        uint32_t found = TW_NONE;
+        for (int it = 0; it < 32 && __ballot((int32_t)h >= 0); ++it) {
+          const bool p = (int32_t)h >= 0;
+          const uint32_t hh = h & (uint32_t)(RT - 1);
+          const uint4 e2 = rtab[hh];
+          const bool empty = e2.w == RT_EMPTY;
+          // the twin holds at least as many k-mers and starts with the same nm1 + k bases
+          const bool hit = p && !empty && (e2.w & 31u) >= nm1 && rec_prefix_equal(e2, rec, (int)nm1 + k);
+          found = hit ? hh : found;
+          h = (p && !hit && !empty) ? ((hh + 1u) & (uint32_t)(RT - 1)) : (h | RT_DONE);
+        }
+        if (found != TW_NONE) tw[i] = TW_TWIN | (found << 8) | (nm1 + 1u);
+        const unsigned long long fb = __ballot(valid && found == TW_NONE);
+        if (lane == 0 && fb) atomicAdd(&nfb, (uint32_t)__popcll(fb));
+      }
+    }
+    __syncthreads();
+    use_anchors = anchors_on && nfb <= (uint32_t)FL_CAP;
+    if (use_anchors) {
+#pragma unroll
+      for (int i = 0; i < TL_PER; ++i) {
+        if (tw[i] == TW_NONE) continue;
+        if (tw[i] & TW_TWIN) trank[i] = atomicAdd(&th[(tw[i] >> 8) & (uint32_t)(RT - 1)], 1u);
+        else flist[atomicAdd(&nfl, 1u)] = (uint16_t)(i * P3_THREADS + tid);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < TL_PER; ++i) {
+        if (tw[i] == TW_NONE) continue;
+        const uint32_t g = (uint32_t)(i * P3_THREADS + tid);
+        tw[i] = trunc[g].w & 31u;                    // (a twin that was found is not used)
         trank[i] = atomicAdd(&thist[tw[i]], 1u);
       }
     }
@@ -865,11 +975,36 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
       if (tid < 32) nhist[31 - tid] = incl - own; else thist[63 - tid] = incl - own;
       if (tid == 31) nocc = incl;
     }
+    uint32_t goff = 0;
+    if (use_anchors) {
+      // group starts: exclusive prefix of the groups' sizes over the record table's slots
+      const uint32_t own = th[tid];
+      uint32_t incl = own;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(incl, d);
+        if (lane >= d) incl += y;
+      }
+      if (lane == 63) wsum[tid >> 6] = incl;
+      __syncthreads();
+      uint32_t base = 0;
+      for (int w = 0; w < (tid >> 6); ++w) base += wsum[w];
+      goff = base + incl - own;
+      __syncthreads();                               // (everybody has read its group's size)
+      th[tid] = goff;
+      if (tid == P3_THREADS - 1) th[RT] = goff + own;
+    }
     __syncthreads();
     if (occ) occ_list[nhist[e.w & 31u] + rank] = (uint16_t)tid;
+    if (use_anchors) {
 #pragma unroll
-    for (int i = 0; i < TL_PER; ++i)
-      if (tw[i] != 0xFFFFFFFFu) tlist[thist[tw[i]] + trank[i]] = (uint16_t)(i * P3_THREADS + tid);
+      for (int i = 0; i < TL_PER; ++i)
+        if (tw[i] != TW_NONE && (tw[i] & TW_TWIN)) tbytes[th[(tw[i] >> 8) & (uint32_t)(RT - 1)] + trank[i]] = (uint8_t)(tw[i] & 63u);
+    } else {
+#pragma unroll
+      for (int i = 0; i < TL_PER; ++i)
+        if (tw[i] != TW_NONE) tlist[thist[tw[i]] + trank[i]] = (uint16_t)(i * P3_THREADS + tid);
+    }
     // Key subsets to count: the whole leaf in one pass -- or, when the record table overflowed (it
     // then held ~10^3 distinct runs, i.e. twice as many distinct k-mers as the k-mer table takes),
     // four quarters to begin with.
@@ -913,9 +1048,17 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
           const bool valid = i < nitems;
           const uint32_t ri = (parts == 1) ? i : (parts == 2) ? (i >> 1) : (i / 3u);
           uint4 rec = make_uint4(0u, 0u, 0u, 0u);
-          if (valid) rec = rtab[occ_list[ri]];
-          count_record_v2<CANON>(keys, cnts, rec, rec.w >> 6, valid, k, kmask, rcsh, t, ss, ovf,
-                                 (int)(i - ri * (uint32_t)parts), parts);
+          uint32_t slot = 0;
+          if (valid) { slot = occ_list[ri]; rec = rtab[slot]; }
+          if (use_anchors) {
+            // ... plus one for every truncated run of this locus that reaches the k-mer
+            const uint32_t g0 = th[slot];
+            count_record_v2<CANON>(keys, cnts, rec, rec.w >> 6, valid, k, kmask, rcsh, t, ss, ovf,
+                                   (int)(i - ri * (uint32_t)parts), parts, tbytes + g0, valid ? th[slot + 1] - g0 : 0u);
+          } else {
+            count_record_v2<CANON>(keys, cnts, rec, rec.w >> 6, valid, k, kmask, rcsh, t, ss, ovf,
+                                   (int)(i - ri * (uint32_t)parts), parts);
+          }
         }
       } else {
         // the complete runs straight from their stream, weight 1 each
@@ -926,10 +1069,12 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
           count_record_v2<CANON>(keys, cnts, rec, 1u, valid, k, kmask, rcsh, t, ss, ovf);
         }
       }
-      for (uint32_t i = tid; i < ((tl + 63u) & ~63u) && !(v.dbg & CFRK_ABL_P3_NO_TRUNC); i += P3_THREADS) {
-        const bool valid = i < tl;
+      // truncated runs: those without a twin (anchored leaf), or all of the sorted list
+      const uint32_t ntr = use_anchors ? nfl : tl;
+      for (uint32_t i = tid; i < ((ntr + 63u) & ~63u) && !(v.dbg & CFRK_ABL_P3_NO_TRUNC); i += P3_THREADS) {
+        const bool valid = i < ntr;
         uint4 rec = make_uint4(0u, 0u, 0u, 0u);
-        if (valid) rec = trunc[tlist[i]];
+        if (valid) rec = trunc[use_anchors ? flist[i] : tlist[i]];
         count_record_v2<CANON>(keys, cnts, rec, 1u, valid, k, kmask, rcsh, t, ss, ovf);
       }
       // truncated runs beyond the sorted list (very large leaves): in stream order

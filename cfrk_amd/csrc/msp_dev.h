@@ -86,7 +86,7 @@ __device__ __forceinline__ void block_scan(const uint32_t *cnt, uint32_t *off, u
 // hi / mid = the lane's own 32 bases and the next lane's 32 bases, 2 bits each, first base in the
 // top bits; chunk = index of the lane's 32-byte chunk (for the absolute-position tag).
 // On return H[0..31] = packed minimizer (hash & ~127 | position tag) of the windows starting at
-// the own positions, H[32..32+W-2] = the next lane's first W-1; the result is the change mask:
+// the own positions (H[32..] is scratch); the result is the change mask:
 // bit(63-p) set when the minimizer OCCURRENCE differs between positions p-1 and p
 // (p = 0: against the previous lane's last position).
 template <int W>
@@ -160,12 +160,7 @@ __device__ __forceinline__ uint64_t msp_minimizers(uint64_t hi, uint64_t mid, in
       for (int i = 0; i < 32; ++i) H[i] = min(H[i], H[i + W - P]);
     }
   }
-  // H[0..31] = minimizers of the own k-mers; fetch the next lane's first W-1 and the previous
-  // lane's last one
-  const uint32_t prevW = dev_lane_prev(H[31]);
-#pragma unroll
-  for (int j = 0; j < W - 1; ++j) H[32 + j] = dev_lane_next(H[j]);
-
+  // H[0..31] = minimizers of the own k-mers.
   // Cx bit(63-p): minimizer occurrence changes between positions p-1 and p (p = 0..NH-1)
   // Two VALU instructions per position: a compare into VCC and an add-with-carry that doubles
   // the accumulator and takes the compare bit in (the first position ends up in the top bit).
@@ -173,12 +168,13 @@ __device__ __forceinline__ uint64_t msp_minimizers(uint64_t hi, uint64_t mid, in
   auto push = [](uint32_t &acc, uint32_t a, uint32_t b) {
     asm("v_cmp_ne_u32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
   };
-  uint32_t ch = 0, cl = 0;
+  const uint32_t prevW = dev_lane_prev(H[31]);
+  uint32_t ch = 0;
   push(ch, H[0], prevW);
 #pragma unroll
   for (int p = 1; p < 32; ++p) push(ch, H[p], H[p - 1]);
-#pragma unroll
-  for (int p = 32; p < NH; ++p) push(cl, H[p], H[p - 1]);
-  cl <<= (64 - NH);
+  // positions 32 .. NH-1 are the next lane's first W-1 (its position 0 compares against this
+  // lane's last one): its change bits, not a second set of minima and compares
+  const uint32_t cl = dev_lane_next(ch) & ~(0xFFFFFFFFu >> (W - 1));
   return ((uint64_t)ch << 32) | cl;
 }

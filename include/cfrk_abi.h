@@ -182,6 +182,9 @@ int cfrk_debug_last_add_passes(cfrk_ctx *ctx, int *out_passes);
 /* Bit 1: the first partition kernel (k >= 16) holds one trip's worth (64) of a wave's runs in
  * registers instead of 4..8: the rest takes the direct-append path meant for pathological waves. */
 #define CFRK_DEBUG_SMALL_WAVE_CAP 0x2
+/* Bit 2: the leaf kernel of the one-word partitioned path counts every truncated run k-mer by k-mer
+ * instead of noting it with the complete run it is a prefix of (same result; for A/B timing and tests). */
+#define CFRK_DEBUG_NO_ANCHORS 0x4
 int cfrk_debug_set_flags(cfrk_ctx *ctx, uint32_t flags);
 
 /* ---- synthetic reads, generated on device ----------------------------------- */

@@ -723,3 +723,42 @@ def test_cli_pipeline_over_two_contexts_per_device_and_batch_mode(tmp_path):
     subprocess.check_call([cli, "--batch", "2", str(tmp_path / "ds"), str(tmp_path / "all"), "2", "4", "256", "--all-chunks"])
     for f in range(2):
         assert (tmp_path / f"all_{f}.cfrk").read_bytes() == want_all(files[f], 2, 256)
+
+
+@pytest.mark.parametrize("k,canonical", [(31, True), (28, True), (32, True), (31, False), (29, False)])
+def test_truncated_runs_anchored_to_their_complete_twin_give_the_same_counts(ctx, k, canonical):
+    """The leaf kernel notes a read-end run with the complete run it is a prefix (or, on the other
+    strand, a suffix) of instead of inserting its k-mers one by one.  Deep coverage with invalid
+    bases, short reads (every run cut on both sides) and repeats: identical to the oracle, and to
+    the same kernel with the shortcut switched off (CFRK_DEBUG_NO_ANCHORS)."""
+    import cfrk_amd
+    rng = np.random.default_rng(77 + k)
+    G = 40_000
+    genome = rng.integers(0, 4, G).astype(np.int8)
+    genome[5000:5400] = genome[1000:1400]              # a repeat: the same k-mers at two loci
+    genome[9000:9060] = 0                              # homopolymer
+    reads = []
+    for _ in range(60_000):
+        L = int(rng.choice([150, 150, 150, 100, 60, k, k + 3, 20]))
+        p = int(rng.integers(0, G - L))
+        r = genome[p:p + L].copy()
+        if rng.random() < 0.5:
+            r = (3 - r)[::-1].copy()
+        if rng.random() < 0.05:
+            r[int(rng.integers(0, L))] = -1
+        reads.append(r)
+    data, start, length = refsem.flatten(reads)
+    flags = cfrk_amd.CFRK_CANONICAL if canonical else 0
+    want = orc.global_count(data, k, orc.ORC_CANONICAL if canonical else 0, threads=8)
+    digests = []
+    for dbg in (0, cfrk_amd.lib.CFRK_DEBUG_NO_ANCHORS):
+        g = cfrk_amd.GlobalCounter(ctx, k, flags, 4 * G)
+        g.set_debug_flags(dbg)
+        g.add(data, start, length)
+        lo, hi, cnt = g.export()
+        g.set_debug_flags(0)
+        assert len(lo) == len(want[0])
+        assert (lo == want[0]).all() and (cnt.astype(np.uint64) == want[2]).all()
+        assert g.msp_info()["spilled_kmers"] == 0
+        digests.append(g.digest())
+    assert digests[0] == digests[1] == orc.digest(*want)
