@@ -58,6 +58,9 @@ def parse():
                         "headline and the weak measurement is reported under \"weak\"")
     p.add_argument("--owner-hash", action="store_true",
                    help="force the generic hash-owner exchange + HBM-table merge")
+    p.add_argument("--exchange", default="auto", choices=["auto", "runs", "leaf", "owner"],
+                   help="N > 1: what the ranks exchange.  runs (auto for 16 <= k <= 32): deduplicated "
+                        "runs, counted by the leaf's owner; leaf: counted per-leaf lists; owner: counted keys")
     a = p.parse_args()
     reads, L, k, glen = CONFIGS[a.config]
     if a.config == "c5" and a.scaling in ("", "both", "strong"):
@@ -248,6 +251,23 @@ def main():
                     return None
                 return keys, hi, cnt, pc, lc
 
+            def export_runs(self, parts):
+                if getattr(self, "rbuf", None) is None:
+                    # rows of 16 bytes: distinct runs (<= the leaf streams) + truncated runs + headers
+                    self.rbuf = torch.empty((max(1 << 20, nN // 8), 2), dtype=torch.int64, device=dev)
+                for _ in range(3):
+                    try:
+                        pr = self.g.export_runs_device(self.rbuf.data_ptr(), self.rbuf.shape[0], parts)
+                        return self.rbuf, pr
+                    except cfrk_amd.CfrkError as e:
+                        if e.code == -9:          # buffer too small: double it
+                            self.rbuf = torch.empty((2 * self.rbuf.shape[0], 2), dtype=torch.int64, device=dev)
+                            continue
+                        if e.code != -4:
+                            raise
+                        return None
+                return None
+
             def export_parts(self, parts):
                 if self.bufs is None:
                     cap = hint
@@ -263,8 +283,14 @@ def main():
         kernel_ms = []
         phase_s = [0.0, 0.0]      # N > 1: seconds until the exchange has returned / spent in the owner merge
 
+        exch = "owner" if args.owner_hash else args.exchange
+        if exch == "auto":
+            exch = "runs" if 16 <= k <= 32 else "leaf"
+        used = {"exchange": exch, "wire_bytes": 0}
+
         def step():
-            eng.g = cfrk_amd.GlobalCounter(ctx, k, flags, hint)
+            runs = world > 1 and exch == "runs"
+            eng.g = cfrk_amd.GlobalCounter(ctx, k, flags | (cfrk_amd.CFRK_RUNS_ONLY if runs else 0), hint)
             if os.environ.get("CFRK_DEBUG_FLAGS"):       # timing ablations (tools/ablate.sh): wrong counts
                 eng.g.set_debug_flags(int(os.environ["CFRK_DEBUG_FLAGS"], 0))
             eng.g.add_device(d_data.data_ptr(), nN)
@@ -273,7 +299,23 @@ def main():
                 return eng.g
             og = cfrk_amd.GlobalCounter(owner_ctx, k, flags, hint // world + 1024)
             ta = time.perf_counter()
-            got = None if args.owner_hash else sharded.exchange_by_leaf(eng, world, dev, wire)
+            if runs:
+                got = sharded.exchange_by_runs(eng, world, dev, wire)
+                if got is not None:   # the owner expands and counts the runs of its leaves
+                    packed, recv_rows = got
+                    tb = time.perf_counter()
+                    og.merge_runs_device(packed.data_ptr(), recv_rows)
+                    owner_ctx.sync()
+                    phase_s[0] += tb - ta
+                    phase_s[1] += time.perf_counter() - tb
+                    used["wire_bytes"] = 16 * (sum(recv_rows) - recv_rows[rank])
+                    used["owner_ms"] = og.last_add_ms()
+                    return og
+                # some rank could not export runs: count the shard after all, then exchange counts
+                used["exchange"] = "leaf (runs export refused)"
+                eng.g = cfrk_amd.GlobalCounter(ctx, k, flags, hint)
+                eng.g.add_device(d_data.data_ptr(), nN)
+            got = None if exch == "owner" else sharded.exchange_by_leaf(eng, world, dev, wire)
             if got is not None:       # per-leaf lists, added in LDS on the owner
                 rkeys, rhi, rcnt, recv_l, rlc = got
                 tb = time.perf_counter()
@@ -353,6 +395,7 @@ def main():
             out["step_breakdown_ms"] = {"count_kernels": avg_ms,
                                         "count_export_exchange": phase_s[0] / args.steps * 1e3,
                                         "owner_merge": phase_s[1] / args.steps * 1e3}
+            out["exchange"] = used
         if info:
             out["msp_info"] = info
         return out, ok, kmers_total
@@ -365,7 +408,7 @@ def main():
         w, wok, _ = measure("weak")
         ok = ok and wok
         out["weak"] = {key: w[key] for key in ("value", "ms_per_step", "config", "distinct", "sum_count_ok",
-                                               "digest", "step_breakdown_ms")}
+                                               "digest", "step_breakdown_ms", "exchange")}
     else:
         out, ok, total = measure(scaling)
 

@@ -221,6 +221,8 @@ int cfrk_per_read_dense(cfrk_ctx *ctx, const int8_t *data, const int64_t *start,
 int cfrk_global_begin(cfrk_ctx *ctx, int k, int flags, uint64_t capacity_hint) {
   if (!ctx) return CFRK_ERR_ARG;
   if (k < 1 || k > 64) return cfrk_fail(ctx, CFRK_ERR_ARG, "k=%d outside 1..64", k);
+  if ((flags & CFRK_RUNS_ONLY) && (k < 16 || k > 32 || (flags & CFRK_FORCE_HASH)))
+    return cfrk_fail(ctx, CFRK_ERR_ARG, "CFRK_RUNS_ONLY needs the partitioned one-word path (16 <= k <= 32)");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   // Was the HBM table left untouched by the previous job (the partitioned path only writes it
@@ -278,6 +280,8 @@ int cfrk_global_add_device(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   if (cfrk_msp_usable(ctx)) rc = cfrk_msp_count(ctx, d_data, nN);
   else if (cfrk_radix_usable(ctx)) rc = cfrk_radix_count(ctx, d_data, nN);
   else if (cfrk_msp2_usable(ctx)) rc = cfrk_msp2_count(ctx, d_data, nN);
+  if (rc == CFRK_ERR_NOMEM && (ctx->g_flags & CFRK_RUNS_ONLY))
+    return cfrk_fail(ctx, CFRK_ERR_NOMEM, "the shard's record buffers do not fit device memory");
   if (rc == CFRK_ERR_NOMEM) {
     // no partitioned path for this k, or its record buffers (about 7 bytes per input byte) do
     // not fit next to the caller's data: count with the general HBM-table path instead

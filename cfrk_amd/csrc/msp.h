@@ -49,6 +49,7 @@ struct MspView {
 
 struct cfrk_msp {
   bool leaf_form;      // the list is grouped by minimizer leaf (msp.hip); false for radix.hip
+  bool runs_ready;     // CFRK_RUNS_ONLY job: the leaf streams hold deduplicated runs ready for cfrk_global_export_runs_device
   bool pending;        // a leaf-output list exists that has not been folded into the table
   bool table_dirty;    // the table holds counts of its own since begin()
   uint64_t list_n;     // entries in the list (valid after resolve)

@@ -668,8 +668,10 @@ __device__ __forceinline__ uint4 revcomp_record(uint4 rec, int len) {
 // the record is placed (lanes without a record start that way).  On return lanes still without
 // RT_DONE found no place.
 constexpr uint32_t RT_DONE = 0x80000000u;
+// inc = the record's weight << 6: 1 << 6 for a record straight from a read, its multiplicity when
+// the stream already holds deduplicated runs (the owner side of the multi-GPU exchange)
 __device__ __forceinline__ void rtab_insert_loop(uint4 *rtab, uint4 rec, uint32_t &h, uint32_t mask = RT - 1,
-                                                 int trips = RT_TRIPS) {
+                                                 int trips = RT_TRIPS, uint32_t inc = 1u << 6) {
   uint32_t *rmeta = reinterpret_cast<uint32_t *>(rtab);
   const uint32_t nm1 = rec.w & 63u;
   for (int it = 0; it < trips && __ballot((int32_t)h >= 0); ++it) {
@@ -683,11 +685,11 @@ __device__ __forceinline__ void rtab_insert_loop(uint4 *rtab, uint4 rec, uint32_
       if (atomicCAS(&rmeta[4 * hh + 3], RT_EMPTY, RT_LOCK) == RT_EMPTY) {
         rmeta[4 * hh + 0] = rec.x; rmeta[4 * hh + 1] = rec.y; rmeta[4 * hh + 2] = rec.z;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        atomicExch(&rmeta[4 * hh + 3], (1u << 6) | nm1);
+        atomicExch(&rmeta[4 * hh + 3], inc | nm1);
         won = 1u;
       }
     }
-    atomicAdd(&rmeta[4 * hh + 3], (p && match) ? (1u << 6) : 0u);
+    atomicAdd(&rmeta[4 * hh + 3], (p && match) ? inc : 0u);
     // an empty slot lost to another lane, or a locked one, is read again; a slot holding another
     // record sends the lane on
     const bool stay = match || empty || e.w == RT_LOCK;
@@ -744,7 +746,25 @@ __device__ __noinline__ uint32_t p3_compact(uint4 *pool, uint4 *stream, uint32_t
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   return total;
 }
-__device__ __noinline__ uint32_t p3_big_dedupe(uint4 *pool, uint4 *stream, uint64_t n1, uint32_t *wsum, uint32_t *fail) {
+// occupied slots of the ordinary record table (one per thread) -> head of the stream; returns their number
+__device__ __noinline__ uint32_t p3_dump_rtab(const uint4 *rtab, uint4 *stream, uint32_t *wsum) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint4 e = rtab[tid];
+  const bool occ = e.w != RT_EMPTY;
+  const unsigned long long m = __ballot(occ);
+  if (lane == 0) wsum[wave] = (uint32_t)__popcll(m);
+  __syncthreads();
+  uint32_t base = 0, total = 0;
+  for (int w = 0; w < P3_THREADS / 64; ++w) {
+    const uint32_t x = wsum[w];
+    base += (w < wave) ? x : 0u;
+    total += x;
+  }
+  if (occ) stream[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = e;
+  return total;
+}
+
+__device__ __noinline__ uint32_t p3_big_dedupe(uint4 *pool, uint4 *stream, uint64_t n1, uint32_t *wsum, uint32_t *fail, bool weighted) {
   const int tid = threadIdx.x;
   __syncthreads();                               // every thread has read *fail (that is why we are here)
   for (int s = tid; s < BT; s += P3_THREADS) pool[s] = make_uint4(0u, 0u, 0u, RT_EMPTY);
@@ -755,7 +775,7 @@ __device__ __noinline__ uint32_t p3_big_dedupe(uint4 *pool, uint4 *stream, uint6
     uint4 rec = make_uint4(0u, 0u, 0u, 0u);
     if (valid) rec = stream[r];
     uint32_t h = valid ? rtab_slot(rec, BT_LOG) : RT_DONE;
-    rtab_insert_loop(pool, rec, h, BT - 1, BT_TRIPS);
+    rtab_insert_loop(pool, rec, h, BT - 1, BT_TRIPS, weighted ? ((rec.w >> 6) << 6) : (1u << 6));
     if ((int32_t)h >= 0) *fail = 1u;
   }
   __syncthreads();
@@ -763,8 +783,12 @@ __device__ __noinline__ uint32_t p3_big_dedupe(uint4 *pool, uint4 *stream, uint6
   return p3_compact(pool, stream, wsum);
 }
 
+// mode: P3_EXPORT = stop after the deduplication and leave the leaf's distinct complete runs, header
+// word = multiplicity << 6 | n-1, at the head of its stream (leaf_n = their number): what a rank
+// ships to the leaf's owner; P3_WEIGHTED = the complete stream holds such entries (from several ranks).
+constexpr uint32_t P3_EXPORT = 1u, P3_WEIGHTED = 2u;
 template <bool CANON>
-__global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void msp_p3_kernel(int k, MspView v, TableView t) {
+__global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void msp_p3_kernel(int k, uint32_t mode, MspView v, TableView t) {
   // k-mer table (keys, counts) and record table in one allocation: p3_big_dedupe uses all of it
   __shared__ uint4 pool[BT];
   static_assert(BT * 16 == TS * 12 + RT * 16, "the pool is exactly the k-mer table plus the record table");
@@ -809,10 +833,12 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
   const int tab_log = big_first ? BT_LOG : RT_LOG;
   const uint32_t tab_mask = (1u << tab_log) - 1u;
   const int tab_trips = big_first ? BT_TRIPS : RT_TRIPS;
+  if ((mode & P3_EXPORT) && n1 == 0) return;      // nothing to deduplicate: the truncated runs leave as they are
   if (big_first) {
     for (int s = tid; s < BT; s += P3_THREADS) pool[s] = make_uint4(0u, 0u, 0u, RT_EMPTY);
   } else {
-    for (int s = tid; s < TS; s += P3_THREADS) { keys[s] = CFRK_EMPTY_KEY; cnts[s] = 0; }
+    if (!(mode & P3_EXPORT))                       // (an exporting leaf never touches its k-mer table)
+      for (int s = tid; s < TS; s += P3_THREADS) { keys[s] = CFRK_EMPTY_KEY; cnts[s] = 0; }
     for (int s = tid; s < RT; s += P3_THREADS) rtab[s] = make_uint4(0u, 0u, 0u, RT_EMPTY);
   }
   if (tid == 0) { wg_total = 0; nocc = 0; rt_fail = 0; kovf = 0; sp = 0; leaf_total = 0; nseg = 0; nfb = 0; nfl = 0; }
@@ -839,9 +865,10 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     uint4 L = zero4;                 // leftover records, lanes [0, c)
     uint32_t Lh = 0;
     int c = 0;                       // wave-uniform
+    const bool weighted = (mode & P3_WEIGHTED) != 0u;
     auto drain = [&](int cnt) {
       uint32_t h = Lh | ((lane < cnt) ? 0u : RT_DONE);
-      rtab_insert_loop(tab, L, h, tab_mask, tab_trips);
+      rtab_insert_loop(tab, L, h, tab_mask, tab_trips, weighted ? ((L.w >> 6) << 6) : (1u << 6));
       // no room in the record table: a leaf with more distinct runs than it holds (low coverage
       // of a large genome).  Dedupe is pointless there: the whole leaf is counted from its streams.
       if ((int32_t)h >= 0) rt_fail = 1u;
@@ -850,7 +877,7 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
       const uint32_t h = big_first ? rtab_slot(rec, tab_log) : rtab_slot_k(rec, k, tab_log);
       const uint4 e = tab[h];
       const bool match = valid && rtab_diff(e, rec) == 0u;
-      if (match) atomicAdd(&rmeta[4 * h + 3], 1u << 6);
+      if (match) atomicAdd(&rmeta[4 * h + 3], weighted ? ((rec.w >> 6) << 6) : (1u << 6));
       const bool left = valid && !match;
       const unsigned long long mask = __ballot(left);
       if (mask == 0ull) return;
@@ -885,8 +912,23 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
   //      LENGTH (counting sort of 16-bit indices in LDS): a wave expands 64 records in lock-step
   //      for as many steps as its longest one, so equal lengths keep every lane busy.
   uint32_t nd = 0xFFFFFFFFu;                     // distinct runs listed in the stream (second chance), ~0: none
+  if (mode & P3_EXPORT) {
+    uint4 *const stream = const_cast<uint4 *>(leaf_rec);
+    const bool weighted = (mode & P3_WEIGHTED) != 0u;
+    if (big_first) { if (rt_fail == 0u) nd = p3_compact(pool, stream, wsum); }
+    else if (rt_fail == 0u) nd = p3_dump_rtab(rtab, stream, wsum);
+    else if (n1 >= (uint64_t)BT_MIN_RUNS || (v.dbg & CFRK_DEBUG_FORCE_RT_OVERFLOW)) nd = p3_big_dedupe(pool, stream, n1, wsum, &rt_fail, weighted);
+    if (nd == 0xFFFFFFFFu) {
+      // nothing to merge (more distinct runs than any table here holds): the runs leave as they are, multiplicity 1
+      if (!weighted)
+        for (uint64_t i = tid; i < n1; i += P3_THREADS) stream[i].w = (1u << 6) | (stream[i].w & 63u);
+      nd = (uint32_t)n1;
+    }
+    if (tid == 0) v.leaf_n[leaf] = nd;
+    return;
+  }
   if (big_first || rt_fail != 0u) {              // (rt_fail read after the barrier above: uniform)
-    if (!big_first && (n1 >= (uint64_t)BT_MIN_RUNS || (v.dbg & CFRK_DEBUG_FORCE_RT_OVERFLOW))) nd = p3_big_dedupe(pool, const_cast<uint4 *>(leaf_rec), n1, wsum, &rt_fail);
+    if (!big_first && (n1 >= (uint64_t)BT_MIN_RUNS || (v.dbg & CFRK_DEBUG_FORCE_RT_OVERFLOW))) nd = p3_big_dedupe(pool, const_cast<uint4 *>(leaf_rec), n1, wsum, &rt_fail, (mode & P3_WEIGHTED) != 0u);
     else if (!big_first) __syncthreads();        // (as below)
     else if (rt_fail == 0u) nd = p3_compact(pool, const_cast<uint4 *>(leaf_rec), wsum);
     else __syncthreads();                        // (the pool is cleared below: everybody has read rt_fail and the table)
@@ -1066,7 +1108,7 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
           const bool valid = i < n1;
           uint4 rec = make_uint4(0u, 0u, 0u, 0u);
           if (valid) rec = leaf_rec[i];
-          count_record_v2<CANON>(keys, cnts, rec, 1u, valid, k, kmask, rcsh, t, ss, ovf);
+          count_record_v2<CANON>(keys, cnts, rec, (mode & P3_WEIGHTED) ? (rec.w >> 6) : 1u, valid, k, kmask, rcsh, t, ss, ovf);
         }
       }
       // truncated runs: those without a twin (anchored leaf), or all of the sorted list
@@ -1217,6 +1259,176 @@ __global__ __launch_bounds__(P3_THREADS) void msp_merge_kernel(const uint64_t *_
   }
 }
 
+// ---------------------------------------------------------------------------- multi-GPU by runs
+// Strong scaling: with the reads split over N ranks every rank still meets almost every locus, so
+// counting on every rank and exchanging (key, count) lists (above) makes each rank expand every
+// distinct run and ship ~D entries -- neither shrinks with N.  Here a rank only partitions and
+// deduplicates (P1, P2, the leaf kernel in P3_EXPORT mode) and ships, per leaf, its distinct
+// complete runs with multiplicities plus its truncated runs to the leaf's owner
+// (owner(leaf) = leaf % parts); the owner lines the N lists of each of its leaves up as that
+// leaf's streams and runs the ordinary leaf kernel on them (P3_WEIGHTED): expansion and counting
+// happen once, for 1/N of the leaves.
+
+// exclusive prefix sum over a block of 1024 threads (wtot: 16 words of LDS); returns the exclusive
+// prefix of x, *total = the block's sum
+__device__ __forceinline__ uint64_t block_scan_u64(uint64_t x, unsigned long long *wtot, uint64_t *total) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint64_t incl = x;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint64_t y = __shfl_up(incl, d);
+    if (lane >= d) incl += y;
+  }
+  __syncthreads();                               // (wtot may still be read from a previous scan)
+  if (lane == 63) wtot[wave] = incl;
+  __syncthreads();
+  uint64_t base = 0, all = 0;
+  for (int w = 0; w < 16; ++w) { const uint64_t t = wtot[w]; base += (w < wave) ? t : 0; all += t; }
+  *total = all;
+  return base + incl - x;
+}
+
+// sender, one workgroup: where every leaf's records go in the packed buffer (owner-major order,
+// a header of hrows rows in front of every owner's segment), the headers themselves, rows per segment
+__global__ __launch_bounds__(1024) void msp_runs_plan_kernel(MspView v, int parts, int lpp, int hrows,
+                                                             uint64_t *__restrict__ dst_off, uint4 *__restrict__ packed,
+                                                             uint64_t cap_rows,
+                                                             uint64_t *__restrict__ part_rows /* [parts]: rows per segment; [parts]: all rows */) {
+  __shared__ unsigned long long wtot[16];
+  __shared__ unsigned long long seg[65];          // first row of every owner's segment
+  const int tid = threadIdx.x;
+  const int n = parts * lpp, per = (n + 1023) / 1024;
+  auto sizes = [&](int i, uint32_t &n1, uint32_t &nt) {
+    const int p = i / lpp, j = i - p * lpp, leaf = p + j * parts;
+    n1 = 0; nt = 0;
+    if (i < n && leaf < NLEAF) {
+      nt = (uint32_t)min((uint64_t)v.cnt2[NCLS * leaf + 0], v.exact ? (uint64_t)v.lcap[NCLS * leaf + 0] : v.cap2t);
+      n1 = v.cnt2[NCLS * leaf + 1] ? v.leaf_n[leaf] : 0u;      // (a leaf without complete runs never wrote its count)
+    }
+  };
+  uint64_t mine = 0;
+  for (int q = 0; q < per; ++q) { uint32_t a, b; sizes(tid * per + q, a, b); mine += (uint64_t)a + b; }
+  uint64_t total;
+  const uint64_t run0 = block_scan_u64(mine, wtot, &total);
+  const uint64_t all_rows = total + (uint64_t)parts * hrows;
+  if (tid == 0) { part_rows[parts] = all_rows; seg[parts] = all_rows; }
+  uint64_t run = run0;
+  for (int q = 0; q < per; ++q) {
+    const int i = tid * per + q;
+    if (i >= n) break;
+    const int p = i / lpp, j = i - p * lpp;
+    if (j == 0) seg[p] = run + (uint64_t)p * hrows;
+    uint32_t a, b;
+    sizes(i, a, b);
+    run += (uint64_t)a + b;
+  }
+  __syncthreads();
+  if (tid < parts) part_rows[tid] = seg[tid + 1] - seg[tid];
+  if (all_rows > cap_rows) return;                 // (the host reports the size the buffer needs)
+  run = run0;
+  for (int q = 0; q < per; ++q) {
+    const int i = tid * per + q;
+    if (i >= n) break;
+    const int p = i / lpp, j = i - p * lpp, leaf = p + j * parts;
+    uint32_t a, b;
+    sizes(i, a, b);
+    if (leaf < NLEAF) dst_off[leaf] = run + (uint64_t)(p + 1) * hrows;
+    uint32_t *hdr = reinterpret_cast<uint32_t *>(packed + seg[p]);
+    hdr[2 * j] = a; hdr[2 * j + 1] = b;
+    run += (uint64_t)a + b;
+  }
+}
+
+// owner, one workgroup: from the received headers, where every (source rank, local leaf) segment
+// starts in the packed buffer and where its two parts go in the leaf's streams; stream bases and
+// sizes (exact layout); err = 1 when a rank's header does not add up to the rows it sent
+struct RunsRecv { uint64_t rstart[64]; uint64_t rows[64]; };
+__global__ __launch_bounds__(1024) void msp_runs_layout_kernel(const uint4 *__restrict__ packed, RunsRecv rr, int parts, int lpp, int hrows,
+                                                               uint64_t *__restrict__ src, uint64_t *__restrict__ d1, uint64_t *__restrict__ d0,
+                                                               uint64_t *__restrict__ lbase, uint32_t *__restrict__ lcap, uint32_t *__restrict__ cnt2,
+                                                               uint64_t *__restrict__ out /* [0]: records in all, [1]: err */) {
+  __shared__ unsigned long long wtot[16];
+  const int tid = threadIdx.x;
+  const int per = (lpp + 1023) / 1024;
+  uint32_t err = 0;
+  // (1) every rank's segments: record offsets inside its part of the buffer
+  for (int r = 0; r < parts; ++r) {
+    const uint32_t *hdr = reinterpret_cast<const uint32_t *>(packed + rr.rstart[r]);
+    uint64_t mine = 0;
+    for (int q = 0; q < per; ++q) { const int ll = tid * per + q; if (ll < lpp) mine += (uint64_t)hdr[2 * ll] + hdr[2 * ll + 1]; }
+    uint64_t total;
+    uint64_t run = block_scan_u64(mine, wtot, &total);
+    if (total + (uint64_t)hrows != rr.rows[r]) err = 1;
+    for (int q = 0; q < per; ++q) {
+      const int ll = tid * per + q;
+      if (ll >= lpp) break;
+      src[(size_t)r * lpp + ll] = rr.rstart[r] + (uint64_t)hrows + run;
+      run += (uint64_t)hdr[2 * ll] + hdr[2 * ll + 1];
+    }
+  }
+  // (2) the owner's leaves = local indices: stream (ll, class) = the ranks' parts in rank order, complete stream first
+  uint64_t mine = 0;
+  for (int q = 0; q < per; ++q) {
+    const int ll = tid * per + q;
+    if (ll >= lpp) break;
+    for (int r = 0; r < parts; ++r) {
+      const uint32_t *hdr = reinterpret_cast<const uint32_t *>(packed + rr.rstart[r]);
+      mine += (uint64_t)hdr[2 * ll] + hdr[2 * ll + 1];
+    }
+  }
+  uint64_t total;
+  uint64_t run = block_scan_u64(mine, wtot, &total);
+  for (int q = 0; q < per; ++q) {
+    const int ll = tid * per + q;
+    if (ll >= lpp) break;
+    uint64_t n1 = 0, n0 = 0;
+    for (int r = 0; r < parts; ++r) {
+      const uint32_t *hdr = reinterpret_cast<const uint32_t *>(packed + rr.rstart[r]);
+      d1[(size_t)r * lpp + ll] = run + n1;
+      n1 += hdr[2 * ll];
+    }
+    for (int r = 0; r < parts; ++r) {
+      const uint32_t *hdr = reinterpret_cast<const uint32_t *>(packed + rr.rstart[r]);
+      d0[(size_t)r * lpp + ll] = run + n1 + n0;
+      n0 += hdr[2 * ll + 1];
+    }
+    if (n1 > 0xFFFFFFFFull || n0 > 0xFFFFFFFFull) err = 1;
+    lbase[(size_t)NCLS * ll + 1] = run; lcap[(size_t)NCLS * ll + 1] = (uint32_t)n1; cnt2[(size_t)NCLS * ll + 1] = (uint32_t)n1;
+    lbase[(size_t)NCLS * ll + 0] = run + n1; lcap[(size_t)NCLS * ll + 0] = (uint32_t)n0; cnt2[(size_t)NCLS * ll + 0] = (uint32_t)n0;
+    run += n1 + n0;
+  }
+  if (tid == 0) out[0] = total;
+  if (err) out[1] = 1;
+}
+
+// sender: leaf -> [nd distinct complete runs][nt truncated runs] at record dst_off[leaf] of the send buffer
+__global__ __launch_bounds__(256) void msp_runs_gather_kernel(MspView v, const uint64_t *__restrict__ dst_off, uint4 *__restrict__ out,
+                                                              const uint64_t *__restrict__ plan_rows, int parts, uint64_t cap_rows) {
+  if (plan_rows[parts] > cap_rows) return;         // the buffer is too small: nothing was planned
+  const uint32_t leaf = blockIdx.x;
+  const uint32_t nd = v.cnt2[NCLS * leaf + 1] ? v.leaf_n[leaf] : 0u;
+  const uint32_t nt = (uint32_t)min((uint64_t)v.cnt2[NCLS * leaf + 0], v.exact ? (uint64_t)v.lcap[NCLS * leaf + 0] : v.cap2t);
+  const uint4 *c1 = v.exact ? v.rec2 + v.lbase[NCLS * leaf + 1] : v.rec2 + (uint64_t)leaf * (v.cap2c + v.cap2t);
+  const uint4 *c0 = v.exact ? v.rec2 + v.lbase[NCLS * leaf + 0] : c1 + v.cap2c;
+  uint4 *dst = out + dst_off[leaf];
+  for (uint32_t i = threadIdx.x; i < nd; i += blockDim.x) dst[i] = c1[i];
+  for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) dst[nd + i] = c0[i];
+}
+
+// owner: segment (source rank, local leaf) of the received buffer -> its place in the leaf's two streams
+__global__ __launch_bounds__(256) void msp_runs_scatter_kernel(const uint4 *__restrict__ in, RunsRecv rr, int lpp,
+                                                               const uint64_t *__restrict__ src_off,
+                                                               const uint64_t *__restrict__ dst1, const uint64_t *__restrict__ dst0,
+                                                               uint4 *__restrict__ rec2) {
+  const uint32_t seg = blockIdx.x;
+  const uint32_t r = seg / (uint32_t)lpp, ll = seg - r * (uint32_t)lpp;
+  const uint32_t *hdr = reinterpret_cast<const uint32_t *>(in + rr.rstart[r]);
+  const uint32_t nd = hdr[2 * ll], nt = hdr[2 * ll + 1];
+  const uint4 *src = in + src_off[seg];
+  for (uint32_t i = threadIdx.x; i < nd; i += blockDim.x) rec2[dst1[seg] + i] = src[i];
+  for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) rec2[dst0[seg] + i] = src[nd + i];
+}
+
 // exact layout of a level from the demand the first attempt counted: base = exclusive prefix sum
 // of the n cursors, cap = the cursors themselves (single workgroup, 1024 threads)
 __global__ __launch_bounds__(1024) void msp_layout_kernel(const uint32_t *__restrict__ cnt, uint32_t n,
@@ -1282,7 +1494,7 @@ bool cfrk_msp_usable(const cfrk_ctx *ctx) {
 }
 
 void cfrk_msp_reset(cfrk_ctx *ctx) {
-  if (ctx->msp) { ctx->msp->pending = false; ctx->msp->table_dirty = false; ctx->msp->list_n_valid = false; }
+  if (ctx->msp) { ctx->msp->pending = false; ctx->msp->table_dirty = false; ctx->msp->list_n_valid = false; ctx->msp->runs_ready = false; }
 }
 
 void cfrk_msp_note_table_write(cfrk_ctx *ctx) {
@@ -1383,6 +1595,9 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
   v.ovf = (uint4 *)p; v.ovf_cap = (uint32_t)std::min<double>((double)OVF_CAP, expect / 256.0);   // "a few": < 0.4 %
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_OVF1, (size_t)OVF_CAP * sizeof(uint4), &p))) return rc;
   v.ovf1 = (uint4 *)p; v.ovf1_cap = v.ovf_cap;
+  // a job that only partitions (CFRK_RUNS_ONLY) has no table of its own for parked records: any
+  // overflow goes straight to the exact re-layout
+  if (ctx->g_flags & CFRK_RUNS_ONLY) v.ovf_cap = v.ovf1_cap = 0;
   v.exact = 0; v.lbase = nullptr; v.lcap = nullptr;
   v.exact1 = 0; v.rbase = nullptr; v.rcap = nullptr;
   const size_t nreg = (size_t)B1 * nxg;
@@ -1452,21 +1667,24 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
     parked2 = st[ST_OVFN];
     break;
   }
-  if (parked1) {
+  if (parked1 && v.ovf1_cap) {
     const uint32_t n = (uint32_t)std::min<uint64_t>(parked1, v.ovf1_cap);
     hipLaunchKernelGGL(msp_spill_list_kernel, dim3((n + 255u) / 256u), dim3(256), 0, ctx->stream, (const uint4 *)v.ovf1, n, k, canon, t);
     HIP_TRY(ctx, hipGetLastError());
   }
-  if (parked2) {
+  if (parked2 && v.ovf_cap) {
     const uint32_t n = (uint32_t)std::min<uint64_t>(parked2, v.ovf_cap);
     hipLaunchKernelGGL(msp_spill_list_kernel, dim3((n + 255u) / 256u), dim3(256), 0, ctx->stream, (const uint4 *)v.ovf, n, k, canon, t);
     HIP_TRY(ctx, hipGetLastError());
   }
-  if (canon) hipLaunchKernelGGL((msp_p3_kernel<true>), dim3(NLEAF), dim3(P3_THREADS), 0, ctx->stream, k, v, t);
-  else hipLaunchKernelGGL((msp_p3_kernel<false>), dim3(NLEAF), dim3(P3_THREADS), 0, ctx->stream, k, v, t);
+  const bool runs_only = (ctx->g_flags & CFRK_RUNS_ONLY) != 0;
+  const uint32_t mode = runs_only ? P3_EXPORT : 0u;
+  if (canon) hipLaunchKernelGGL((msp_p3_kernel<true>), dim3(NLEAF), dim3(P3_THREADS), 0, ctx->stream, k, mode, v, t);
+  else hipLaunchKernelGGL((msp_p3_kernel<false>), dim3(NLEAF), dim3(P3_THREADS), 0, ctx->stream, k, mode, v, t);
   HIP_TRY(ctx, hipGetLastError());
-  ms->pending = true;
-  ms->leaf_form = true;
+  ms->pending = !runs_only;
+  ms->runs_ready = runs_only;
+  ms->leaf_form = !runs_only;
   ms->list_n_valid = false;
   return CFRK_OK;
 }
@@ -1515,6 +1733,10 @@ int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   const int64_t per = (ntiles + groups - 1) / groups;
   const int passes = (int)((ntiles + per - 1) / per);
   ctx->last_passes = passes;
+  if (ctx->g_flags & CFRK_RUNS_ONLY) {
+    if (ms->runs_ready) return cfrk_fail(ctx, CFRK_ERR_STATE, "a CFRK_RUNS_ONLY job takes one add");
+    if (passes != 1) return cfrk_fail(ctx, CFRK_ERR_STATE, "a CFRK_RUNS_ONLY job must fit device memory in one pass");
+  }
   if (ms->pending && (rc = cfrk_msp_flush_to_table(ctx))) return rc;
   if (passes == 1) {
     // Leaves are lumpy when the genome is small (few distinct runs per leaf, each repeated by
@@ -1611,6 +1833,8 @@ int cfrk_msp_flush_to_table(cfrk_ctx *ctx) {
 
 int cfrk_msp_resolve(cfrk_ctx *ctx, ResultSrc *src, bool *use_list) {
   *use_list = false;
+  if (ctx->g_flags & CFRK_RUNS_ONLY)
+    return cfrk_fail(ctx, CFRK_ERR_STATE, "a CFRK_RUNS_ONLY job holds runs, not counts: cfrk_global_export_runs_device");
   cfrk_msp *ms = ctx->msp;
   if (!ms || !ms->pending) return CFRK_OK;
   uint64_t st[ST_NWORDS];
@@ -1765,6 +1989,118 @@ extern "C" int cfrk_global_merge_leaves_device(cfrk_ctx *ctx, const uint64_t *d_
   }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // so / sn are host temporaries
   ctx->h_stats_valid = false;                          // this kernel may have spilled into the table
+  ms->pending = true;
+  ms->leaf_form = false;
+  ms->list_n_valid = false;
+  return CFRK_OK;
+}
+
+// ------------------------------------------------------------------ multi-GPU exchange by runs
+// Packed form, one segment per owner: [header: the owner's leaves_per_part x (distinct, truncated)
+// sizes, uint32 pairs, padded to whole 16-byte rows][the records, leaf after leaf].
+static int runs_header_rows(int lpp) { return (lpp * 2 * (int)sizeof(uint32_t) + 15) / 16; }
+
+extern "C" int cfrk_global_export_runs_device(cfrk_ctx *ctx, void *d_packed, uint64_t cap_rows, int parts,
+                                              uint64_t *part_rows) {
+  if (!ctx || !part_rows || parts < 1 || parts > 64) return CFRK_ERR_ARG;
+  cfrk_msp *ms = ctx->msp;
+  if (!ctx->g_active || !ms || !ms->runs_ready)
+    return cfrk_fail(ctx, CFRK_ERR_STATE, "no deduplicated runs to export (begin with CFRK_RUNS_ONLY, then one add)");
+  if (!d_packed) return cfrk_fail(ctx, CFRK_ERR_ARG, "NULL buffer");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const MspView &v = ms->view;
+  const int lpp = (NLEAF + parts - 1) / parts;           // leaves per part (owner p: leaves p, p+parts, ...)
+  const int hrows = runs_header_rows(lpp);
+  int rc;
+  void *p;
+  // offsets, headers and segment sizes are worked out on the device (one workgroup); the host
+  // only learns the segment sizes -- together with the job's flags, in ONE copy
+  if ((rc = cfrk_pool_get(ctx, BUF_SCRATCH, (NLEAF + 65 + ST_NWORDS) * sizeof(uint64_t), &p))) return rc;
+  uint64_t *d_off = (uint64_t *)p, *d_rows = d_off + NLEAF;
+  hipLaunchKernelGGL(msp_runs_plan_kernel, dim3(1), dim3(1024), 0, ctx->stream, v, parts, lpp, hrows, d_off, (uint4 *)d_packed,
+                     cap_rows, d_rows);
+  HIP_TRY(ctx, hipGetLastError());
+  hipLaunchKernelGGL(msp_runs_gather_kernel, dim3(NLEAF), dim3(256), 0, ctx->stream, v, (const uint64_t *)d_off, (uint4 *)d_packed,
+                     (const uint64_t *)d_rows, parts, cap_rows);
+  HIP_TRY(ctx, hipGetLastError());
+  uint64_t h[65 + ST_NWORDS];
+  HIP_TRY(ctx, hipMemcpyAsync(d_rows + 65, ctx->g_stats, ST_NWORDS * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(h, d_rows, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  const uint64_t *st = h + 65;
+  if (st[ST_SPILLED] || st[ST_ONES]) return cfrk_fail(ctx, CFRK_ERR_STATE, "part of the batch was counted in the HBM table");
+  if (h[parts] > cap_rows) return cfrk_fail(ctx, CFRK_ERR_SMALL_BUF, "%llu rows, room for %llu", (unsigned long long)h[parts], (unsigned long long)cap_rows);
+  for (int q = 0; q < parts; ++q) part_rows[q] = h[q];
+  return CFRK_OK;
+}
+
+extern "C" int cfrk_global_merge_runs_device(cfrk_ctx *ctx, const void *d_packed, const uint64_t *recv_rows, int parts) {
+  if (!ctx || parts < 1 || parts > 64 || !recv_rows || !d_packed) return CFRK_ERR_ARG;
+  if (!ctx->g_active) return cfrk_fail(ctx, CFRK_ERR_STATE, "merge_runs needs an active job");
+  if (!cfrk_msp_usable(ctx) || (ctx->g_flags & CFRK_RUNS_ONLY)) return cfrk_fail(ctx, CFRK_ERR_ARG, "merge_runs needs a counting job with 16 <= k <= 32");
+  cfrk_msp *ms = cfrk_msp_get(ctx);
+  if (!ms) return cfrk_fail(ctx, CFRK_ERR_NOMEM, "host allocation failed");
+  if (ms->pending || ms->table_dirty) return cfrk_fail(ctx, CFRK_ERR_STATE, "merge_runs needs an empty job (call cfrk_global_begin first)");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  const int k = ctx->g_k;
+  const int canon = (ctx->g_flags & CFRK_CANONICAL) ? 1 : 0;
+  const int lpp = (NLEAF + parts - 1) / parts;
+  const int hrows = runs_header_rows(lpp);
+  const size_t nseg = (size_t)parts * lpp;
+  int rc;
+  void *p;
+  RunsRecv rr;
+  memset(&rr, 0, sizeof rr);
+  uint64_t rows_all = 0;
+  for (int r = 0; r < parts; ++r) {
+    if (recv_rows[r] < (uint64_t)hrows) return cfrk_fail(ctx, CFRK_ERR_ARG, "rank %d sent %llu rows, fewer than its header", r, (unsigned long long)recv_rows[r]);
+    rr.rstart[r] = rows_all; rr.rows[r] = recv_rows[r];
+    rows_all += recv_rows[r];
+  }
+  // the leaf streams can never hold more than what arrived
+  MspView &v = ms->view;
+  memset(&v, 0, sizeof v);
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)(rows_all ? rows_all : 1) * sizeof(uint4), &p))) return rc;
+  v.rec2 = (uint4 *)p;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_AUX, (size_t)NLEAF * 8 + (size_t)(B1 * NXG + (NCLS + 1) * NLEAF) * sizeof(uint32_t), &p))) return rc;
+  v.leaf_off = (uint64_t *)p;
+  v.cnt1 = (uint32_t *)(v.leaf_off + NLEAF); v.nxg = NXG; v.cnt2 = v.cnt1 + B1 * NXG; v.leaf_n = v.cnt2 + NCLS * NLEAF;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_LAYOUT, (size_t)NCLS * NLEAF * (sizeof(uint64_t) + sizeof(uint32_t)), &p))) return rc;
+  uint64_t *d_lbase = (uint64_t *)p;
+  uint32_t *d_lcap = (uint32_t *)(d_lbase + NCLS * NLEAF);
+  v.exact = 1; v.lbase = d_lbase; v.lcap = d_lcap;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTK, (size_t)ctx->g_cap * 8, &p))) return rc;
+  v.out_keys = (uint64_t *)p;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTC, (size_t)ctx->g_cap * 4, &p))) return rc;
+  v.out_cnt = (uint32_t *)p; v.out_cap = ctx->g_cap;
+  v.stats = ctx->g_stats; v.dbg = ctx->dbg_flags;
+  if ((rc = cfrk_pool_get(ctx, BUF_SCRATCH, (nseg * 3 + 2) * sizeof(uint64_t), &p))) return rc;
+  uint64_t *d_src = (uint64_t *)p, *d_d1 = d_src + nseg, *d_d0 = d_d1 + nseg, *d_out = d_d0 + nseg;
+  HIP_TRY(ctx, hipMemsetAsync(d_out, 0, 2 * sizeof(uint64_t), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_CURSOR, 0, sizeof(uint64_t), ctx->stream));
+  TableView t = cfrk_table_view(ctx);
+  // segment (source rank, local leaf): the ranks' headers say how large; all offsets on the device
+  hipLaunchKernelGGL(msp_runs_layout_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint4 *)d_packed, rr, parts, lpp, hrows,
+                     d_src, d_d1, d_d0, d_lbase, d_lcap, v.cnt2, d_out);
+  HIP_TRY(ctx, hipGetLastError());
+  hipLaunchKernelGGL(msp_runs_scatter_kernel, dim3((unsigned)nseg), dim3(256), 0, ctx->stream, (const uint4 *)d_packed, rr, lpp,
+                     (const uint64_t *)d_src, (const uint64_t *)d_d1, (const uint64_t *)d_d0, v.rec2);
+  HIP_TRY(ctx, hipGetLastError());
+  if (canon) hipLaunchKernelGGL((msp_p3_kernel<true>), dim3(lpp), dim3(P3_THREADS), 0, ctx->stream, k, P3_WEIGHTED, v, t);
+  else hipLaunchKernelGGL((msp_p3_kernel<false>), dim3(lpp), dim3(P3_THREADS), 0, ctx->stream, k, P3_WEIGHTED, v, t);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  ctx->ev_valid = true;
+  uint64_t h[2];
+  HIP_TRY(ctx, hipMemcpyAsync(h, d_out, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->h_stats_valid = false;                          // the leaf kernel may have spilled into the table
+  if (h[1]) {
+    // nothing of a malformed message may stay behind as a result
+    HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_CURSOR, 0, sizeof(uint64_t), ctx->stream));
+    return cfrk_fail(ctx, CFRK_ERR_ARG, "a rank's header does not add up to the rows it sent");
+  }
   ms->pending = true;
   ms->leaf_form = false;
   ms->list_n_valid = false;

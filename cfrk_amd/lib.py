@@ -13,6 +13,7 @@ import numpy as np
 CFRK_COMPAT = 0x1
 CFRK_CANONICAL = 0x2
 CFRK_FORCE_HASH = 0x4
+CFRK_RUNS_ONLY = 0x8
 CFRK_DEBUG_FORCE_RT_OVERFLOW = 0x1   # cfrk_debug_set_flags
 CFRK_DEBUG_SMALL_WAVE_CAP = 0x2
 CFRK_DEBUG_NO_ANCHORS = 0x4
@@ -78,6 +79,8 @@ def load_library():
         "cfrk_global_leaves_per_part": ([C.c_int], C.c_int),
         "cfrk_global_export_leaves_device": ([vp, vp, vp, vp, u64, C.c_int, C.POINTER(u64), vp], C.c_int),
         "cfrk_global_merge_leaves_device": ([vp, vp, vp, vp, C.POINTER(u64), vp, C.c_int], C.c_int),
+        "cfrk_global_export_runs_device": ([vp, vp, u64, C.c_int, C.POINTER(u64)], C.c_int),
+        "cfrk_global_merge_runs_device": ([vp, vp, C.POINTER(u64), C.c_int], C.c_int),
         "cfrk_debug_msp_info": ([vp, C.POINTER(u64)], C.c_int),
         "cfrk_debug_set_mem_budget": ([vp, u64], C.c_int),
         "cfrk_debug_set_flags": ([vp, C.c_uint32], C.c_int),
@@ -227,6 +230,20 @@ class GlobalCounter:
                                                                C.c_void_p(d_cnt), rc,
                                                                C.c_void_p(d_leaf_counts), parts),
                        "cfrk_global_merge_leaves_device")
+
+    def export_runs_device(self, d_packed, cap_rows, parts):
+        """CFRK_RUNS_ONLY job: per-leaf deduplicated runs, one packed segment per owner -> rows per
+        segment; raises CfrkError(code -4) when the shard's runs are not all in the leaf streams"""
+        pr = (C.c_uint64 * parts)()
+        self.ctx.check(self._L.cfrk_global_export_runs_device(self.ctx._h, C.c_void_p(d_packed), cap_rows, parts, pr),
+                       "cfrk_global_export_runs_device")
+        return [int(x) for x in pr]
+
+    def merge_runs_device(self, d_packed, recv_rows):
+        parts = len(recv_rows)
+        rr = (C.c_uint64 * parts)(*[int(x) for x in recv_rows])
+        self.ctx.check(self._L.cfrk_global_merge_runs_device(self.ctx._h, C.c_void_p(d_packed), rr, parts),
+                       "cfrk_global_merge_runs_device")
 
     def msp_info(self):
         out = (C.c_uint64 * 9)()

@@ -11,6 +11,11 @@ ncclReduce of the raw tables would be wrong because slot positions depend on ins
 The counting engine is passed in (duck-typed):
     engine.export_parts(parts) -> (lo, hi_or_None, cnt, part_counts)   torch tensors + list
     engine.merge(lo, hi_or_None, cnt)                                  add pairs into the owner table
+
+Three exchange forms, from the cheapest for a job of FIXED size split over the ranks to the most
+general: exchange_by_runs (ranks only partition and deduplicate, owners count: per-rank work and
+bytes on the wire shrink with N), exchange_by_leaf (counted per-leaf lists, LDS merge on the owner),
+exchange_by_owner (counted keys by owner hash, HBM-table merge).
 """
 import torch
 import torch.distributed as dist
@@ -88,6 +93,36 @@ def exchange_by_leaf(engine, world, device, wire_device=None):
     rlc = rlc.to(device)
     _fence(device)
     return rkeys, rhi, rcnt, recv_l, rlc
+
+
+def exchange_by_runs(engine, world, device, wire_device=None):
+    """Strong-scaling exchange: every rank has only PARTITIONED and DEDUPLICATED its shard
+    (CFRK_RUNS_ONLY) and ships each leaf's distinct runs with multiplicities plus its truncated runs
+    to the leaf's owner, which expands and counts them once.  Two collectives: the segment sizes
+    (with every rank's "I can export runs" vote riding along) and one packed payload of 16-byte
+    rows (segment = header with the per-leaf sizes + records).  Returns (packed, recv_rows) for
+    engine-side `merge_runs`, or None when some rank cannot export runs.
+
+    engine.export_runs(parts) -> (packed int64 tensor [rows, 2], part_rows) or None."""
+    wire = torch.device(wire_device) if wire_device is not None else torch.device(device)
+    exp = engine.export_runs(world)
+    part_rows = exp[1] if exp is not None else [0] * world
+    mine = 1 if exp is not None else 0
+    send = torch.tensor([[int(c), mine] for c in part_rows], dtype=torch.int64, device=wire)
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send)
+    got = recv.cpu().tolist()
+    if mine == 0 or min(int(g[1]) for g in got) == 0:
+        return None
+    packed = exp[0]
+    send_l = [int(x) for x in part_rows]
+    recv_l = [int(g[0]) for g in got]
+    src = packed[:sum(send_l)].contiguous().to(wire)
+    out = torch.empty((sum(recv_l), 2), dtype=torch.int64, device=wire)
+    dist.all_to_all_single(out, src, recv_l, send_l)
+    out = out.to(device)
+    _fence(device)
+    return out, recv_l
 
 
 def _fence(device):

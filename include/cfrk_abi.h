@@ -59,6 +59,9 @@ extern "C" {
 #define CFRK_CANONICAL  0x2  /* global only: key = min(kmer, reverse complement)                     */
 #define CFRK_FORCE_HASH 0x4  /* global only: count with one HBM atomic per occurrence (the general
                                 path) even where the minimizer-partitioned LDS path applies          */
+#define CFRK_RUNS_ONLY  0x8  /* global only, 16 <= k <= 32: the job partitions and deduplicates ONE add
+                                and stops there; its result leaves through
+                                cfrk_global_export_runs_device (multi-GPU strong scaling)            */
 
 typedef struct cfrk_ctx cfrk_ctx;
 
@@ -150,6 +153,24 @@ int cfrk_global_export_leaves_device(cfrk_ctx *ctx, uint64_t *d_keys, uint64_t *
 int cfrk_global_merge_leaves_device(cfrk_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_keys_hi,
                                     const uint32_t *d_counts, const uint64_t *recv_counts,
                                     const uint32_t *d_leaf_counts, int parts);
+
+/* Multi-GPU exchange at RUN granularity -- the strong-scaling form (replaces the pthread fan-out of
+ * src/main.cu:277-295; the reference has no merge step).  With the reads of ONE job split over N
+ * ranks every rank still meets almost every locus, so counting per rank and exchanging counted
+ * k-mers makes every rank expand every distinct k-mer.  Instead a rank begins with CFRK_RUNS_ONLY,
+ * adds its shard once (partition + deduplication only) and exports, per leaf, its distinct complete
+ * runs with multiplicities followed by its truncated runs.  The export is PACKED for one all-to-all:
+ * 16-byte rows, one segment per owner (owner p = leaves p, p+parts, ...) = a header (the owner's
+ * leaves_per_part x (distinct, truncated) sizes as uint32 pairs, padded to whole rows) followed by
+ * the records; part_rows[p] = rows of segment p.  The owner, on a context fresh from
+ * cfrk_global_begin (same k and strand flag, without CFRK_RUNS_ONLY), passes the received segments
+ * in rank order (recv_rows[r] rows from rank r): the lists of each of its leaves become that leaf's
+ * streams and are expanded and counted once.  Afterwards the owner holds the final counts of its
+ * leaves' k-mers (finish / export / digest as usual).  parts <= 64.  CFRK_ERR_STATE from the export
+ * when part of the shard was counted in the HBM table instead: use the leaf or key-owner exchange. */
+int cfrk_global_export_runs_device(cfrk_ctx *ctx, void *d_packed, uint64_t cap_rows, int parts,
+                                   uint64_t *part_rows);
+int cfrk_global_merge_runs_device(cfrk_ctx *ctx, const void *d_packed, const uint64_t *recv_rows, int parts);
 
 /* Order-independent digest: out[0]=distinct, out[1]=sum count,
  * out[2]=sum count*splitmix64(kh) mod 2^64, out[3]=xor splitmix64(kh ^ count);

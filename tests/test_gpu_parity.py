@@ -762,3 +762,58 @@ def test_truncated_runs_anchored_to_their_complete_twin_give_the_same_counts(ctx
         assert g.msp_info()["spilled_kmers"] == 0
         digests.append(g.digest())
     assert digests[0] == digests[1] == orc.digest(*want)
+
+
+@pytest.mark.parametrize("k,canonical,world", [(31, True, 2), (31, True, 8), (21, True, 4), (28, False, 3)])
+def test_runs_exchange_emulated_ranks_equals_one_gpu_and_oracle(ctx, k, canonical, world):
+    """Strong-scaling exchange with `world` emulated ranks on one GPU: every rank only
+    partitions and deduplicates its read range (CFRK_RUNS_ONLY) and exports per-leaf runs packed per
+    owner; every owner counts the runs of its leaves.  The union of the owners' results equals the
+    oracle's count of ALL reads, key by key."""
+    import cfrk_amd
+    R, L, G = 24_000, 150, 30_000
+    data, _, _ = orc.synth_reads(0, R, L, G)
+    data = data.copy()
+    data[::1013] = -1
+    data.reshape(R, L + 1)[:, L] = -1
+    flags = cfrk_amd.CFRK_CANONICAL if canonical else 0
+    sends = []                                        # per rank: (packed rows as uint64 [rows, 2], part_rows)
+    for r in range(world):
+        r0, r1 = R * r // world, R * (r + 1) // world
+        shard = data[r0 * (L + 1):r1 * (L + 1)]
+        g = cfrk_amd.GlobalCounter(ctx, k, flags | cfrk_amd.CFRK_RUNS_ONLY, 2 * G)
+        g.add(shard)
+        with pytest.raises(cfrk_amd.CfrkError):       # a job that holds runs has no counts
+            g.digest()
+        cap = 1 << 20
+        d = ctx.alloc(cap * 16)
+        rows = g.export_runs_device(d, cap, world)
+        host = np.empty((sum(rows), 2), np.uint64)
+        ctx.d2h(host, d)
+        ctx.free(d)
+        sends.append((host, rows))
+    merged = {}
+    total_rows = 0
+    for owner in range(world):
+        segs, recv = [], []
+        for host, rows in sends:
+            a = sum(rows[:owner])
+            segs.append(host[a:a + rows[owner]])
+            recv.append(rows[owner])
+        buf = np.concatenate(segs)
+        total_rows += len(buf)
+        d = ctx.alloc(max(len(buf), 1) * 16)
+        ctx.h2d(d, buf)
+        og = cfrk_amd.GlobalCounter(ctx, k, flags, 2 * G)
+        og.merge_runs_device(d, recv)
+        lo, hi, cnt = og.export()
+        ctx.free(d)
+        for key, c in zip(lo, cnt):
+            assert int(key) not in merged            # owners hold disjoint key sets
+            merged[int(key)] = int(c)
+    wlo, whi, wcnt = orc.global_count(data, k, orc.ORC_CANONICAL if canonical else 0, threads=4)
+    assert len(merged) == len(wlo)
+    assert all(merged[int(a)] == int(b) for a, b in zip(wlo, wcnt))
+    # deduplication really happened on the ranks: far fewer records than super-k-mers (8 per read at least)
+    lpp = (65536 + world - 1) // world
+    assert total_rows - world * world * ((lpp * 8 + 15) // 16) < 6 * R

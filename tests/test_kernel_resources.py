@@ -20,8 +20,8 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 # (file, {symbol fragment: allowed scratch instructions}); everything else must have none.
 # msp_p3_kernel<true> spills two dwords per thread once per workgroup (64 VGPRs at 8 waves/SIMD);
-# p3_big_dedupe is the out-of-line second-chance path and saves a callee-saved pair.
-FILES = [("msp.hip", {"msp_p3_kernelILb1E": 6, "msp_p3_kernelILb0E": 6, "p3_big_dedupe": 2}),
+# p3_big_dedupe / p3_dump_rtab are out-of-line, once-per-workgroup paths and save callee-saved registers.
+FILES = [("msp.hip", {"msp_p3_kernelILb1E": 6, "msp_p3_kernelILb0E": 6, "p3_big_dedupe": 4, "p3_dump_rtab": 4}),
          ("msp2.hip", {}),
          ("radix.hip", {}),
          ("dense.hip", {}),

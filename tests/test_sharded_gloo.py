@@ -78,6 +78,19 @@ def _worker(rank, world, port, q):
     rkeys, rhi_, rcnt_, recv_l, rlc = sharded.exchange_by_leaf(eng, world, torch.device("cpu"))
     assert rhi_ is None and sum(recv_l) == len(rkeys) == len(rcnt_) == int(rlc.sum())
     assert all(orc.splitmix64(int(x)) % OracleEngine.NL % world == rank for x in rkeys.numpy().view(np.uint64))
+    # runs exchange (strong scaling): two collectives, ragged packed segments; rows carry their
+    # (source, destination, index) so that the receiver can tell where everything came from
+    def fake_runs(parts, me=rank):
+        rows = [3 + 2 * me + p for p in range(parts)]
+        packed = torch.tensor([[me * 1000 + p, i] for p in range(parts) for i in range(rows[p])], dtype=torch.int64)
+        return packed, rows
+    eng.export_runs = (lambda parts: None) if rank == 0 else fake_runs
+    assert sharded.exchange_by_runs(eng, world, torch.device("cpu")) is None          # one rank cannot: nobody does
+    eng.export_runs = fake_runs
+    packed, recv_rows = sharded.exchange_by_runs(eng, world, torch.device("cpu"))
+    assert recv_rows == [3 + 2 * src + rank for src in range(world)]
+    want_rows = [[src * 1000 + rank, i] for src in range(world) for i in range(3 + 2 * src + rank)]
+    assert packed.tolist() == want_rows
     eng.export_leaves = lambda parts: None
     rlo, rhi, rcnt = sharded.exchange_by_owner(eng, world, torch.device("cpu"))
     eng.merge(rlo, rhi, rcnt)
