@@ -54,7 +54,7 @@ constexpr int NCLS = 4;                                   // 0..2 truncated (n<=
 constexpr int NSUB = NCLS * B2;
 __device__ __forceinline__ uint32_t cls_of(uint32_t w) {
   const uint32_t n = (w & 63u) + 1u;
-  return (w & 64u) ? 3u : (n <= 4u ? 0u : (n <= 10u ? 1u : 2u));
+  return ((w & 192u) == 192u) ? 3u : (n <= 4u ? 0u : (n <= 10u ? 1u : 2u));
 }
 __device__ __forceinline__ uint32_t sub_of(uint32_t w) { return (((w >> 8) & (B2 - 1)) << 2) | cls_of(w); }
 
@@ -144,7 +144,9 @@ __device__ __forceinline__ Rec2 q1_build(const Stage2 &st, uint32_t d, int k, in
   for (int i = 0; i < 7; ++i) D[i] = st.str[idx0 + i];
   const uint64_t rest = Es << (a + 1);
   const int n = min(__clzll(rest) + 1, W2);
-  const uint32_t complete = ((uint32_t)(Ws >> (63 - a)) & (uint32_t)(Ws >> (62 - a - n)) & 1u) << 6;
+  // which ends of the run are closed (a minimizer change between valid k-mers): bit 6 left, bit 7
+  // right; both = a complete run (see msp.hip)
+  const uint32_t complete = (((uint32_t)(Ws >> (63 - a)) & 1u) << 6) | (((uint32_t)(Ws >> (62 - a - n)) & 1u) << 7);
   const int nb = n + k - 1;                                     // bases that belong to the run
   uint32_t T[6];
 #pragma unroll
@@ -512,7 +514,10 @@ template <bool CANON>
 __device__ __forceinline__ void count_record2(ulonglong2 *keys, uint32_t *cnts, const Rec2 &rec, uint32_t add,
                                               bool valid, int k, const TableView &t,
                                               KeySubset2 ss = KeySubset2{0u, 0u}, uint32_t *ovf = nullptr,
-                                              int part = 0, int parts = 1) {
+                                              int part = 0, int parts = 1,
+                                              const uint8_t *tb = nullptr, uint32_t tb_n = 0u) {
+  // tb[0 .. tb_n): lengths (in k-mers) of the truncated runs that are prefixes of this record: k-mer J
+  // of the record is counted once more for every one of them that is longer than J (msp.hip)
   if (ovf && *(volatile uint32_t *)ovf) return;
   // a record may be shared by `parts` lanes, each expanding a contiguous share of its k-mers
   const int nall = valid ? (int)(rec.b.w & 63u) + 1 : 0;
@@ -522,17 +527,22 @@ __device__ __forceinline__ void count_record2(ulonglong2 *keys, uint32_t *cnts, 
   Roll2 roll;
   roll.init(rec, k, j0);
   for (int j = j0; __ballot(j < nk); ++j) {
+    uint32_t addj = add;
+    if (tb) {
+      for (uint32_t e = 0; __ballot(e < tb_n); ++e)         // (as many steps as the wave's longest list)
+        addj += (e < tb_n && (uint32_t)tb[e] > (uint32_t)j) ? 1u : 0u;
+    }
     const u128 key = (CANON && roll.rc < roll.fwd) ? roll.rc : roll.fwd;
     const uint64_t lo = (uint64_t)key, hi = (uint64_t)(key >> 64);
     uint32_t h = t2_slot(lo, hi) | ((j < nk && in_subset2(lo, hi, ss)) ? 0u : T2_DONE);
-    for (int it = 0; it < T2_TRIPS && __ballot((int32_t)h >= 0); ++it) t2_step(keys, cnts, lo, hi, add, h);
+    for (int it = 0; it < T2_TRIPS && __ballot((int32_t)h >= 0); ++it) t2_step(keys, cnts, lo, hi, addj, h);
     if ((int32_t)h >= 0) {
       if (ovf) {
         *ovf = 1u;
       } else {
         t.stats[ST_SPILLED] = 1;
         dev_count_event(&t.stats[ST_AUX1]);
-        table_add2(t, lo, hi, add);
+        table_add2(t, lo, hi, addj);
       }
     }
     roll.next();
@@ -548,12 +558,58 @@ constexpr uint32_t R2_LOCK = 0xFFFFFFFFu;
 constexpr uint32_t R2_EMPTY = 62u;                 // n-1 = 62 does not occur
 constexpr uint32_t R2_DONE = 0x80000000u;
 constexpr int R2_TRIPS = 96;
+constexpr int TL2_PER = 4, TL2_CAP = TL2_PER * 1024;   // truncated runs that may be anchored per leaf
+constexpr int FL2_CAP = 1024;                           // ... of which so many may lack a twin
 
 __device__ __forceinline__ uint32_t r2_slot(const Rec2 &r) {
   uint32_t h = (r.a.x * 0x9E3779B1u) ^ (r.a.y * 0x85EBCA77u) ^ (r.a.z * 0xC2B2AE3Du) ^ (r.a.w * 0x27D4EB2Fu) ^
                (r.b.x * 0x165667B1u) ^ (r.b.y * 0xD3A2646Cu) ^ ((r.b.w & 63u) * 0xFD7046C5u);
   h = (h ^ (h >> 15)) * 0x2C1B3C6Du;
   return h >> (32 - R2_LOG);
+}
+
+// The record table is keyed by the record's FIRST k-mer (its top 2k bits, 66 .. 128 of them): a
+// truncated run that is a prefix of a complete run finds its twin by probing from the same slot
+// (msp.hip explains the scheme).
+__device__ __forceinline__ uint32_t r2_slot_k(const Rec2 &r, int k) {
+  const int nb = 2 * k - 64;                       // bits of the first k-mer beyond a.x, a.y: 2 .. 64
+  const uint32_t z = (nb >= 32) ? r.a.z : (r.a.z & ~(0xFFFFFFFFu >> nb));
+  const uint32_t w = (nb <= 32) ? 0u : ((nb >= 64) ? r.a.w : (r.a.w & ~(0xFFFFFFFFu >> (nb - 32))));
+  uint32_t h = (r.a.x * 0x9E3779B1u) ^ (r.a.y * 0x85EBCA77u) ^ (z * 0xC2B2AE3Du) ^ (w * 0x27D4EB2Fu);
+  h = (h ^ (h >> 15)) * 0x2C1B3C6Du;
+  return h >> (32 - R2_LOG);
+}
+// do the first `len` bases (33 <= len <= 96) of two records agree?
+__device__ __forceinline__ bool rec2_prefix_equal(const Rec2 &e, const Rec2 &r, int len) {
+  auto mk = [&](int i) {                           // mask of word i: bits 32 i .. 32 i + 31 of the string
+    const int b = 2 * len - 32 * i;
+    return (b >= 32) ? 0xFFFFFFFFu : ((b <= 0) ? 0u : ~(0xFFFFFFFFu >> b));
+  };
+  return ((e.a.x ^ r.a.x) | (e.a.y ^ r.a.y) | ((e.a.z ^ r.a.z) & mk(2)) | ((e.a.w ^ r.a.w) & mk(3)) |
+          ((e.b.x ^ r.b.x) & mk(4)) | ((e.b.y ^ r.b.y) & mk(5))) == 0u;
+}
+// reverse complement of a record's run (len bases, 33 <= len <= 96); header word unchanged
+__device__ __forceinline__ Rec2 revcomp_record2(const Rec2 &rec, int len) {
+  auto rcw = [](uint32_t x) {                      // reverse the 16 bases of a word and complement them
+    x = __brev(x);
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+    return ~x;
+  };
+  // the 96-base field reversed: the reverse complement preceded by 96 - len complemented pad bases
+  uint64_t s0 = ((uint64_t)rcw(rec.b.y) << 32) | rcw(rec.b.x);
+  uint64_t s1 = ((uint64_t)rcw(rec.a.w) << 32) | rcw(rec.a.z);
+  uint64_t s2 = ((uint64_t)rcw(rec.a.y) << 32) | rcw(rec.a.x);
+  int sh = 2 * (96 - len);                         // 0 .. 126: shift the pad out at the top
+  if (sh >= 64) { s0 = s1; s1 = s2; s2 = 0; sh -= 64; }
+  if (sh) {
+    s0 = (s0 << sh) | (s1 >> (64 - sh));
+    s1 = (s1 << sh) | (s2 >> (64 - sh));
+    s2 <<= sh;
+  }
+  Rec2 out = rec;
+  out.a = make_uint4((uint32_t)(s0 >> 32), (uint32_t)s0, (uint32_t)(s1 >> 32), (uint32_t)s1);
+  out.b.x = (uint32_t)(s2 >> 32); out.b.y = (uint32_t)s2;
+  return out;
 }
 
 // insert-or-count one record per lane; state = slot h with R2_DONE or-ed in once placed.  On
@@ -594,6 +650,13 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
   __shared__ uint32_t cnts[T2];
   __shared__ Rec2 rtab[R2];
   __shared__ uint16_t occ_list[R2];
+  // truncated runs anchored to their complete twin (msp.hip): per record-table slot the start of
+  // the group of lengths noted with it, the lengths, and the runs without a twin
+  __shared__ uint32_t th[R2 + 1];
+  __shared__ uint8_t tbytes[TL2_CAP];
+  __shared__ uint16_t flist[FL2_CAP];
+  __shared__ uint32_t nfb, nfl;
+  __shared__ uint32_t wsum2[Q3_THREADS / 64];
   __shared__ uint32_t nhist[32];
   __shared__ uint32_t nocc;
   __shared__ uint32_t wg_total;
@@ -619,8 +682,9 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
     z.a = make_uint4(0u, 0u, 0u, 0u); z.b = make_uint4(0u, 0u, 0u, R2_EMPTY);
     rtab[tid] = z;
   }
-  if (tid == 0) { wg_total = 0; nocc = 0; rt_fail = 0; kovf = 0; sp = 0; leaf_total = 0; nseg = 0; }
+  if (tid == 0) { wg_total = 0; nocc = 0; rt_fail = 0; kovf = 0; sp = 0; leaf_total = 0; nseg = 0; nfb = 0; nfl = 0; }
   if (tid < 32) nhist[tid] = 0;
+  for (int s = tid; s < R2 + 1; s += Q3_THREADS) th[s] = 0;
   __syncthreads();
 
   const Rec2 *leaf_rec = v.exact ? v.rec2 + v.lbase[NCLS * leaf + 3] : v.rec2 + (uint64_t)leaf * (v.cap2c + 3 * v.cap2t);
@@ -643,7 +707,7 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
       if ((int32_t)h >= 0) rt_fail = 1u;
     };
     auto home = [&](const Rec2 &rec, bool valid) {
-      const uint32_t h = r2_slot(rec);
+      const uint32_t h = r2_slot_k(rec, k);
       const uint4 eb = rtab[h].b;                              // state word + bases 64..95
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // bases 0..63 only after the state
       const uint4 ea = rtab[h].a;
@@ -708,7 +772,90 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
       else { stk[0] = 0u; sp = 1; }
     }
   }
+  // ---- truncated runs: the first TL2_CAP of the three class streams (class 0 first) look for the
+  //      complete run they are a prefix of (other strand: suffix) and leave their length with it
+  const uint32_t c0 = (uint32_t)min(ns[0], (uint64_t)TL2_CAP);
+  const uint32_t c1 = c0 + (uint32_t)min(ns[1], (uint64_t)(TL2_CAP - c0));
+  const uint32_t tl = c1 + (uint32_t)min(ns[2], (uint64_t)(TL2_CAP - c1));
+  auto trunc_at = [&](uint32_t g) -> const Rec2 * {          // record g of the concatenated class streams
+    const int cl = (g < c0) ? 0 : (g < c1) ? 1 : 2;
+    const uint32_t i = g - ((cl == 0) ? 0u : (cl == 1) ? c0 : c1);
+    const Rec2 *src = v.exact ? v.rec2 + v.lbase[NCLS * leaf + cl] : leaf_rec + v.cap2c + (uint64_t)cl * v.cap2t;
+    return src + i;
+  };
+  const bool anchors_on = !big && !(v.dbg & CFRK_DEBUG_NO_ANCHORS);
+  bool use_anchors = false;
+  {
+    constexpr uint32_t TW_NONE = 0xFFFFFFFFu, TW_TWIN = 0x80000000u;
+    uint32_t tw[TL2_PER], trank[TL2_PER];
+#pragma unroll
+    for (int i = 0; i < TL2_PER; ++i) {
+      const uint32_t g = (uint32_t)(i * Q3_THREADS + tid);
+      const bool valid = anchors_on && g < tl;
+      tw[i] = TW_NONE; trank[i] = 0u;
+      if (!anchors_on || !__ballot(valid)) continue;
+      Rec2 rec = zrec;
+      if (valid) rec = *trunc_at(g);
+      const uint32_t nm1 = rec.b.w & 31u;
+      if (valid) tw[i] = nm1;
+      const bool lc = (rec.b.w & 64u) != 0u, rc_ = (rec.b.w & 128u) != 0u;
+      const bool suf = CANON && valid && !lc && rc_;
+      if (suf) rec = revcomp_record2(rec, (int)nm1 + k);
+      const bool anchored = suf || (valid && lc && !rc_);
+      uint32_t h = anchored ? r2_slot_k(rec, k) : R2_DONE;
+      uint32_t found = TW_NONE;
+      for (int it = 0; it < 32 && __ballot((int32_t)h >= 0); ++it) {
+        const bool p = (int32_t)h >= 0;
+        const uint32_t hh = h & (uint32_t)(R2 - 1);
+        const Rec2 e2 = rtab[hh];
+        const bool empty = e2.b.w == R2_EMPTY;
+        // the twin holds at least as many k-mers and starts with the same nm1 + k bases
+        const bool hit = p && !empty && (e2.b.w & 31u) >= nm1 && rec2_prefix_equal(e2, rec, (int)nm1 + k);
+        found = hit ? hh : found;
+        h = (p && !hit && !empty) ? ((hh + 1u) & (uint32_t)(R2 - 1)) : (h | R2_DONE);
+      }
+      if (found != TW_NONE) tw[i] = TW_TWIN | (found << 8) | (nm1 + 1u);
+      const unsigned long long fb = __ballot(valid && found == TW_NONE);
+      if (lane == 0 && fb) atomicAdd(&nfb, (uint32_t)__popcll(fb));
+    }
+    __syncthreads();
+    use_anchors = anchors_on && nfb <= (uint32_t)FL2_CAP;
+    if (use_anchors) {
+#pragma unroll
+      for (int i = 0; i < TL2_PER; ++i) {
+        if (tw[i] == TW_NONE) continue;
+        if (tw[i] & TW_TWIN) trank[i] = atomicAdd(&th[(tw[i] >> 8) & (uint32_t)(R2 - 1)], 1u);
+        else flist[atomicAdd(&nfl, 1u)] = (uint16_t)(i * Q3_THREADS + tid);
+      }
+    }
+    __syncthreads();
+    if (use_anchors) {
+      // group starts: exclusive prefix of the groups' sizes over the record table's slots
+      const uint32_t own = th[tid];
+      uint32_t incl = own;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(incl, d);
+        if (lane >= d) incl += y;
+      }
+      if (lane == 63) wsum2[tid >> 6] = incl;
+      __syncthreads();
+      uint32_t base = 0;
+      for (int w = 0; w < (tid >> 6); ++w) base += wsum2[w];
+      const uint32_t goff = base + incl - own;
+      __syncthreads();                               // (everybody has read its group's size)
+      th[tid] = goff;
+      if (tid == Q3_THREADS - 1) th[R2] = goff + own;
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < TL2_PER; ++i)
+        if (tw[i] != TW_NONE && (tw[i] & TW_TWIN)) tbytes[th[(tw[i] >> 8) & (uint32_t)(R2 - 1)] + trank[i]] = (uint8_t)(tw[i] & 63u);
+    }
+  }
   __syncthreads();
+  // truncated runs of every class that the anchoring covered (they are skipped by the stream loops below)
+  uint32_t cov[3] = {0u, 0u, 0u};
+  if (use_anchors) { cov[0] = c0; cov[1] = c1 - c0; cov[2] = tl - c1; }
   constexpr uint32_t SUBSET_BITS_MAX = 8;
   bool first_pass = true;
   while (true) {
@@ -735,8 +882,23 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
         const bool valid = i < nitems;
         const uint32_t ri = (parts == 1) ? i : (parts == 2) ? (i >> 1) : (parts == 3) ? (i / 3u) : (i >> 2);
         Rec2 rec = zrec;
-        if (valid) rec = rtab[occ_list[ri]];
-        count_record2<CANON>(keys, cnts, rec, rec.b.w >> 6, valid, k, t, ss, ovf, (int)(i - ri * (uint32_t)parts), parts);
+        uint32_t slot = 0;
+        if (valid) { slot = occ_list[ri]; rec = rtab[slot]; }
+        if (use_anchors) {
+          // ... plus one for every truncated run of this locus that reaches the k-mer
+          const uint32_t g0 = th[slot];
+          count_record2<CANON>(keys, cnts, rec, rec.b.w >> 6, valid, k, t, ss, ovf, (int)(i - ri * (uint32_t)parts), parts,
+                               tbytes + g0, valid ? th[slot + 1] - g0 : 0u);
+        } else {
+          count_record2<CANON>(keys, cnts, rec, rec.b.w >> 6, valid, k, t, ss, ovf, (int)(i - ri * (uint32_t)parts), parts);
+        }
+      }
+      // truncated runs without a twin
+      for (uint32_t i = tid; i < ((nfl + 63u) & ~63u) && use_anchors; i += Q3_THREADS) {
+        const bool valid = i < nfl;
+        Rec2 rec = zrec;
+        if (valid) rec = *trunc_at(flist[i]);
+        count_record2<CANON>(keys, cnts, rec, 1u, valid, k, t, ss, ovf);
       }
     } else {
       for (uint64_t r = tid; r < ((ns[3] + 63) & ~63ull); r += Q3_THREADS) {
@@ -749,8 +911,9 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
     for (int cl = 2; cl >= 0; --cl) {
       const Rec2 *src = v.exact ? v.rec2 + v.lbase[NCLS * leaf + cl] : leaf_rec + v.cap2c + (uint64_t)cl * v.cap2t;
       Rec2 nxt = zrec;
-      if ((uint64_t)tid < ns[cl]) nxt = src[tid];
-      for (uint64_t r = tid; r < ((ns[cl] + 63) & ~63ull); r += Q3_THREADS) {
+      const uint64_t r_first = (uint64_t)cov[cl] + tid;        // (the anchored ones are done)
+      if (r_first < ns[cl]) nxt = src[r_first];
+      for (uint64_t r = r_first; r < (uint64_t)cov[cl] + ((ns[cl] - cov[cl] + 63) & ~63ull); r += Q3_THREADS) {
         const bool valid = r < ns[cl];
         const Rec2 rec = nxt;
         nxt = zrec;
