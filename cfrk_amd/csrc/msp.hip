@@ -123,10 +123,18 @@ __global__ __launch_bounds__(P1_THREADS, (P1B_TR <= 6 ? 6 : 4)) void msp_p1b_ker
                                                              int64_t tile0, MspView v, TableView t) {
   constexpr int NH = 32 + W - 1;
   constexpr int P1B_STAGE = 4096 + 3 * 512 + P1B_TR * 128;     // bytes of staging per wave
-  constexpr int P1B_RCAP = P1_WAVES * P1B_STAGE / 16;          // sorted records share the staging bytes
-  __shared__ uint4 arena[P1B_RCAP];              // per-wave staging, later the bin-sorted records
+  // sorted records share the staging bytes; the last 2.5 KB hold the copy-out table (dabs, plim)
+  constexpr int P1B_TAIL = B1 * 10;
+  constexpr int P1B_RCAP = (P1_WAVES * P1B_STAGE - P1B_TAIL) / 16;
+  __shared__ uint4 arena[P1_WAVES * P1B_STAGE / 16];   // per-wave staging, later the bin-sorted records (P1B_RCAP of them)
   __shared__ uint32_t hist[B1], loff[B1];
   uint32_t *const gbase = hist;                  // the global bases take the histogram's place once it is scanned
+  // copy-out fast path, worked out once per bin and tile by the thread that reserved the segment:
+  // arena position p of bin b goes to record dabs[b] + p of the level-1 buffer while p < plim[b]
+  // (at the end of the arena: the staging area is dead by then and three workgroups keep fitting a CU's LDS)
+  unsigned long long *const dabs = reinterpret_cast<unsigned long long *>(reinterpret_cast<uint8_t *>(arena) + P1B_RCAP * 16);
+  uint16_t *const plim = reinterpret_cast<uint16_t *>(dabs + B1);
+  static_assert((P1_WAVES * P1B_STAGE - P1B_TAIL) % 16 == 0, "the table starts on a record boundary");
   __shared__ uint32_t wtot[4];
   __shared__ uint32_t nrec_s;
 
@@ -293,7 +301,17 @@ __global__ __launch_bounds__(P1_THREADS, (P1B_TR <= 6 ? 6 : 4)) void msp_p1b_ker
       if (pos < (uint32_t)P1B_RCAP) arena[pos] = rc[tr];
     }
   }
-  if (tid < B1) gbase[tid] = my_base;
+  if (tid < B1) {
+    gbase[tid] = my_base;
+    const uint32_t reg = l1_reg(tid, blockIdx.x & (v.nxg - 1));
+    const uint64_t cap = v.exact1 ? (uint64_t)v.rcap[reg] : v.cap1;
+    const uint64_t at = v.exact1 ? v.rbase[reg] : (uint64_t)reg * v.cap1;
+    const uint32_t lo = loff[tid];
+    dabs[tid] = at + my_base - lo;
+    const uint64_t room = cap > (uint64_t)my_base ? cap - my_base : 0;       // records of this segment that fit the region
+    plim[tid] = (uint16_t)min((uint64_t)lo + room, (uint64_t)0xFFFFu);
+    static_assert(P1B_RCAP <= 0xFFFF, "arena positions fit 16 bits");
+  }
   __syncthreads();
 
   // ---- D: copy out in bin order ----
@@ -301,7 +319,8 @@ __global__ __launch_bounds__(P1_THREADS, (P1B_TR <= 6 ? 6 : 4)) void msp_p1b_ker
   for (uint32_t p = tid; p < nrec; p += P1_THREADS) {
     const uint4 rec = arena[p];
     const uint32_t b = rec.w >> 16;
-    l1_put(v, l1_reg(b, blockIdx.x & (v.nxg - 1)), gbase[b] + (p - loff[b]), rec, k, canon != 0, t);
+    if (p < (uint32_t)plim[b]) v.rec1[dabs[b] + p] = rec;
+    else l1_put(v, l1_reg(b, blockIdx.x & (v.nxg - 1)), gbase[b] + (p - loff[b]), rec, k, canon != 0, t);   // region full: park / flag
   }
   if (nrec_s > (uint32_t)P1B_RCAP) {             // records beyond the LDS arena go to their reserved places
 #pragma unroll
@@ -329,10 +348,15 @@ constexpr int NCLS = 2;
 constexpr int NSUB = NCLS * B2;                           // 512 sub-bins of a level-1 bin
 __device__ __forceinline__ uint32_t sub_of(uint32_t w) { return (((w >> 8) & (B2 - 1)) << 1) | ((((w >> 6) & 3u) == 3u) ? 1u : 0u); }
 
-__global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int groups_per_bin, int k, int canon,
+__global__ __launch_bounds__(P2_THREADS, 4) void msp_p2_kernel(int groups_per_bin, int k, int canon,
                                                             MspView v, TableView t) {
   __shared__ uint4 sorted[P2_TILE];
   __shared__ uint32_t hist[NSUB], loff[NSUB], gbase[NSUB];   // hist doubles as the fill cursor
+  // copy-out fast path, once per stream and tile: sorted position p of sub-bin sb goes to record
+  // dabs[sb] + p of the leaf buffer while p < plim[sb]
+  __shared__ unsigned long long dabs[NSUB];
+  __shared__ uint16_t plim[NSUB];
+  static_assert(P2_TILE <= 0xFFFF, "tile positions fit 16 bits");
   __shared__ uint32_t wtot[P2_THREADS / 64];
   __shared__ uint32_t rpre[NXG + 1];             // exclusive prefix of the bin's sub-region sizes
   static_assert(NSUB <= P2_THREADS && NSUB % 64 == 0, "the scan below gives one thread per sub-bin");
@@ -361,15 +385,22 @@ __global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int groups_per_bin, 
   // sorts and writes the current one: the load latency hides under the LDS work
   const uint64_t g0r = (uint64_t)grp * P2_GROUP * P2_TILE;
   if (g0r >= n) return;
-  // record `idx` of the bin's stream: find its sub-region (binary search over <= 64 prefixes)
-  auto fetch = [&](uint64_t idx) {
-    uint32_t lo = 0, hi = v.nxg;               // invariant: rpre[lo] <= idx < rpre[hi]
-    while (hi - lo > 1) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (rpre[mid] <= idx) lo = mid; else hi = mid;
+  // record `idx` of the bin's stream lies in the sub-region `sr` with rpre[sr] <= idx < rpre[sr + 1]: one
+  // binary search for a thread's first record, then the cursor only moves forward (a thread's
+  // indices grow from fetch to fetch)
+  uint32_t sr = 0;
+  {
+    uint32_t hi = v.nxg;                         // invariant: rpre[sr] <= idx < rpre[hi]
+    const uint64_t idx = g0r + tid;
+    while (hi - sr > 1) {
+      const uint32_t mid = (sr + hi) >> 1;
+      if (rpre[mid] <= idx) sr = mid; else hi = mid;
     }
-    if (v.exact1) return v.rec1[v.rbase[l1_reg(b1, lo)] + (idx - rpre[lo])];
-    return v.rec1[(uint64_t)l1_reg(b1, lo) * v.cap1 + (idx - rpre[lo])];
+  }
+  auto fetch = [&](uint64_t idx) {
+    while (sr + 1 < v.nxg && rpre[sr + 1] <= idx) ++sr;
+    if (v.exact1) return v.rec1[v.rbase[l1_reg(b1, sr)] + (idx - rpre[sr])];
+    return v.rec1[(uint64_t)l1_reg(b1, sr) * v.cap1 + (idx - rpre[sr])];
   };
   const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
   uint4 nx[P2_PER];
@@ -435,12 +466,25 @@ __global__ __launch_bounds__(P2_THREADS) void msp_p2_kernel(int groups_per_bin, 
         sorted[loff[sb] + atomicAdd(&hist[sb], 1u)] = r[i];
       }
     }
-    if (tid < NSUB) gbase[tid] = g0;
+    if (tid < NSUB) {
+      gbase[tid] = g0;
+      const uint64_t leaf = ((uint64_t)b1 * NSUB + tid) >> 1;
+      const uint32_t cls = tid & 1u;
+      uint64_t cap = cls ? v.cap2c : v.cap2t;
+      uint64_t at = leaf * (v.cap2c + v.cap2t) + (cls ? 0 : v.cap2c);
+      if (v.exact) { cap = v.lcap[b1 * NSUB + tid]; at = v.lbase[b1 * NSUB + tid]; }
+      const uint32_t lo = loff[tid];
+      dabs[tid] = at + g0 - lo;
+      const uint64_t room = cap > (uint64_t)g0 ? cap - g0 : 0;
+      plim[tid] = (uint16_t)min((uint64_t)lo + room, (uint64_t)0xFFFFu);
+    }
     __syncthreads();
     // copy out: consecutive lanes -> consecutive records of the same stream
     for (uint32_t p = tid; p < nt; p += P2_THREADS) {
       const uint4 rec = sorted[p];
       const uint32_t sb = sub_of(rec.w);
+      if (p < (uint32_t)plim[sb]) { v.rec2[dabs[sb] + p] = rec; continue; }
+      // the stream is full: park the record or raise the flag (below)
       const uint32_t dst = gbase[sb] + (p - loff[sb]);
       const uint64_t leaf = ((uint64_t)b1 * NSUB + sb) >> 1;
       const uint32_t cls = sb & 1u;
