@@ -45,7 +45,7 @@ def parse():
     p.add_argument("--glen", type=int, default=0, help="genome length (default: = reads)")
     p.add_argument("--uniform", action="store_true", help="uniform random reads (all-distinct variant)")
     p.add_argument("--no-canonical", action="store_true")
-    p.add_argument("--cpu-reads", type=int, default=2_000_000,
+    p.add_argument("--cpu-reads", type=int, default=10_000_000,
                    help="reads of the same generator timed on the host cores (0: skip)")
     p.add_argument("--cpu-threads", type=int, default=0)
     p.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -254,7 +254,7 @@ def main():
             def export_runs(self, parts):
                 if getattr(self, "rbuf", None) is None:
                     # rows of 16 bytes: distinct runs (<= the leaf streams) + truncated runs + headers
-                    self.rbuf = torch.empty((max(1 << 20, nN // 8), 2), dtype=torch.int64, device=dev)
+                    self.rbuf = torch.empty((max(1 << 20, 3 * Rl + (1 << 17)), 2), dtype=torch.int64, device=dev)
                 for _ in range(3):
                     try:
                         pr = self.g.export_runs_device(self.rbuf.data_ptr(), self.rbuf.shape[0], parts)
@@ -285,7 +285,10 @@ def main():
 
         exch = "owner" if args.owner_hash else args.exchange
         if exch == "auto":
-            exch = "runs" if 16 <= k <= 32 else "leaf"
+            # strong scaling (a job of fixed size): ranks ship deduplicated runs, the owners count.
+            # weak scaling: every rank has a full-depth shard, whose counted lists (~D entries) are
+            # smaller than its runs (two truncated runs per read on top of the distinct ones)
+            exch = "runs" if 16 <= k <= 32 and scaling == "strong" else "leaf"
         used = {"exchange": exch, "wire_bytes": 0}
 
         def step():

@@ -43,6 +43,9 @@ struct MspView {
   // the same one level up: exact level-1 layout (region r starts at record rbase[r], holds rcap[r])
   const uint64_t *rbase; const uint32_t *rcap; uint32_t exact1;
   uint32_t dbg;                                  // cfrk_debug_set_flags
+  // leaf subset of this pass (a batch whose records do not fit device memory is counted in several
+  // passes over the input, each emitting only the runs of the leaves with (leaf & sel_mask) == sel_val)
+  uint32_t sel_mask, sel_val, sel_bits;          // (the pass's leaves are laid out densely: stream index = leaf >> sel_bits)
   uint4 *ovf1; uint32_t ovf1_cap;
   uint64_t *stats;
 };

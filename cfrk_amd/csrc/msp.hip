@@ -265,6 +265,7 @@ __global__ __launch_bounds__(P1_THREADS, (P1B_TR <= 6 ? 6 : 4)) void msp_p1b_ker
     const int a = __clz(S2);
     S2 &= ~(0x80000000u >> a);
     const uint4 rec = build(((uint32_t)lane << 5) | (uint32_t)a);
+    if (((rec.w >> 8) & v.sel_mask) != v.sel_val) continue;    // not a leaf of this pass
     const uint32_t reg = l1_reg(rec.w >> 16, blockIdx.x & (v.nxg - 1));
     const uint32_t dst = atomicAdd(&v.cnt1[reg], 1u);
     l1_put(v, reg, dst, rec, k, canon != 0, t);
@@ -281,7 +282,8 @@ __global__ __launch_bounds__(P1_THREADS, (P1B_TR <= 6 ? 6 : 4)) void msp_p1b_ker
     const uint32_t i = (uint32_t)(tr * 64 + lane);
     if (i < cnt_w) {
       rc[tr] = build(s_dsc[i]);
-      rk[tr] = atomicAdd(&hist[rc[tr].w >> 16], 1u);
+      if (((rc[tr].w >> 8) & v.sel_mask) == v.sel_val)       // (all leaves, unless the batch takes several passes)
+        rk[tr] = atomicAdd(&hist[rc[tr].w >> 16], 1u);
     }
   }
   __syncthreads();
@@ -471,7 +473,7 @@ __global__ __launch_bounds__(P2_THREADS, 4) void msp_p2_kernel(int groups_per_bi
       const uint64_t leaf = ((uint64_t)b1 * NSUB + tid) >> 1;
       const uint32_t cls = tid & 1u;
       uint64_t cap = cls ? v.cap2c : v.cap2t;
-      uint64_t at = leaf * (v.cap2c + v.cap2t) + (cls ? 0 : v.cap2c);
+      uint64_t at = (leaf >> v.sel_bits) * (v.cap2c + v.cap2t) + (cls ? 0 : v.cap2c);
       if (v.exact) { cap = v.lcap[b1 * NSUB + tid]; at = v.lbase[b1 * NSUB + tid]; }
       const uint32_t lo = loff[tid];
       dabs[tid] = at + g0 - lo;
@@ -489,7 +491,7 @@ __global__ __launch_bounds__(P2_THREADS, 4) void msp_p2_kernel(int groups_per_bi
       const uint64_t leaf = ((uint64_t)b1 * NSUB + sb) >> 1;
       const uint32_t cls = sb & 1u;
       uint64_t cap = cls ? v.cap2c : v.cap2t;
-      uint64_t at = leaf * (v.cap2c + v.cap2t) + (cls ? 0 : v.cap2c);
+      uint64_t at = (leaf >> v.sel_bits) * (v.cap2c + v.cap2t) + (cls ? 0 : v.cap2c);
       if (v.exact) { cap = v.lcap[b1 * NSUB + sb]; at = v.lbase[b1 * NSUB + sb]; }
       if (dst < cap) v.rec2[at + dst] = rec;
       else if (v.exact) spill_record(rec, k, canon != 0, t);      // cannot happen: cap is the exact count
@@ -864,7 +866,7 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
   const uint32_t leaf = blockIdx.x;
   const uint64_t nt = min((uint64_t)v.cnt2[NCLS * leaf + 0], v.exact ? (uint64_t)v.lcap[NCLS * leaf + 0] : v.cap2t);  // truncated runs
   const uint64_t n1 = min((uint64_t)v.cnt2[NCLS * leaf + 1], v.exact ? (uint64_t)v.lcap[NCLS * leaf + 1] : v.cap2c);  // complete runs
-  const uint4 *leaf_rec = v.exact ? v.rec2 + v.lbase[NCLS * leaf + 1] : v.rec2 + (uint64_t)leaf * (v.cap2c + v.cap2t);
+  const uint4 *leaf_rec = v.exact ? v.rec2 + v.lbase[NCLS * leaf + 1] : v.rec2 + (uint64_t)(leaf >> v.sel_bits) * (v.cap2c + v.cap2t);
   if (nt + n1 == 0) return;
   // Short windows (k < 28) mean more distinct runs per leaf than the record table holds (~600 at
   // k = 21, heavy leaves several times that): the complete runs are then deduplicated in a table
@@ -1452,7 +1454,7 @@ __global__ __launch_bounds__(256) void msp_runs_gather_kernel(MspView v, const u
   const uint32_t leaf = blockIdx.x;
   const uint32_t nd = v.cnt2[NCLS * leaf + 1] ? v.leaf_n[leaf] : 0u;
   const uint32_t nt = (uint32_t)min((uint64_t)v.cnt2[NCLS * leaf + 0], v.exact ? (uint64_t)v.lcap[NCLS * leaf + 0] : v.cap2t);
-  const uint4 *c1 = v.exact ? v.rec2 + v.lbase[NCLS * leaf + 1] : v.rec2 + (uint64_t)leaf * (v.cap2c + v.cap2t);
+  const uint4 *c1 = v.exact ? v.rec2 + v.lbase[NCLS * leaf + 1] : v.rec2 + (uint64_t)(leaf >> v.sel_bits) * (v.cap2c + v.cap2t);
   const uint4 *c0 = v.exact ? v.rec2 + v.lbase[NCLS * leaf + 0] : c1 + v.cap2c;
   uint4 *dst = out + dst_off[leaf];
   for (uint32_t i = threadIdx.x; i < nd; i += blockDim.x) dst[i] = c1[i];
@@ -1585,8 +1587,10 @@ static size_t msp_need(const cfrk_ctx *ctx, int64_t span) {
 // those tiles (P1 reads its neighbours' bases from the whole buffer, so a tile range produces
 // exactly the records it produces in a full launch)
 // slack >= 1 widens the per-leaf streams beyond what msp_need() accounts for (memory permitting)
+// sel_bits / sel_val: only the leaves with (leaf & (2^sel_bits - 1)) == sel_val are emitted and counted;
+// first: the first pass of an add (later passes append to the result list and keep the leaf index)
 static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, int64_t nN, int64_t tile0,
-                           int64_t ntiles, double slack) {
+                           int64_t ntiles, double slack, int sel_bits = 0, uint32_t sel_val = 0, bool first = true) {
   int rc;
   const int k = ctx->g_k;
   int W, m;
@@ -1596,12 +1600,14 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
 
   // expected records: one per minimizer change (2/(W+1) per position) plus read ends
   const double dens = 2.0 / (W + 1) + 1.0 / 64.0;
-  const double expect = (double)span * dens;
+  const double expect_all = (double)span * dens;                 // records of the whole batch
+  const double expect = expect_all / (double)(1u << sel_bits);   // ... of this pass (1 / 2^sel_bits of the leaves)
   const int nxg = msp_nxg(expect);
   const uint64_t cap1 = (uint64_t)(expect / (B1 * nxg) * 1.35) + 2048;   // per sub-region
   // per leaf: complete runs dominate at depth; truncated ones are ~2 per read plus invalid bases
-  const uint64_t cap2c = (uint64_t)(expect / NLEAF * 2.1 * slack) + 96;
-  const uint64_t cap2t = (uint64_t)(expect / NLEAF * 0.6 * slack) + 96;   // truncated runs: ~15 % of the records
+  // (a leaf of the pass holds ALL its records: the pass has fewer leaves, not lighter ones)
+  const uint64_t cap2c = (uint64_t)(expect_all / NLEAF * 2.1 * slack) + 96;
+  const uint64_t cap2t = (uint64_t)(expect_all / NLEAF * 0.6 * slack) + 96;   // truncated runs: ~15 % of the records
   // P2 reads a bin's sub-regions as one stream: tile groups per BIN, enough for full regions
   const int64_t tiles_per_sub = (int64_t)(((uint64_t)nxg * cap1 + (uint64_t)P2_TILE * P2_GROUP - 1) /
                                           ((uint64_t)P2_TILE * P2_GROUP));
@@ -1611,7 +1617,8 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
   MspView &v = ms->view;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_L1, (size_t)B1 * nxg * cap1 * sizeof(uint4), &p))) return rc;
   v.rec1 = (uint4 *)p; v.cap1 = cap1; v.nxg = (uint32_t)nxg; v.dbg = ctx->dbg_flags;
-  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)NLEAF * (cap2c + cap2t) * sizeof(uint4), &p))) return rc;
+  v.sel_mask = (1u << sel_bits) - 1u; v.sel_val = sel_val; v.sel_bits = (uint32_t)sel_bits;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)(NLEAF >> sel_bits) * (cap2c + cap2t) * sizeof(uint4), &p))) return rc;
   v.rec2 = (uint4 *)p; v.cap2c = cap2c; v.cap2t = cap2t;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_AUX, (size_t)NLEAF * 8 + (size_t)(B1 * nxg + (NCLS + 1) * NLEAF) * sizeof(uint32_t), &p))) return rc;
   v.leaf_off = (uint64_t *)p;
@@ -1623,8 +1630,9 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
   v.stats = ctx->g_stats;
   TableView t = cfrk_table_view(ctx);
 
-  HIP_TRY(ctx, hipMemsetAsync(v.cnt1, 0, (size_t)(B1 * nxg + (NCLS + 1) * NLEAF) * sizeof(uint32_t), ctx->stream));
-  HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_CURSOR, 0, sizeof(uint64_t), ctx->stream));
+  // (cnt1, cnt2 and -- first pass only -- the leaf index and the list cursor)
+  HIP_TRY(ctx, hipMemsetAsync(v.cnt1, 0, (size_t)(B1 * nxg + (NCLS + (first ? 1 : 0)) * NLEAF) * sizeof(uint32_t), ctx->stream));
+  if (first) HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_CURSOR, 0, sizeof(uint64_t), ctx->stream));
 
   // Both levels are laid out for an input that spreads evenly over the minimizer space.  One that
   // does not -- deep coverage of a small genome puts tens of thousands of records into a handful of
@@ -1738,19 +1746,22 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
 int cfrk_msp_plan_groups(cfrk_ctx *ctx, int64_t nN, int64_t ntiles, int64_t tile_span,
                          size_t (*need_fn)(const cfrk_ctx *, int64_t), size_t acc_bytes, size_t have,
                          int *groups) {
+  (void)ntiles; (void)tile_span; (void)acc_bytes;
   *groups = 1;
   if (need_fn(ctx, nN) <= have && !ctx->mem_budget) return CFRK_OK;   // fits what the pool already holds
   size_t free_b = 0, total_b = 0;
   HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
   size_t budget = have + free_b;
   if (ctx->mem_budget) budget = std::min(budget, ctx->mem_budget);
+  // a pass over 1/g of the leaves needs the record buffers of 1/g of the batch (power-of-two g:
+  // the subset is picked by the leaf id's low bits)
   int g = 1;
-  while (need_fn(ctx, std::min(nN, ((ntiles + g - 1) / g) * tile_span)) + (g > 1 ? (size_t)g * acc_bytes : 0) > budget) {
-    if ((ntiles + g - 1) / g <= 64 || g >= 4096) {
+  while (need_fn(ctx, (nN + g - 1) / g) > budget) {
+    if (g >= 256) {
       *groups = 0;
       return CFRK_OK;
     }
-    g += (g < 8) ? 1 : g / 4;
+    g *= 2;
   }
   *groups = g;
   return CFRK_OK;
@@ -1765,17 +1776,14 @@ int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   const int64_t ntiles = (nwaves + P1_WAVES - 1) / P1_WAVES;
   if (ntiles > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
   // every buffer a pass needs must fit: decide before touching the pool so that a refusal leaves
-  // the context usable for the fallback path.  A batch too large for one pass is counted in
-  // several passes over tile ranges; the passes' per-leaf lists are kept and added leaf by leaf
-  // in LDS at the end (the same kernel that merges the ranks' lists on a multi-GPU job).
+  // the context usable for the fallback path
   const size_t have = ctx->pool[BUF_MSP_L1].cap + ctx->pool[BUF_MSP_L2].cap + ctx->pool[BUF_MSP_OUTK].cap +
-                      ctx->pool[BUF_MSP_OUTC].cap + ctx->pool[BUF_MSP_ACCK].cap + ctx->pool[BUF_MSP_ACCC].cap;
+                      ctx->pool[BUF_MSP_OUTC].cap;
   int groups = 1;
   if ((rc = cfrk_msp_plan_groups(ctx, nN, ntiles, (int64_t)P1_WAVES * P1_OWN * 32, msp_need, (size_t)ctx->g_cap * 12,
                                  have, &groups))) return rc;
   if (groups == 0) return cfrk_fail(ctx, CFRK_ERR_NOMEM, "partitioned path does not fit device memory");
-  const int64_t per = (ntiles + groups - 1) / groups;
-  const int passes = (int)((ntiles + per - 1) / per);
+  const int passes = groups;
   ctx->last_passes = passes;
   if (ctx->g_flags & CFRK_RUNS_ONLY) {
     if (ms->runs_ready) return cfrk_fail(ctx, CFRK_ERR_STATE, "a CFRK_RUNS_ONLY job takes one add");
@@ -1799,59 +1807,20 @@ int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
     }
     return msp_count_tiles(ctx, ms, d_data, nN, 0, ntiles, slack);
   }
-
-  void *p;
-  if ((rc = cfrk_pool_get(ctx, BUF_MSP_ACCK, (size_t)passes * ctx->g_cap * 8, &p))) return rc;
-  uint64_t *acc_k = (uint64_t *)p;
-  if ((rc = cfrk_pool_get(ctx, BUF_MSP_ACCC, (size_t)passes * ctx->g_cap * 4, &p))) return rc;
-  uint32_t *acc_c = (uint32_t *)p;
-  const size_t nseg = (size_t)passes * NLEAF;
-  std::vector<uint64_t> so(nseg), lo1(NLEAF);
-  std::vector<uint32_t> sn(nseg);
-  uint64_t acc_n = 0;
-  int pass = 0;
-  for (int64_t t0 = 0; t0 < ntiles; t0 += per, ++pass) {
-    if ((rc = msp_count_tiles(ctx, ms, d_data, nN, t0, std::min(per, ntiles - t0), 1.0))) {
+  // A batch whose records do not fit beside the caller's data is counted in `passes` passes over
+  // the WHOLE input, each emitting only the runs of 1/passes of the leaves (leaf id low bits): the
+  // partition kernel's front end runs again every pass, but every pass produces the FINAL counts
+  // of its leaves -- nothing to merge afterwards, and the result stays in per-leaf list form.
+  int sel_bits = 0;
+  while ((1 << sel_bits) < passes) ++sel_bits;
+  for (int pass = 0; pass < passes; ++pass) {
+    if ((rc = msp_count_tiles(ctx, ms, d_data, nN, 0, ntiles, 1.0, sel_bits, (uint32_t)pass, pass == 0))) {
       // a refusal after the first pass must not reach the caller's fallback (it would count
       // the finished passes twice)
-      if (t0 > 0 && rc == CFRK_ERR_NOMEM) return cfrk_fail(ctx, CFRK_ERR_STATE, "out of device memory in pass %d of a multi-pass add", pass);
+      if (pass > 0 && rc == CFRK_ERR_NOMEM) return cfrk_fail(ctx, CFRK_ERR_STATE, "out of device memory in pass %d of a multi-pass add", pass);
       return rc;
     }
-    uint64_t st[ST_NWORDS];
-    if ((rc = cfrk_msp_sync_stats(ctx, st))) return rc;
-    if (st[ST_OVERFLOW]) return cfrk_fail(ctx, CFRK_ERR_TABLE_FULL, "result list of %llu entries overflowed", (unsigned long long)ms->view.out_cap);
-    const uint64_t n = st[ST_CURSOR];
-    if (st[ST_MULTISEG]) {
-      // leaves counted in several key-subset passes have no per-leaf index: this pass's list goes
-      // through the HBM table instead of the per-leaf merge
-      for (int l = 0; l < NLEAF; ++l) { so[(size_t)pass * NLEAF + l] = acc_n; sn[(size_t)pass * NLEAF + l] = 0; }
-      if ((rc = cfrk_msp_flush_to_table(ctx))) return rc;
-      HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_MULTISEG, 0, sizeof(uint64_t), ctx->stream));
-      continue;
-    }
-    HIP_TRY(ctx, hipMemcpyAsync(acc_k + acc_n, ms->view.out_keys, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(acc_c + acc_n, ms->view.out_cnt, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(lo1.data(), ms->view.leaf_off, NLEAF * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(sn.data() + (size_t)pass * NLEAF, ms->view.leaf_n, NLEAF * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    for (int l = 0; l < NLEAF; ++l) so[(size_t)pass * NLEAF + l] = acc_n + lo1[l];   // leaf_n == 0: offset unused
-    acc_n += n;
-    ms->pending = false;                     // the pass's list now lives in the accumulation buffers
   }
-  if ((rc = cfrk_pool_get(ctx, BUF_SCRATCH, nseg * (sizeof(uint64_t) + sizeof(uint32_t)), &p))) return rc;
-  uint64_t *d_so = (uint64_t *)p;
-  uint32_t *d_sn = (uint32_t *)(d_so + nseg);
-  HIP_TRY(ctx, hipMemcpyAsync(d_so, so.data(), nseg * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(d_sn, sn.data(), nseg * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_CURSOR, 0, sizeof(uint64_t), ctx->stream));
-  hipLaunchKernelGGL(msp_merge_kernel, dim3(NLEAF), dim3(P3_THREADS), 0, ctx->stream, (const uint64_t *)acc_k,
-                     (const uint32_t *)acc_c, (const uint64_t *)d_so, (const uint32_t *)d_sn, passes, (int)NLEAF,
-                     ms->view, cfrk_table_view(ctx));
-  HIP_TRY(ctx, hipGetLastError());
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // so / sn are host temporaries
-  ms->pending = true;
-  ms->leaf_form = false;
-  ms->list_n_valid = false;
   return CFRK_OK;
 }
 

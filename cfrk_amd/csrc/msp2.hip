@@ -45,6 +45,7 @@ struct View2 {
   const uint64_t *lbase; const uint32_t *lcap; uint32_t exact;
   Rec2 *ovf; uint32_t ovf_cap;                           // parking for a few overflowing records
   uint32_t dbg;                                          // cfrk_debug_set_flags
+  uint32_t sel_mask, sel_val, sel_bits;                  // leaf subset of this pass (msp.h: MspView)
   uint64_t *stats;
 };
 
@@ -270,6 +271,7 @@ __global__ __launch_bounds__(Q1_THREADS, 6) void msp2_p1_kernel(const int8_t *__
     const int a = __clz(S2);
     S2 &= ~(0x80000000u >> a);
     const Rec2 rec = q1_build(st, ((uint32_t)lane << 5) | (uint32_t)a, k, c);
+    if (((rec.b.w >> 8) & v.sel_mask) != v.sel_val) continue;    // not a leaf of this pass
     const uint32_t reg = q1_reg(rec.b.w >> 16, blockIdx.x & (NXG - 1));
     const uint32_t dst = atomicAdd(&v.cnt1[reg], 1u);
     if (dst < v.cap1) v.rec1[(uint64_t)reg * v.cap1 + dst] = rec;
@@ -288,7 +290,8 @@ __global__ __launch_bounds__(Q1_THREADS, 6) void msp2_p1_kernel(const int8_t *__
     const uint32_t i = (uint32_t)(tr * 64 + lane);
     if (i < cnt_w) {
       rc[tr] = q1_build(st, s_dsc[i], k, c);
-      rk[tr] = atomicAdd(&hist[rc[tr].b.w >> 16], 1u);
+      if (((rc[tr].b.w >> 8) & v.sel_mask) == v.sel_val)     // (all leaves, unless the batch takes several passes)
+        rk[tr] = atomicAdd(&hist[rc[tr].b.w >> 16], 1u);
     }
     __builtin_amdgcn_sched_barrier(0);             // one trip at a time: interleaved trips spill registers
   }
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(Q2_THREADS) void msp2_p2_kernel(int groups_per_bin,
       const uint64_t leaf = ((uint64_t)b1 * NSUB + sb) >> 2;
       const uint32_t cls = sb & 3u;
       uint64_t cap = (cls == 3u) ? v.cap2c : v.cap2t;
-      uint64_t at = leaf * (v.cap2c + 3 * v.cap2t) + ((cls == 3u) ? 0 : v.cap2c + cls * v.cap2t);
+      uint64_t at = (leaf >> v.sel_bits) * (v.cap2c + 3 * v.cap2t) + ((cls == 3u) ? 0 : v.cap2c + cls * v.cap2t);
       if (v.exact) { cap = v.lcap[b1 * NSUB + sb]; at = v.lbase[b1 * NSUB + sb]; }
       if (dst < cap) v.rec2[at + dst] = rec;
       else if (v.exact) spill_record2(rec.a, rec.b, k, canon != 0, t);    // cannot happen: cap is the exact count
@@ -687,7 +690,7 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
   for (int s = tid; s < R2 + 1; s += Q3_THREADS) th[s] = 0;
   __syncthreads();
 
-  const Rec2 *leaf_rec = v.exact ? v.rec2 + v.lbase[NCLS * leaf + 3] : v.rec2 + (uint64_t)leaf * (v.cap2c + 3 * v.cap2t);
+  const Rec2 *leaf_rec = v.exact ? v.rec2 + v.lbase[NCLS * leaf + 3] : v.rec2 + (uint64_t)(leaf >> v.sel_bits) * (v.cap2c + 3 * v.cap2t);
   const Rec2 zrec = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
   // ---- phase 1: complete runs, one record-table update per record; when the table runs out of
   //      room (more distinct runs than it holds: low coverage of a large genome) the dedupe is
@@ -1081,8 +1084,9 @@ static size_t msp2_need(const cfrk_ctx *ctx, int64_t span) {
 
 // one pass of Q1 -> Q2 -> Q3 over the Q1 tiles [tile0, tile0 + ntiles)
 // slack >= 1 widens the per-leaf streams beyond what msp2_need() accounts for (memory permitting)
+// sel_bits / sel_val / first: the leaf subset of this pass (msp.hip: msp_count_tiles)
 static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, int64_t nN, int64_t tile0,
-                            int64_t ntiles, double slack) {
+                            int64_t ntiles, double slack, int sel_bits = 0, uint32_t sel_val = 0, bool first = true) {
   int rc;
   const int k = ctx->g_k;
   const int m = (k & 1) ? 14 : 13;                       // k - m + 1 - 18 must be even
@@ -1091,18 +1095,21 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
   const int64_t span = std::min(nN + 32, ntiles * (int64_t)Q1_WAVES * Q1_OWN * 32);
 
   const double dens = 2.0 / (W2 + 1) + 1.0 / 64.0;
-  const double expect = (double)span * dens;
+  const double expect_all = (double)span * dens;                 // records of the whole batch
+  const double expect = expect_all / (double)(1u << sel_bits);   // ... of this pass
   const uint64_t cap1 = (uint64_t)(expect / (B1 * NXG) * 1.35) + 2048;
-  const uint64_t cap2c = (uint64_t)(expect / NLEAF * 2.1 * slack) + 96;
-  const uint64_t cap2t = (uint64_t)(expect / NLEAF * 0.4 * slack) + 96;
+  // (a leaf of the pass holds ALL its records: the pass has fewer leaves, not lighter ones)
+  const uint64_t cap2c = (uint64_t)(expect_all / NLEAF * 2.1 * slack) + 96;
+  const uint64_t cap2t = (uint64_t)(expect_all / NLEAF * 0.4 * slack) + 96;
   const int64_t tiles_per_sub = (int64_t)(((uint64_t)NXG * cap1 + (uint64_t)Q2_TILE * Q2_GROUP - 1) / ((uint64_t)Q2_TILE * Q2_GROUP));   // tile groups per bin
   if (tiles_per_sub * B1 > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
   void *p;
   View2 v;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_L1, (size_t)B1 * NXG * cap1 * sizeof(Rec2), &p))) return rc;
   v.rec1 = (Rec2 *)p; v.cap1 = cap1;
-  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)NLEAF * (cap2c + 3 * cap2t) * sizeof(Rec2), &p))) return rc;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)(NLEAF >> sel_bits) * (cap2c + 3 * cap2t) * sizeof(Rec2), &p))) return rc;
   v.rec2 = (Rec2 *)p; v.cap2c = cap2c; v.cap2t = cap2t;
+  v.sel_mask = (1u << sel_bits) - 1u; v.sel_val = sel_val; v.sel_bits = (uint32_t)sel_bits;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_AUX, (size_t)NLEAF * 8 + (size_t)(B1 * NXG + (NCLS + 1) * NLEAF) * sizeof(uint32_t), &p))) return rc;
   v.leaf_off = (uint64_t *)p;
   v.cnt1 = (uint32_t *)(v.leaf_off + NLEAF); v.cnt2 = v.cnt1 + B1 * NXG; v.leaf_n = v.cnt2 + NCLS * NLEAF;
@@ -1115,8 +1122,9 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
   v.stats = ctx->g_stats; v.dbg = ctx->dbg_flags;
   TableView t = cfrk_table_view(ctx);
 
-  HIP_TRY(ctx, hipMemsetAsync(v.cnt1, 0, (size_t)(B1 * NXG + (NCLS + 1) * NLEAF) * sizeof(uint32_t), ctx->stream));
-  HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_CURSOR, 0, sizeof(uint64_t), ctx->stream));
+  // (cnt1, cnt2 and -- first pass only -- the leaf index and the list cursor)
+  HIP_TRY(ctx, hipMemsetAsync(v.cnt1, 0, (size_t)(B1 * NXG + (NCLS + (first ? 1 : 0)) * NLEAF) * sizeof(uint32_t), ctx->stream));
+  if (first) HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_CURSOR, 0, sizeof(uint64_t), ctx->stream));
   hipLaunchKernelGGL(msp2_p1_kernel, dim3((unsigned)ntiles), dim3(Q1_THREADS), 0, ctx->stream, d_data, nN, k, m, c,
                      canon, tile0, v, t);
   HIP_TRY(ctx, hipGetLastError());
@@ -1176,7 +1184,7 @@ int cfrk_msp2_merge_lists(cfrk_ctx *ctx, const uint64_t *d_lo, const uint64_t *d
   v.rec1 = nullptr; v.cnt1 = nullptr; v.cap1 = 0; v.rec2 = nullptr; v.cnt2 = nullptr; v.cap2c = v.cap2t = 0;
   v.out_lo = ms->view.out_keys; v.out_hi = ms->view.out_hi; v.out_cnt = ms->view.out_cnt; v.out_cap = ms->view.out_cap;
   v.leaf_off = nullptr; v.leaf_n = nullptr; v.stats = ctx->g_stats;
-  v.exact = 0; v.lbase = nullptr; v.lcap = nullptr; v.ovf = nullptr; v.ovf_cap = 0;
+  v.exact = 0; v.lbase = nullptr; v.lcap = nullptr; v.ovf = nullptr; v.ovf_cap = 0; v.sel_mask = v.sel_val = v.sel_bits = 0; v.dbg = 0;
   hipLaunchKernelGGL(msp2_merge_kernel, dim3(leaves_per_part), dim3(Q3_THREADS), 0, ctx->stream, d_lo, d_hi, d_cnt,
                      d_seg_off, d_seg_n, parts, leaves_per_part, v, cfrk_table_view(ctx));
   HIP_TRY(ctx, hipGetLastError());
@@ -1192,14 +1200,12 @@ int cfrk_msp2_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   const int64_t ntiles = (nwaves + Q1_WAVES - 1) / Q1_WAVES;
   if (ntiles > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
   const size_t have = ctx->pool[BUF_MSP_L1].cap + ctx->pool[BUF_MSP_L2].cap + ctx->pool[BUF_MSP_OUTK].cap +
-                      ctx->pool[BUF_MSP_OUTC].cap + ctx->pool[BUF_MSP_OUTH].cap + ctx->pool[BUF_MSP_ACCK].cap +
-                      ctx->pool[BUF_MSP_ACCH].cap + ctx->pool[BUF_MSP_ACCC].cap;
+                      ctx->pool[BUF_MSP_OUTC].cap + ctx->pool[BUF_MSP_OUTH].cap;
   int groups = 1;
   if ((rc = cfrk_msp_plan_groups(ctx, nN + 32, ntiles, (int64_t)Q1_WAVES * Q1_OWN * 32, msp2_need,
                                  (size_t)ctx->g_cap * 20, have, &groups))) return rc;
   if (groups == 0) return cfrk_fail(ctx, CFRK_ERR_NOMEM, "partitioned path does not fit device memory");
-  const int64_t per = (ntiles + groups - 1) / groups;
-  const int passes = (int)((ntiles + per - 1) / per);
+  const int passes = groups;
   ctx->last_passes = passes;
   if (ms->pending && (rc = cfrk_msp_flush_to_table(ctx))) return rc;
   if (passes == 1) {
@@ -1216,58 +1222,16 @@ int cfrk_msp2_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
     return msp2_count_tiles(ctx, ms, d_data, nN, 0, ntiles, slack);
   }
 
-  // several passes over tile ranges: keep every pass's per-leaf list, add them leaf by leaf in
-  // LDS at the end (as msp.hip does)
-  void *p;
-  if ((rc = cfrk_pool_get(ctx, BUF_MSP_ACCK, (size_t)passes * ctx->g_cap * 8, &p))) return rc;
-  uint64_t *acc_lo = (uint64_t *)p;
-  if ((rc = cfrk_pool_get(ctx, BUF_MSP_ACCH, (size_t)passes * ctx->g_cap * 8, &p))) return rc;
-  uint64_t *acc_hi = (uint64_t *)p;
-  if ((rc = cfrk_pool_get(ctx, BUF_MSP_ACCC, (size_t)passes * ctx->g_cap * 4, &p))) return rc;
-  uint32_t *acc_c = (uint32_t *)p;
-  const size_t nseg = (size_t)passes * NLEAF;
-  std::vector<uint64_t> so(nseg), lo1(NLEAF);
-  std::vector<uint32_t> sn(nseg);
-  uint64_t acc_n = 0;
-  int pass = 0;
-  for (int64_t t0 = 0; t0 < ntiles; t0 += per, ++pass) {
-    if ((rc = msp2_count_tiles(ctx, ms, d_data, nN, t0, std::min(per, ntiles - t0), 1.0))) {
+  // several passes over the WHOLE input, each emitting and counting 1/passes of the leaves (msp.hip)
+  int sel_bits = 0;
+  while ((1 << sel_bits) < passes) ++sel_bits;
+  for (int pass = 0; pass < passes; ++pass) {
+    if ((rc = msp2_count_tiles(ctx, ms, d_data, nN, 0, ntiles, 1.0, sel_bits, (uint32_t)pass, pass == 0))) {
       // a refusal after the first pass must not reach the caller's fallback (it would count
       // the finished passes twice)
-      if (t0 > 0 && rc == CFRK_ERR_NOMEM) return cfrk_fail(ctx, CFRK_ERR_STATE, "out of device memory in pass %d of a multi-pass add", pass);
+      if (pass > 0 && rc == CFRK_ERR_NOMEM) return cfrk_fail(ctx, CFRK_ERR_STATE, "out of device memory in pass %d of a multi-pass add", pass);
       return rc;
     }
-    uint64_t st[ST_NWORDS];
-    if ((rc = cfrk_msp_sync_stats(ctx, st))) return rc;
-    if (st[ST_OVERFLOW]) return cfrk_fail(ctx, CFRK_ERR_TABLE_FULL, "result list of %llu entries overflowed", (unsigned long long)ms->view.out_cap);
-    const uint64_t n = st[ST_CURSOR];
-    if (st[ST_MULTISEG]) {
-      // leaves counted in several key-subset passes have no per-leaf index: through the HBM table
-      for (int l = 0; l < NLEAF; ++l) { so[(size_t)pass * NLEAF + l] = acc_n; sn[(size_t)pass * NLEAF + l] = 0; }
-      if ((rc = cfrk_msp_flush_to_table(ctx))) return rc;
-      HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_MULTISEG, 0, sizeof(uint64_t), ctx->stream));
-      continue;
-    }
-    HIP_TRY(ctx, hipMemcpyAsync(acc_lo + acc_n, ms->view.out_keys, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(acc_hi + acc_n, ms->view.out_hi, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(acc_c + acc_n, ms->view.out_cnt, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(lo1.data(), ms->view.leaf_off, NLEAF * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(sn.data() + (size_t)pass * NLEAF, ms->view.leaf_n, NLEAF * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    for (int l = 0; l < NLEAF; ++l) so[(size_t)pass * NLEAF + l] = acc_n + lo1[l];   // leaf_n == 0: offset unused
-    acc_n += n;
-    ms->pending = false;                     // the pass's list now lives in the accumulation buffers
   }
-  if ((rc = cfrk_pool_get(ctx, BUF_SCRATCH, nseg * (sizeof(uint64_t) + sizeof(uint32_t)), &p))) return rc;
-  uint64_t *d_so = (uint64_t *)p;
-  uint32_t *d_sn = (uint32_t *)(d_so + nseg);
-  HIP_TRY(ctx, hipMemcpyAsync(d_so, so.data(), nseg * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(d_sn, sn.data(), nseg * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_CURSOR, 0, sizeof(uint64_t), ctx->stream));
-  if ((rc = cfrk_msp2_merge_lists(ctx, acc_lo, acc_hi, acc_c, d_so, d_sn, passes, (int)NLEAF))) return rc;
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // so / sn are host temporaries
-  ms->pending = true;
-  ms->leaf_form = false;
-  ms->list_n_valid = false;
   return CFRK_OK;
 }

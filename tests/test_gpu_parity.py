@@ -766,14 +766,17 @@ def test_truncated_runs_anchored_to_their_complete_twin_give_the_same_counts(ctx
     assert digests[0] == digests[1] == orc.digest(*want, two_word=k > 32)
 
 
-@pytest.mark.parametrize("k,canonical,world", [(31, True, 2), (31, True, 8), (21, True, 4), (28, False, 3)])
-def test_runs_exchange_emulated_ranks_equals_one_gpu_and_oracle(ctx, k, canonical, world):
+@pytest.mark.parametrize("k,canonical,world,G", [(31, True, 2, 30_000), (31, True, 8, 30_000), (21, True, 4, 30_000),
+                                                 (28, False, 3, 30_000), (31, True, 4, 1_200), (16, True, 2, 5_000_000)])
+def test_runs_exchange_emulated_ranks_equals_one_gpu_and_oracle(ctx, k, canonical, world, G):
     """Strong-scaling exchange with `world` emulated ranks on one GPU: every rank only
     partitions and deduplicates its read range (CFRK_RUNS_ONLY) and exports per-leaf runs packed per
     owner; every owner counts the runs of its leaves.  The union of the owners' results equals the
     oracle's count of ALL reads, key by key."""
     import cfrk_amd
-    R, L, G = 24_000, 150, 30_000
+    # G = 1200: everything in a few hundred leaves, far beyond their fixed stride (exact re-layout on the
+    # ranks); G = 5e6: hardly any run repeats (nothing to deduplicate)
+    R, L = 24_000, 150
     data, _, _ = orc.synth_reads(0, R, L, G)
     data = data.copy()
     data[::1013] = -1
@@ -818,4 +821,5 @@ def test_runs_exchange_emulated_ranks_equals_one_gpu_and_oracle(ctx, k, canonica
     assert all(merged[int(a)] == int(b) for a, b in zip(wlo, wcnt))
     # deduplication really happened on the ranks: far fewer records than super-k-mers (8 per read at least)
     lpp = (65536 + world - 1) // world
-    assert total_rows - world * world * ((lpp * 8 + 15) // 16) < 6 * R
+    if G <= 30_000:
+        assert total_rows - world * world * ((lpp * 8 + 15) // 16) < 6 * R
