@@ -254,7 +254,10 @@ def main():
             def export_runs(self, parts):
                 if getattr(self, "rbuf", None) is None:
                     # rows of 16 bytes: distinct runs (<= the leaf streams) + truncated runs + headers
-                    self.rbuf = torch.empty((max(1 << 20, 3 * Rl + (1 << 17)), 2), dtype=torch.int64, device=dev)
+                    # (truncated runs: two per read; distinct complete runs: ~2 strands x 2/(W+1) per genome base,
+                    #  never more than the shard's super-k-mers; a too small buffer is doubled below)
+                    rows = int(min(14 * Rl, 2.5 * Rl + 0.3 * glen)) + (1 << 17)
+                    self.rbuf = torch.empty((max(1 << 20, rows), 2), dtype=torch.int64, device=dev)
                 for _ in range(3):
                     try:
                         pr = self.g.export_runs_device(self.rbuf.data_ptr(), self.rbuf.shape[0], parts)

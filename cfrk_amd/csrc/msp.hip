@@ -1314,6 +1314,98 @@ __global__ __launch_bounds__(P3_THREADS) void msp_merge_kernel(const uint64_t *_
   }
 }
 
+// The exporting side of the runs exchange needs none of the leaf kernel's k-mer machinery: a small
+// workgroup per leaf (256 threads, 16 KB of LDS: eight or more per CU) deduplicates the leaf's
+// complete runs in the 1024-entry record table and leaves the distinct ones, header word =
+// multiplicity << 6 | n-1, at the head of the leaf's own stream (leaf_n = their number).  A shard
+// of a multi-GPU job holds ~2000 complete runs per leaf; the 65536 workgroups are mostly fixed cost.
+// A leaf with more distinct runs than the table holds leaves as it is (multiplicity 1 each): the
+// owner's table merges what can be merged.
+constexpr int DX_THREADS = 256;
+__global__ __launch_bounds__(DX_THREADS) void msp_dedupe_export_kernel(int k, MspView v) {
+  __shared__ uint4 rtab[RT];
+  __shared__ uint32_t wsum[DX_THREADS / 64];
+  __shared__ uint32_t rt_fail;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t leaf = blockIdx.x;
+  const uint64_t n1 = min((uint64_t)v.cnt2[NCLS * leaf + 1], v.exact ? (uint64_t)v.lcap[NCLS * leaf + 1] : v.cap2c);
+  if (n1 == 0) return;
+  uint4 *const stream = v.exact ? v.rec2 + v.lbase[NCLS * leaf + 1] : v.rec2 + (uint64_t)(leaf >> v.sel_bits) * (v.cap2c + v.cap2t);
+  for (int s = tid; s < RT; s += DX_THREADS) rtab[s] = make_uint4(0u, 0u, 0u, RT_EMPTY);
+  if (tid == 0) rt_fail = (v.dbg & CFRK_DEBUG_FORCE_RT_OVERFLOW) ? 1u : 0u;
+  __syncthreads();
+  {
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t *rmeta = reinterpret_cast<uint32_t *>(rtab);
+    uint4 L = zero4;                 // leftover records, lanes [0, c) (see the leaf kernel's phase 1a)
+    uint32_t Lh = 0;
+    int c = 0;                       // wave-uniform
+    auto drain = [&](int cnt) {
+      uint32_t h = Lh | ((lane < cnt) ? 0u : RT_DONE);
+      rtab_insert_loop(rtab, L, h, RT - 1, RT_TRIPS);
+      if ((int32_t)h >= 0) rt_fail = 1u;
+    };
+    for (uint64_t r = tid; r < ((n1 + 63) & ~63ull); r += DX_THREADS) {
+      const bool valid = r < n1;
+      uint4 rec = zero4;
+      if (valid) rec = stream[r];
+      const uint32_t h = rtab_slot_k(rec, k, RT_LOG);
+      const uint4 e = rtab[h];
+      const bool match = valid && rtab_diff(e, rec) == 0u;
+      if (match) atomicAdd(&rmeta[4 * h + 3], 1u << 6);
+      const bool left = valid && !match;
+      const unsigned long long mask = __ballot(left);
+      if (mask == 0ull) continue;
+      const int n = __popcll(mask);
+      if (c + n > 64) { drain(c); c = 0; }
+      const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+      const int dst = left ? (c + rank) : ((c + n) & 63);      // the others aim at a lane nobody keeps
+      const int da = dst << 2;
+      const uint32_t px = __builtin_amdgcn_ds_permute(da, rec.x), py = __builtin_amdgcn_ds_permute(da, rec.y);
+      const uint32_t pz = __builtin_amdgcn_ds_permute(da, rec.z), pw = __builtin_amdgcn_ds_permute(da, rec.w);
+      const uint32_t ph = __builtin_amdgcn_ds_permute(da, h);
+      const bool take = lane >= c && lane < c + n;
+      L.x = take ? px : L.x; L.y = take ? py : L.y; L.z = take ? pz : L.z; L.w = take ? pw : L.w;
+      Lh = take ? ph : Lh;
+      c += n;
+    }
+    if (c) drain(c);
+  }
+  __syncthreads();
+  uint32_t nd;
+  if (rt_fail) {
+    // (every record was read before the barrier; the rewrite touches the header word only)
+    for (uint64_t i = tid; i < n1; i += DX_THREADS) stream[i].w = (1u << 6) | (stream[i].w & 63u);
+    nd = (uint32_t)n1;
+  } else {
+    // occupied slots -> head of the stream (four slots per thread)
+    // (two passes over LDS: an array of entries would live in scratch memory)
+    constexpr int PER = RT / DX_THREADS;
+    const uint32_t *meta = reinterpret_cast<const uint32_t *>(rtab);
+    uint32_t mine = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) mine += (meta[4 * (PER * tid + i) + 3] != RT_EMPTY) ? 1u : 0u;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t y = __shfl_up(incl, d);
+      if (lane >= d) incl += y;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+    for (int w = 0; w < DX_THREADS / 64; ++w) { const uint32_t x = wsum[w]; base += (w < wave) ? x : 0u; total += x; }
+    uint32_t at = base + incl - mine;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const uint4 e = rtab[PER * tid + i];
+      if (e.w != RT_EMPTY) stream[at++] = e;
+    }
+    nd = total;
+  }
+  if (tid == 0) v.leaf_n[leaf] = nd;
+}
+
 // ---------------------------------------------------------------------------- multi-GPU by runs
 // Strong scaling: with the reads split over N ranks every rank still meets almost every locus, so
 // counting on every rank and exchanging (key, count) lists (above) makes each rank expand every
@@ -1739,9 +1831,9 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
     HIP_TRY(ctx, hipGetLastError());
   }
   const bool runs_only = (ctx->g_flags & CFRK_RUNS_ONLY) != 0;
-  const uint32_t mode = runs_only ? P3_EXPORT : 0u;
-  if (canon) hipLaunchKernelGGL((msp_p3_kernel<true>), dim3(NLEAF), dim3(P3_THREADS), 0, ctx->stream, k, mode, v, t);
-  else hipLaunchKernelGGL((msp_p3_kernel<false>), dim3(NLEAF), dim3(P3_THREADS), 0, ctx->stream, k, mode, v, t);
+  if (runs_only) hipLaunchKernelGGL(msp_dedupe_export_kernel, dim3(NLEAF), dim3(DX_THREADS), 0, ctx->stream, k, v);
+  else if (canon) hipLaunchKernelGGL((msp_p3_kernel<true>), dim3(NLEAF), dim3(P3_THREADS), 0, ctx->stream, k, 0u, v, t);
+  else hipLaunchKernelGGL((msp_p3_kernel<false>), dim3(NLEAF), dim3(P3_THREADS), 0, ctx->stream, k, 0u, v, t);
   HIP_TRY(ctx, hipGetLastError());
   ms->pending = !runs_only;
   ms->runs_ready = runs_only;
