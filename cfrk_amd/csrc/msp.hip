@@ -2198,6 +2198,12 @@ extern "C" int cfrk_global_merge_runs_device(cfrk_ctx *ctx, const void *d_packed
   hipLaunchKernelGGL(msp_runs_layout_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint4 *)d_packed, rr, parts, lpp, hrows,
                      d_src, d_d1, d_d0, d_lbase, d_lcap, v.cnt2, d_out);
   HIP_TRY(ctx, hipGetLastError());
+  // the headers are checked before anything is copied by them: sizes that add up to the rows each
+  // rank sent keep every segment inside its rank's part of the buffer and every stream inside rec2
+  uint64_t h[2];
+  HIP_TRY(ctx, hipMemcpyAsync(h, d_out, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (h[1]) return cfrk_fail(ctx, CFRK_ERR_ARG, "a rank's header does not add up to the rows it sent");
   hipLaunchKernelGGL(msp_runs_scatter_kernel, dim3((unsigned)nseg), dim3(256), 0, ctx->stream, (const uint4 *)d_packed, rr, lpp,
                      (const uint64_t *)d_src, (const uint64_t *)d_d1, (const uint64_t *)d_d0, v.rec2);
   HIP_TRY(ctx, hipGetLastError());
@@ -2206,15 +2212,8 @@ extern "C" int cfrk_global_merge_runs_device(cfrk_ctx *ctx, const void *d_packed
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   ctx->ev_valid = true;
-  uint64_t h[2];
-  HIP_TRY(ctx, hipMemcpyAsync(h, d_out, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   ctx->h_stats_valid = false;                          // the leaf kernel may have spilled into the table
-  if (h[1]) {
-    // nothing of a malformed message may stay behind as a result
-    HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_CURSOR, 0, sizeof(uint64_t), ctx->stream));
-    return cfrk_fail(ctx, CFRK_ERR_ARG, "a rank's header does not add up to the rows it sent");
-  }
   ms->pending = true;
   ms->leaf_form = false;
   ms->list_n_valid = false;

@@ -19,7 +19,10 @@
 //   --device N       first GPU ordinal (the reference picks the GPU with most memory, src/main.cu:83-108)
 //   --gpus N         chunks (per-read modes) or files (--batch) are dealt round-robin to N devices,
 //                    one cfrk_ctx pair per device; replaces the reference's pthread fan-out, whose
-//                    threads all use the same device (src/main.cu:208-230,277-295)
+//                    threads all use the same device (src/main.cu:208-230,277-295).  With --global
+//                    (16 <= k <= 32) the reads are range-partitioned over the N devices, every device
+//                    partitions and deduplicates its shard, and the owner of a leaf counts it (the
+//                    runs exchange of cfrk_abi.h, staged through host memory here)
 //   --batch N        the Swift/T workflow's loop (swift/cfrk.swf:15-20) in one process: for i < N
 //                    count <dataset_prefix>_<i>.fasta into <out_prefix>_<i>.cfrk
 // Chunk pipeline: every device runs two contexts (two HIP streams), each on a host thread of its
@@ -174,14 +177,111 @@ int run_global(const Options &o, const cfrk_batch &batch, Worker &w, FILE *out) 
   return 0;
 }
 
+// --global over several devices: shard s of the reads goes to device s (first context of the pair);
+// device s then owns the leaves s, s + N, ...: it receives its segment of every shard's packed runs
+// and counts them on its second context.  The owners' key sets are disjoint; their sorted lists are
+// merged into one ascending output.
+int run_global_multi(const Options &o, const cfrk_batch &batch, std::vector<std::vector<Worker>> &per_dev, FILE *out) {
+  const int N = (int)per_dev.size();
+  const int flags = o.canonical ? CFRK_CANONICAL : 0;
+  uint64_t hint = (uint64_t)(batch.nN > 0 ? batch.nN : 1);
+  if (hint < (1ull << 20)) hint = 1ull << 20;
+  if (hint > (1ull << 31)) hint = 1ull << 31;
+  std::vector<std::vector<uint64_t>> packed((size_t)N);            // shard s: packed rows (two words per row)
+  std::vector<std::vector<uint64_t>> rows((size_t)N, std::vector<uint64_t>((size_t)N, 0));
+  std::vector<int> status((size_t)N, 0);
+  {
+    std::vector<std::thread> th;
+    for (int sh = 0; sh < N; ++sh)
+      th.emplace_back([&, sh] {
+        cfrk_ctx *ctx = per_dev[(size_t)sh][0].ctx;
+        const int64_t r0 = batch.nS * sh / N, r1 = batch.nS * (sh + 1) / N;
+        const int64_t b0 = (r0 < batch.nS) ? batch.start[r0] : batch.nN, b1 = (r1 < batch.nS) ? batch.start[r1] : batch.nN;
+        int rc;
+        if ((rc = cfrk_global_begin(ctx, o.k, flags | CFRK_RUNS_ONLY, hint))) { status[(size_t)sh] = die(ctx, rc, "cfrk_global_begin"); return; }
+        if (b1 > b0 && (rc = cfrk_global_add(ctx, batch.data + b0, nullptr, nullptr, b1 - b0, 0))) { status[(size_t)sh] = die(ctx, rc, "cfrk_global_add"); return; }
+        // distinct runs never exceed the shard's super-k-mers (about one per 8 bases), plus the headers
+        uint64_t cap = (uint64_t)(b1 - b0) / 4 + (uint64_t)N * 70000 + 4096;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+          void *d = nullptr;
+          if ((rc = cfrk_device_alloc(ctx, cap * 16, &d))) { status[(size_t)sh] = die(ctx, rc, "cfrk_device_alloc"); return; }
+          rc = (b1 > b0) ? cfrk_global_export_runs_device(ctx, d, cap, N, rows[(size_t)sh].data()) : 0;
+          if (rc == CFRK_ERR_SMALL_BUF && attempt == 0) { cfrk_device_free(ctx, d); cap *= 4; continue; }
+          if (rc) { cfrk_device_free(ctx, d); status[(size_t)sh] = die(ctx, rc, "cfrk_global_export_runs_device"); return; }
+          uint64_t total = 0;
+          for (uint64_t x : rows[(size_t)sh]) total += x;
+          packed[(size_t)sh].resize(total * 2);
+          if (total && (rc = cfrk_memcpy_d2h(ctx, packed[(size_t)sh].data(), d, total * 16))) status[(size_t)sh] = die(ctx, rc, "cfrk_memcpy_d2h");
+          cfrk_device_free(ctx, d);
+          return;
+        }
+      });
+    for (auto &t : th) t.join();
+    for (int r : status) if (r) return r;
+  }
+  std::vector<std::vector<uint64_t>> keys((size_t)N);
+  std::vector<std::vector<uint32_t>> cnts((size_t)N);
+  {
+    std::vector<std::thread> th;
+    for (int ow = 0; ow < N; ++ow)
+      th.emplace_back([&, ow] {
+        cfrk_ctx *ctx = per_dev[(size_t)ow][1].ctx;
+        std::vector<uint64_t> recv((size_t)N), buf;
+        for (int sh = 0; sh < N; ++sh) {
+          uint64_t off = 0;
+          for (int q = 0; q < ow; ++q) off += rows[(size_t)sh][(size_t)q];
+          recv[(size_t)sh] = rows[(size_t)sh][(size_t)ow];
+          buf.insert(buf.end(), packed[(size_t)sh].begin() + (ptrdiff_t)(off * 2), packed[(size_t)sh].begin() + (ptrdiff_t)((off + recv[(size_t)sh]) * 2));
+        }
+        int rc;
+        if ((rc = cfrk_global_begin(ctx, o.k, flags, hint / (uint64_t)N + 1024))) { status[(size_t)ow] = die(ctx, rc, "cfrk_global_begin"); return; }
+        if (!buf.empty()) {
+          void *d = nullptr;
+          if ((rc = cfrk_device_alloc(ctx, buf.size() * 8, &d))) { status[(size_t)ow] = die(ctx, rc, "cfrk_device_alloc"); return; }
+          if ((rc = cfrk_memcpy_h2d(ctx, d, buf.data(), buf.size() * 8)) || (rc = cfrk_global_merge_runs_device(ctx, d, recv.data(), N))) {
+            cfrk_device_free(ctx, d);
+            status[(size_t)ow] = die(ctx, rc, "cfrk_global_merge_runs_device");
+            return;
+          }
+          cfrk_device_free(ctx, d);
+        }
+        uint64_t n = 0;
+        if ((rc = cfrk_global_finish(ctx, &n))) { status[(size_t)ow] = die(ctx, rc, "cfrk_global_finish"); return; }
+        keys[(size_t)ow].resize(n); cnts[(size_t)ow].resize(n);
+        std::vector<uint64_t> hi(n);
+        if ((rc = cfrk_global_export(ctx, keys[(size_t)ow].data(), hi.data(), cnts[(size_t)ow].data(), n, &n))) status[(size_t)ow] = die(ctx, rc, "cfrk_global_export");
+      });
+    for (auto &t : th) t.join();
+    for (int r : status) if (r) return r;
+  }
+  // N ascending lists with disjoint keys -> one ascending list
+  size_t total = 0;
+  for (auto &kk : keys) total += kk.size();
+  std::vector<uint64_t> mk(total);
+  std::vector<uint32_t> mc(total);
+  std::vector<size_t> at((size_t)N, 0);
+  for (size_t i = 0; i < total; ++i) {
+    int best = -1;
+    for (int q = 0; q < N; ++q)
+      if (at[(size_t)q] < keys[(size_t)q].size() && (best < 0 || keys[(size_t)q][at[(size_t)q]] < keys[(size_t)best][at[(size_t)best]])) best = q;
+    mk[i] = keys[(size_t)best][at[(size_t)best]]; mc[i] = cnts[(size_t)best][at[(size_t)best]]; ++at[(size_t)best];
+  }
+  std::string text(cfrk_host_format_sparse(mk.data(), mc.data(), total, nullptr, 0), '\0');
+  cfrk_host_format_sparse(mk.data(), mc.data(), total, &text[0], text.size());
+  fwrite(text.data(), 1, text.size(), out);
+  return 0;
+}
+
 // one FASTA file -> one .cfrk file on the given workers
-int run_file(const Options &o, const char *in, const char *outp, std::vector<Worker> &workers) {
+int run_file(const Options &o, const char *in, const char *outp, std::vector<Worker> &workers,
+             std::vector<std::vector<Worker>> *per_dev = nullptr) {
   cfrk_batch batch;
   int rc = cfrk_host_read_fasta(in, (o.native || o.global) ? 0 : CFRK_INGEST_COMPAT, &batch);
   if (rc) { fprintf(stderr, "cfrk: cannot read %s (error %d)\n", in, rc); return 1; }
   FILE *out = fopen(outp, "wb");                      // PrintFreq opens with "w" even when empty
   if (!out) { fprintf(stderr, "cfrk: cannot write %s\n", outp); cfrk_host_free_batch(&batch); return 1; }
-  rc = o.global ? run_global(o, batch, workers[0], out) : run_per_read(o, batch, workers, out);
+  if (o.global && per_dev && per_dev->size() > 1 && o.k >= 16 && o.k <= 32 && batch.nS >= (int64_t)per_dev->size()) rc = run_global_multi(o, batch, *per_dev, out);
+  else rc = o.global ? run_global(o, batch, workers[0], out) : run_per_read(o, batch, workers, out);
   fclose(out);
   cfrk_host_free_batch(&batch);
   return rc;
@@ -239,7 +339,7 @@ int main(int argc, char **argv) {
     std::vector<Worker> all;
     for (int s = 0; s < 2; ++s)                       // device-major would put both streams of a device first
       for (int g = 0; g < o.gpus; ++g) all.push_back(per_dev[(size_t)g][(size_t)s]);
-    status = run_file(o, pos[0], pos[1], all);
+    status = run_file(o, pos[0], pos[1], all, &per_dev);
   } else {
     // file i goes to device i % gpus (swift/cfrk.swf:15-20 starts one cfrk process per file)
     std::vector<int> st((size_t)o.gpus, 0);

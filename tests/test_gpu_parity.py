@@ -823,3 +823,88 @@ def test_runs_exchange_emulated_ranks_equals_one_gpu_and_oracle(ctx, k, canonica
     lpp = (65536 + world - 1) // world
     if G <= 30_000:
         assert total_rows - world * world * ((lpp * 8 + 15) // 16) < 6 * R
+
+
+def test_runs_exchange_call_sequence_and_malformed_messages(ctx):
+    """error behaviour of the runs exchange: CFRK_RUNS_ONLY outside 16 <= k <= 32, a second add,
+    counts asked of a job that holds runs, a too small send buffer (the needed size is reported and the
+    export can be repeated), an owner that is not fresh, and a received segment whose header does not
+    add up to its rows"""
+    import cfrk_amd
+    data, _, _ = orc.synth_reads(0, 4000, 150, 20_000)
+    for k in (15, 33):
+        with pytest.raises(cfrk_amd.CfrkError) as e:
+            cfrk_amd.GlobalCounter(ctx, k, cfrk_amd.CFRK_CANONICAL | cfrk_amd.CFRK_RUNS_ONLY, 1000)
+        assert e.value.code == -1
+    g = cfrk_amd.GlobalCounter(ctx, 31, cfrk_amd.CFRK_CANONICAL | cfrk_amd.CFRK_RUNS_ONLY, 100_000)
+    g.add(data)
+    with pytest.raises(cfrk_amd.CfrkError) as e:
+        g.add(data)
+    assert e.value.code == -4
+    for call in (g.finish, g.digest, g.export):
+        with pytest.raises(cfrk_amd.CfrkError) as e:
+            call()
+        assert e.value.code == -4
+    d = ctx.alloc(1 << 24)
+    with pytest.raises(cfrk_amd.CfrkError) as e:
+        g.export_runs_device(d, 1000, 2)
+    assert e.value.code == -9 and "rows" in str(e.value)
+    rows = g.export_runs_device(d, (1 << 24) // 16, 2)       # ... and with room it goes through
+    host = np.empty((sum(rows), 2), np.uint64)
+    ctx.d2h(host, d)
+    # a counting job cannot export runs, a runs job cannot be the owner
+    gc = cfrk_amd.GlobalCounter(ctx, 31, cfrk_amd.CFRK_CANONICAL, 100_000)
+    gc.add(data)
+    with pytest.raises(cfrk_amd.CfrkError) as e:
+        gc.export_runs_device(d, (1 << 24) // 16, 2)
+    assert e.value.code == -4
+    with pytest.raises(cfrk_amd.CfrkError) as e:              # not fresh: it already counted something
+        gc.merge_runs_device(d, [rows[0], rows[0]])
+    assert e.value.code == -4
+    # owner 0 gets rank 0's segment twice (two "ranks"): fine; with a row count that contradicts the header: refused
+    seg0 = host[:rows[0]]
+    buf = np.concatenate([seg0, seg0])
+    ctx.h2d(d, buf)
+    og = cfrk_amd.GlobalCounter(ctx, 31, cfrk_amd.CFRK_CANONICAL, 100_000)
+    og.merge_runs_device(d, [rows[0], rows[0]])
+    lo, hi, cnt = og.export()
+    wlo, _, wcnt = orc.global_count(data, 31, orc.ORC_CANONICAL)
+    assert 0 < len(lo) < len(wlo) and int(cnt.sum()) % 2 == 0        # owner 0's leaves only, every count doubled
+    og2 = cfrk_amd.GlobalCounter(ctx, 31, cfrk_amd.CFRK_CANONICAL, 100_000)
+    with pytest.raises(cfrk_amd.CfrkError) as e:
+        og2.merge_runs_device(d, [rows[0] - 1, rows[0] + 1])
+    assert e.value.code == -1
+    assert og2.finish() == 0                                           # nothing of the refused message stays
+    ctx.free(d)
+
+
+def test_cli_global_over_several_devices_equals_one_device(tmp_path):
+    """`cfrk ... --global --canonical --gpus N`: reads range-partitioned over N devices (rehearsed on one
+    with --same-device), runs exchange staged through host memory, owners' lists merged: the same
+    bytes as the single-device run"""
+    import subprocess
+    cli = _cli()
+    rng = np.random.default_rng(21)
+    G = 20_000
+    genome = rng.integers(0, 4, G)
+    seqs = []
+    for _ in range(6000):
+        L = int(rng.integers(20, 200))
+        p = int(rng.integers(0, G - L))
+        r = genome[p:p + L]
+        if rng.random() < 0.5:
+            r = (3 - r)[::-1]
+        sq = "".join("ACGT"[c] for c in r)
+        if rng.random() < 0.05:
+            sq = sq[:L // 2] + "N" + sq[L // 2 + 1:]
+        seqs.append(sq)
+    fa = tmp_path / "g.fasta"
+    fa.write_text("".join(f">r{i}\n{s}\n" for i, s in enumerate(seqs)))
+    one = tmp_path / "one.cfrk"
+    for k, extra in ((31, ["--canonical"]), (21, [])):
+        subprocess.check_call([cli, str(fa), str(one), str(k), "--global"] + extra)
+        for n in (2, 3):
+            many = tmp_path / f"many{n}.cfrk"
+            subprocess.check_call([cli, str(fa), str(many), str(k), "--global", "--gpus", str(n), "--same-device"] + extra)
+            assert many.read_bytes() == one.read_bytes()
+        assert one.stat().st_size > 100_000
