@@ -442,7 +442,7 @@ __global__ __launch_bounds__(P2_THREADS, 4) void msp_p2_kernel(int groups_per_bi
       const bool mine = tid < NSUB;
       const uint32_t x0 = mine ? hist[tid] : 0u;
       // returning atomic: issued here, consumed after the sort (its latency flies under it)
-      if (x0) g0 = atomicAdd(&v.cnt2[b1 * NSUB + tid], x0);
+      if (x0 && !(v.dbg & CFRK_ABL_P2_NO_ATOMIC)) g0 = atomicAdd(&v.cnt2[b1 * NSUB + tid], x0);
       uint32_t incl = x0;
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) {
