@@ -58,7 +58,8 @@ def exchange_by_leaf(engine, world, device, wire_device=None):
     """Owner exchange at leaf granularity (the partitioned path's result form): returns
     (keys, keys_hi_or_None, counts, recv_counts, leaf_counts) for engine-side `merge_leaves`, or
     None when some rank cannot export by leaf -- every rank then takes the generic
-    exchange_by_owner path.
+    exchange_by_owner path.  Two collectives: the segment sizes with every rank's vote, then ONE
+    payload of 8-byte words per destination: [per-leaf counts | keys | high key words | counts].
 
     engine.export_leaves(parts) -> (keys, keys_hi_or_None, counts, part_counts, leaf_counts) or None."""
     wire = torch.device(wire_device) if wire_device is not None else torch.device(device)
@@ -76,21 +77,41 @@ def exchange_by_leaf(engine, world, device, wire_device=None):
     keys, hi, cnt, part_counts, leaf_counts = exp
     send_l = [int(x) for x in part_counts]
     recv_l = [int(g[0]) for g in got]
-    n_send, n_recv = sum(send_l), sum(recv_l)
+    lc = leaf_counts.view(torch.int32).reshape(world, -1)                  # [world][leaves_per_part]
+    lpp = lc.shape[1]
+    lw = (lpp + 1) // 2                                                   # words of a segment's leaf counts
 
-    def a2a(t):
-        src = t[:n_send].contiguous().to(wire)
-        out = torch.empty(n_recv, dtype=t.dtype, device=wire)
-        dist.all_to_all_single(out, src, recv_l, send_l)
-        return out.to(device)
+    def words(n):                                                         # words of a segment with n entries
+        return lw + n * (2 if hi is not None else 1) + (n + 1) // 2
 
-    rkeys = a2a(keys.view(torch.int64))
-    rhi = a2a(hi.view(torch.int64)) if hi is not None else None
-    rcnt = a2a(cnt.view(torch.int32))
-    lc = leaf_counts.view(torch.int32).contiguous().to(wire)        # [world][leaves_per_part]
-    rlc = torch.empty_like(lc)
-    dist.all_to_all_single(rlc, lc)
-    rlc = rlc.to(device)
+    def pad32(t):                                                         # int32 vector -> whole int64 words (a copy:
+        return torch.cat([t, t.new_zeros(t.numel() % 2)]).view(torch.int64)   # a slice may start on an odd element)
+
+    k64, c32 = keys.view(torch.int64), cnt.view(torch.int32)
+    h64 = hi.view(torch.int64) if hi is not None else None
+    parts, off = [], 0
+    for p, n in enumerate(send_l):
+        parts.append(pad32(lc[p]))
+        parts.append(k64[off:off + n])
+        if h64 is not None:
+            parts.append(h64[off:off + n])
+        parts.append(pad32(c32[off:off + n]))
+        off += n
+    src = torch.cat(parts).to(wire)
+    out = torch.empty(sum(words(n) for n in recv_l), dtype=torch.int64, device=wire)
+    dist.all_to_all_single(out, src, [words(n) for n in recv_l], [words(n) for n in send_l])
+    out = out.to(device)
+    rk, rh, rc, rl, off = [], [], [], [], 0
+    for n in recv_l:
+        rl.append(out[off:off + lw].view(torch.int32)[:lpp]); off += lw
+        rk.append(out[off:off + n]); off += n
+        if h64 is not None:
+            rh.append(out[off:off + n]); off += n
+        rc.append(out[off:off + (n + 1) // 2].view(torch.int32)[:n]); off += (n + 1) // 2
+    rkeys = torch.cat(rk)
+    rhi = torch.cat(rh) if h64 is not None else None
+    rcnt = torch.cat(rc).contiguous()
+    rlc = torch.cat(rl).contiguous()
     _fence(device)
     return rkeys, rhi, rcnt, recv_l, rlc
 
