@@ -867,7 +867,9 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
   __shared__ int sp;
   __shared__ uint32_t leaf_total, nseg;
   const int tid = threadIdx.x, lane = tid & 63;
-  const uint32_t leaf = blockIdx.x;
+  // (the grid holds the leaves of this pass only: were the others launched and left at once, the
+  //  pass's leaves -- equal low bits -- would all sit on 8 / 2^sel_bits of the 8 XCDs)
+  const uint32_t leaf = (blockIdx.x << v.sel_bits) | v.sel_val;
   const uint64_t nt = min((uint64_t)v.cnt2[NCLS * leaf + 0], v.exact ? (uint64_t)v.lcap[NCLS * leaf + 0] : v.cap2t);  // truncated runs
   const uint64_t n1 = min((uint64_t)v.cnt2[NCLS * leaf + 1], v.exact ? (uint64_t)v.lcap[NCLS * leaf + 1] : v.cap2c);  // complete runs
   const uint4 *leaf_rec = v.exact ? v.rec2 + v.lbase[NCLS * leaf + 1] : v.rec2 + (uint64_t)(leaf >> v.sel_bits) * (v.cap2c + v.cap2t);
@@ -1832,8 +1834,8 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
   }
   const bool runs_only = (ctx->g_flags & CFRK_RUNS_ONLY) != 0;
   if (runs_only) hipLaunchKernelGGL(msp_dedupe_export_kernel, dim3(NLEAF), dim3(DX_THREADS), 0, ctx->stream, k, v);
-  else if (canon) hipLaunchKernelGGL((msp_p3_kernel<true>), dim3(NLEAF), dim3(P3_THREADS), 0, ctx->stream, k, 0u, v, t);
-  else hipLaunchKernelGGL((msp_p3_kernel<false>), dim3(NLEAF), dim3(P3_THREADS), 0, ctx->stream, k, 0u, v, t);
+  else if (canon) hipLaunchKernelGGL((msp_p3_kernel<true>), dim3((unsigned)NLEAF >> sel_bits), dim3(P3_THREADS), 0, ctx->stream, k, 0u, v, t);
+  else hipLaunchKernelGGL((msp_p3_kernel<false>), dim3((unsigned)NLEAF >> sel_bits), dim3(P3_THREADS), 0, ctx->stream, k, 0u, v, t);
   HIP_TRY(ctx, hipGetLastError());
   ms->pending = !runs_only;
   ms->runs_ready = runs_only;

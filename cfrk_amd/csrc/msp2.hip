@@ -26,7 +26,7 @@ namespace {
 constexpr int W2 = 18;
 constexpr int Q1_THREADS = 512, Q1_WAVES = Q1_THREADS / 64;
 constexpr int Q1_OWN = 60;                 // owner lanes 1..60; lane 0 and lanes 61..63 are halo lanes
-constexpr int Q1_RCAP = 1536;              // 32-byte records staged in LDS per workgroup (48 KB: three workgroups per CU)
+constexpr int Q1_RCAP_BASE = 1536;         // 32-byte records staged in LDS per workgroup (48 KB: three workgroups per CU)
 constexpr int Q2_THREADS = 1024, Q2_PER = 2, Q2_TILE = Q2_THREADS * Q2_PER;
 constexpr int Q2_GROUP = 4;                      // consecutive tiles per workgroup (next tile prefetched)
 constexpr int Q3_THREADS = 1024;
@@ -46,6 +46,7 @@ struct View2 {
   Rec2 *ovf; uint32_t ovf_cap;                           // parking for a few overflowing records
   uint32_t dbg;                                          // cfrk_debug_set_flags
   uint32_t sel_mask, sel_val, sel_bits;                  // leaf subset of this pass (msp.h: MspView)
+  uint32_t sub_bits;                                     // records carry so many more minimizer-hash bits in b.z (0: none)
   uint64_t *stats;
 };
 
@@ -127,11 +128,11 @@ __device__ __forceinline__ uint32_t q1_reg(uint32_t bin, uint32_t xg) { return x
 // lane i builds the wave's i-th record; records wait in registers for the bin offsets and go to
 // LDS in bin order (the staging bytes are reused).
 constexpr int Q1_TR = 3;                           // balanced trips held in registers (192 runs per wave; ~131 expected at k = 63, ~170 at k = 33)
-constexpr int Q1_STAGE = 4096 + 3 * 512 + Q1_TR * 128;        // staging bytes per wave
-static_assert(Q1_WAVES * Q1_STAGE <= Q1_RCAP * 32, "staging fits the record arena");
+constexpr int Q1_STAGE_BASE = 4096 + 3 * 512 + Q1_TR * 128;   // staging bytes per wave
 
 struct Stage2 {
   const uint16_t *leaf; const uint32_t *str; const uint64_t *E, *Wv;
+  const uint8_t *sub;            // SUB_BITS more bits of the minimizer hash per position, or nullptr
 };
 // record of the run that starts at window position d & 31 of lane d >> 5
 __device__ __forceinline__ Rec2 q1_build(const Stage2 &st, uint32_t d, int k, int c) {
@@ -159,14 +160,24 @@ __device__ __forceinline__ Rec2 q1_build(const Stage2 &st, uint32_t d, int k, in
   }
   Rec2 rec;
   rec.a = make_uint4(T[0], T[1], T[2], T[3]);
-  rec.b = make_uint4(T[4], T[5], 0u, (leaf << 8) | complete | (uint32_t)(n - 1));
+  rec.b = make_uint4(T[4], T[5], st.sub ? (uint32_t)st.sub[d] : 0u, (leaf << 8) | complete | (uint32_t)(n - 1));
   return rec;
 }
 
-__global__ __launch_bounds__(Q1_THREADS, 6) void msp2_p1_kernel(const int8_t *__restrict__ data, int64_t nN,
+// SUB: a job with far more distinct k-mers than the leaf tables hold (capacity hint > ~2.7e8) also
+// stages SUB_BITS bits of every position's minimizer hash that the leaf id does not use (bits 24..27
+// and 7 of the packed minimum: hash bits, equal for every occurrence of a k-mer) and writes them to
+// the record's spare word: the leaf kernel then splits an overfull leaf by RECORD, not by key, so
+// that every record is expanded once.  2 KB more staging per wave: two workgroups per CU.
+constexpr int SUB_BITS = 5;
+template <bool SUB>
+__global__ __launch_bounds__(Q1_THREADS, (SUB ? 4 : 6)) void msp2_p1_kernel(const int8_t *__restrict__ data, int64_t nN,
                                                              int k, int m, int c, int canon, int64_t tile0,
                                                              View2 v, TableView t) {
   constexpr int NH = 32 + W2 - 1;
+  constexpr int Q1_STAGE = Q1_STAGE_BASE + (SUB ? 2048 : 0);
+  constexpr int Q1_RCAP = SUB ? 2048 : Q1_RCAP_BASE;
+  static_assert(Q1_WAVES * Q1_STAGE <= Q1_RCAP * 32, "staging fits the record arena");
   __shared__ Rec2 arena[Q1_RCAP];                  // per-wave staging, later the bin-sorted records
   __shared__ uint32_t hist[B1], loff[B1], gbase[B1];
   __shared__ uint32_t wtot[4];
@@ -178,6 +189,7 @@ __global__ __launch_bounds__(Q1_THREADS, 6) void msp2_p1_kernel(const int8_t *__
   uint64_t *const s_E = reinterpret_cast<uint64_t *>(stage + 4096 + 512);     // run terminators
   uint64_t *const s_W = reinterpret_cast<uint64_t *>(stage + 4096 + 1024);    // validity of position p-1
   uint16_t *const s_dsc = reinterpret_cast<uint16_t *>(stage + 4096 + 1536);  // (lane << 5) | position
+  uint8_t *const s_sub = stage + Q1_STAGE_BASE;                                // [64 lanes][32 positions] (SUB only)
 
   if (tid < B1) hist[tid] = 0;
   __syncthreads();
@@ -237,8 +249,24 @@ __global__ __launch_bounds__(Q1_THREADS, 6) void msp2_p1_kernel(const int8_t *__
     reinterpret_cast<uint2 *>(s_str)[lane] = make_uint2(b0, b1);
     s_E[lane] = E;
     s_W[lane] = (Vx >> 1) | ((uint64_t)prevV << 63);
+    if (SUB) {
+      uint32_t sw[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        uint32_t x = 0;
+#pragma unroll
+        for (int j = 3; j >= 0; --j) {
+          const uint32_t h = H[4 * i + j];
+          x = (x << 8) | (((h >> 24) & 15u) << 1) | ((h >> 7) & 1u);
+        }
+        sw[i] = x;
+      }
+      uint4 *sp = reinterpret_cast<uint4 *>(s_sub + lane * 32);
+      sp[0] = make_uint4(sw[0], sw[1], sw[2], sw[3]);
+      sp[1] = make_uint4(sw[4], sw[5], sw[6], sw[7]);
+    }
   }
-  const Stage2 st = {s_leaf, s_str, s_E, s_W};
+  const Stage2 st = {s_leaf, s_str, s_E, s_W, SUB ? s_sub : nullptr};
   uint32_t cnt_w;
   uint32_t widx, S2 = 0;                           // S2: run starts beyond the balanced phase's capacity
   const uint32_t wcap = (v.dbg & CFRK_DEBUG_SMALL_WAVE_CAP) ? 64u : (uint32_t)(Q1_TR * 64);
@@ -638,7 +666,7 @@ __device__ __forceinline__ void r2_insert_loop(Rec2 *rtab, const Rec2 &rec, uint
     if (p && empty) {
       if (atomicCAS(&words[8 * hh + 7], R2_EMPTY, R2_LOCK) == R2_EMPTY) {
         rtab[hh].a = rec.a;
-        words[8 * hh + 4] = rec.b.x; words[8 * hh + 5] = rec.b.y;
+        words[8 * hh + 4] = rec.b.x; words[8 * hh + 5] = rec.b.y; words[8 * hh + 6] = rec.b.z;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         atomicExch(&words[8 * hh + 7], (1u << 6) | nm1);
         won = 1u;
@@ -673,7 +701,18 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
   __shared__ int sp;
   __shared__ uint32_t leaf_total, nseg;
   const int tid = threadIdx.x, lane = tid & 63;
-  const uint32_t leaf = blockIdx.x;
+  // sub_bits > 0: 2^sub_bits workgroups share a leaf, each taking the records whose extra
+  // minimizer-hash bits (b.z, written by msp2_p1_kernel<true>) name it -- every occurrence of a
+  // k-mer has the same minimizer, so the workgroups' key sets are disjoint.  The workgroups of a
+  // leaf run next to each other on one XCD (workgroup b goes to XCD b % 8), whose L2 then serves
+  // all but the first read of the leaf's streams.
+  const uint32_t rmask = (1u << v.sub_bits) - 1u;
+  const uint32_t vq = blockIdx.x >> 3;
+  const uint32_t rsel = vq & rmask;
+  // (the grid holds the leaves of this pass only: were the others launched and left at once, the
+  //  pass's leaves -- equal low bits -- would all sit on 8 / 2^sel_bits of the 8 XCDs)
+  const uint32_t leaf = (((((vq >> v.sub_bits) << 3) | (blockIdx.x & 7u))) << v.sel_bits) | v.sel_val;
+  auto mine = [&](const Rec2 &r) { return (r.b.z & rmask) == rsel; };
   uint64_t ns[NCLS];
   uint64_t total = 0;
 #pragma unroll
@@ -732,21 +771,40 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
       const uint32_t p0 = __builtin_amdgcn_ds_permute(da, rec.a.x), p1 = __builtin_amdgcn_ds_permute(da, rec.a.y);
       const uint32_t p2 = __builtin_amdgcn_ds_permute(da, rec.a.z), p3 = __builtin_amdgcn_ds_permute(da, rec.a.w);
       const uint32_t p4 = __builtin_amdgcn_ds_permute(da, rec.b.x), p5 = __builtin_amdgcn_ds_permute(da, rec.b.y);
+      const uint32_t p6 = __builtin_amdgcn_ds_permute(da, rec.b.z);
       const uint32_t p7 = __builtin_amdgcn_ds_permute(da, rec.b.w), ph = __builtin_amdgcn_ds_permute(da, h);
       const bool take = lane >= c && lane < c + n;
       Lr.a.x = take ? p0 : Lr.a.x; Lr.a.y = take ? p1 : Lr.a.y; Lr.a.z = take ? p2 : Lr.a.z; Lr.a.w = take ? p3 : Lr.a.w;
-      Lr.b.x = take ? p4 : Lr.b.x; Lr.b.y = take ? p5 : Lr.b.y; Lr.b.w = take ? p7 : Lr.b.w;
+      Lr.b.x = take ? p4 : Lr.b.x; Lr.b.y = take ? p5 : Lr.b.y; Lr.b.z = take ? p6 : Lr.b.z; Lr.b.w = take ? p7 : Lr.b.w;
       Lh = take ? ph : Lh;
       c += n;
     };
-    Rec2 nxt = zrec;
-    if ((uint64_t)tid < ns[3]) nxt = leaf_rec[tid];
-    for (uint64_t r = tid; r < ((ns[3] + 63) & ~63ull); r += Q3_THREADS) {
-      const bool valid = r < ns[3];
-      const Rec2 rec = nxt;
-      nxt = zrec;
-      if (r + Q3_THREADS < ns[3]) nxt = leaf_rec[r + Q3_THREADS];
-      home(rec, valid);
+    if (v.sub_bits == 0u) {
+      Rec2 nxt = zrec;
+      if ((uint64_t)tid < ns[3]) nxt = leaf_rec[tid];
+      for (uint64_t r = tid; r < ((ns[3] + 63) & ~63ull); r += Q3_THREADS) {
+        const bool valid = r < ns[3];
+        const Rec2 rec = nxt;
+        nxt = zrec;
+        if (r + Q3_THREADS < ns[3]) nxt = leaf_rec[r + Q3_THREADS];
+        home(rec, valid);
+      }
+    } else {
+      // a shared leaf: most records read here are another workgroup's.  Four loads are in flight per
+      // lane (the stream comes from the XCD's L2, and latency, not work, bounds this loop)
+      for (uint64_t r = tid; r < ((ns[3] + 63) & ~63ull); r += 4 * Q3_THREADS) {
+        Rec2 q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          q[u] = zrec;
+          if (r + (uint64_t)u * Q3_THREADS < ns[3]) q[u] = leaf_rec[r + (uint64_t)u * Q3_THREADS];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (r + (uint64_t)u * Q3_THREADS >= ((ns[3] + 63) & ~63ull)) break;      // (wave-uniform)
+          home(q[u], r + (uint64_t)u * Q3_THREADS < ns[3] && mine(q[u]));
+        }
+      }
     }
     if (c) drain(c);
   }
@@ -779,7 +837,7 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
         // no dedupe: the leaf holds thousands of distinct runs.  Start with as many key subsets as
         // its size suggests (one per ~6000 records, 4 .. 32) instead of finding out by overflowing
         uint32_t b0 = 2u;
-        while (b0 < 5u && (total >> b0) > 6000ull) ++b0;
+        while (b0 < 5u && (total >> (b0 + v.sub_bits)) > 6000ull) ++b0;
         for (uint32_t q = 0; q < (1u << b0); ++q) stk[q] = (b0 << 16) | q;
         sp = (int)(1u << b0);
       } else { stk[0] = 0u; sp = 1; }
@@ -801,14 +859,20 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
   {
     constexpr uint32_t TW_NONE = 0xFFFFFFFFu, TW_TWIN = 0x80000000u;
     uint32_t tw[TL2_PER], trank[TL2_PER];
+    Rec2 tq[TL2_PER];                                  // (all loads first: their latencies overlap)
 #pragma unroll
     for (int i = 0; i < TL2_PER; ++i) {
       const uint32_t g = (uint32_t)(i * Q3_THREADS + tid);
-      const bool valid = anchors_on && g < tl;
+      tq[i] = zrec;
+      if (anchors_on && g < tl) tq[i] = *trunc_at(g);
+    }
+#pragma unroll
+    for (int i = 0; i < TL2_PER; ++i) {
+      const uint32_t g = (uint32_t)(i * Q3_THREADS + tid);
+      Rec2 rec = tq[i];
+      const bool valid = anchors_on && g < tl && mine(rec);
       tw[i] = TW_NONE; trank[i] = 0u;
       if (!anchors_on || !__ballot(valid)) continue;
-      Rec2 rec = zrec;
-      if (valid) rec = *trunc_at(g);
       const uint32_t nm1 = rec.b.w & 31u;
       if (valid) tw[i] = nm1;
       const bool lc = (rec.b.w & 64u) != 0u, rc_ = (rec.b.w & 128u) != 0u;
@@ -913,7 +977,7 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
         if (valid) rec = *trunc_at(flist[i]);
         count_record2<CANON>(keys, cnts, rec, 1u, valid, k, t, ss, ovf);
       }
-    } else {
+    } else if (v.sub_bits == 0u) {
       for (uint64_t r = tid; r < ((ns[3] + 63) & ~63ull); r += Q3_THREADS) {
         const bool valid = r < ns[3];
         Rec2 rec = zrec;
@@ -921,18 +985,63 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
         count_record2<CANON>(keys, cnts, rec, 1u, valid, k, t, ss, ovf);
       }
     }
-    for (int cl = 2; cl >= 0; --cl) {
-      const Rec2 *src = v.exact ? v.rec2 + v.lbase[NCLS * leaf + cl] : leaf_rec + v.cap2c + (uint64_t)cl * v.cap2t;
-      Rec2 nxt = zrec;
-      const uint64_t r_first = (uint64_t)cov[cl] + tid;        // (the anchored ones are done)
-      if (r_first < ns[cl]) nxt = src[r_first];
-      for (uint64_t r = r_first; r < (uint64_t)cov[cl] + ((ns[cl] - cov[cl] + 63) & ~63ull); r += Q3_THREADS) {
-        const bool valid = r < ns[cl];
-        const Rec2 rec = nxt;
-        nxt = zrec;
-        if (r + Q3_THREADS < ns[cl]) nxt = src[r + Q3_THREADS];
-        count_record2<CANON>(keys, cnts, rec, 1u, valid, k, t, ss, ovf);
+    if (v.sub_bits == 0u) {
+      for (int cl = 2; cl >= 0; --cl) {
+        const Rec2 *src = v.exact ? v.rec2 + v.lbase[NCLS * leaf + cl] : leaf_rec + v.cap2c + (uint64_t)cl * v.cap2t;
+        Rec2 nxt = zrec;
+        const uint64_t r_first = (uint64_t)cov[cl] + tid;        // (the anchored ones are done)
+        if (r_first < ns[cl]) nxt = src[r_first];
+        for (uint64_t r = r_first; r < (uint64_t)cov[cl] + ((ns[cl] - cov[cl] + 63) & ~63ull); r += Q3_THREADS) {
+          const bool valid = r < ns[cl];
+          const Rec2 rec = nxt;
+          nxt = zrec;
+          if (r + Q3_THREADS < ns[cl]) nxt = src[r + Q3_THREADS];
+          count_record2<CANON>(keys, cnts, rec, 1u, valid, k, t, ss, ovf);
+        }
       }
+    } else {
+      // a shared leaf: one lane in 2^sub_bits holds a record of this workgroup.  They are gathered
+      // across the wave into full sets of 64 before they are expanded (lock-step: a wave expands
+      // for as long as its longest record, however few of its lanes hold one)
+      Rec2 Sr = zrec;
+      int sc = 0;                        // wave-uniform
+      auto sflush = [&]() {
+        count_record2<CANON>(keys, cnts, Sr, 1u, lane < sc, k, t, ss, ovf);
+        sc = 0;
+      };
+      auto sfeed = [&](const Rec2 &rec, bool keep) {
+        const unsigned long long mask = __ballot(keep);
+        if (mask == 0ull) return;
+        const int n = __popcll(mask);
+        if (sc + n > 64) sflush();
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        const int dst = keep ? (sc + rank) : ((sc + n) & 63);    // the others aim at a lane nobody keeps
+        const int da = dst << 2;
+        const uint32_t p0 = __builtin_amdgcn_ds_permute(da, rec.a.x), p1 = __builtin_amdgcn_ds_permute(da, rec.a.y);
+        const uint32_t p2 = __builtin_amdgcn_ds_permute(da, rec.a.z), p3 = __builtin_amdgcn_ds_permute(da, rec.a.w);
+        const uint32_t p4 = __builtin_amdgcn_ds_permute(da, rec.b.x), p5 = __builtin_amdgcn_ds_permute(da, rec.b.y);
+        const uint32_t p7 = __builtin_amdgcn_ds_permute(da, rec.b.w);
+        const bool take = lane >= sc && lane < sc + n;
+        Sr.a.x = take ? p0 : Sr.a.x; Sr.a.y = take ? p1 : Sr.a.y; Sr.a.z = take ? p2 : Sr.a.z; Sr.a.w = take ? p3 : Sr.a.w;
+        Sr.b.x = take ? p4 : Sr.b.x; Sr.b.y = take ? p5 : Sr.b.y; Sr.b.w = take ? p7 : Sr.b.w;
+        sc += n;
+      };
+      for (int cl = big ? 3 : 2; cl >= 0; --cl) {
+        const Rec2 *src = (cl == 3) ? leaf_rec
+                          : v.exact ? v.rec2 + v.lbase[NCLS * leaf + cl] : leaf_rec + v.cap2c + (uint64_t)cl * v.cap2t;
+        const uint64_t done = (cl == 3) ? 0ull : (uint64_t)cov[cl];   // (the anchored ones are done)
+        Rec2 nxt = zrec;
+        const uint64_t r_first = done + tid;
+        if (r_first < ns[cl]) nxt = src[r_first];
+        for (uint64_t r = r_first; r < done + ((ns[cl] - done + 63) & ~63ull); r += Q3_THREADS) {
+          const Rec2 rec = nxt;
+          const bool keep = r < ns[cl] && mine(rec);
+          nxt = zrec;
+          if (r + Q3_THREADS < ns[cl]) nxt = src[r + Q3_THREADS];
+          sfeed(rec, keep);
+        }
+      }
+      if (sc) sflush();
     }
     __syncthreads();
     if (kovf) {
@@ -959,11 +1068,15 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
     __syncthreads();
     if (tid == 0) {
       wg_base = atomicAdd((unsigned long long *)&v.stats[ST_CURSOR], (unsigned long long)wg_total);
-      if (nseg == 0) v.leaf_off[leaf] = wg_base;
-      else if (wg_total) v.stats[ST_MULTISEG] = 1;
-      if (wg_total) nseg = nseg + 1;
-      leaf_total += wg_total;
-      v.leaf_n[leaf] = leaf_total;
+      if (v.sub_bits) {
+        if (wg_total) v.stats[ST_MULTISEG] = 1;          // the leaf's entries come from several workgroups
+      } else {
+        if (nseg == 0) v.leaf_off[leaf] = wg_base;
+        else if (wg_total) v.stats[ST_MULTISEG] = 1;
+        if (wg_total) nseg = nseg + 1;
+        leaf_total += wg_total;
+        v.leaf_n[leaf] = leaf_total;
+      }
     }
     __syncthreads();
     const unsigned long long gb = wg_base;
@@ -1120,6 +1233,14 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)(NLEAF >> sel_bits) * (cap2c + 3 * cap2t) * sizeof(Rec2), &p))) return rc;
   v.rec2 = (Rec2 *)p; v.cap2c = cap2c; v.cap2t = cap2t;
   v.sel_mask = (1u << sel_bits) - 1u; v.sel_val = sel_val; v.sel_bits = (uint32_t)sel_bits;
+  // far more distinct k-mers expected than the leaf tables hold (65536 x ~2500): records carry extra
+  // minimizer-hash bits and 2^sub_bits workgroups share a leaf (~2000 distinct k-mers each)
+  uint32_t sub_bits = 0;
+  while (sub_bits < (uint32_t)SUB_BITS && ((ctx->g_cap / NLEAF) >> sub_bits) > 2048u) ++sub_bits;
+  if (ctx->g_cap / NLEAF <= 4096u) sub_bits = 0;
+  if ((ctx->dbg_flags & CFRK_DEBUG_RECORD_SUBSETS) && sub_bits < 2u) sub_bits = 2u;
+  const bool sub = sub_bits != 0u;
+  v.sub_bits = sub_bits;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_AUX, (size_t)NLEAF * 8 + (size_t)(B1 * NXG + (NCLS + 1) * NLEAF) * sizeof(uint32_t), &p))) return rc;
   v.leaf_off = (uint64_t *)p;
   v.cnt1 = (uint32_t *)(v.leaf_off + NLEAF); v.cnt2 = v.cnt1 + B1 * NXG; v.leaf_n = v.cnt2 + NCLS * NLEAF;
@@ -1135,8 +1256,10 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
   // (cnt1, cnt2 and -- first pass only -- the leaf index and the list cursor)
   HIP_TRY(ctx, hipMemsetAsync(v.cnt1, 0, (size_t)(B1 * NXG + (NCLS + (first ? 1 : 0)) * NLEAF) * sizeof(uint32_t), ctx->stream));
   if (first) HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_CURSOR, 0, sizeof(uint64_t), ctx->stream));
-  hipLaunchKernelGGL(msp2_p1_kernel, dim3((unsigned)ntiles), dim3(Q1_THREADS), 0, ctx->stream, d_data, nN, k, m, c,
-                     canon, tile0, v, t);
+  if (sub) hipLaunchKernelGGL((msp2_p1_kernel<true>), dim3((unsigned)ntiles), dim3(Q1_THREADS), 0, ctx->stream, d_data, nN, k, m, c,
+                              canon, tile0, v, t);
+  else hipLaunchKernelGGL((msp2_p1_kernel<false>), dim3((unsigned)ntiles), dim3(Q1_THREADS), 0, ctx->stream, d_data, nN, k, m, c,
+                          canon, tile0, v, t);
   HIP_TRY(ctx, hipGetLastError());
   v.exact = 0; v.lbase = nullptr; v.lcap = nullptr;
   constexpr uint32_t OVF_CAP = 1u << 19;
@@ -1173,8 +1296,8 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
       HIP_TRY(ctx, hipGetLastError());
     }
   }
-  if (canon) hipLaunchKernelGGL((msp2_p3_kernel<true>), dim3(NLEAF), dim3(Q3_THREADS), 0, ctx->stream, k, v, t);
-  else hipLaunchKernelGGL((msp2_p3_kernel<false>), dim3(NLEAF), dim3(Q3_THREADS), 0, ctx->stream, k, v, t);
+  if (canon) hipLaunchKernelGGL((msp2_p3_kernel<true>), dim3(((unsigned)NLEAF >> sel_bits) << v.sub_bits), dim3(Q3_THREADS), 0, ctx->stream, k, v, t);
+  else hipLaunchKernelGGL((msp2_p3_kernel<false>), dim3(((unsigned)NLEAF >> sel_bits) << v.sub_bits), dim3(Q3_THREADS), 0, ctx->stream, k, v, t);
   HIP_TRY(ctx, hipGetLastError());
   ms->view.out_keys = v.out_lo; ms->view.out_hi = v.out_hi; ms->view.out_cnt = v.out_cnt;
   ms->view.out_cap = v.out_cap; ms->view.stats = v.stats; ms->view.cnt1 = nullptr;
@@ -1194,7 +1317,7 @@ int cfrk_msp2_merge_lists(cfrk_ctx *ctx, const uint64_t *d_lo, const uint64_t *d
   v.rec1 = nullptr; v.cnt1 = nullptr; v.cap1 = 0; v.rec2 = nullptr; v.cnt2 = nullptr; v.cap2c = v.cap2t = 0;
   v.out_lo = ms->view.out_keys; v.out_hi = ms->view.out_hi; v.out_cnt = ms->view.out_cnt; v.out_cap = ms->view.out_cap;
   v.leaf_off = nullptr; v.leaf_n = nullptr; v.stats = ctx->g_stats;
-  v.exact = 0; v.lbase = nullptr; v.lcap = nullptr; v.ovf = nullptr; v.ovf_cap = 0; v.sel_mask = v.sel_val = v.sel_bits = 0; v.dbg = 0;
+  v.exact = 0; v.lbase = nullptr; v.lcap = nullptr; v.ovf = nullptr; v.ovf_cap = 0; v.sel_mask = v.sel_val = v.sel_bits = 0; v.sub_bits = 0; v.dbg = 0;
   hipLaunchKernelGGL(msp2_merge_kernel, dim3(leaves_per_part), dim3(Q3_THREADS), 0, ctx->stream, d_lo, d_hi, d_cnt,
                      d_seg_off, d_seg_n, parts, leaves_per_part, v, cfrk_table_view(ctx));
   HIP_TRY(ctx, hipGetLastError());

@@ -206,6 +206,10 @@ int cfrk_debug_last_add_passes(cfrk_ctx *ctx, int *out_passes);
 /* Bit 2: the leaf kernel of the one-word partitioned path counts every truncated run k-mer by k-mer
  * instead of noting it with the complete run it is a prefix of (same result; for A/B timing and tests). */
 #define CFRK_DEBUG_NO_ANCHORS 0x4
+/* Bit 3: the two-word partitioned path (33 <= k <= 64) writes the extra minimizer-hash bits into its
+ * records and splits overfull leaves by record whatever the capacity hint (normally only for hints
+ * above ~2.7e8 distinct k-mers): makes that path reachable with small inputs (tests). */
+#define CFRK_DEBUG_RECORD_SUBSETS 0x8
 int cfrk_debug_set_flags(cfrk_ctx *ctx, uint32_t flags);
 
 /* ---- synthetic reads, generated on device ----------------------------------- */

@@ -908,3 +908,34 @@ def test_cli_global_over_several_devices_equals_one_device(tmp_path):
             subprocess.check_call([cli, str(fa), str(many), str(k), "--global", "--gpus", str(n), "--same-device"] + extra)
             assert many.read_bytes() == one.read_bytes()
         assert one.stat().st_size > 100_000
+
+
+def test_two_word_leaves_with_more_keys_than_their_table_are_split_by_record(ctx):
+    """k = 63, all-distinct input with ~4000 distinct k-mers per leaf (the LDS table has 4096 slots):
+    with a capacity hint above 2.7e8 the records carry more minimizer-hash bits and several workgroups
+    share a leaf, each taking the records its bits name (every record expanded once); with a smaller
+    hint an overfull leaf is split by key.  Both give the digest of the general HBM-table path."""
+    import cfrk_amd
+    R, L, k = 3_000_000, 150, 63
+    data, _, _ = orc.synth_reads(0, R, L, 0, uniform=True)             # 2.64e8 k-mers, ~all distinct
+    K = R * (L - k + 1)
+    digests = []
+    for hint in (300_000_000, 134_000_000):                            # record subsets on / off
+        g = cfrk_amd.GlobalCounter(ctx, k, cfrk_amd.CFRK_CANONICAL, hint)
+        g.add(data)
+        d = g.digest()
+        assert d[1] == K and d[0] > 0.999 * K
+        digests.append(d)
+        del g
+    gh = cfrk_amd.GlobalCounter(ctx, k, cfrk_amd.CFRK_CANONICAL | cfrk_amd.CFRK_FORCE_HASH, 300_000_000)
+    gh.add(data)
+    assert digests[0] == digests[1] == gh.digest()
+    # the same switch on a small, deep input (anchored truncated runs, record table in use)
+    small, _, _ = orc.synth_reads(0, 40_000, 150, 30_000)
+    want = orc.global_count(small, k, orc.ORC_CANONICAL, threads=4)
+    g = cfrk_amd.GlobalCounter(ctx, k, cfrk_amd.CFRK_CANONICAL, 100_000)
+    g.set_debug_flags(cfrk_amd.lib.CFRK_DEBUG_RECORD_SUBSETS)
+    g.add(small)
+    lo, hi, cnt = g.export()
+    g.set_debug_flags(0)
+    assert (lo == want[0]).all() and (hi == want[1]).all() and (cnt.astype(np.uint64) == want[2]).all()
