@@ -1323,21 +1323,30 @@ __global__ __launch_bounds__(P3_THREADS) void msp_merge_kernel(const uint64_t *_
 // of a multi-GPU job holds ~2000 complete runs per leaf; the 65536 workgroups are mostly fixed cost.
 // A leaf with more distinct runs than the table holds leaves as it is (multiplicity 1 each): the
 // owner's table merges what can be merged.
+// Truncated runs (read ends: two per read, each unique -- most of what a rank would ship) are then
+// looked up in the same table, exactly as the leaf kernel anchors them: one that is a prefix of a
+// distinct complete run of this rank (a suffix, read on the other strand; canonical counting only)
+// is replaced by a 16-bit NOTE, position of that run in the leaf's list << 5 | n-1.  The owner
+// rebuilds the run from its twin.  A noted record is marked in place (w = RUN_NOTED, x = the note);
+// leaf_off[leaf] = how many were noted.
 constexpr int DX_THREADS = 256;
-__global__ __launch_bounds__(DX_THREADS) void msp_dedupe_export_kernel(int k, MspView v) {
+constexpr uint32_t RUN_NOTED = 0xFFFFFFFFu;        // (a record's header word has the top 8 bits clear)
+constexpr int NOTES_PER_ROW = 8;
+__global__ __launch_bounds__(DX_THREADS) void msp_dedupe_export_kernel(int k, int canon, MspView v) {
   __shared__ uint4 rtab[RT];
+  __shared__ uint16_t sidx[RT];                    // record-table slot -> position in the leaf's list
   __shared__ uint32_t wsum[DX_THREADS / 64];
-  __shared__ uint32_t rt_fail;
+  __shared__ uint32_t rt_fail, noted;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t leaf = blockIdx.x;
   const uint64_t n1 = min((uint64_t)v.cnt2[NCLS * leaf + 1], v.exact ? (uint64_t)v.lcap[NCLS * leaf + 1] : v.cap2c);
   if (n1 == 0) return;
   uint4 *const stream = v.exact ? v.rec2 + v.lbase[NCLS * leaf + 1] : v.rec2 + (uint64_t)(leaf >> v.sel_bits) * (v.cap2c + v.cap2t);
   for (int s = tid; s < RT; s += DX_THREADS) rtab[s] = make_uint4(0u, 0u, 0u, RT_EMPTY);
-  if (tid == 0) rt_fail = (v.dbg & CFRK_DEBUG_FORCE_RT_OVERFLOW) ? 1u : 0u;
+  if (tid == 0) { rt_fail = (v.dbg & CFRK_DEBUG_FORCE_RT_OVERFLOW) ? 1u : 0u; noted = 0u; }
   __syncthreads();
+  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
   {
-    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
     uint32_t *rmeta = reinterpret_cast<uint32_t *>(rtab);
     uint4 L = zero4;                 // leftover records, lanes [0, c) (see the leaf kernel's phase 1a)
     uint32_t Lh = 0;
@@ -1401,11 +1410,42 @@ __global__ __launch_bounds__(DX_THREADS) void msp_dedupe_export_kernel(int k, Ms
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const uint4 e = rtab[PER * tid + i];
+      sidx[PER * tid + i] = (uint16_t)at;
       if (e.w != RT_EMPTY) stream[at++] = e;
     }
     nd = total;
+    __syncthreads();
+    // truncated runs -> notes (the lookup of the leaf kernel's anchoring, msp_p3_kernel)
+    const uint64_t nt = min((uint64_t)v.cnt2[NCLS * leaf + 0], v.exact ? (uint64_t)v.lcap[NCLS * leaf + 0] : v.cap2t);
+    uint4 *const trunc = v.exact ? v.rec2 + v.lbase[NCLS * leaf + 0] : stream + v.cap2c;
+    for (uint64_t g = tid; g < ((nt + 63) & ~63ull) && !(v.dbg & CFRK_DEBUG_NO_ANCHORS); g += DX_THREADS) {
+      const bool valid = g < nt;
+      uint4 rec = zero4;
+      if (valid) rec = trunc[g];
+      const uint32_t nm1 = rec.w & 31u;
+      const bool lc = (rec.w & 64u) != 0u, rc_ = (rec.w & 128u) != 0u;
+      const bool suf = canon && valid && !lc && rc_;
+      if (suf) rec = revcomp_record(rec, (int)nm1 + k);
+      const bool anchored = suf || (valid && lc && !rc_);
+      uint32_t h = anchored ? rtab_slot_k(rec, k, RT_LOG) : RT_DONE;
+      uint32_t found = 0xFFFFFFFFu;
+      for (int it = 0; it < 32 && __ballot((int32_t)h >= 0); ++it) {
+        const bool p = (int32_t)h >= 0;
+        const uint32_t hh = h & (uint32_t)(RT - 1);
+        const uint4 e2 = rtab[hh];
+        const bool empty = e2.w == RT_EMPTY;
+        const bool hit = p && !empty && (e2.w & 31u) >= nm1 && rec_prefix_equal(e2, rec, (int)nm1 + k);
+        found = hit ? hh : found;
+        h = (p && !hit && !empty) ? ((hh + 1u) & (uint32_t)(RT - 1)) : (h | RT_DONE);
+      }
+      const bool hit = found != 0xFFFFFFFFu;
+      if (hit) { trunc[g].x = ((uint32_t)sidx[found] << 5) | nm1; trunc[g].w = RUN_NOTED; }
+      const unsigned long long hb = __ballot(hit);
+      if (lane == 0 && hb) atomicAdd(&noted, (uint32_t)__popcll(hb));
+    }
+    __syncthreads();
   }
-  if (tid == 0) v.leaf_n[leaf] = nd;
+  if (tid == 0) { v.leaf_n[leaf] = nd; v.leaf_off[leaf] = noted; }
 }
 
 // ---------------------------------------------------------------------------- multi-GPU by runs
@@ -1447,16 +1487,22 @@ __global__ __launch_bounds__(1024) void msp_runs_plan_kernel(MspView v, int part
   __shared__ unsigned long long seg[65];          // first row of every owner's segment
   const int tid = threadIdx.x;
   const int n = parts * lpp, per = (n + 1023) / 1024;
-  auto sizes = [&](int i, uint32_t &n1, uint32_t &nt) {
+  // n1 distinct complete runs, nt truncated runs as records, na as notes; rows in all
+  auto sizes = [&](int i, uint32_t &n1, uint32_t &nt, uint32_t &na) -> uint64_t {
     const int p = i / lpp, j = i - p * lpp, leaf = p + j * parts;
-    n1 = 0; nt = 0;
+    n1 = 0; nt = 0; na = 0;
     if (i < n && leaf < NLEAF) {
       nt = (uint32_t)min((uint64_t)v.cnt2[NCLS * leaf + 0], v.exact ? (uint64_t)v.lcap[NCLS * leaf + 0] : v.cap2t);
-      n1 = v.cnt2[NCLS * leaf + 1] ? v.leaf_n[leaf] : 0u;      // (a leaf without complete runs never wrote its count)
+      if (v.cnt2[NCLS * leaf + 1]) {                           // (a leaf without complete runs never wrote its counts)
+        n1 = v.leaf_n[leaf];
+        na = min((uint32_t)v.leaf_off[leaf], nt);
+      }
+      nt -= na;
     }
+    return (uint64_t)n1 + nt + (na + NOTES_PER_ROW - 1) / NOTES_PER_ROW;
   };
   uint64_t mine = 0;
-  for (int q = 0; q < per; ++q) { uint32_t a, b; sizes(tid * per + q, a, b); mine += (uint64_t)a + b; }
+  for (int q = 0; q < per; ++q) { uint32_t a, b, c; mine += sizes(tid * per + q, a, b, c); }
   uint64_t total;
   const uint64_t run0 = block_scan_u64(mine, wtot, &total);
   const uint64_t all_rows = total + (uint64_t)parts * hrows;
@@ -1467,9 +1513,8 @@ __global__ __launch_bounds__(1024) void msp_runs_plan_kernel(MspView v, int part
     if (i >= n) break;
     const int p = i / lpp, j = i - p * lpp;
     if (j == 0) seg[p] = run + (uint64_t)p * hrows;
-    uint32_t a, b;
-    sizes(i, a, b);
-    run += (uint64_t)a + b;
+    uint32_t a, b, c;
+    run += sizes(i, a, b, c);
   }
   __syncthreads();
   if (tid < parts) part_rows[tid] = seg[tid + 1] - seg[tid];
@@ -1479,12 +1524,12 @@ __global__ __launch_bounds__(1024) void msp_runs_plan_kernel(MspView v, int part
     const int i = tid * per + q;
     if (i >= n) break;
     const int p = i / lpp, j = i - p * lpp, leaf = p + j * parts;
-    uint32_t a, b;
-    sizes(i, a, b);
+    uint32_t a, b, c;
+    const uint64_t rows = sizes(i, a, b, c);
     if (leaf < NLEAF) dst_off[leaf] = run + (uint64_t)(p + 1) * hrows;
     uint32_t *hdr = reinterpret_cast<uint32_t *>(packed + seg[p]);
-    hdr[2 * j] = a; hdr[2 * j + 1] = b;
-    run += (uint64_t)a + b;
+    hdr[3 * j] = a; hdr[3 * j + 1] = b; hdr[3 * j + 2] = c;
+    run += rows;
   }
 }
 
@@ -1503,8 +1548,16 @@ __global__ __launch_bounds__(1024) void msp_runs_layout_kernel(const uint4 *__re
   // (1) every rank's segments: record offsets inside its part of the buffer
   for (int r = 0; r < parts; ++r) {
     const uint32_t *hdr = reinterpret_cast<const uint32_t *>(packed + rr.rstart[r]);
+    auto rows_of = [&](int ll) {
+      return (uint64_t)hdr[3 * ll] + hdr[3 * ll + 1] + ((uint64_t)hdr[3 * ll + 2] + NOTES_PER_ROW - 1) / NOTES_PER_ROW;
+    };
     uint64_t mine = 0;
-    for (int q = 0; q < per; ++q) { const int ll = tid * per + q; if (ll < lpp) mine += (uint64_t)hdr[2 * ll] + hdr[2 * ll + 1]; }
+    for (int q = 0; q < per; ++q) {
+      const int ll = tid * per + q;
+      if (ll >= lpp) break;
+      mine += rows_of(ll);
+      if (hdr[3 * ll + 2] && !hdr[3 * ll]) err = 1;            // notes without a run they could point at
+    }
     uint64_t total;
     uint64_t run = block_scan_u64(mine, wtot, &total);
     if (total + (uint64_t)hrows != rr.rows[r]) err = 1;
@@ -1512,7 +1565,7 @@ __global__ __launch_bounds__(1024) void msp_runs_layout_kernel(const uint4 *__re
       const int ll = tid * per + q;
       if (ll >= lpp) break;
       src[(size_t)r * lpp + ll] = rr.rstart[r] + (uint64_t)hrows + run;
-      run += (uint64_t)hdr[2 * ll] + hdr[2 * ll + 1];
+      run += rows_of(ll);
     }
   }
   // (2) the owner's leaves = local indices: stream (ll, class) = the ranks' parts in rank order, complete stream first
@@ -1522,7 +1575,7 @@ __global__ __launch_bounds__(1024) void msp_runs_layout_kernel(const uint4 *__re
     if (ll >= lpp) break;
     for (int r = 0; r < parts; ++r) {
       const uint32_t *hdr = reinterpret_cast<const uint32_t *>(packed + rr.rstart[r]);
-      mine += (uint64_t)hdr[2 * ll] + hdr[2 * ll + 1];
+      mine += (uint64_t)hdr[3 * ll] + hdr[3 * ll + 1] + hdr[3 * ll + 2];      // (a note becomes a record again)
     }
   }
   uint64_t total;
@@ -1534,12 +1587,12 @@ __global__ __launch_bounds__(1024) void msp_runs_layout_kernel(const uint4 *__re
     for (int r = 0; r < parts; ++r) {
       const uint32_t *hdr = reinterpret_cast<const uint32_t *>(packed + rr.rstart[r]);
       d1[(size_t)r * lpp + ll] = run + n1;
-      n1 += hdr[2 * ll];
+      n1 += hdr[3 * ll];
     }
     for (int r = 0; r < parts; ++r) {
       const uint32_t *hdr = reinterpret_cast<const uint32_t *>(packed + rr.rstart[r]);
       d0[(size_t)r * lpp + ll] = run + n1 + n0;
-      n0 += hdr[2 * ll + 1];
+      n0 += (uint64_t)hdr[3 * ll + 1] + hdr[3 * ll + 2];
     }
     if (n1 > 0xFFFFFFFFull || n0 > 0xFFFFFFFFull) err = 1;
     lbase[(size_t)NCLS * ll + 1] = run; lcap[(size_t)NCLS * ll + 1] = (uint32_t)n1; cnt2[(size_t)NCLS * ll + 1] = (uint32_t)n1;
@@ -1550,32 +1603,75 @@ __global__ __launch_bounds__(1024) void msp_runs_layout_kernel(const uint4 *__re
   if (err) out[1] = 1;
 }
 
-// sender: leaf -> [nd distinct complete runs][nt truncated runs] at record dst_off[leaf] of the send buffer
+// sender: leaf -> [nd distinct complete runs][nu truncated runs][na notes, 8 per row] at record
+// dst_off[leaf] of the send buffer (the truncated stream holds records and noted records mixed)
 __global__ __launch_bounds__(256) void msp_runs_gather_kernel(MspView v, const uint64_t *__restrict__ dst_off, uint4 *__restrict__ out,
                                                               const uint64_t *__restrict__ plan_rows, int parts, uint64_t cap_rows) {
+  __shared__ uint32_t cu, cn;
   if (plan_rows[parts] > cap_rows) return;         // the buffer is too small: nothing was planned
   const uint32_t leaf = blockIdx.x;
-  const uint32_t nd = v.cnt2[NCLS * leaf + 1] ? v.leaf_n[leaf] : 0u;
+  const int lane = threadIdx.x & 63;
+  const bool has1 = v.cnt2[NCLS * leaf + 1] != 0u;
+  const uint32_t nd = has1 ? v.leaf_n[leaf] : 0u;
   const uint32_t nt = (uint32_t)min((uint64_t)v.cnt2[NCLS * leaf + 0], v.exact ? (uint64_t)v.lcap[NCLS * leaf + 0] : v.cap2t);
+  const uint32_t na = has1 ? min((uint32_t)v.leaf_off[leaf], nt) : 0u;
+  const uint32_t nu = nt - na;
   const uint4 *c1 = v.exact ? v.rec2 + v.lbase[NCLS * leaf + 1] : v.rec2 + (uint64_t)(leaf >> v.sel_bits) * (v.cap2c + v.cap2t);
   const uint4 *c0 = v.exact ? v.rec2 + v.lbase[NCLS * leaf + 0] : c1 + v.cap2c;
   uint4 *dst = out + dst_off[leaf];
   for (uint32_t i = threadIdx.x; i < nd; i += blockDim.x) dst[i] = c1[i];
-  for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) dst[nd + i] = c0[i];
+  if (na == 0u) {
+    for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) dst[nd + i] = c0[i];
+    return;
+  }
+  if (threadIdx.x == 0) { cu = 0u; cn = 0u; }
+  __syncthreads();
+  uint16_t *notes = reinterpret_cast<uint16_t *>(dst + nd + nu);
+  for (uint32_t i = threadIdx.x; i < ((nt + 63u) & ~63u); i += blockDim.x) {
+    const bool valid = i < nt;
+    uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+    if (valid) rec = c0[i];
+    const bool isn = valid && rec.w == RUN_NOTED;
+    const unsigned long long mn = __ballot(isn), mu = __ballot(valid && !isn);
+    uint32_t bn = 0, bu = 0;
+    if (lane == 0) {
+      if (mn) bn = atomicAdd(&cn, (uint32_t)__popcll(mn));
+      if (mu) bu = atomicAdd(&cu, (uint32_t)__popcll(mu));
+    }
+    bn = __shfl(bn, 0); bu = __shfl(bu, 0);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    // (the counts of the plan bound both: a stream that changed under us cannot write outside the leaf's rows)
+    if (isn) { const uint32_t at = bn + (uint32_t)__popcll(mn & below); if (at < na) notes[at] = (uint16_t)rec.x; }
+    else if (valid) { const uint32_t at = bu + (uint32_t)__popcll(mu & below); if (at < nu) dst[nd + at] = rec; }
+  }
+  const uint32_t pad = (NOTES_PER_ROW - na % NOTES_PER_ROW) % NOTES_PER_ROW;
+  if (threadIdx.x < pad) notes[na + threadIdx.x] = 0xFFFFu;
 }
 
 // owner: segment (source rank, local leaf) of the received buffer -> its place in the leaf's two streams
-__global__ __launch_bounds__(256) void msp_runs_scatter_kernel(const uint4 *__restrict__ in, RunsRecv rr, int lpp,
+// A note becomes the run it stands for: the first n k-mers of its twin, closed on the left only (a
+// prefix -- of the twin as the sender stored it, whichever strand the read showed).
+__global__ __launch_bounds__(256) void msp_runs_scatter_kernel(const uint4 *__restrict__ in, RunsRecv rr, int lpp, int k,
                                                                const uint64_t *__restrict__ src_off,
                                                                const uint64_t *__restrict__ dst1, const uint64_t *__restrict__ dst0,
                                                                uint4 *__restrict__ rec2) {
   const uint32_t seg = blockIdx.x;
   const uint32_t r = seg / (uint32_t)lpp, ll = seg - r * (uint32_t)lpp;
   const uint32_t *hdr = reinterpret_cast<const uint32_t *>(in + rr.rstart[r]);
-  const uint32_t nd = hdr[2 * ll], nt = hdr[2 * ll + 1];
+  const uint32_t nd = hdr[3 * ll], nt = hdr[3 * ll + 1], na = hdr[3 * ll + 2];
   const uint4 *src = in + src_off[seg];
   for (uint32_t i = threadIdx.x; i < nd; i += blockDim.x) rec2[dst1[seg] + i] = src[i];
   for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) rec2[dst0[seg] + i] = src[nd + i];
+  const uint16_t *notes = reinterpret_cast<const uint16_t *>(src + nd + nt);
+  for (uint32_t i = threadIdx.x; i < na; i += blockDim.x) {          // (nd > 0: the layout kernel checked)
+    const uint32_t note = notes[i];
+    const uint4 twin = src[min(note >> 5, nd - 1u)];                  // a position outside the list is not followed
+    const uint32_t nm1 = min(note & 31u, twin.w & 31u);
+    const int rb = 2 * ((int)nm1 + k) - 32;                           // bits of the run beyond the first word: 0 .. 64
+    const uint32_t my = (rb >= 32) ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> rb);
+    const uint32_t mz = (rb <= 32) ? 0u : ((rb >= 64) ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> (rb - 32)));
+    rec2[dst0[seg] + nt + i] = make_uint4(twin.x, twin.y & my, twin.z & mz, 64u | nm1);
+  }
 }
 
 // exact layout of a level from the demand the first attempt counted: base = exclusive prefix sum
@@ -1833,7 +1929,7 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
     HIP_TRY(ctx, hipGetLastError());
   }
   const bool runs_only = (ctx->g_flags & CFRK_RUNS_ONLY) != 0;
-  if (runs_only) hipLaunchKernelGGL(msp_dedupe_export_kernel, dim3(NLEAF), dim3(DX_THREADS), 0, ctx->stream, k, v);
+  if (runs_only) hipLaunchKernelGGL(msp_dedupe_export_kernel, dim3(NLEAF), dim3(DX_THREADS), 0, ctx->stream, k, canon, v);
   else if (canon) hipLaunchKernelGGL((msp_p3_kernel<true>), dim3((unsigned)NLEAF >> sel_bits), dim3(P3_THREADS), 0, ctx->stream, k, 0u, v, t);
   else hipLaunchKernelGGL((msp_p3_kernel<false>), dim3((unsigned)NLEAF >> sel_bits), dim3(P3_THREADS), 0, ctx->stream, k, 0u, v, t);
   HIP_TRY(ctx, hipGetLastError());
@@ -2112,9 +2208,10 @@ extern "C" int cfrk_global_merge_leaves_device(cfrk_ctx *ctx, const uint64_t *d_
 }
 
 // ------------------------------------------------------------------ multi-GPU exchange by runs
-// Packed form, one segment per owner: [header: the owner's leaves_per_part x (distinct, truncated)
-// sizes, uint32 pairs, padded to whole 16-byte rows][the records, leaf after leaf].
-static int runs_header_rows(int lpp) { return (lpp * 2 * (int)sizeof(uint32_t) + 15) / 16; }
+// Packed form, one segment per owner: [header: the owner's leaves_per_part x (distinct, truncated,
+// noted) sizes, uint32 triples, padded to whole 16-byte rows][leaf after leaf: the distinct complete
+// runs, the truncated runs, the notes (16 bits each, eight per row)].
+static int runs_header_rows(int lpp) { return (lpp * 3 * (int)sizeof(uint32_t) + 15) / 16; }
 
 extern "C" int cfrk_global_export_runs_device(cfrk_ctx *ctx, void *d_packed, uint64_t cap_rows, int parts,
                                               uint64_t *part_rows) {
@@ -2174,11 +2271,8 @@ extern "C" int cfrk_global_merge_runs_device(cfrk_ctx *ctx, const void *d_packed
     rr.rstart[r] = rows_all; rr.rows[r] = recv_rows[r];
     rows_all += recv_rows[r];
   }
-  // the leaf streams can never hold more than what arrived
   MspView &v = ms->view;
   memset(&v, 0, sizeof v);
-  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)(rows_all ? rows_all : 1) * sizeof(uint4), &p))) return rc;
-  v.rec2 = (uint4 *)p;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_AUX, (size_t)NLEAF * 8 + (size_t)(B1 * NXG + (NCLS + 1) * NLEAF) * sizeof(uint32_t), &p))) return rc;
   v.leaf_off = (uint64_t *)p;
   v.cnt1 = (uint32_t *)(v.leaf_off + NLEAF); v.nxg = NXG; v.cnt2 = v.cnt1 + B1 * NXG; v.leaf_n = v.cnt2 + NCLS * NLEAF;
@@ -2206,7 +2300,11 @@ extern "C" int cfrk_global_merge_runs_device(cfrk_ctx *ctx, const void *d_packed
   HIP_TRY(ctx, hipMemcpyAsync(h, d_out, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (h[1]) return cfrk_fail(ctx, CFRK_ERR_ARG, "a rank's header does not add up to the rows it sent");
-  hipLaunchKernelGGL(msp_runs_scatter_kernel, dim3((unsigned)nseg), dim3(256), 0, ctx->stream, (const uint4 *)d_packed, rr, lpp,
+  // the leaf streams: what arrived, every note a record again (h[0] records; at most eight per row)
+  if (h[0] > rows_all * NOTES_PER_ROW) return cfrk_fail(ctx, CFRK_ERR_ARG, "the headers announce more records than the rows can hold");
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)(h[0] ? h[0] : 1) * sizeof(uint4), &p))) return rc;
+  v.rec2 = (uint4 *)p;
+  hipLaunchKernelGGL(msp_runs_scatter_kernel, dim3((unsigned)nseg), dim3(256), 0, ctx->stream, (const uint4 *)d_packed, rr, lpp, k,
                      (const uint64_t *)d_src, (const uint64_t *)d_d1, (const uint64_t *)d_d0, v.rec2);
   HIP_TRY(ctx, hipGetLastError());
   if (canon) hipLaunchKernelGGL((msp_p3_kernel<true>), dim3(lpp), dim3(P3_THREADS), 0, ctx->stream, k, P3_WEIGHTED, v, t);

@@ -821,8 +821,46 @@ def test_runs_exchange_emulated_ranks_equals_one_gpu_and_oracle(ctx, k, canonica
     assert all(merged[int(a)] == int(b) for a, b in zip(wlo, wcnt))
     # deduplication really happened on the ranks: far fewer records than super-k-mers (8 per read at least)
     lpp = (65536 + world - 1) // world
+    # ... and read ends travel as 2-byte notes: before they alone were 2 rows per read
     if G <= 30_000:
-        assert total_rows - world * world * ((lpp * 8 + 15) // 16) < 6 * R
+        assert total_rows - world * world * ((lpp * 12 + 15) // 16) < 3 * R
+
+
+def test_runs_exchange_notes_outnumber_the_rows_that_carry_them(ctx):
+    """300 k reads of a 1200-base genome on two emulated ranks: 600 k read ends travel as 75 k rows of
+    notes, so an owner's leaf streams hold several times more records than the rows it received (the
+    streams are sized from the headers, not from the rows); result = the oracle's, key by key"""
+    import cfrk_amd
+    R, L, k, world = 300_000, 150, 31, 2
+    data, _, _ = orc.synth_reads(0, R, L, 1_200)
+    sends = []
+    for r in range(world):
+        g = cfrk_amd.GlobalCounter(ctx, k, cfrk_amd.CFRK_CANONICAL | cfrk_amd.CFRK_RUNS_ONLY, 10_000)
+        g.add(data[(R * r // world) * (L + 1):(R * (r + 1) // world) * (L + 1)])
+        cap = 1 << 20
+        d = ctx.alloc(cap * 16)
+        rows = g.export_runs_device(d, cap, world)
+        host = np.empty((sum(rows), 2), np.uint64)
+        ctx.d2h(host, d)
+        ctx.free(d)
+        sends.append((host, rows))
+    lpp = 65536 // world
+    assert sum(sum(rows) for _, rows in sends) < R           # 2 R read ends and the headers in fewer than R rows
+    keys, cnts = [], []
+    for owner in range(world):
+        segs = [host[sum(rows[:owner]):sum(rows[:owner + 1])] for host, rows in sends]
+        buf = np.concatenate(segs)
+        d = ctx.alloc(len(buf) * 16)
+        ctx.h2d(d, buf)
+        og = cfrk_amd.GlobalCounter(ctx, k, cfrk_amd.CFRK_CANONICAL, 10_000)
+        og.merge_runs_device(d, [len(x) for x in segs])
+        lo, hi, cnt = og.export()
+        ctx.free(d)
+        keys.append(lo); cnts.append(cnt)
+    lo = np.concatenate(keys); cnt = np.concatenate(cnts)
+    order = np.argsort(lo)
+    wlo, _, wcnt = orc.global_count(data, k, orc.ORC_CANONICAL, threads=8)
+    assert len(lo) == len(wlo) and (lo[order] == wlo).all() and (cnt[order].astype(np.uint64) == wcnt).all()
 
 
 def test_runs_exchange_call_sequence_and_malformed_messages(ctx):
@@ -875,6 +913,33 @@ def test_runs_exchange_call_sequence_and_malformed_messages(ctx):
         og2.merge_runs_device(d, [rows[0] - 1, rows[0] + 1])
     assert e.value.code == -1
     assert og2.finish() == 0                                           # nothing of the refused message stays
+    # notes (16-bit stand-ins for truncated runs: position of the twin << 5 | n-1, after a leaf's records):
+    # one that points outside its leaf's list is not followed out of the segment, and a header that
+    # announces notes for a leaf without runs is refused
+    lpp = 65536 // 2
+    hdr = seg0.reshape(-1).view(np.uint32)[:3 * lpp].reshape(lpp, 3).copy()
+    rows_of = hdr[:, 0].astype(np.int64) + hdr[:, 1] + (hdr[:, 2].astype(np.int64) + 7) // 8
+    first = np.concatenate([[0], np.cumsum(rows_of)[:-1]]) + (lpp * 12 + 15) // 16
+    ll = int(np.argmax(hdr[:, 2] > 0))
+    assert hdr[ll, 2] > 0 and hdr[:, 2].sum() > 0.5 * (hdr[:, 1].sum() + hdr[:, 2].sum())   # most read ends are notes
+    bad = seg0.copy()
+    bad.reshape(-1).view(np.uint16)[8 * int(first[ll] + hdr[ll, 0] + hdr[ll, 1])] = (1023 << 5) | 31
+    ctx.h2d(d, np.concatenate([bad, seg0]))
+    og3 = cfrk_amd.GlobalCounter(ctx, 31, cfrk_amd.CFRK_CANONICAL, 100_000)
+    og3.merge_runs_device(d, [rows[0], rows[0]])
+    assert og3.finish() > 0
+    bad = seg0.copy()
+    bh = bad.reshape(-1).view(np.uint32)
+    empty = int(np.argmax((hdr[:, 0] == 0) & (hdr[:, 2] == 0)))
+    one = int(np.argmax(hdr[:, 2] % 8 == 1))                 # a leaf whose last note has a row of its own
+    assert hdr[empty, 0] == 0 and hdr[one, 2] % 8 == 1
+    bh[3 * one + 2] -= 1                                      # (the rows still add up)
+    bh[3 * empty + 2] = 1
+    ctx.h2d(d, np.concatenate([bad, seg0]))
+    og4 = cfrk_amd.GlobalCounter(ctx, 31, cfrk_amd.CFRK_CANONICAL, 100_000)
+    with pytest.raises(cfrk_amd.CfrkError) as e:
+        og4.merge_runs_device(d, [rows[0], rows[0]])
+    assert e.value.code == -1
     ctx.free(d)
 
 
