@@ -159,10 +159,13 @@ int cfrk_global_merge_leaves_device(cfrk_ctx *ctx, const uint64_t *d_keys, const
  * ranks every rank still meets almost every locus, so counting per rank and exchanging counted
  * k-mers makes every rank expand every distinct k-mer.  Instead a rank begins with CFRK_RUNS_ONLY,
  * adds its shard once (partition + deduplication only) and exports, per leaf, its distinct complete
- * runs with multiplicities followed by its truncated runs.  The export is PACKED for one all-to-all:
- * 16-byte rows, one segment per owner (owner p = leaves p, p+parts, ...) = a header (the owner's
- * leaves_per_part x (distinct, truncated) sizes as uint32 pairs, padded to whole rows) followed by
- * the records; part_rows[p] = rows of segment p.  The owner, on a context fresh from
+ * runs with multiplicities followed by its truncated runs (read ends).  A truncated run that is a
+ * prefix of one of the rank's own distinct complete runs is sent as a 16-bit NOTE (position of that
+ * run in the leaf's list << 5 | k-mers - 1) instead of a 16-byte record.  The export is PACKED for
+ * one all-to-all: 16-byte rows, one segment per owner (owner p = leaves p, p+parts, ...) = a header
+ * (the owner's leaves_per_part x (distinct, truncated, noted) sizes as uint32 triples, padded to
+ * whole rows) followed, leaf after leaf, by the distinct runs, the truncated runs and the notes
+ * (eight per row); part_rows[p] = rows of segment p.  The owner, on a context fresh from
  * cfrk_global_begin (same k and strand flag, without CFRK_RUNS_ONLY), passes the received segments
  * in rank order (recv_rows[r] rows from rank r): the lists of each of its leaves become that leaf's
  * streams and are expanded and counted once.  Afterwards the owner holds the final counts of its
