@@ -679,7 +679,9 @@ __device__ __forceinline__ void r2_insert_loop(Rec2 *rtab, const Rec2 &rec, uint
   }
 }
 
-template <bool CANON>
+// SHARED: 2^sub_bits workgroups per leaf (an instantiation of its own: the ordinary kernel is short
+// of scalar registers as it is)
+template <bool CANON, bool SHARED>
 __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, TableView t) {
   __shared__ ulonglong2 keys[T2];
   __shared__ uint32_t cnts[T2];
@@ -706,13 +708,14 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
   // k-mer has the same minimizer, so the workgroups' key sets are disjoint.  The workgroups of a
   // leaf run next to each other on one XCD (workgroup b goes to XCD b % 8), whose L2 then serves
   // all but the first read of the leaf's streams.
-  const uint32_t rmask = (1u << v.sub_bits) - 1u;
+  const uint32_t sub_bits = SHARED ? v.sub_bits : 0u;
+  const uint32_t rmask = (1u << sub_bits) - 1u;
   const uint32_t vq = blockIdx.x >> 3;
   const uint32_t rsel = vq & rmask;
   // (the grid holds the leaves of this pass only: were the others launched and left at once, the
   //  pass's leaves -- equal low bits -- would all sit on 8 / 2^sel_bits of the 8 XCDs)
-  const uint32_t leaf = (((((vq >> v.sub_bits) << 3) | (blockIdx.x & 7u))) << v.sel_bits) | v.sel_val;
-  auto mine = [&](const Rec2 &r) { return (r.b.z & rmask) == rsel; };
+  const uint32_t leaf = (SHARED ? ((((vq >> sub_bits) << 3) | (blockIdx.x & 7u))) : blockIdx.x) << v.sel_bits | v.sel_val;
+  auto mine = [&](const Rec2 &r) { return !SHARED || (r.b.z & rmask) == rsel; };
   uint64_t ns[NCLS];
   uint64_t total = 0;
 #pragma unroll
@@ -771,7 +774,7 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
       const uint32_t p0 = __builtin_amdgcn_ds_permute(da, rec.a.x), p1 = __builtin_amdgcn_ds_permute(da, rec.a.y);
       const uint32_t p2 = __builtin_amdgcn_ds_permute(da, rec.a.z), p3 = __builtin_amdgcn_ds_permute(da, rec.a.w);
       const uint32_t p4 = __builtin_amdgcn_ds_permute(da, rec.b.x), p5 = __builtin_amdgcn_ds_permute(da, rec.b.y);
-      const uint32_t p6 = __builtin_amdgcn_ds_permute(da, rec.b.z);
+      const uint32_t p6 = SHARED ? __builtin_amdgcn_ds_permute(da, rec.b.z) : 0u;
       const uint32_t p7 = __builtin_amdgcn_ds_permute(da, rec.b.w), ph = __builtin_amdgcn_ds_permute(da, h);
       const bool take = lane >= c && lane < c + n;
       Lr.a.x = take ? p0 : Lr.a.x; Lr.a.y = take ? p1 : Lr.a.y; Lr.a.z = take ? p2 : Lr.a.z; Lr.a.w = take ? p3 : Lr.a.w;
@@ -779,7 +782,7 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
       Lh = take ? ph : Lh;
       c += n;
     };
-    if (v.sub_bits == 0u) {
+    if (!SHARED) {
       Rec2 nxt = zrec;
       if ((uint64_t)tid < ns[3]) nxt = leaf_rec[tid];
       for (uint64_t r = tid; r < ((ns[3] + 63) & ~63ull); r += Q3_THREADS) {
@@ -837,7 +840,7 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
         // no dedupe: the leaf holds thousands of distinct runs.  Start with as many key subsets as
         // its size suggests (one per ~6000 records, 4 .. 32) instead of finding out by overflowing
         uint32_t b0 = 2u;
-        while (b0 < 5u && (total >> (b0 + v.sub_bits)) > 6000ull) ++b0;
+        while (b0 < 5u && (total >> (b0 + sub_bits)) > 6000ull) ++b0;
         for (uint32_t q = 0; q < (1u << b0); ++q) stk[q] = (b0 << 16) | q;
         sp = (int)(1u << b0);
       } else { stk[0] = 0u; sp = 1; }
@@ -859,20 +862,15 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
   {
     constexpr uint32_t TW_NONE = 0xFFFFFFFFu, TW_TWIN = 0x80000000u;
     uint32_t tw[TL2_PER], trank[TL2_PER];
-    Rec2 tq[TL2_PER];                                  // (all loads first: their latencies overlap)
 #pragma unroll
     for (int i = 0; i < TL2_PER; ++i) {
       const uint32_t g = (uint32_t)(i * Q3_THREADS + tid);
-      tq[i] = zrec;
-      if (anchors_on && g < tl) tq[i] = *trunc_at(g);
-    }
-#pragma unroll
-    for (int i = 0; i < TL2_PER; ++i) {
-      const uint32_t g = (uint32_t)(i * Q3_THREADS + tid);
-      Rec2 rec = tq[i];
-      const bool valid = anchors_on && g < tl && mine(rec);
+      bool valid = anchors_on && g < tl;
       tw[i] = TW_NONE; trank[i] = 0u;
       if (!anchors_on || !__ballot(valid)) continue;
+      Rec2 rec = zrec;
+      if (valid) rec = *trunc_at(g);
+      valid = valid && mine(rec);
       const uint32_t nm1 = rec.b.w & 31u;
       if (valid) tw[i] = nm1;
       const bool lc = (rec.b.w & 64u) != 0u, rc_ = (rec.b.w & 128u) != 0u;
@@ -977,7 +975,7 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
         if (valid) rec = *trunc_at(flist[i]);
         count_record2<CANON>(keys, cnts, rec, 1u, valid, k, t, ss, ovf);
       }
-    } else if (v.sub_bits == 0u) {
+    } else if (!SHARED) {
       for (uint64_t r = tid; r < ((ns[3] + 63) & ~63ull); r += Q3_THREADS) {
         const bool valid = r < ns[3];
         Rec2 rec = zrec;
@@ -985,7 +983,7 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
         count_record2<CANON>(keys, cnts, rec, 1u, valid, k, t, ss, ovf);
       }
     }
-    if (v.sub_bits == 0u) {
+    if (!SHARED) {
       for (int cl = 2; cl >= 0; --cl) {
         const Rec2 *src = v.exact ? v.rec2 + v.lbase[NCLS * leaf + cl] : leaf_rec + v.cap2c + (uint64_t)cl * v.cap2t;
         Rec2 nxt = zrec;
@@ -1068,7 +1066,7 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
     __syncthreads();
     if (tid == 0) {
       wg_base = atomicAdd((unsigned long long *)&v.stats[ST_CURSOR], (unsigned long long)wg_total);
-      if (v.sub_bits) {
+      if (SHARED) {
         if (wg_total) v.stats[ST_MULTISEG] = 1;          // the leaf's entries come from several workgroups
       } else {
         if (nseg == 0) v.leaf_off[leaf] = wg_base;
@@ -1296,8 +1294,16 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
       HIP_TRY(ctx, hipGetLastError());
     }
   }
-  if (canon) hipLaunchKernelGGL((msp2_p3_kernel<true>), dim3(((unsigned)NLEAF >> sel_bits) << v.sub_bits), dim3(Q3_THREADS), 0, ctx->stream, k, v, t);
-  else hipLaunchKernelGGL((msp2_p3_kernel<false>), dim3(((unsigned)NLEAF >> sel_bits) << v.sub_bits), dim3(Q3_THREADS), 0, ctx->stream, k, v, t);
+  {
+    const dim3 g3(((unsigned)NLEAF >> sel_bits) << v.sub_bits), b3(Q3_THREADS);
+    if (sub) {
+      if (canon) hipLaunchKernelGGL((msp2_p3_kernel<true, true>), g3, b3, 0, ctx->stream, k, v, t);
+      else hipLaunchKernelGGL((msp2_p3_kernel<false, true>), g3, b3, 0, ctx->stream, k, v, t);
+    } else {
+      if (canon) hipLaunchKernelGGL((msp2_p3_kernel<true, false>), g3, b3, 0, ctx->stream, k, v, t);
+      else hipLaunchKernelGGL((msp2_p3_kernel<false, false>), g3, b3, 0, ctx->stream, k, v, t);
+    }
+  }
   HIP_TRY(ctx, hipGetLastError());
   ms->view.out_keys = v.out_lo; ms->view.out_hi = v.out_hi; ms->view.out_cnt = v.out_cnt;
   ms->view.out_cap = v.out_cap; ms->view.stats = v.stats; ms->view.cnt1 = nullptr;
