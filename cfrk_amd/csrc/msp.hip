@@ -2085,13 +2085,15 @@ extern "C" int cfrk_debug_msp_info(cfrk_ctx *ctx, uint64_t out[9]) {
   if (!ctx || !out) return CFRK_ERR_ARG;
   cfrk_msp *ms = ctx->msp;
   for (int i = 0; i < 9; ++i) out[i] = 0;
-  if (!ms || !ms->view.cnt1) return CFRK_OK;
-  void *p;
-  int rc = cfrk_pool_get(ctx, BUF_SCRATCH, 64 * sizeof(uint64_t), &p);
-  if (rc) return rc;
-  hipLaunchKernelGGL(msp_info_kernel, dim3(1), dim3(1024), 0, ctx->stream, ms->view, (uint64_t *)p);
-  HIP_TRY(ctx, hipGetLastError());
-  HIP_TRY(ctx, hipMemcpyAsync(out, p, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  if (!ms) return CFRK_OK;
+  int rc;
+  if (ms->view.cnt1) {                                   // (the two-word path keeps no view of its record levels)
+    void *p;
+    if ((rc = cfrk_pool_get(ctx, BUF_SCRATCH, 64 * sizeof(uint64_t), &p))) return rc;
+    hipLaunchKernelGGL(msp_info_kernel, dim3(1), dim3(1024), 0, ctx->stream, ms->view, (uint64_t *)p);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(out, p, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  }
   uint64_t st[ST_NWORDS];
   rc = cfrk_msp_sync_stats(ctx, st);
   if (rc) return rc;

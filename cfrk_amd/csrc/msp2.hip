@@ -44,6 +44,9 @@ struct View2 {
   // starts at record lbase[NCLS * leaf + class] and holds exactly lcap[...] records
   const uint64_t *lbase; const uint32_t *lcap; uint32_t exact;
   Rec2 *ovf; uint32_t ovf_cap;                           // parking for a few overflowing records
+  // the same for the level-1 regions (msp.hip): region reg starts at record rbase[reg], holds rcap[reg]
+  const uint64_t *rbase; const uint32_t *rcap; uint32_t exact1;
+  Rec2 *ovf1; uint32_t ovf1_cap;
   uint32_t dbg;                                          // cfrk_debug_set_flags
   uint32_t sel_mask, sel_val, sel_bits;                  // leaf subset of this pass (msp.h: MspView)
   uint32_t sub_bits;                                     // records carry so many more minimizer-hash bits in b.z (0: none)
@@ -122,7 +125,23 @@ __device__ __noinline__ void spill_record2(uint4 ra, uint4 rb, int k, bool canon
 // ---------------------------------------------------------------------------------------- Q1
 // level-1 region / cursor of (bin, sub-region): sub-region major, so that a workgroup's 256
 // reservations (memory-side atomics, one request per touched 64 bytes) are 16 requests (msp.hip: l1_reg)
-__device__ __forceinline__ uint32_t q1_reg(uint32_t bin, uint32_t xg) { return xg * (uint32_t)B1 + bin; }
+__host__ __device__ __forceinline__ uint32_t q1_reg(uint32_t bin, uint32_t xg) { return xg * (uint32_t)B1 + bin; }
+__device__ __forceinline__ uint64_t q1_cap(const View2 &v, uint32_t reg) { return v.exact1 ? (uint64_t)v.rcap[reg] : v.cap1; }
+__device__ __forceinline__ uint64_t q1_at(const View2 &v, uint32_t reg) { return v.exact1 ? v.rbase[reg] : (uint64_t)reg * v.cap1; }
+// a record that found its level-1 region full: a few are parked (and counted through the HBM table
+// afterwards), beyond that ST_L1OVF is raised -- the cursors keep counting, and the host lays the
+// level out again with the exact sizes and reruns the kernel (msp.hip: l1_put)
+// (cold, and a leaf function: a whole view, or a call from here, would go through scratch memory)
+__device__ __noinline__ void q1_park(uint64_t *stats, Rec2 *ovf1, uint32_t ovf1_cap, uint4 ra, uint4 rb) {
+  if (*(volatile uint64_t *)&stats[ST_L1OVF] != 0) return;
+  const unsigned long long o = atomicAdd((unsigned long long *)&stats[ST_OVFN1], 1ull);
+  if (o < ovf1_cap) { ovf1[o].a = ra; ovf1[o].b = rb; }
+  else stats[ST_L1OVF] = 1;
+}
+__device__ __forceinline__ void q1_overflow(const View2 &v, uint4 ra, uint4 rb, int k, bool canon, const TableView &t) {
+  // (with the exact layout this cannot happen; if it does the flag makes the host try again and give up)
+  q1_park(v.stats, v.ovf1, v.exact1 ? 0u : v.ovf1_cap, ra, rb);
+}
 // Emission is wave-balanced as in msp.hip's msp_p1b_kernel: a lane lists its run starts, the wave
 // stages its base string, run terminators, validity and the leaf id of every position in LDS, and
 // lane i builds the wave's i-th record; records wait in registers for the bin offsets and go to
@@ -302,8 +321,8 @@ __global__ __launch_bounds__(Q1_THREADS, (SUB ? 4 : 6)) void msp2_p1_kernel(cons
     if (((rec.b.w >> 8) & v.sel_mask) != v.sel_val) continue;    // not a leaf of this pass
     const uint32_t reg = q1_reg(rec.b.w >> 16, blockIdx.x & (NXG - 1));
     const uint32_t dst = atomicAdd(&v.cnt1[reg], 1u);
-    if (dst < v.cap1) v.rec1[(uint64_t)reg * v.cap1 + dst] = rec;
-    else spill_record2(rec.a, rec.b, k, canon != 0, t);
+    if (dst < q1_cap(v, reg)) v.rec1[q1_at(v, reg) + dst] = rec;
+    else q1_overflow(v, rec.a, rec.b, k, canon != 0, t);
   }
 
   // ---- B2: lane i builds the wave's i-th record ----
@@ -345,8 +364,9 @@ __global__ __launch_bounds__(Q1_THREADS, (SUB ? 4 : 6)) void msp2_p1_kernel(cons
 
   // ---- D: copy out in bin order ----
   auto put = [&](uint32_t b, uint32_t dst, const Rec2 &rec) {
-    if (dst < v.cap1) v.rec1[(uint64_t)q1_reg(b, blockIdx.x & (NXG - 1)) * v.cap1 + dst] = rec;
-    else spill_record2(rec.a, rec.b, k, canon != 0, t);
+    const uint32_t reg = q1_reg(b, blockIdx.x & (NXG - 1));
+    if (dst < q1_cap(v, reg)) v.rec1[q1_at(v, reg) + dst] = rec;
+    else q1_overflow(v, rec.a, rec.b, k, canon != 0, t);
   };
   if (nrec_s > (uint32_t)Q1_RCAP) {                // records beyond the LDS arena go to their reserved places
 #pragma unroll
@@ -367,8 +387,9 @@ __global__ __launch_bounds__(Q1_THREADS, (SUB ? 4 : 6)) void msp2_p1_kernel(cons
     const uint32_t p = q >> 1;
     const uint32_t b = arena[p].b.w >> 16;
     const uint32_t dst = gbase[b] + (p - loff[b]);
-    if (dst < v.cap1) out4[((uint64_t)q1_reg(b, blockIdx.x & (NXG - 1)) * v.cap1 + dst) * 2 + (q & 1u)] = arena4[q];
-    else if (!(q & 1u)) spill_record2(arena[p].a, arena[p].b, k, canon != 0, t);
+    const uint32_t reg = q1_reg(b, blockIdx.x & (NXG - 1));
+    if (dst < q1_cap(v, reg)) out4[(q1_at(v, reg) + dst) * 2 + (q & 1u)] = arena4[q];
+    else if (!(q & 1u)) q1_overflow(v, arena[p].a, arena[p].b, k, canon != 0, t);
   }
 }
 
@@ -388,7 +409,7 @@ __global__ __launch_bounds__(Q2_THREADS) void msp2_p2_kernel(int groups_per_bin,
   const uint32_t grp = seq % (uint32_t)groups_per_bin;
   // the bin's sub-regions are read as one stream (as in msp.hip's P2)
   if (tid < 64) {
-    const uint32_t c = (tid < NXG) ? (uint32_t)min((uint64_t)v.cnt1[q1_reg(b1, tid)], v.cap1) : 0u;
+    const uint32_t c = (tid < NXG) ? (uint32_t)min((uint64_t)v.cnt1[q1_reg(b1, tid)], q1_cap(v, q1_reg(b1, tid))) : 0u;
     uint32_t incl = c;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -410,7 +431,7 @@ __global__ __launch_bounds__(Q2_THREADS) void msp2_p2_kernel(int groups_per_bin,
       const uint32_t mid = (lo + hi) >> 1;
       if (rpre[mid] <= idx) lo = mid; else hi = mid;
     }
-    return v.rec1[(uint64_t)q1_reg(b1, lo) * v.cap1 + (idx - rpre[lo])];
+    return v.rec1[q1_at(v, q1_reg(b1, lo)) + (idx - rpre[lo])];
   };
   const Rec2 zrec = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
   Rec2 nx[Q2_PER];
@@ -1095,13 +1116,14 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
 }
 
 // exact layout of the second level from the demand the first attempt counted (see msp.hip)
-__global__ __launch_bounds__(1024) void msp2_layout_kernel(const uint32_t *__restrict__ cnt2, uint64_t *__restrict__ lbase,
-                                                           uint32_t *__restrict__ lcap) {
+// (either level: base = exclusive prefix sum of the n cursors, cap = the cursors themselves)
+__global__ __launch_bounds__(1024) void msp2_layout_kernel(const uint32_t *__restrict__ cnt, uint32_t n, uint64_t *__restrict__ base,
+                                                           uint32_t *__restrict__ cap) {
   __shared__ unsigned long long part[1024];
-  constexpr int N = NCLS * NLEAF, PER = N / 1024;
-  const int tid = threadIdx.x;
+  const uint32_t per = (n + 1023u) / 1024u;
+  const uint32_t tid = threadIdx.x;
   unsigned long long s = 0;
-  for (int i = 0; i < PER; ++i) s += cnt2[tid * PER + i];
+  for (uint32_t i = 0; i < per; ++i) { const uint32_t l = tid * per + i; if (l < n) s += cnt[l]; }
   part[tid] = s;
   __syncthreads();
   if (tid == 0) {
@@ -1110,11 +1132,9 @@ __global__ __launch_bounds__(1024) void msp2_layout_kernel(const uint32_t *__res
   }
   __syncthreads();
   unsigned long long run = part[tid];
-  for (int i = 0; i < PER; ++i) {
-    const uint32_t c = cnt2[tid * PER + i];
-    lbase[tid * PER + i] = run;
-    lcap[tid * PER + i] = c;
-    run += c;
+  for (uint32_t i = 0; i < per; ++i) {
+    const uint32_t l = tid * per + i;
+    if (l < n) { const uint32_t c = cnt[l]; base[l] = run; cap[l] = c; run += c; }
   }
 }
 
@@ -1254,45 +1274,95 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
   // (cnt1, cnt2 and -- first pass only -- the leaf index and the list cursor)
   HIP_TRY(ctx, hipMemsetAsync(v.cnt1, 0, (size_t)(B1 * NXG + (NCLS + (first ? 1 : 0)) * NLEAF) * sizeof(uint32_t), ctx->stream));
   if (first) HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_CURSOR, 0, sizeof(uint64_t), ctx->stream));
-  if (sub) hipLaunchKernelGGL((msp2_p1_kernel<true>), dim3((unsigned)ntiles), dim3(Q1_THREADS), 0, ctx->stream, d_data, nN, k, m, c,
-                              canon, tile0, v, t);
-  else hipLaunchKernelGGL((msp2_p1_kernel<false>), dim3((unsigned)ntiles), dim3(Q1_THREADS), 0, ctx->stream, d_data, nN, k, m, c,
-                          canon, tile0, v, t);
-  HIP_TRY(ctx, hipGetLastError());
-  v.exact = 0; v.lbase = nullptr; v.lcap = nullptr;
+  // Both levels are laid out for an input that spreads evenly over the minimizer space; one that does
+  // not overflows its regions.  The cursors keep counting past the capacity, so after Q2 the host
+  // knows the exact demand of both levels (one D2H + stream sync per add): a few overflowing records
+  // were parked and are counted through the HBM table, more than that and the level is laid out again
+  // back to back with exactly the room each region needs, and its kernel runs again (msp.hip).
   constexpr uint32_t OVF_CAP = 1u << 19;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_OVF, (size_t)OVF_CAP * sizeof(Rec2), &p))) return rc;
   v.ovf = (Rec2 *)p; v.ovf_cap = (uint32_t)std::min<double>((double)OVF_CAP, expect / 256.0);
-  HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_L2OVF, 0, 2 * sizeof(uint64_t), ctx->stream));   // ST_L2OVF, ST_OVFN
-  hipLaunchKernelGGL(msp2_p2_kernel, dim3((unsigned)(tiles_per_sub * B1)), dim3(Q2_THREADS), 0, ctx->stream,
-                     (int)tiles_per_sub, k, canon, v, t);
-  HIP_TRY(ctx, hipGetLastError());
-  {
-    // leaf streams too small (deep coverage of a small genome)?  As in msp.hip: a few records are
-    // parked and counted through the HBM table, many make the host lay the streams out again
-    // with the exact sizes the cursors counted and rerun Q2.
-    uint64_t ovf[2] = {0, 0};                              // ST_L2OVF, ST_OVFN
-    HIP_TRY(ctx, hipMemcpyAsync(ovf, ctx->g_stats + ST_L2OVF, sizeof ovf, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (!ovf[0] && ovf[1]) {
-      const uint32_t n = (uint32_t)ovf[1];
-      hipLaunchKernelGGL(msp2_spill_list_kernel, dim3((n + 255u) / 256u), dim3(256), 0, ctx->stream, (const Rec2 *)v.ovf, n,
-                         k, canon, t);
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_OVF1, (size_t)OVF_CAP * sizeof(Rec2), &p))) return rc;
+  v.ovf1 = (Rec2 *)p; v.ovf1_cap = v.ovf_cap;
+  v.exact = 0; v.lbase = nullptr; v.lcap = nullptr;
+  v.exact1 = 0; v.rbase = nullptr; v.rcap = nullptr;
+  const size_t nreg = (size_t)B1 * NXG;
+  int64_t q2_groups = tiles_per_sub;             // tile groups per bin Q2 is launched with
+  bool run_q1 = true, settled = false;
+  uint64_t parked1 = 0, parked2 = 0;
+  for (int attempt = 0; attempt < 4; ++attempt) {
+    if (run_q1) {
+      HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_L1OVF, 0, 2 * sizeof(uint64_t), ctx->stream));   // ST_L1OVF, ST_OVFN1
+      if (sub) hipLaunchKernelGGL((msp2_p1_kernel<true>), dim3((unsigned)ntiles), dim3(Q1_THREADS), 0, ctx->stream, d_data, nN, k, m, c,
+                                  canon, tile0, v, t);
+      else hipLaunchKernelGGL((msp2_p1_kernel<false>), dim3((unsigned)ntiles), dim3(Q1_THREADS), 0, ctx->stream, d_data, nN, k, m, c,
+                              canon, tile0, v, t);
       HIP_TRY(ctx, hipGetLastError());
     }
-    if (ovf[0]) {
+    HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_L2OVF, 0, 2 * sizeof(uint64_t), ctx->stream));   // ST_L2OVF, ST_OVFN
+    hipLaunchKernelGGL(msp2_p2_kernel, dim3((unsigned)(q2_groups * B1)), dim3(Q2_THREADS), 0, ctx->stream,
+                       (int)q2_groups, k, canon, v, t);
+    HIP_TRY(ctx, hipGetLastError());
+    uint64_t st[ST_NWORDS];
+    HIP_TRY(ctx, hipMemcpyAsync(st, ctx->g_stats, sizeof st, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (st[ST_L1OVF]) {
+      // exact level-1 layout; Q2 ran on an incomplete level 1 and is redone as well
+      if ((rc = cfrk_pool_get(ctx, BUF_MSP_LAYOUT1, nreg * (sizeof(uint64_t) + sizeof(uint32_t)), &p))) return rc;
+      uint64_t *rbase = (uint64_t *)p;
+      uint32_t *rcap = (uint32_t *)(rbase + nreg);
+      hipLaunchKernelGGL(msp2_layout_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)v.cnt1, (uint32_t)nreg, rbase, rcap);
+      HIP_TRY(ctx, hipGetLastError());
+      {
+        // the heaviest bin decides how many tile groups per bin Q2 needs from now on
+        std::vector<uint32_t> c1(nreg);
+        HIP_TRY(ctx, hipMemcpyAsync(c1.data(), v.cnt1, nreg * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        uint64_t maxbin = 0, all = 0;
+        for (int b = 0; b < B1; ++b) {
+          uint64_t sum = 0;
+          for (int r = 0; r < NXG; ++r) sum += c1[q1_reg((uint32_t)b, (uint32_t)r)];
+          maxbin = std::max(maxbin, sum);
+          all += sum;
+        }
+        if (all > (uint64_t)B1 * NXG * cap1) {           // (more records than the density estimate allowed for)
+          if ((rc = cfrk_pool_get(ctx, BUF_MSP_L1, (size_t)all * sizeof(Rec2), &p))) return rc;
+          v.rec1 = (Rec2 *)p;
+        }
+        q2_groups = (int64_t)((maxbin + (uint64_t)Q2_TILE * Q2_GROUP - 1) / ((uint64_t)Q2_TILE * Q2_GROUP)) + 1;
+        if (q2_groups * B1 > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
+      }
+      HIP_TRY(ctx, hipMemsetAsync(v.cnt1, 0, (nreg + (size_t)NCLS * NLEAF) * sizeof(uint32_t), ctx->stream));   // cnt1 and cnt2
+      v.exact1 = 1; v.rbase = rbase; v.rcap = rcap;
+      run_q1 = true;
+      continue;
+    }
+    parked1 = st[ST_OVFN1];
+    if (st[ST_L2OVF]) {
       if ((rc = cfrk_pool_get(ctx, BUF_MSP_LAYOUT, (size_t)NCLS * NLEAF * (sizeof(uint64_t) + 2 * sizeof(uint32_t)), &p))) return rc;
       uint64_t *lbase = (uint64_t *)p;
       uint32_t *lcap = (uint32_t *)(lbase + NCLS * NLEAF);
-      hipLaunchKernelGGL(msp2_layout_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)v.cnt2, lbase, lcap);
+      hipLaunchKernelGGL(msp2_layout_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)v.cnt2, (uint32_t)(NCLS * NLEAF), lbase, lcap);
       HIP_TRY(ctx, hipGetLastError());
       HIP_TRY(ctx, hipMemsetAsync(v.cnt2, 0, (size_t)NCLS * NLEAF * sizeof(uint32_t), ctx->stream));
-      HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_L2OVF, 0, 2 * sizeof(uint64_t), ctx->stream));
       v.exact = 1; v.lbase = lbase; v.lcap = lcap;
-      hipLaunchKernelGGL(msp2_p2_kernel, dim3((unsigned)(tiles_per_sub * B1)), dim3(Q2_THREADS), 0, ctx->stream,
-                         (int)tiles_per_sub, k, canon, v, t);
-      HIP_TRY(ctx, hipGetLastError());
+      run_q1 = false;
+      continue;
     }
+    parked2 = st[ST_OVFN];
+    settled = true;
+    break;
+  }
+  if (!settled) return cfrk_fail(ctx, CFRK_ERR_STATE, "the record regions did not settle after an exact layout");
+  if (parked1) {
+    const uint32_t n = (uint32_t)std::min<uint64_t>(parked1, v.ovf1_cap);
+    hipLaunchKernelGGL(msp2_spill_list_kernel, dim3((n + 255u) / 256u), dim3(256), 0, ctx->stream, (const Rec2 *)v.ovf1, n, k, canon, t);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  if (parked2) {
+    const uint32_t n = (uint32_t)std::min<uint64_t>(parked2, v.ovf_cap);
+    hipLaunchKernelGGL(msp2_spill_list_kernel, dim3((n + 255u) / 256u), dim3(256), 0, ctx->stream, (const Rec2 *)v.ovf, n, k, canon, t);
+    HIP_TRY(ctx, hipGetLastError());
   }
   {
     const dim3 g3(((unsigned)NLEAF >> sel_bits) << v.sub_bits), b3(Q3_THREADS);
@@ -1324,6 +1394,7 @@ int cfrk_msp2_merge_lists(cfrk_ctx *ctx, const uint64_t *d_lo, const uint64_t *d
   v.out_lo = ms->view.out_keys; v.out_hi = ms->view.out_hi; v.out_cnt = ms->view.out_cnt; v.out_cap = ms->view.out_cap;
   v.leaf_off = nullptr; v.leaf_n = nullptr; v.stats = ctx->g_stats;
   v.exact = 0; v.lbase = nullptr; v.lcap = nullptr; v.ovf = nullptr; v.ovf_cap = 0; v.sel_mask = v.sel_val = v.sel_bits = 0; v.sub_bits = 0; v.dbg = 0;
+  v.exact1 = 0; v.rbase = nullptr; v.rcap = nullptr; v.ovf1 = nullptr; v.ovf1_cap = 0;
   hipLaunchKernelGGL(msp2_merge_kernel, dim3(leaves_per_part), dim3(Q3_THREADS), 0, ctx->stream, d_lo, d_hi, d_cnt,
                      d_seg_off, d_seg_n, parts, leaves_per_part, v, cfrk_table_view(ctx));
   HIP_TRY(ctx, hipGetLastError());

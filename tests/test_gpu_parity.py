@@ -359,6 +359,27 @@ def test_c5_high_collision_variant_small_genome(ctx, k):
     assert gh.digest() == g.digest() == orc.digest(wlo, whi, wcnt, two_word=k > 32)
 
 
+@pytest.mark.parametrize("k", [33, 63])
+def test_two_word_single_amplicon_overflows_its_level1_regions_and_is_laid_out_again(ctx, k):
+    """300 k copies of ONE 150-base read: every record lands in one of ~9 level-1 bins, twice what
+    their regions hold.  The first partition kernel's cursors keep counting, the host lays the level
+    out again with the exact sizes and reruns it (as msp.hip does for 16 <= k <= 32): nothing is
+    counted through the HBM table, and the counts are the oracle's."""
+    import cfrk_amd
+    rng = np.random.default_rng(5)
+    read = np.append(rng.integers(0, 4, 150).astype(np.int8), np.int8(-1))
+    R = 300_000
+    data = np.tile(read, R)
+    want = orc.global_count(data, k, orc.ORC_CANONICAL)
+    assert len(want[0]) == 150 - k + 1 and int(want[2].min()) == R
+    g = cfrk_amd.GlobalCounter(ctx, k, cfrk_amd.CFRK_CANONICAL, 100_000)
+    g.add(data)
+    lo, hi, cnt = g.export()
+    assert (lo == want[0]).all() and (hi == want[1]).all() and (cnt.astype(np.uint64) == want[2]).all()
+    info = g.msp_info()
+    assert info["spilled_records"] == 0 and info["spilled_kmers"] == 0
+
+
 def test_export_partition_and_merge_roundtrip(ctx):
     """key-owner partitioned export, then count-add merge into another table"""
     import cfrk_amd
