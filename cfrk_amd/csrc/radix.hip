@@ -20,6 +20,7 @@
 #include "table.h"
 
 #include <algorithm>
+#include <vector>
 
 namespace {
 
@@ -37,6 +38,9 @@ struct RxView {
   // exact layout after a leaf stream overflowed the fixed stride (few distinct keys, each seen
   // very often): leaf l starts at key lbase[l] and holds exactly lcap[l] keys
   const uint64_t *lbase; const uint32_t *lcap; uint32_t exact;
+  // the same for the level-1 regions (one amplicon: all keys in a few bins): region r starts at
+  // key rbase[r] and holds exactly rcap[r] keys
+  const uint64_t *rbase; const uint32_t *rcap; uint32_t exact1;
   uint64_t *out_keys; uint32_t *out_cnt; uint64_t out_cap;
   uint64_t *stats;
   int k, b1, b2, idx;
@@ -136,8 +140,15 @@ __global__ __launch_bounds__(RX1_THREADS) void rx1_kernel(const int8_t *__restri
     const uint32_t key = sorted[p];
     const uint32_t b = key >> sh1;
     const uint32_t dst = gbase[b] + (p - loff[b]);
-    if (dst < v.cap1) v.key1[(uint64_t)rx_reg(v, b, blockIdx.x & (RX_NREG - 1)) * v.cap1 + dst] = key;
-    else { t.stats[ST_SPILLED] = 1; table_add1(t, (uint64_t)rx_unmix(v, key), 1u); }
+    const uint32_t reg = rx_reg(v, b, blockIdx.x & (RX_NREG - 1));
+    if (v.exact1) {
+      if (dst < v.rcap[reg]) v.key1[v.rbase[reg] + dst] = key;
+      else { t.stats[ST_SPILLED] = 1; table_add1(t, (uint64_t)rx_unmix(v, key), 1u); }   // cannot happen
+    } else if (dst < v.cap1) {
+      v.key1[(uint64_t)reg * v.cap1 + dst] = key;
+    } else {
+      v.stats[ST_L1OVF] = 1;       // the cursor keeps counting: the host redoes RX1 with exact sizes
+    }
   }
 }
 
@@ -159,13 +170,13 @@ __global__ __launch_bounds__(RX2_THREADS) void rx2_kernel(int tiles_per_sub, RxV
   const uint32_t sub = (seq % per_bin) / (uint32_t)tiles_per_sub;
   const uint32_t tile = (seq % per_bin) % (uint32_t)tiles_per_sub;
   const uint32_t reg = rx_reg(v, bin1, sub);
-  const uint64_t n = min((uint64_t)v.cnt1[reg], v.cap1);
+  const uint64_t n = min((uint64_t)v.cnt1[reg], v.exact1 ? (uint64_t)v.rcap[reg] : v.cap1);
   const uint64_t r0 = (uint64_t)tile * RX2_KEYS;
   if (r0 >= n) return;
   const uint32_t nt = (uint32_t)min((uint64_t)RX2_KEYS, n - r0);
   hist[tid] = 0; fill[tid] = 0;
   __syncthreads();
-  const uint32_t *src = v.key1 + (uint64_t)reg * v.cap1 + r0;
+  const uint32_t *src = v.key1 + (v.exact1 ? v.rbase[reg] : (uint64_t)reg * v.cap1) + r0;
   const uint32_t m2 = (1u << v.b2) - 1u;
   uint32_t kk[RX2_PER];
 #pragma unroll
@@ -456,37 +467,62 @@ int cfrk_radix_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   const int64_t tiles = (nN + (int64_t)RX1_KEYS - 1) / RX1_KEYS;
   if (tiles > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
   const bool canon = (ctx->g_flags & CFRK_CANONICAL) != 0;
-  if (canon) hipLaunchKernelGGL((rx1_kernel<true>), dim3((unsigned)tiles), dim3(RX1_THREADS), 0, ctx->stream, d_data, nN, v, t);
-  else hipLaunchKernelGGL((rx1_kernel<false>), dim3((unsigned)tiles), dim3(RX1_THREADS), 0, ctx->stream, d_data, nN, v, t);
-  HIP_TRY(ctx, hipGetLastError());
-  const int64_t tiles_per_sub = (int64_t)((cap1 + RX2_KEYS - 1) / RX2_KEYS);
-  const int64_t bins_per_group = (int64_t)((nb1 + RX_NXG - 1) / RX_NXG);
-  const int64_t g2 = bins_per_group * RX_NXG * RX_NREG * tiles_per_sub;
-  if (g2 > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
   v.exact = 0; v.lbase = nullptr; v.lcap = nullptr;
-  HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_L2OVF, 0, sizeof(uint64_t), ctx->stream));
-  hipLaunchKernelGGL(rx2_kernel, dim3((unsigned)g2), dim3(RX2_THREADS), 0, ctx->stream, (int)tiles_per_sub, v, t);
-  HIP_TRY(ctx, hipGetLastError());
-  {
-    // few distinct keys, each seen very often (deep coverage of a small genome): their leaves
-    // overflow the fixed stride.  The cursors counted the exact demand: lay the leaves out back
-    // to back (all keys together never exceed the buffer) and run RX2 again (see msp.hip).
-    uint64_t ovf = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&ovf, ctx->g_stats + ST_L2OVF, sizeof ovf, hipMemcpyDeviceToHost, ctx->stream));
+  v.exact1 = 0; v.rbase = nullptr; v.rcap = nullptr;
+  int64_t tiles_per_sub = (int64_t)((cap1 + RX2_KEYS - 1) / RX2_KEYS);
+  const int64_t bins_per_group = (int64_t)((nb1 + RX_NXG - 1) / RX_NXG);
+  const size_t nreg = (size_t)nb1 * RX_NREG;
+  // Few distinct keys, each seen very often (deep coverage of a small genome, a single amplicon):
+  // their level-1 regions or their leaves overflow the fixed stride.  The cursors counted the exact
+  // demand: the level is laid out back to back (all keys together never exceed the buffer) and its
+  // kernel runs again (see msp.hip).
+  bool run_rx1 = true, settled = false;
+  for (int attempt = 0; attempt < 4 && !settled; ++attempt) {
+    if (run_rx1) {
+      HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_L1OVF, 0, sizeof(uint64_t), ctx->stream));
+      if (canon) hipLaunchKernelGGL((rx1_kernel<true>), dim3((unsigned)tiles), dim3(RX1_THREADS), 0, ctx->stream, d_data, nN, v, t);
+      else hipLaunchKernelGGL((rx1_kernel<false>), dim3((unsigned)tiles), dim3(RX1_THREADS), 0, ctx->stream, d_data, nN, v, t);
+      HIP_TRY(ctx, hipGetLastError());
+    }
+    const int64_t g2 = bins_per_group * RX_NXG * RX_NREG * tiles_per_sub;
+    if (g2 > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
+    HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_L2OVF, 0, sizeof(uint64_t), ctx->stream));
+    hipLaunchKernelGGL(rx2_kernel, dim3((unsigned)g2), dim3(RX2_THREADS), 0, ctx->stream, (int)tiles_per_sub, v, t);
+    HIP_TRY(ctx, hipGetLastError());
+    uint64_t st[ST_NWORDS];
+    HIP_TRY(ctx, hipMemcpyAsync(st, ctx->g_stats, sizeof st, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (ovf) {
+    if (st[ST_L1OVF]) {
+      if ((rc = cfrk_pool_get(ctx, BUF_MSP_LAYOUT1, nreg * (sizeof(uint64_t) + sizeof(uint32_t)), &p))) return rc;
+      uint64_t *rbase = (uint64_t *)p;
+      uint32_t *rcap = (uint32_t *)(rbase + nreg);
+      hipLaunchKernelGGL(rx_layout_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)v.cnt1, (uint32_t)nreg, rbase, rcap);
+      HIP_TRY(ctx, hipGetLastError());
+      std::vector<uint32_t> c1(nreg);
+      HIP_TRY(ctx, hipMemcpyAsync(c1.data(), v.cnt1, nreg * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      uint64_t maxreg = 0;
+      for (size_t r = 0; r < nreg; ++r) maxreg = std::max<uint64_t>(maxreg, c1[r]);
+      tiles_per_sub = (int64_t)((maxreg + RX2_KEYS - 1) / RX2_KEYS);     // the largest region decides RX2's grid
+      HIP_TRY(ctx, hipMemsetAsync(v.cnt1, 0, (nreg + (size_t)nleaf) * sizeof(uint32_t), ctx->stream));   // cnt1 and cnt2
+      v.exact1 = 1; v.rbase = rbase; v.rcap = rcap;
+      run_rx1 = true;
+      continue;
+    }
+    if (st[ST_L2OVF]) {
       if ((rc = cfrk_pool_get(ctx, BUF_MSP_LAYOUT, (size_t)nleaf * (sizeof(uint64_t) + sizeof(uint32_t)), &p))) return rc;
       uint64_t *lbase = (uint64_t *)p;
       uint32_t *lcap = (uint32_t *)(lbase + nleaf);
       hipLaunchKernelGGL(rx_layout_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)v.cnt2, (uint32_t)nleaf, lbase, lcap);
       HIP_TRY(ctx, hipGetLastError());
       HIP_TRY(ctx, hipMemsetAsync(v.cnt2, 0, (size_t)nleaf * sizeof(uint32_t), ctx->stream));
-      HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_L2OVF, 0, sizeof(uint64_t), ctx->stream));
       v.exact = 1; v.lbase = lbase; v.lcap = lcap;
-      hipLaunchKernelGGL(rx2_kernel, dim3((unsigned)g2), dim3(RX2_THREADS), 0, ctx->stream, (int)tiles_per_sub, v, t);
-      HIP_TRY(ctx, hipGetLastError());
+      run_rx1 = false;
+      continue;
     }
+    settled = true;
   }
+  if (!settled) return cfrk_fail(ctx, CFRK_ERR_STATE, "the key regions did not settle after an exact layout");
   hipLaunchKernelGGL(rx3_kernel, dim3((unsigned)nleaf), dim3(RX3_THREADS), 0, ctx->stream, v);
   HIP_TRY(ctx, hipGetLastError());
   // the result list lives where msp.hip keeps its own: digest / export / fold are shared

@@ -380,6 +380,27 @@ def test_two_word_single_amplicon_overflows_its_level1_regions_and_is_laid_out_a
     assert info["spilled_records"] == 0 and info["spilled_kmers"] == 0
 
 
+@pytest.mark.parametrize("k", [9, 15])
+def test_radix_single_amplicon_overflows_its_level1_regions_and_is_laid_out_again(ctx, k):
+    """the same for 8 <= k <= 15 (radix.hip): a million copies of one read put every key into ~140 of
+    the first level's regions' bins, more than their fixed stride holds; the level is laid out again
+    with exact sizes instead of counting the excess through the HBM table"""
+    import cfrk_amd
+    rng = np.random.default_rng(6)
+    read = np.append(rng.integers(0, 4, 150).astype(np.int8), np.int8(-1))
+    R = 1_000_000
+    data = np.tile(read, R)
+    want = orc.global_count(data, k, orc.ORC_CANONICAL, threads=8)
+    assert int(want[2].min()) >= R
+    g = cfrk_amd.GlobalCounter(ctx, k, cfrk_amd.CFRK_CANONICAL, 100_000)
+    g.add(data)
+    lo, hi, cnt = g.export()
+    assert (lo == want[0]).all() and (cnt.astype(np.uint64) == want[2]).all()
+    gh = cfrk_amd.GlobalCounter(ctx, k, cfrk_amd.CFRK_CANONICAL | cfrk_amd.CFRK_FORCE_HASH, 100_000)
+    gh.add(data)
+    assert gh.digest() == g.digest()
+
+
 def test_export_partition_and_merge_roundtrip(ctx):
     """key-owner partitioned export, then count-add merge into another table"""
     import cfrk_amd
