@@ -23,7 +23,13 @@
 
 namespace {
 
-constexpr int W2 = 18;
+// Window (m-mers per k-mer the minimizer is taken over = longest run): 18, the one-word path's
+// longest, for k < 44; 30 from there on (k - m + 1 >= 32 m-mers: the window still leaves a margin of
+// c >= 1 on both sides, and a run of 30 k-mers, k + 29 <= 93 bases, fits the 96-base record).  Longer
+// runs = fewer records: 2/31 instead of 2/19 per position.  (Position tags are 5 bits and the change
+// mask of a lane covers 32 + W - 1 <= 64 positions with one to spare for the right-end flag: W <= 30.)
+constexpr int W2_SHORT = 18, W2_LONG = 30;
+__host__ __device__ constexpr int msp2_window(int k) { return k >= 44 ? W2_LONG : W2_SHORT; }
 constexpr int Q1_THREADS = 512, Q1_WAVES = Q1_THREADS / 64;
 constexpr int Q1_OWN = 60;                 // owner lanes 1..60; lane 0 and lanes 61..63 are halo lanes
 constexpr int Q1_RCAP_BASE = 1536;         // 32-byte records staged in LDS per workgroup (48 KB: three workgroups per CU)
@@ -154,7 +160,7 @@ struct Stage2 {
   const uint8_t *sub;            // SUB_BITS more bits of the minimizer hash per position, or nullptr
 };
 // record of the run that starts at window position d & 31 of lane d >> 5
-__device__ __forceinline__ Rec2 q1_build(const Stage2 &st, uint32_t d, int k, int c) {
+__device__ __forceinline__ Rec2 q1_build(const Stage2 &st, uint32_t d, int k, int c, int wmax) {
   const uint32_t L = d >> 5, a = d & 31u;
   const uint64_t Es = st.E[L], Ws = st.Wv[L];
   const uint32_t leaf = st.leaf[d];
@@ -164,7 +170,7 @@ __device__ __forceinline__ Rec2 q1_build(const Stage2 &st, uint32_t d, int k, in
 #pragma unroll
   for (int i = 0; i < 7; ++i) D[i] = st.str[idx0 + i];
   const uint64_t rest = Es << (a + 1);
-  const int n = min(__clzll(rest) + 1, W2);
+  const int n = min(__clzll(rest) + 1, wmax);
   // which ends of the run are closed (a minimizer change between valid k-mers): bit 6 left, bit 7
   // right; both = a complete run (see msp.hip)
   const uint32_t complete = (((uint32_t)(Ws >> (63 - a)) & 1u) << 6) | (((uint32_t)(Ws >> (62 - a - n)) & 1u) << 7);
@@ -189,7 +195,7 @@ __device__ __forceinline__ Rec2 q1_build(const Stage2 &st, uint32_t d, int k, in
 // the record's spare word: the leaf kernel then splits an overfull leaf by RECORD, not by key, so
 // that every record is expanded once.  2 KB more staging per wave: two workgroups per CU.
 constexpr int SUB_BITS = 5;
-template <bool SUB>
+template <int W2, bool SUB>
 __global__ __launch_bounds__(Q1_THREADS, (SUB ? 4 : 6)) void msp2_p1_kernel(const int8_t *__restrict__ data, int64_t nN,
                                                              int k, int m, int c, int canon, int64_t tile0,
                                                              View2 v, TableView t) {
@@ -317,7 +323,7 @@ __global__ __launch_bounds__(Q1_THREADS, (SUB ? 4 : 6)) void msp2_p1_kernel(cons
   while (S2) {
     const int a = __clz(S2);
     S2 &= ~(0x80000000u >> a);
-    const Rec2 rec = q1_build(st, ((uint32_t)lane << 5) | (uint32_t)a, k, c);
+    const Rec2 rec = q1_build(st, ((uint32_t)lane << 5) | (uint32_t)a, k, c, W2);
     if (((rec.b.w >> 8) & v.sel_mask) != v.sel_val) continue;    // not a leaf of this pass
     const uint32_t reg = q1_reg(rec.b.w >> 16, blockIdx.x & (NXG - 1));
     const uint32_t dst = atomicAdd(&v.cnt1[reg], 1u);
@@ -336,7 +342,7 @@ __global__ __launch_bounds__(Q1_THREADS, (SUB ? 4 : 6)) void msp2_p1_kernel(cons
     rc[tr].b = make_uint4(0, 0, 0, 0);
     const uint32_t i = (uint32_t)(tr * 64 + lane);
     if (i < cnt_w) {
-      rc[tr] = q1_build(st, s_dsc[i], k, c);
+      rc[tr] = q1_build(st, s_dsc[i], k, c, W2);
       if (((rc[tr].b.w >> 8) & v.sel_mask) == v.sel_val)     // (all leaves, unless the batch takes several passes)
         rk[tr] = atomicAdd(&hist[rc[tr].b.w >> 16], 1u);
     }
@@ -1216,6 +1222,7 @@ bool cfrk_msp2_usable(const cfrk_ctx *ctx) {
 }
 
 static size_t msp2_need(const cfrk_ctx *ctx, int64_t span) {
+  const int W2 = msp2_window(ctx->g_k);
   const double expect = (double)span * (2.0 / (W2 + 1) + 1.0 / 64.0);
   const uint64_t cap1 = (uint64_t)(expect / (B1 * NXG) * 1.35) + 2048;
   const uint64_t cap2c = (uint64_t)(expect / NLEAF * 2.1) + 96;
@@ -1230,8 +1237,9 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
                             int64_t ntiles, double slack, int sel_bits = 0, uint32_t sel_val = 0, bool first = true) {
   int rc;
   const int k = ctx->g_k;
-  const int m = (k & 1) ? 14 : 13;                       // k - m + 1 - 18 must be even
-  const int c = (k - m + 1 - W2) / 2;                    // 1..17
+  const int W2 = msp2_window(k);
+  const int m = (k & 1) ? 14 : 13;                       // k - m + 1 - W2 must be even
+  const int c = (k - m + 1 - W2) / 2;                    // 1..15 (W2 = 18), 1..11 (W2 = 30)
   const int canon = (ctx->g_flags & CFRK_CANONICAL) ? 1 : 0;
   const int64_t span = std::min(nN + 32, ntiles * (int64_t)Q1_WAVES * Q1_OWN * 32);
 
@@ -1293,10 +1301,14 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
   for (int attempt = 0; attempt < 4; ++attempt) {
     if (run_q1) {
       HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_L1OVF, 0, 2 * sizeof(uint64_t), ctx->stream));   // ST_L1OVF, ST_OVFN1
-      if (sub) hipLaunchKernelGGL((msp2_p1_kernel<true>), dim3((unsigned)ntiles), dim3(Q1_THREADS), 0, ctx->stream, d_data, nN, k, m, c,
-                                  canon, tile0, v, t);
-      else hipLaunchKernelGGL((msp2_p1_kernel<false>), dim3((unsigned)ntiles), dim3(Q1_THREADS), 0, ctx->stream, d_data, nN, k, m, c,
-                              canon, tile0, v, t);
+      const dim3 g1((unsigned)ntiles), b1(Q1_THREADS);
+      if (W2 == W2_LONG) {
+        if (sub) hipLaunchKernelGGL((msp2_p1_kernel<W2_LONG, true>), g1, b1, 0, ctx->stream, d_data, nN, k, m, c, canon, tile0, v, t);
+        else hipLaunchKernelGGL((msp2_p1_kernel<W2_LONG, false>), g1, b1, 0, ctx->stream, d_data, nN, k, m, c, canon, tile0, v, t);
+      } else {
+        if (sub) hipLaunchKernelGGL((msp2_p1_kernel<W2_SHORT, true>), g1, b1, 0, ctx->stream, d_data, nN, k, m, c, canon, tile0, v, t);
+        else hipLaunchKernelGGL((msp2_p1_kernel<W2_SHORT, false>), g1, b1, 0, ctx->stream, d_data, nN, k, m, c, canon, tile0, v, t);
+      }
       HIP_TRY(ctx, hipGetLastError());
     }
     HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_L2OVF, 0, 2 * sizeof(uint64_t), ctx->stream));   // ST_L2OVF, ST_OVFN
@@ -1423,7 +1435,7 @@ int cfrk_msp2_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
     double slack = 1.0;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-      const double l2 = (double)(nN + 32) * (2.0 / (W2 + 1) + 1.0 / 64.0) * 3.3 * 32;
+      const double l2 = (double)(nN + 32) * (2.0 / (msp2_window(ctx->g_k) + 1) + 1.0 / 64.0) * 3.3 * 32;
       size_t budget = have + free_b;
       if (ctx->mem_budget) budget = std::min(budget, ctx->mem_budget);
       const double room = 0.5 * (double)budget - (double)msp2_need(ctx, nN + 32);
