@@ -583,11 +583,35 @@ __device__ __forceinline__ void count_record2(ulonglong2 *keys, uint32_t *cnts, 
   const int per = (parts == 1) ? nall : (parts == 2) ? ((nall + 1) >> 1) : (parts == 3) ? ((nall + 2) / 3) : ((nall + 3) >> 2);
   const int j0 = part * per;
   const int nk = min(nall, j0 + per);
+  // The lists are walked ONCE when every lane of the wave has at most 8 k-mers to expand and at most
+  // 127 noted runs (the usual case: 4 lanes share a run of <= 30 k-mers): a lane counts its list's
+  // entries by d = clamp(length - j0, 0, 8) in nine 7-bit fields of one 64-bit register; k-mer j0 + q is
+  // counted once more for every entry with d > q, i.e. the fields' suffix sums, kept as eight bytes.
+  // (One pass over the list per K-MER was a third of the expansion's instructions at k = 63.)
+  unsigned long long exq = 0ull;
+  const bool tb_fast = tb && !__ballot(valid && (nk - j0 > 8 || tb_n > 127u));
+  if (tb_fast) {
+    unsigned long long hist = 0ull;
+    for (uint32_t e = 0; __ballot(e < tb_n); ++e) {         // (as many steps as the wave's longest list)
+      if (e < tb_n) {
+        const int d = min(max((int)tb[e] - j0, 0), 8);
+        hist += 1ull << (7 * d);
+      }
+    }
+    uint32_t run = 0;
+#pragma unroll
+    for (int d = 8; d >= 1; --d) {
+      run += (uint32_t)(hist >> (7 * d)) & 127u;
+      exq |= (unsigned long long)run << (8 * (d - 1));
+    }
+  }
   Roll2 roll;
   roll.init(rec, k, j0);
   for (int j = j0; __ballot(j < nk); ++j) {
     uint32_t addj = add;
-    if (tb) {
+    if (tb_fast) {
+      addj += (uint32_t)(exq >> (8 * ((j - j0) & 7))) & 255u;
+    } else if (tb) {
       for (uint32_t e = 0; __ballot(e < tb_n); ++e)         // (as many steps as the wave's longest list)
         addj += (e < tb_n && (uint32_t)tb[e] > (uint32_t)j) ? 1u : 0u;
     }
