@@ -178,15 +178,33 @@ __global__ __launch_bounds__(RX2_THREADS) void rx2_kernel(int tiles_per_sub, RxV
   __syncthreads();
   const uint32_t *src = v.key1 + (v.exact1 ? v.rbase[reg] : (uint64_t)reg * v.cap1) + r0;
   const uint32_t m2 = (1u << v.b2) - 1u;
+  // four 16-byte loads per thread (a region starts on a 16-byte boundary unless the level was laid
+  // out again: cap1 is a multiple of 4 and the buffer has 16 bytes to spare) instead of sixteen
+  // 4-byte ones; which key a thread holds does not matter to a counting sort
   uint32_t kk[RX2_PER];
+  static_assert(RX2_PER % 4 == 0, "keys are loaded four at a time");
+  const bool vec = !v.exact1;
+  auto idx_of = [&](int i) {                     // tile position of key i of this thread
+    return vec ? (((uint32_t)(i >> 2) * RX2_THREADS + tid) << 2) + (uint32_t)(i & 3) : (uint32_t)i * RX2_THREADS + tid;
+  };
+  if (vec) {
 #pragma unroll
-  for (int i = 0; i < RX2_PER; ++i) {
-    const uint32_t idx = (uint32_t)i * RX2_THREADS + tid;
-    uint32_t x = 0;
-    if (idx < nt) x = src[idx];
-    kk[i] = x;
-    if (idx < nt) atomicAdd(&hist[(x >> v.idx) & m2], 1u);
+    for (int q = 0; q < RX2_PER / 4; ++q) {
+      const uint32_t idx4 = ((uint32_t)q * RX2_THREADS + tid) << 2;
+      uint4 x = make_uint4(0u, 0u, 0u, 0u);
+      if (idx4 < nt) x = *reinterpret_cast<const uint4 *>(src + idx4);
+      kk[4 * q] = x.x; kk[4 * q + 1] = x.y; kk[4 * q + 2] = x.z; kk[4 * q + 3] = x.w;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < RX2_PER; ++i) {
+      const uint32_t idx = (uint32_t)i * RX2_THREADS + tid;
+      kk[i] = (idx < nt) ? src[idx] : 0u;
+    }
   }
+#pragma unroll
+  for (int i = 0; i < RX2_PER; ++i)
+    if (idx_of(i) < nt) atomicAdd(&hist[(kk[i] >> v.idx) & m2], 1u);
   __syncthreads();
   uint32_t my_base = 0;
   {
@@ -196,8 +214,7 @@ __global__ __launch_bounds__(RX2_THREADS) void rx2_kernel(int tiles_per_sub, RxV
   rx_scan<512>(hist, loff, wtot);
 #pragma unroll
   for (int i = 0; i < RX2_PER; ++i) {
-    const uint32_t idx = (uint32_t)i * RX2_THREADS + tid;
-    if (idx < nt) {
+    if (idx_of(i) < nt) {
       const uint32_t b = (kk[i] >> v.idx) & m2;
       sorted[loff[b] + atomicAdd(&fill[b], 1u)] = kk[i];
     }
@@ -439,7 +456,7 @@ int cfrk_radix_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   v.mul = 0x9E3779B1u;
   v.inv = inv_odd32(v.mul);
   const uint64_t nb1 = 1ull << v.b1, nleaf = 1ull << (v.b1 + v.b2);
-  const uint64_t cap1 = (uint64_t)((double)nN / (double)(nb1 * RX_NREG) * 1.3) + 4096;
+  const uint64_t cap1 = ((uint64_t)((double)nN / (double)(nb1 * RX_NREG) * 1.3) + 4096 + 3) & ~3ull;   // (RX2 loads 16 bytes at a time)
   const uint64_t cap2 = (uint64_t)((double)nN / (double)nleaf * 1.5) + 1024;
   const size_t need = (size_t)nb1 * RX_NREG * cap1 * 4 + (size_t)nleaf * cap2 * 4 + (size_t)ctx->g_cap * 12;
   const size_t have = ctx->pool[BUF_MSP_L1].cap + ctx->pool[BUF_MSP_L2].cap + ctx->pool[BUF_MSP_OUTK].cap + ctx->pool[BUF_MSP_OUTC].cap;
@@ -449,7 +466,7 @@ int cfrk_radix_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
     if (need > have + free_b) return cfrk_fail(ctx, CFRK_ERR_NOMEM, "radix path needs %zu B, %zu B available", need, have + free_b);
   }
   void *p;
-  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L1, (size_t)nb1 * RX_NREG * cap1 * 4, &p))) return rc;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L1, (size_t)nb1 * RX_NREG * cap1 * 4 + 16, &p))) return rc;
   v.key1 = (uint32_t *)p; v.cap1 = cap1;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)nleaf * cap2 * 4, &p))) return rc;
   v.key2 = (uint32_t *)p; v.cap2 = cap2;
