@@ -99,22 +99,39 @@ __global__ __launch_bounds__(RX1_THREADS) void rx1_kernel(const int8_t *__restri
   dev_load_chunk32(data, off, nN, b0, b1w, bad);
   uint32_t n0 = dev_lane_next(b0), n1 = dev_lane_next(b1w), nbad = dev_lane_next(bad);
   if (lane == 63) dev_load_chunk32(data, off + 32, nN, n0, n1, nbad);
-  const uint64_t hi = ((uint64_t)b0 << 32) | b1w;
-  const uint64_t lo = ((uint64_t)n0 << 32) | n1;
-  const uint64_t M = ((uint64_t)bad << 32) | nbad;
+  (void)n1;
   const int sh1 = 2 * k - v.b1;
+  // The k-mer at position i is the top 2k bits of the 32-bit window of the base string that starts
+  // there (one v_alignbit with a static shift), its reverse complement the low 2k bits of a window
+  // of the reverse-complemented string that ENDS where the k-mer starts (msp_dev.h: msp_minimizers),
+  // its validity the top k bits of a window of the invalid-base mask: 32-bit work throughout
+  // (64-bit shifts and a bit reversal per position took twice the instructions).
+  const uint32_t D[3] = {b0, b1w, n0};
+  uint32_t R[4];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    uint32_t x = __brev(D[i]);
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+    R[3 - i] = ~x;
+  }
+  R[0] = 0;
+  const int fsh = 32 - 2 * k;
+  const uint32_t vlim = 1u << (32 - k);            // a window whose top k mask bits are clear is below this
 
   uint32_t keys[32];
   uint32_t V = 0;
 #pragma unroll
   for (int i = 0; i < 32; ++i) {
-    const uint64_t x = i ? ((hi << (2 * i)) | (lo >> (64 - 2 * i))) : hi;
-    const bool ok = ((M << i) >> (64 - k)) == 0;
-    uint32_t key = (uint32_t)(x >> (64 - 2 * k));
+    const int o = 2 * i, q = o >> 5, r = o & 31;
+    const uint32_t X = r ? __builtin_amdgcn_alignbit(D[q], D[q + 1], 32 - r) : D[q];
+    uint32_t key = X >> fsh;
     if (CANON) {
-      const uint32_t rc = (uint32_t)dev_revcomp64((uint64_t)key, k);
-      key = min(key, rc);
+      const int o2 = 96 - 2 * i, q2 = o2 >> 5, r2 = o2 & 31;
+      const uint32_t Y = r2 ? __builtin_amdgcn_alignbit(R[q2], R[q2 + 1], 32 - r2) : R[q2];
+      key = min(key, Y & v.kmask);
     }
+    const uint32_t Wm = i ? __builtin_amdgcn_alignbit(bad, nbad, 32 - i) : bad;
+    const bool ok = Wm < vlim;
     key = rx_mix(v, key);
     keys[i] = key;
     if (ok) { V |= 1u << i; atomicAdd(&hist[key >> sh1], 1u); }
