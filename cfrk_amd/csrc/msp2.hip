@@ -23,13 +23,17 @@
 
 namespace {
 
-// Window (m-mers per k-mer the minimizer is taken over = longest run): 18, the one-word path's
-// longest, for k < 44; 30 from there on (k - m + 1 >= 32 m-mers: the window still leaves a margin of
-// c >= 1 on both sides, and a run of 30 k-mers, k + 29 <= 93 bases, fits the 96-base record).  Longer
-// runs = fewer records: 2/31 instead of 2/19 per position.  (Position tags are 5 bits and the change
-// mask of a lane covers 32 + W - 1 <= 64 positions with one to spare for the right-end flag: W <= 30.)
-constexpr int W2_SHORT = 18, W2_LONG = 30;
-__host__ __device__ constexpr int msp2_window(int k) { return k >= 44 ? W2_LONG : W2_SHORT; }
+// Window (m-mers per k-mer the minimizer is taken over = longest run): all but a margin of c = 1 on
+// both sides of the k-mer's k - m + 1 m-mers (m = 13 / 14 for even / odd k, so the count is even),
+// i.e. 18 at k = 33, 20 at k = 34 ... and 30 from k = 44 on: a run of 30 k-mers is k + 29 <= 93 bases
+// and fits the 96-base record, position tags are 5 bits, and a lane's change mask covers 32 + W - 1 <= 64
+// positions with one to spare for the right-end flag.  Longer runs = fewer records (2 / (W + 1) per
+// position).
+constexpr int W2_LONG = 30;
+__host__ __device__ constexpr int msp2_window(int k) {
+  const int nm = k - ((k & 1) ? 14 : 13) + 1;
+  return nm - 2 > W2_LONG ? W2_LONG : nm - 2;
+}
 constexpr int Q1_THREADS = 512, Q1_WAVES = Q1_THREADS / 64;
 constexpr int Q1_OWN = 60;                 // owner lanes 1..60; lane 0 and lanes 61..63 are halo lanes
 constexpr int Q1_RCAP_BASE = 1536;         // 32-byte records staged in LDS per workgroup (48 KB: three workgroups per CU)
@@ -1263,7 +1267,7 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
   const int k = ctx->g_k;
   const int W2 = msp2_window(k);
   const int m = (k & 1) ? 14 : 13;                       // k - m + 1 - W2 must be even
-  const int c = (k - m + 1 - W2) / 2;                    // 1..15 (W2 = 18), 1..11 (W2 = 30)
+  const int c = (k - m + 1 - W2) / 2;                    // 1 for k < 44, 1..11 (k = 44..64) with the window of 30
   const int canon = (ctx->g_flags & CFRK_CANONICAL) ? 1 : 0;
   const int64_t span = std::min(nN + 32, ntiles * (int64_t)Q1_WAVES * Q1_OWN * 32);
 
@@ -1326,13 +1330,16 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
     if (run_q1) {
       HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_L1OVF, 0, 2 * sizeof(uint64_t), ctx->stream));   // ST_L1OVF, ST_OVFN1
       const dim3 g1((unsigned)ntiles), b1(Q1_THREADS);
-      if (W2 == W2_LONG) {
-        if (sub) hipLaunchKernelGGL((msp2_p1_kernel<W2_LONG, true>), g1, b1, 0, ctx->stream, d_data, nN, k, m, c, canon, tile0, v, t);
-        else hipLaunchKernelGGL((msp2_p1_kernel<W2_LONG, false>), g1, b1, 0, ctx->stream, d_data, nN, k, m, c, canon, tile0, v, t);
-      } else {
-        if (sub) hipLaunchKernelGGL((msp2_p1_kernel<W2_SHORT, true>), g1, b1, 0, ctx->stream, d_data, nN, k, m, c, canon, tile0, v, t);
-        else hipLaunchKernelGGL((msp2_p1_kernel<W2_SHORT, false>), g1, b1, 0, ctx->stream, d_data, nN, k, m, c, canon, tile0, v, t);
+#define CFRK_Q1_CASE(WW) \
+      case WW: \
+        if (sub) hipLaunchKernelGGL((msp2_p1_kernel<WW, true>), g1, b1, 0, ctx->stream, d_data, nN, k, m, c, canon, tile0, v, t); \
+        else hipLaunchKernelGGL((msp2_p1_kernel<WW, false>), g1, b1, 0, ctx->stream, d_data, nN, k, m, c, canon, tile0, v, t); \
+        break;
+      switch (W2) {
+        CFRK_Q1_CASE(18) CFRK_Q1_CASE(20) CFRK_Q1_CASE(22) CFRK_Q1_CASE(24) CFRK_Q1_CASE(26) CFRK_Q1_CASE(28) CFRK_Q1_CASE(30)
+        default: return cfrk_fail(ctx, CFRK_ERR_ARG, "no partition kernel for a window of %d", W2);
       }
+#undef CFRK_Q1_CASE
       HIP_TRY(ctx, hipGetLastError());
     }
     HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_L2OVF, 0, 2 * sizeof(uint64_t), ctx->stream));   // ST_L2OVF, ST_OVFN

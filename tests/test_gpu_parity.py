@@ -134,7 +134,7 @@ def _cmp_global(ctx, data, k, canonical, hint=0, start=None, length=None, force_
     return g
 
 
-@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 6, 7, 8, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 40, 47, 48, 55, 62, 63, 64])
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 6, 7, 8, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 38, 40, 41, 43, 44, 45, 46, 47, 48, 55, 62, 63, 64])
 @pytest.mark.parametrize("canonical", [False, True])
 @pytest.mark.parametrize("force_hash", [False, True])
 def test_global_vs_oracle(ctx, k, canonical, force_hash):
