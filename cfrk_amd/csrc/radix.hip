@@ -279,7 +279,6 @@ __global__ __launch_bounds__(1024) void rx_layout_kernel(const uint32_t *__restr
 // ------------------------------------------------------------------------------------------ RX3
 __global__ __launch_bounds__(RX3_THREADS) void rx3_kernel(RxView v) {
   __shared__ uint32_t cnt[1 << RX_IDX_MAX];
-  __shared__ uint32_t wg_total;
   __shared__ unsigned long long wg_base;
   const int tid = threadIdx.x, lane = tid & 63;
   const uint32_t leaf = blockIdx.x;
@@ -291,7 +290,6 @@ __global__ __launch_bounds__(RX3_THREADS) void rx3_kernel(RxView v) {
   const int rlog = min(RX_IDX_MAX - v.idx, 8);
   const uint32_t rmask = (1u << rlog) - 1u;
   for (uint32_t s = tid; s < (nidx << rlog); s += RX3_THREADS) cnt[s] = 0;
-  if (tid == 0) wg_total = 0;
   __syncthreads();
   const uint32_t *src = v.exact ? v.key2 + v.lbase[leaf] : v.key2 + (uint64_t)leaf * v.cap2;
   {
@@ -330,29 +328,33 @@ __global__ __launch_bounds__(RX3_THREADS) void rx3_kernel(RxView v) {
     }
     __syncthreads();
   }
-  // compaction: count, reserve once per workgroup, then write
-  for (uint32_t s0 = 0; s0 < nidx; s0 += RX3_THREADS) {
-    const uint32_t s = s0 + tid;
-    const uint32_t c = (s < nidx) ? cnt[s << rlog] : 0u;
-    const unsigned long long m = __ballot(c != 0u);
-    if (lane == 0 && m) atomicAdd(&wg_total, (uint32_t)__popcll(m));
+  // compaction: every thread counts the non-zero counters among its own (counter q * 256 + tid: the
+  // reads are conflict-free), one block scan gives it a range of the workgroup's reservation, and it
+  // writes its entries there -- no ballot and no LDS atomic per 256 counters (the two passes of 32
+  // such steps were half of this kernel's instructions at k = 15)
+  __shared__ uint32_t wsum[RX3_THREADS / 64];
+  uint32_t mine = 0;
+  for (uint32_t s = tid; s < nidx; s += RX3_THREADS) mine += (cnt[s << rlog] != 0u) ? 1u : 0u;
+  uint32_t incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t y = __shfl_up(incl, d);
+    if (lane >= d) incl += y;
   }
+  if (lane == 63) wsum[tid >> 6] = incl;
   __syncthreads();
-  if (tid == 0) { wg_base = atomicAdd((unsigned long long *)&v.stats[ST_CURSOR], (unsigned long long)wg_total); wg_total = 0; }
+  uint32_t base = 0, total = 0;
+  for (int w = 0; w < RX3_THREADS / 64; ++w) { const uint32_t x = wsum[w]; base += (w < (tid >> 6)) ? x : 0u; total += x; }
+  if (tid == 0) wg_base = atomicAdd((unsigned long long *)&v.stats[ST_CURSOR], (unsigned long long)total);
   __syncthreads();
-  const unsigned long long gb = wg_base;
-  for (uint32_t s0 = 0; s0 < nidx; s0 += RX3_THREADS) {
-    const uint32_t s = s0 + tid;
-    const uint32_t c = (s < nidx) ? cnt[s << rlog] : 0u;
-    const unsigned long long m = __ballot(c != 0u);
-    uint32_t b = 0;
-    if (lane == 0 && m) b = atomicAdd(&wg_total, (uint32_t)__popcll(m));
-    b = __shfl(b, 0);
+  unsigned long long dst = wg_base + base + incl - mine;
+  for (uint32_t s = tid; s < nidx; s += RX3_THREADS) {
+    const uint32_t c = cnt[s << rlog];
     if (c) {
-      const unsigned long long dst = gb + b + __popcll(m & ((1ull << lane) - 1ull));
       const uint32_t mixed = (leaf << v.idx) | s;
       if (dst < v.out_cap) { v.out_keys[dst] = (uint64_t)rx_unmix(v, mixed); v.out_cnt[dst] = c; }
       else v.stats[ST_OVERFLOW] = 1;
+      ++dst;
     }
   }
 }
