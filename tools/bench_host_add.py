@@ -39,3 +39,22 @@ for tables in (False, True):
         del g
     print(f"{R} reads x {L} bp, k={k}, {'with' if tables else 'without'} start/length tables: "
           f"{best * 1e3:.1f} ms per add + finish = {nN / best / 1e9:.1f} GB/s, {R * (L - k + 1) / best / 1e9:.1f} G k-mers/s, {n} distinct", flush=True)
+
+# the kmer_main drop-in with host buffers (pageable, touched before): H2D of the chunk, kernel, D2H of the rows
+import ctypes as C  # noqa: E402
+from cfrk_amd.lib import _ptr  # noqa: E402
+for nS, kk in ((8192, 8), (1_000_000, 4), (200_000, 6)):
+    sub = data[:nS * (L + 1)]
+    st = start[:nS]
+    ln = length[:nS]
+    freq = np.zeros(nS * 4 ** kk, np.int32)
+    best = None
+    for it in range(4):
+        t0 = time.perf_counter()
+        ctx.check(ctx._L.cfrk_per_read_dense(ctx._h, _ptr(sub), _ptr(st), _ptr(ln), len(sub), nS, kk,
+                                             cfrk_amd.CFRK_COMPAT, _ptr(freq)), "cfrk_per_read_dense")
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    nbytes = len(sub) + 12 * nS + freq.nbytes
+    print(f"per-read dense, {nS} reads, k={kk}: {best * 1e3:.1f} ms per call, {nbytes / best / 1e9:.1f} GB/s over PCIe "
+          f"({freq.nbytes / 1e9:.2f} GB of rows)", flush=True)
