@@ -411,6 +411,7 @@ __global__ __launch_bounds__(Q2_THREADS) void msp2_p2_kernel(int groups_per_bin,
   __shared__ uint32_t hist[NSUB], loff[NSUB], gbase[NSUB];
   __shared__ uint32_t wtot[Q2_THREADS / 64];
   __shared__ uint32_t rpre[NXG + 1];             // exclusive prefix of the bin's sub-region sizes
+  __shared__ unsigned long long rfirst[NXG];     // first record of every sub-region (looked up once: msp.hip's P2)
   static_assert(NSUB == Q2_THREADS, "one sub-bin per thread");
   static_assert(NXG <= 64, "one wave scans the sub-region sizes");
   const int tid = threadIdx.x;
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(Q2_THREADS) void msp2_p2_kernel(int groups_per_bin,
       const uint32_t y = __shfl_up(incl, d);
       if (tid >= d) incl += y;
     }
-    if (tid < NXG) rpre[tid] = incl - c;
+    if (tid < NXG) { rpre[tid] = incl - c; rfirst[tid] = q1_at(v, q1_reg(b1, tid)); }
     if (tid == 63) rpre[NXG] = incl;
   }
   __syncthreads();
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(Q2_THREADS) void msp2_p2_kernel(int groups_per_bin,
       const uint32_t mid = (lo + hi) >> 1;
       if (rpre[mid] <= idx) lo = mid; else hi = mid;
     }
-    return v.rec1[q1_at(v, q1_reg(b1, lo)) + (idx - rpre[lo])];
+    return v.rec1[rfirst[lo] + (idx - rpre[lo])];
   };
   const Rec2 zrec = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
   Rec2 nx[Q2_PER];
