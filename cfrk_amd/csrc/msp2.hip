@@ -851,6 +851,27 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
     } else {
       // a shared leaf: most records read here are another workgroup's.  Four loads are in flight per
       // lane (the stream comes from the XCD's L2, and latency, not work, bounds this loop)
+      // The one lane in 2^s that holds a record of this workgroup is gathered into full sets of 64
+      // before the table look-up: home() costs the wave ~100 instructions however few lanes take part.
+      Rec2 Cr = zrec;
+      int cc = 0;                        // wave-uniform
+      auto cfeed = [&](const Rec2 &rec, bool keep) {
+        const unsigned long long mask = __ballot(keep);
+        if (mask == 0ull) return;
+        const int n = __popcll(mask);
+        if (cc + n > 64) { home(Cr, lane < cc); cc = 0; }
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        const int dst = keep ? (cc + rank) : ((cc + n) & 63);    // the others aim at a lane nobody keeps
+        const int da = dst << 2;
+        const uint32_t p0 = __builtin_amdgcn_ds_permute(da, rec.a.x), p1 = __builtin_amdgcn_ds_permute(da, rec.a.y);
+        const uint32_t p2 = __builtin_amdgcn_ds_permute(da, rec.a.z), p3 = __builtin_amdgcn_ds_permute(da, rec.a.w);
+        const uint32_t p4 = __builtin_amdgcn_ds_permute(da, rec.b.x), p5 = __builtin_amdgcn_ds_permute(da, rec.b.y);
+        const uint32_t p6 = __builtin_amdgcn_ds_permute(da, rec.b.z), p7 = __builtin_amdgcn_ds_permute(da, rec.b.w);
+        const bool take = lane >= cc && lane < cc + n;
+        Cr.a.x = take ? p0 : Cr.a.x; Cr.a.y = take ? p1 : Cr.a.y; Cr.a.z = take ? p2 : Cr.a.z; Cr.a.w = take ? p3 : Cr.a.w;
+        Cr.b.x = take ? p4 : Cr.b.x; Cr.b.y = take ? p5 : Cr.b.y; Cr.b.z = take ? p6 : Cr.b.z; Cr.b.w = take ? p7 : Cr.b.w;
+        cc += n;
+      };
       for (uint64_t r = tid; r < ((ns[3] + 63) & ~63ull); r += 4 * Q3_THREADS) {
         Rec2 q[4];
 #pragma unroll
@@ -861,9 +882,10 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           if (r + (uint64_t)u * Q3_THREADS >= ((ns[3] + 63) & ~63ull)) break;      // (wave-uniform)
-          home(q[u], r + (uint64_t)u * Q3_THREADS < ns[3] && mine(q[u]));
+          cfeed(q[u], r + (uint64_t)u * Q3_THREADS < ns[3] && mine(q[u]));
         }
       }
+      if (cc) home(Cr, lane < cc);
     }
     if (c) drain(c);
   }
