@@ -56,6 +56,9 @@ struct cfrk_msp {
   bool runs_ready;     // CFRK_RUNS_ONLY job: the leaf streams hold deduplicated runs ready for cfrk_global_export_runs_device
   bool pending;        // a leaf-output list exists that has not been folded into the table
   bool table_dirty;    // the table holds counts of its own since begin()
+  // expected records = positions x density x dens_scale: 1 unless a batch did not fit and its invalid
+  // bytes were counted (reads much shorter than 8 k make far fewer records than positions suggest)
+  double dens_scale;
   uint64_t list_n;     // entries in the list (valid after resolve)
   bool list_n_valid;
   MspView view;

@@ -57,6 +57,7 @@ struct View2 {
   // the same for the level-1 regions (msp.hip): region reg starts at record rbase[reg], holds rcap[reg]
   const uint64_t *rbase; const uint32_t *rcap; uint32_t exact1;
   Rec2 *ovf1; uint32_t ovf1_cap;
+  uint32_t count_only;                                   // second-level kernel: count the streams' records, write nothing
   uint32_t dbg;                                          // cfrk_debug_set_flags
   uint32_t sel_mask, sel_val, sel_bits;                  // leaf subset of this pass (msp.h: MspView)
   uint32_t sub_bits;                                     // records carry so many more minimizer-hash bits in b.z (0: none)
@@ -480,6 +481,9 @@ __global__ __launch_bounds__(Q2_THREADS) void msp2_p2_kernel(int groups_per_bin,
       const int lane = tid & 63, wave = tid >> 6;
       const uint32_t x0 = hist[tid];
       if (x0) g0 = atomicAdd(&v.cnt2[b1 * NSUB + tid], x0);
+      // (sizing pass of a batch that would not fit otherwise: the streams are then laid out with
+      //  exactly the room they need and the kernel runs again)
+      if (v.count_only) { __syncthreads(); continue; }
       uint32_t incl = x0;
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) {
@@ -1173,6 +1177,31 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
 }
 
 // exact layout of the second level from the demand the first attempt counted (see msp.hip)
+// bytes that are not a base (read terminators, N): one 64-bit sum (a batch that does not fit is looked
+// at before it is planned again: every such byte ends up to k k-mers)
+__global__ __launch_bounds__(256) void msp2_count_invalid_kernel(const int8_t *__restrict__ data, int64_t nN,
+                                                                 unsigned long long *__restrict__ out) {
+  unsigned long long mine = 0;
+  const int64_t n16 = nN >> 4;
+  const uint4 *d4 = reinterpret_cast<const uint4 *>(data);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) {
+    const uint4 x = d4[i];
+    // a byte is a base iff its top six bits are clear
+    const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      uint32_t b = w[c] & 0xFCFCFCFCu;
+      b |= b >> 4; b |= b >> 2; b |= b >> 1;               // bit 0 of every byte: any of its top six bits set
+      mine += (unsigned long long)__popc(b & 0x01010101u);
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (int64_t i = n16 << 4; i < nN; ++i) mine += ((uint8_t)data[i] > 3u) ? 1u : 0u;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) mine += __shfl_down(mine, d);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(out, mine);
+}
+
 // (either level: base = exclusive prefix sum of the n cursors, cap = the cursors themselves)
 __global__ __launch_bounds__(1024) void msp2_layout_kernel(const uint32_t *__restrict__ cnt, uint32_t n, uint64_t *__restrict__ base,
                                                            uint32_t *__restrict__ cap) {
@@ -1272,9 +1301,23 @@ bool cfrk_msp2_usable(const cfrk_ctx *ctx) {
   return ctx->g_two && ctx->g_k >= 33 && ctx->g_k <= 64 && !(ctx->g_flags & CFRK_FORCE_HASH);
 }
 
-static size_t msp2_need(const cfrk_ctx *ctx, int64_t span) {
+// expected records per input byte: one per minimizer change (2 / (W + 1)) plus read ends, scaled by the
+// measured share of positions that start a k-mer when the batch had to be looked at (dens_scale)
+static double msp2_density(const cfrk_ctx *ctx) {
   const int W2 = msp2_window(ctx->g_k);
-  const double expect = (double)span * (2.0 / (W2 + 1) + 1.0 / 64.0);
+  const double sc = (ctx->msp && ctx->msp->dens_scale > 0.0) ? ctx->msp->dens_scale : 1.0;
+  return (2.0 / (W2 + 1)) * sc + 1.0 / 64.0;
+}
+
+// ... with the leaf streams sized from a counting pass (at most one record per expected record)
+static size_t msp2_need_lean(const cfrk_ctx *ctx, int64_t span) {
+  const double expect = (double)span * msp2_density(ctx);
+  const uint64_t cap1 = (uint64_t)(expect / (B1 * NXG) * 1.35) + 2048;
+  return (size_t)B1 * NXG * cap1 * 32 + (size_t)(expect * 32) + (size_t)ctx->g_cap * 20;
+}
+
+static size_t msp2_need(const cfrk_ctx *ctx, int64_t span) {
+  const double expect = (double)span * msp2_density(ctx);
   const uint64_t cap1 = (uint64_t)(expect / (B1 * NXG) * 1.35) + 2048;
   const uint64_t cap2c = (uint64_t)(expect / NLEAF * 2.1) + 96;
   const uint64_t cap2t = (uint64_t)(expect / NLEAF * 0.4) + 96;
@@ -1284,8 +1327,12 @@ static size_t msp2_need(const cfrk_ctx *ctx, int64_t span) {
 // one pass of Q1 -> Q2 -> Q3 over the Q1 tiles [tile0, tile0 + ntiles)
 // slack >= 1 widens the per-leaf streams beyond what msp2_need() accounts for (memory permitting)
 // sel_bits / sel_val / first: the leaf subset of this pass (msp.hip: msp_count_tiles)
+// lean: the leaf streams get no room up front; the second-level kernel first only COUNTS them, they are
+// laid out back to back with exactly that room, and the kernel runs again (a batch that would need
+// more passes over the input otherwise: one more read of the level-1 records is cheaper than a pass)
 static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, int64_t nN, int64_t tile0,
-                            int64_t ntiles, double slack, int sel_bits = 0, uint32_t sel_val = 0, bool first = true) {
+                            int64_t ntiles, double slack, int sel_bits = 0, uint32_t sel_val = 0, bool first = true,
+                            bool lean = false) {
   int rc;
   const int k = ctx->g_k;
   const int W2 = msp2_window(k);
@@ -1294,21 +1341,25 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
   const int canon = (ctx->g_flags & CFRK_CANONICAL) ? 1 : 0;
   const int64_t span = std::min(nN + 32, ntiles * (int64_t)Q1_WAVES * Q1_OWN * 32);
 
-  const double dens = 2.0 / (W2 + 1) + 1.0 / 64.0;
+  const double dens = msp2_density(ctx);
   const double expect_all = (double)span * dens;                 // records of the whole batch
   const double expect = expect_all / (double)(1u << sel_bits);   // ... of this pass
   const uint64_t cap1 = (uint64_t)(expect / (B1 * NXG) * 1.35) + 2048;
   // (a leaf of the pass holds ALL its records: the pass has fewer leaves, not lighter ones)
-  const uint64_t cap2c = (uint64_t)(expect_all / NLEAF * 2.1 * slack) + 96;
-  const uint64_t cap2t = (uint64_t)(expect_all / NLEAF * 0.4 * slack) + 96;
+  const uint64_t cap2c = lean ? 0 : (uint64_t)(expect_all / NLEAF * 2.1 * slack) + 96;
+  const uint64_t cap2t = lean ? 0 : (uint64_t)(expect_all / NLEAF * 0.4 * slack) + 96;
   const int64_t tiles_per_sub = (int64_t)(((uint64_t)NXG * cap1 + (uint64_t)Q2_TILE * Q2_GROUP - 1) / ((uint64_t)Q2_TILE * Q2_GROUP));   // tile groups per bin
   if (tiles_per_sub * B1 > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
   void *p;
   View2 v;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_L1, (size_t)B1 * NXG * cap1 * sizeof(Rec2), &p))) return rc;
   v.rec1 = (Rec2 *)p; v.cap1 = cap1;
-  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)(NLEAF >> sel_bits) * (cap2c + 3 * cap2t) * sizeof(Rec2), &p))) return rc;
-  v.rec2 = (Rec2 *)p; v.cap2c = cap2c; v.cap2t = cap2t;
+  v.rec2 = nullptr;
+  if (!lean) {
+    if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)(NLEAF >> sel_bits) * (cap2c + 3 * cap2t) * sizeof(Rec2), &p))) return rc;
+    v.rec2 = (Rec2 *)p;
+  }
+  v.cap2c = cap2c; v.cap2t = cap2t; v.count_only = lean ? 1u : 0u;
   v.sel_mask = (1u << sel_bits) - 1u; v.sel_val = sel_val; v.sel_bits = (uint32_t)sel_bits;
   // far more distinct k-mers expected than the leaf tables hold (65536 x ~2500): records carry extra
   // minimizer-hash bits and 2^sub_bits workgroups share a leaf (~2000 distinct k-mers each)
@@ -1404,12 +1455,22 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
       continue;
     }
     parked1 = st[ST_OVFN1];
-    if (st[ST_L2OVF]) {
+    if (st[ST_L2OVF] || v.count_only) {
       if ((rc = cfrk_pool_get(ctx, BUF_MSP_LAYOUT, (size_t)NCLS * NLEAF * (sizeof(uint64_t) + 2 * sizeof(uint32_t)), &p))) return rc;
       uint64_t *lbase = (uint64_t *)p;
       uint32_t *lcap = (uint32_t *)(lbase + NCLS * NLEAF);
       hipLaunchKernelGGL(msp2_layout_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)v.cnt2, (uint32_t)(NCLS * NLEAF), lbase, lcap);
       HIP_TRY(ctx, hipGetLastError());
+      if (v.count_only) {
+        // the streams' buffer: exactly what was counted (last stream's start + size)
+        uint64_t lb = 0; uint32_t lc = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&lb, lbase + NCLS * NLEAF - 1, sizeof lb, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(&lc, lcap + NCLS * NLEAF - 1, sizeof lc, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)(lb + lc + 1) * sizeof(Rec2), &p))) return rc;
+        v.rec2 = (Rec2 *)p;
+        v.count_only = 0;
+      }
       HIP_TRY(ctx, hipMemsetAsync(v.cnt2, 0, (size_t)NCLS * NLEAF * sizeof(uint32_t), ctx->stream));
       v.exact = 1; v.lbase = lbase; v.lcap = lcap;
       run_q1 = false;
@@ -1460,7 +1521,7 @@ int cfrk_msp2_merge_lists(cfrk_ctx *ctx, const uint64_t *d_lo, const uint64_t *d
   v.out_lo = ms->view.out_keys; v.out_hi = ms->view.out_hi; v.out_cnt = ms->view.out_cnt; v.out_cap = ms->view.out_cap;
   v.leaf_off = nullptr; v.leaf_n = nullptr; v.stats = ctx->g_stats;
   v.exact = 0; v.lbase = nullptr; v.lcap = nullptr; v.ovf = nullptr; v.ovf_cap = 0; v.sel_mask = v.sel_val = v.sel_bits = 0; v.sub_bits = 0; v.dbg = 0;
-  v.exact1 = 0; v.rbase = nullptr; v.rcap = nullptr; v.ovf1 = nullptr; v.ovf1_cap = 0;
+  v.exact1 = 0; v.rbase = nullptr; v.rcap = nullptr; v.ovf1 = nullptr; v.ovf1_cap = 0; v.count_only = 0;
   hipLaunchKernelGGL(msp2_merge_kernel, dim3(leaves_per_part), dim3(Q3_THREADS), 0, ctx->stream, d_lo, d_hi, d_cnt,
                      d_seg_off, d_seg_n, parts, leaves_per_part, v, cfrk_table_view(ctx));
   HIP_TRY(ctx, hipGetLastError());
@@ -1480,16 +1541,44 @@ int cfrk_msp2_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   int groups = 1;
   if ((rc = cfrk_msp_plan_groups(ctx, nN + 32, ntiles, (int64_t)Q1_WAVES * Q1_OWN * 32, msp2_need,
                                  (size_t)ctx->g_cap * 20, have, &groups))) return rc;
+  // a batch that does not fit in one pass with the generous fixed-stride streams: would it with streams
+  // sized from a counting pass?  (fewer passes over the input for one more read of the level-1 records)
+  bool lean = false;
+  ms->dens_scale = 1.0;
+  if (groups != 1) {
+    // first, how many positions start a k-mer at all: reads of a few k make far fewer records than
+    // one per 2 / (W + 1) bytes (250-base reads at k = 63: 0.75 of it) -- a 5 TB/s look at the batch
+    void *sp;
+    if ((rc = cfrk_pool_get(ctx, BUF_SCRATCH, 64, &sp))) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(sp, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(msp2_count_invalid_kernel, dim3((unsigned)std::min<int64_t>(ctx->num_cus * 16, (nN >> 12) + 1)), dim3(256), 0,
+                       ctx->stream, d_data, nN, (unsigned long long *)sp);
+    HIP_TRY(ctx, hipGetLastError());
+    uint64_t ninv = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&ninv, sp, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const double starts = std::max(0.0, (double)nN - (double)ninv * (double)ctx->g_k);
+    ms->dens_scale = std::min(1.0, std::max(0.05, starts / (double)std::max<int64_t>(nN, 1)));
+    if ((rc = cfrk_msp_plan_groups(ctx, nN + 32, ntiles, (int64_t)Q1_WAVES * Q1_OWN * 32, msp2_need,
+                                   (size_t)ctx->g_cap * 20, have, &groups))) return rc;
+  }
+  if (groups != 1) {
+    int lg = 1;
+    if ((rc = cfrk_msp_plan_groups(ctx, nN + 32, ntiles, (int64_t)Q1_WAVES * Q1_OWN * 32, msp2_need_lean,
+                                   (size_t)ctx->g_cap * 20, have, &lg))) return rc;
+    if (lg != 0 && (groups == 0 || lg < groups)) { groups = lg; lean = true; }
+  }
   if (groups == 0) return cfrk_fail(ctx, CFRK_ERR_NOMEM, "partitioned path does not fit device memory");
   const int passes = groups;
   ctx->last_passes = passes;
   if (ms->pending && (rc = cfrk_msp_flush_to_table(ctx))) return rc;
+  if (passes == 1 && lean) return msp2_count_tiles(ctx, ms, d_data, nN, 0, ntiles, 1.0, 0, 0, true, true);
   if (passes == 1) {
     // lumpy leaves (small genomes): up to twice the stream room when memory is plentiful (msp.hip)
     double slack = 1.0;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-      const double l2 = (double)(nN + 32) * (2.0 / (msp2_window(ctx->g_k) + 1) + 1.0 / 64.0) * 3.3 * 32;
+      const double l2 = (double)(nN + 32) * msp2_density(ctx) * 3.3 * 32;
       size_t budget = have + free_b;
       if (ctx->mem_budget) budget = std::min(budget, ctx->mem_budget);
       const double room = 0.5 * (double)budget - (double)msp2_need(ctx, nN + 32);
@@ -1502,7 +1591,7 @@ int cfrk_msp2_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   int sel_bits = 0;
   while ((1 << sel_bits) < passes) ++sel_bits;
   for (int pass = 0; pass < passes; ++pass) {
-    if ((rc = msp2_count_tiles(ctx, ms, d_data, nN, 0, ntiles, 1.0, sel_bits, (uint32_t)pass, pass == 0))) {
+    if ((rc = msp2_count_tiles(ctx, ms, d_data, nN, 0, ntiles, 1.0, sel_bits, (uint32_t)pass, pass == 0, lean))) {
       // a refusal after the first pass must not reach the caller's fallback (it would count
       // the finished passes twice)
       if (pass > 0 && rc == CFRK_ERR_NOMEM) return cfrk_fail(ctx, CFRK_ERR_STATE, "out of device memory in pass %d of a multi-pass add", pass);
