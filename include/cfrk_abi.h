@@ -106,7 +106,10 @@ int cfrk_per_read_dense_device(cfrk_ctx *ctx, const int8_t *d_data, const int64_
 /* Semantics: the guarded ComputeFreq (src/kmer_kernel.cu:52-70) summed over all reads of all
  * cfrk_global_add calls since begin; a window counts iff its k codes are all valid, so no
  * window crosses a terminator.  Result = set of (key, count), count < 2^32.
- * capacity_hint = expected number of DISTINCT keys (0: library default). */
+ * capacity_hint = expected number of DISTINCT keys (0: library default).  It sizes the result list
+ * and the HBM table; a hint above ~2.7e8 also makes the two-word path (33 <= k <= 64) share its
+ * leaves between several workgroups (~2000 distinct k-mers each) -- a job that holds far more
+ * distinct k-mers than it announced still counts exactly, but splits overfull leaves by key. */
 int cfrk_global_begin(cfrk_ctx *ctx, int k, int flags, uint64_t capacity_hint);
 
 /* Host buffers (struct read fields).  start/length may be NULL; when given they are checked
@@ -209,9 +212,10 @@ int cfrk_debug_last_add_passes(cfrk_ctx *ctx, int *out_passes);
 /* Bit 2: the leaf kernel of the one-word partitioned path counts every truncated run k-mer by k-mer
  * instead of noting it with the complete run it is a prefix of (same result; for A/B timing and tests). */
 #define CFRK_DEBUG_NO_ANCHORS 0x4
-/* Bit 3: the two-word partitioned path (33 <= k <= 64) writes the extra minimizer-hash bits into its
- * records and splits overfull leaves by record whatever the capacity hint (normally only for hints
- * above ~2.7e8 distinct k-mers): makes that path reachable with small inputs (tests). */
+/* Bit 3: the two-word partitioned path (33 <= k <= 64) writes extra minimizer-hash bits into its
+ * records and lets four workgroups share every leaf, each taking the records its bits name,
+ * whatever the capacity hint (normally only for hints above ~2.7e8 distinct k-mers, 2..32
+ * workgroups per leaf): makes that path reachable with small inputs (tests). */
 #define CFRK_DEBUG_RECORD_SUBSETS 0x8
 int cfrk_debug_set_flags(cfrk_ctx *ctx, uint32_t flags);
 
