@@ -569,7 +569,9 @@ __device__ __forceinline__ void t2_step(ulonglong2 *keys, uint32_t *cnts, uint64
 }
 
 // key subsets as in msp.hip: selector bits from the slot hash's unused bits
-struct KeySubset2 { uint32_t mask, val; };
+// (rmask / rval: a shared leaf's workgroup counts the records of one of its sub-values at a time --
+//  the extra minimizer-hash bits in b.z; 0 / 0 elsewhere)
+struct KeySubset2 { uint32_t mask, val, rmask, rval; };
 __device__ __forceinline__ bool in_subset2(uint64_t lo, uint64_t hi, KeySubset2 ss) {
   const uint32_t x = (uint32_t)lo ^ (uint32_t)(lo >> 32) ^ ((uint32_t)hi * 0x85EBCA77u) ^ (uint32_t)(hi >> 32);
   return (((x * 0x9E3779B1u) >> 6) & ss.mask) == ss.val;
@@ -581,15 +583,16 @@ __device__ __forceinline__ bool in_subset2(uint64_t lo, uint64_t hi, KeySubset2 
 template <bool CANON>
 __device__ __forceinline__ void count_record2(ulonglong2 *keys, uint32_t *cnts, const Rec2 &rec, uint32_t add,
                                               bool valid, int k, const TableView &t,
-                                              KeySubset2 ss = KeySubset2{0u, 0u}, uint32_t *ovf = nullptr,
+                                              KeySubset2 ss = KeySubset2{0u, 0u, 0u, 0u}, uint32_t *ovf = nullptr,
                                               int part = 0, int parts = 1,
                                               const uint8_t *tb = nullptr, uint32_t tb_n = 0u) {
   // tb[0 .. tb_n): lengths (in k-mers) of the truncated runs that are prefixes of this record: k-mer J
   // of the record is counted once more for every one of them that is longer than J (msp.hip)
   if (ovf && *(volatile uint32_t *)ovf) return;
   // a record may be shared by `parts` lanes, each expanding a contiguous share of its k-mers
-  const int nall = valid ? (int)(rec.b.w & 63u) + 1 : 0;
-  const int per = (parts == 1) ? nall : (parts == 2) ? ((nall + 1) >> 1) : (parts == 3) ? ((nall + 2) / 3) : ((nall + 3) >> 2);
+  const int nall = (valid && (rec.b.z & ss.rmask) == ss.rval) ? (int)(rec.b.w & 63u) + 1 : 0;
+  // (parts <= 8, nall <= 64: the quotient by multiplication with ceil(2^16 / parts) is exact)
+  const int per = (parts == 1) ? nall : (int)(((uint32_t)(nall + parts - 1) * ((65536u + (uint32_t)parts - 1u) / (uint32_t)parts)) >> 16);
   const int j0 = part * per;
   const int nk = min(nall, j0 + per);
   // The lists are walked ONCE when every lane of the wave has at most 8 k-mers to expand and at most
@@ -754,12 +757,13 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
   __shared__ uint16_t flist[FL2_CAP];
   __shared__ uint32_t nfb, nfl;
   __shared__ uint32_t wsum2[Q3_THREADS / 64];
-  __shared__ uint32_t nhist[32];
+  constexpr int NSV = SHARED ? 4 : 1;             // sub-values a workgroup of a shared leaf counts, one after the other
+  __shared__ uint32_t nhist[NSV * 32 + 1];       // distinct runs by (sub-value, length): counts, then list positions
   __shared__ uint32_t nocc;
   __shared__ uint32_t wg_total;
   __shared__ unsigned long long wg_base;
   __shared__ uint32_t rt_fail, kovf;             // record table / k-mer table ran out of room (msp.hip)
-  __shared__ uint32_t stk[40];                   // key subsets still to count: bits << 16 | value
+  __shared__ uint32_t stk[SHARED ? 192 : 40];     // subsets still to count: sub-value << 24 | bits << 16 | value
   __shared__ int sp;
   __shared__ uint32_t leaf_total, nseg;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -768,14 +772,21 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
   // k-mer has the same minimizer, so the workgroups' key sets are disjoint.  The workgroups of a
   // leaf run next to each other on one XCD (workgroup b goes to XCD b % 8), whose L2 then serves
   // all but the first read of the leaf's streams.
+  // A workgroup takes up to four sub-values (the low hbits of the extra bits) and counts them one
+  // after the other from ONE pass over the leaf's streams: the record table holds the distinct runs
+  // of all four (~4 x 120), the k-mer table one sub-value's keys at a time.  2^(sub_bits - hbits)
+  // workgroups per leaf: every one of them reads the whole leaf, and that was most of the kernel's
+  // time with eight of them.
   const uint32_t sub_bits = SHARED ? v.sub_bits : 0u;
-  const uint32_t rmask = (1u << sub_bits) - 1u;
+  const uint32_t hbits = SHARED ? min(sub_bits, 2u) : 0u, hmask = (1u << hbits) - 1u;
+  const uint32_t gbits = sub_bits - hbits;
+  const uint32_t rmask = (1u << gbits) - 1u;
   const uint32_t vq = blockIdx.x >> 3;
   const uint32_t rsel = vq & rmask;
   // (the grid holds the leaves of this pass only: were the others launched and left at once, the
   //  pass's leaves -- equal low bits -- would all sit on 8 / 2^sel_bits of the 8 XCDs)
-  const uint32_t leaf = (SHARED ? ((((vq >> sub_bits) << 3) | (blockIdx.x & 7u))) : blockIdx.x) << v.sel_bits | v.sel_val;
-  auto mine = [&](const Rec2 &r) { return !SHARED || (r.b.z & rmask) == rsel; };
+  const uint32_t leaf = (SHARED ? ((((vq >> gbits) << 3) | (blockIdx.x & 7u))) : blockIdx.x) << v.sel_bits | v.sel_val;
+  auto mine = [&](const Rec2 &r) { return !SHARED || ((r.b.z >> hbits) & rmask) == rsel; };
   uint64_t ns[NCLS];
   uint64_t total = 0;
 #pragma unroll
@@ -792,7 +803,7 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
     rtab[tid] = z;
   }
   if (tid == 0) { wg_total = 0; nocc = 0; rt_fail = 0; kovf = 0; sp = 0; leaf_total = 0; nseg = 0; nfb = 0; nfl = 0; }
-  if (tid < 32) nhist[tid] = 0;
+  if (tid < NSV * 32 + 1) nhist[tid] = 0;
   for (int s = tid; s < R2 + 1; s += Q3_THREADS) th[s] = 0;
   __syncthreads();
 
@@ -901,31 +912,42 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
   {
     const uint32_t st = rtab[tid].b.w;
     const bool occ = !big && st != R2_EMPTY;
+    // list position: by sub-value (shared leaves), then longest first -- entry hidx of the histogram
+    const uint32_t hidx = (SHARED ? (rtab[tid].b.z & hmask) * 32u : 0u) + (31u - (st & 31u));
     uint32_t rank = 0;
-    if (occ) rank = atomicAdd(&nhist[st & 31u], 1u);
+    if (occ) rank = atomicAdd(&nhist[hidx], 1u);
     __syncthreads();
-    if (tid < 32) {
-      const uint32_t own = nhist[31 - tid];
-      uint32_t incl = own;
+    if (tid < 64) {                                // exclusive prefix over the NSV * 32 entries (one wave, two rounds)
+      uint32_t carry = 0;
 #pragma unroll
-      for (int d = 1; d < 32; d <<= 1) {
-        const uint32_t y = __shfl_up(incl, d, 32);
-        if (tid >= d) incl += y;
+      for (int base = 0; base < NSV * 32; base += 64) {
+        const uint32_t own = (base + tid < NSV * 32) ? nhist[base + tid] : 0u;
+        uint32_t incl = own;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const uint32_t y = __shfl_up(incl, d);
+          if (tid >= d) incl += y;
+        }
+        if (base + tid < NSV * 32) nhist[base + tid] = carry + incl - own;
+        carry += __shfl(incl, 63);
       }
-      nhist[31 - tid] = incl - own;
-      if (tid == 31) nocc = incl;
+      if (tid == 0) { nhist[NSV * 32] = carry; nocc = carry; }
     }
     __syncthreads();
-    if (occ) occ_list[nhist[st & 31u] + rank] = (uint16_t)tid;
+    if (occ) occ_list[nhist[hidx] + rank] = (uint16_t)tid;
     if (tid == 0) {
-      if (big) {
-        // no dedupe: the leaf holds thousands of distinct runs.  Start with as many key subsets as
-        // its size suggests (one per ~6000 records, 4 .. 32) instead of finding out by overflowing
-        uint32_t b0 = 2u;
-        while (b0 < 5u && (total >> (b0 + sub_bits)) > 6000ull) ++b0;
-        for (uint32_t q = 0; q < (1u << b0); ++q) stk[q] = (b0 << 16) | q;
-        sp = (int)(1u << b0);
-      } else { stk[0] = 0u; sp = 1; }
+      // one item per sub-value (shared leaves: 2^hbits of them; pushed so that 0 comes first) ...
+      int d0 = 0;
+      for (int sv = (int)hmask; sv >= 0; --sv) {
+        if (big) {
+          // ... no dedupe: the leaf holds thousands of distinct runs.  Start with as many key subsets as
+          // its size suggests (one per ~6000 records, 4 .. 32) instead of finding out by overflowing
+          uint32_t b0 = 2u;
+          while (b0 < 5u && (total >> (b0 + sub_bits)) > 6000ull) ++b0;
+          for (uint32_t q = 0; q < (1u << b0); ++q) stk[d0++] = ((uint32_t)sv << 24) | (b0 << 16) | q;
+        } else stk[d0++] = (uint32_t)sv << 24;
+      }
+      sp = d0;
     }
   }
   // ---- truncated runs: the first TL2_CAP of the three class streams (class 0 first) look for the
@@ -1021,8 +1043,8 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
     const uint32_t item = stk[depth - 1];
     __syncthreads();
     if (tid == 0) { sp = depth - 1; kovf = 0; wg_total = 0; }
-    const uint32_t bits = item >> 16;
-    const KeySubset2 ss{(1u << bits) - 1u, item & 0xFFFFu};
+    const uint32_t bits = (item >> 16) & 0xFFu, sv = item >> 24;
+    const KeySubset2 ss{(1u << bits) - 1u, item & 0xFFFFu, hmask, sv};
     uint32_t *ovf = (bits < SUBSET_BITS_MAX) ? &kovf : nullptr;
     if (!first_pass)
       for (int s = tid; s < T2; s += Q3_THREADS) cnts[s] = 0;
@@ -1031,16 +1053,20 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
     if (!big) {
       // few distinct runs (~320) for 1024 lanes, and a wave works for as many steps as its longest
       // run has k-mers: up to four lanes share a record, each expanding a quarter of its k-mers
-      const uint32_t nocc_ = nocc;
-      const int parts = (nocc_ * 4u <= (uint32_t)Q3_THREADS) ? 4 : (nocc_ * 3u <= (uint32_t)Q3_THREADS) ? 3
-                        : (nocc_ * 2u <= (uint32_t)Q3_THREADS) ? 2 : 1;
+      // (a shared leaf: the part of the list that holds this pass's sub-value)
+      const uint32_t occ0 = SHARED ? nhist[sv * 32u] : 0u;
+      const uint32_t nocc_ = SHARED ? nhist[sv * 32u + 32u] - occ0 : nocc;
+      // (up to eight: a shared leaf's sub-value has ~120 runs, and half-empty waves wait for LDS twice as long)
+      int parts = 1;
+      while (parts < 8 && nocc_ * (uint32_t)(parts + 1) <= (uint32_t)Q3_THREADS) ++parts;
+      const uint32_t precip = (65536u + (uint32_t)parts - 1u) / (uint32_t)parts;     // i / parts for i < 8192
       const uint32_t nitems = nocc_ * (uint32_t)parts;
       for (uint32_t i = tid; i < ((nitems + 63u) & ~63u); i += Q3_THREADS) {
         const bool valid = i < nitems;
-        const uint32_t ri = (parts == 1) ? i : (parts == 2) ? (i >> 1) : (parts == 3) ? (i / 3u) : (i >> 2);
+        const uint32_t ri = (i * precip) >> 16;
         Rec2 rec = zrec;
         uint32_t slot = 0;
-        if (valid) { slot = occ_list[ri]; rec = rtab[slot]; }
+        if (valid) { slot = occ_list[occ0 + ri]; rec = rtab[slot]; }
         if (use_anchors) {
           // ... plus one for every truncated run of this locus that reaches the k-mer
           const uint32_t g0 = th[slot];
@@ -1086,7 +1112,7 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
       Rec2 Sr = zrec;
       int sc = 0;                        // wave-uniform
       auto sflush = [&]() {
-        count_record2<CANON>(keys, cnts, Sr, 1u, lane < sc, k, t, ss, ovf);
+        count_record2<CANON>(keys, cnts, Sr, 1u, lane < sc, k, t, KeySubset2{ss.mask, ss.val, 0u, 0u}, ovf);   // (sub-value: filtered when fed)
         sc = 0;
       };
       auto sfeed = [&](const Rec2 &rec, bool keep) {
@@ -1115,7 +1141,7 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
         if (r_first < ns[cl]) nxt = src[r_first];
         for (uint64_t r = r_first; r < done + ((ns[cl] - done + 63) & ~63ull); r += Q3_THREADS) {
           const Rec2 rec = nxt;
-          const bool keep = r < ns[cl] && mine(rec);
+          const bool keep = r < ns[cl] && mine(rec) && (rec.b.z & hmask) == sv;
           nxt = zrec;
           if (r + Q3_THREADS < ns[cl]) nxt = src[r + Q3_THREADS];
           sfeed(rec, keep);
@@ -1127,8 +1153,8 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
     if (kovf) {
       if (tid == 0) {
         const int d0 = sp;
-        stk[d0] = ((bits + 1u) << 16) | ss.val;
-        stk[d0 + 1] = ((bits + 1u) << 16) | ss.val | (1u << bits);
+        stk[d0] = (sv << 24) | ((bits + 1u) << 16) | ss.val;
+        stk[d0 + 1] = (sv << 24) | ((bits + 1u) << 16) | ss.val | (1u << bits);
         sp = d0 + 2;
       }
       __syncthreads();
@@ -1492,7 +1518,8 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
     HIP_TRY(ctx, hipGetLastError());
   }
   {
-    const dim3 g3(((unsigned)NLEAF >> sel_bits) << v.sub_bits), b3(Q3_THREADS);
+    // (a shared leaf: one workgroup per four sub-values)
+    const dim3 g3(((unsigned)NLEAF >> sel_bits) << (v.sub_bits - std::min(v.sub_bits, 2u))), b3(Q3_THREADS);
     if (sub) {
       if (canon) hipLaunchKernelGGL((msp2_p3_kernel<true, true>), g3, b3, 0, ctx->stream, k, v, t);
       else hipLaunchKernelGGL((msp2_p3_kernel<false, true>), g3, b3, 0, ctx->stream, k, v, t);
