@@ -59,6 +59,9 @@ while time.time() < t_end:
         want = gh.digest()
         del gh
         g = cfrk_amd.GlobalCounter(ctx, k, flags, hint)
+        shared = k > 32 and rng.random() < 0.4       # leaves shared by record whatever the hint (msp2.hip)
+        if shared:
+            g.set_debug_flags(cfrk_amd.lib.CFRK_DEBUG_RECORD_SUBSETS)
         forced = rng.random() < 0.25 and k >= 16
         if forced:                                   # several leaf-subset passes
             g.set_mem_budget(int(nN * float(rng.choice([4, 8, 14]))) + (64 << 20))
@@ -67,9 +70,11 @@ while time.time() < t_end:
         passes = g.last_add_passes()
         if forced:
             g.set_mem_budget(0)
+        if shared:
+            g.set_debug_flags(0)
         del g
         ok = got == want and got[1] == nk
-        line = f"{tag} passes={passes} distinct={got[0]} {'ok' if ok else 'MISMATCH ' + str(got) + ' != ' + str(want)}"
+        line = f"{tag} passes={passes}{' shared' if shared else ''} distinct={got[0]} {'ok' if ok else 'MISMATCH ' + str(got) + ' != ' + str(want)}"
         if ok and 16 <= k <= 32 and rng.random() < 0.5:
             world = int(rng.integers(2, 6))
             Rl = [R * r // world for r in range(world + 1)]
