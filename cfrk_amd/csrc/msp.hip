@@ -1250,12 +1250,17 @@ __global__ __launch_bounds__(256) void msp_gather_kernel(MspView v, const uint64
                                                          uint64_t *__restrict__ out_hi,
                                                          uint32_t *__restrict__ out_cnt) {
   const uint32_t leaf = blockIdx.x;
-  const uint32_t n = v.leaf_n[leaf];
-  const uint64_t so = v.leaf_off[leaf], dof = dst_off[leaf];
-  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-    out_keys[dof + i] = v.out_keys[so + i];
-    if (out_hi) out_hi[dof + i] = v.out_hi[so + i];
-    out_cnt[dof + i] = v.out_cnt[so + i];
+  uint64_t dof = dst_off[leaf];
+  for (uint32_t j = 0; j < (1u << v.seg_bits); ++j) {          // (one segment unless the leaf was shared by record)
+    const uint32_t sg = (leaf << v.seg_bits) | j;
+    const uint32_t n = v.leaf_n[sg];
+    const uint64_t so = v.leaf_off[sg];
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+      out_keys[dof + i] = v.out_keys[so + i];
+      if (out_hi) out_hi[dof + i] = v.out_hi[so + i];
+      out_cnt[dof + i] = v.out_cnt[so + i];
+    }
+    dof += n;
   }
 }
 
@@ -1739,6 +1744,7 @@ bool cfrk_msp_usable(const cfrk_ctx *ctx) {
 }
 
 void cfrk_msp_reset(cfrk_ctx *ctx) {
+  if (ctx->msp) ctx->msp->view.seg_bits = 0;
   if (ctx->msp) { ctx->msp->pending = false; ctx->msp->table_dirty = false; ctx->msp->list_n_valid = false; ctx->msp->runs_ready = false; }
 }
 
@@ -2120,8 +2126,21 @@ extern "C" int cfrk_global_export_leaves_device(cfrk_ctx *ctx, uint64_t *d_keys,
   const int lpp = (NLEAF + parts - 1) / parts;           // leaves per part (owner p: leaves p, p+parts, ...)
   std::vector<uint32_t> ln(NLEAF), ordered((size_t)parts * lpp, 0u);
   std::vector<uint64_t> doff(NLEAF);
-  HIP_TRY(ctx, hipMemcpyAsync(ln.data(), ms->view.leaf_n, NLEAF * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  const uint32_t sgb = ms->view.seg_bits;
+  if (sgb == 0) {
+    HIP_TRY(ctx, hipMemcpyAsync(ln.data(), ms->view.leaf_n, NLEAF * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  } else {
+    // a leaf shared by record: its entries sit in 2^seg_bits segments (one per sub-value)
+    std::vector<uint32_t> sn((size_t)NLEAF << sgb);
+    HIP_TRY(ctx, hipMemcpyAsync(sn.data(), ms->view.leaf_n, sn.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t l = 0; l < (size_t)NLEAF; ++l) {
+      uint32_t t = 0;
+      for (uint32_t j = 0; j < (1u << sgb); ++j) t += sn[(l << sgb) | j];
+      ln[l] = t;
+    }
+  }
   uint64_t run = 0;
   for (int p = 0; p < parts; ++p) {
     uint64_t pc = 0;

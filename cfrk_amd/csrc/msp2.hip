@@ -49,7 +49,8 @@ struct View2 {
   Rec2 *rec1; uint32_t *cnt1; uint64_t cap1;            // B1 x NXG regions
   Rec2 *rec2; uint32_t *cnt2; uint64_t cap2c, cap2t;    // per leaf: complete stream, 3 truncated classes
   uint64_t *out_lo, *out_hi; uint32_t *out_cnt; uint64_t out_cap;
-  uint64_t *leaf_off; uint32_t *leaf_n;                  // where each leaf's entries sit in the result list
+  uint64_t *leaf_off; uint32_t *leaf_n;                  // where each leaf's entries sit in the result list (shared leaves: one
+                                                         // segment per sub-value, entry (leaf << sub_bits) | sub-value)
   // exact layout after leaf streams overflowed the fixed stride (see msp.hip): stream (leaf, class)
   // starts at record lbase[NCLS * leaf + class] and holds exactly lcap[...] records
   const uint64_t *lbase; const uint32_t *lcap; uint32_t exact;
@@ -1175,7 +1176,10 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
     if (tid == 0) {
       wg_base = atomicAdd((unsigned long long *)&v.stats[ST_CURSOR], (unsigned long long)wg_total);
       if (SHARED) {
-        if (wg_total) v.stats[ST_MULTISEG] = 1;          // the leaf's entries come from several workgroups
+        // one segment per sub-value; one that took several key-subset passes has no single segment
+        const uint32_t sg = (leaf << sub_bits) | (rsel << hbits) | sv;
+        if (bits == 0u) { v.leaf_off[sg] = wg_base; v.leaf_n[sg] = wg_total; }
+        else if (wg_total) v.stats[ST_MULTISEG] = 1;
       } else {
         if (nseg == 0) v.leaf_off[leaf] = wg_base;
         else if (wg_total) v.stats[ST_MULTISEG] = 1;
@@ -1395,9 +1399,11 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
   if ((ctx->dbg_flags & CFRK_DEBUG_RECORD_SUBSETS) && sub_bits < 2u) sub_bits = 2u;
   const bool sub = sub_bits != 0u;
   v.sub_bits = sub_bits;
-  if ((rc = cfrk_pool_get(ctx, BUF_MSP_AUX, (size_t)NLEAF * 8 + (size_t)(B1 * NXG + (NCLS + 1) * NLEAF) * sizeof(uint32_t), &p))) return rc;
+  // (leaf index: one entry per leaf, or per (leaf, sub-value) when leaves are shared)
+  const size_t nseg = (size_t)NLEAF << sub_bits;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_AUX, nseg * 8 + ((size_t)B1 * NXG + (size_t)NCLS * NLEAF + nseg) * sizeof(uint32_t), &p))) return rc;
   v.leaf_off = (uint64_t *)p;
-  v.cnt1 = (uint32_t *)(v.leaf_off + NLEAF); v.cnt2 = v.cnt1 + B1 * NXG; v.leaf_n = v.cnt2 + NCLS * NLEAF;
+  v.cnt1 = (uint32_t *)(v.leaf_off + nseg); v.cnt2 = v.cnt1 + B1 * NXG; v.leaf_n = v.cnt2 + NCLS * NLEAF;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTK, (size_t)ctx->g_cap * 8, &p))) return rc;
   v.out_lo = (uint64_t *)p;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTH, (size_t)ctx->g_cap * 8, &p))) return rc;
@@ -1408,7 +1414,7 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
   TableView t = cfrk_table_view(ctx);
 
   // (cnt1, cnt2 and -- first pass only -- the leaf index and the list cursor)
-  HIP_TRY(ctx, hipMemsetAsync(v.cnt1, 0, (size_t)(B1 * NXG + (NCLS + (first ? 1 : 0)) * NLEAF) * sizeof(uint32_t), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(v.cnt1, 0, ((size_t)B1 * NXG + (size_t)NCLS * NLEAF + (first ? nseg : 0)) * sizeof(uint32_t), ctx->stream));
   if (first) HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_CURSOR, 0, sizeof(uint64_t), ctx->stream));
   // Both levels are laid out for an input that spreads evenly over the minimizer space; one that does
   // not overflows its regions.  The cursors keep counting past the capacity, so after Q2 the host
@@ -1531,7 +1537,7 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
   HIP_TRY(ctx, hipGetLastError());
   ms->view.out_keys = v.out_lo; ms->view.out_hi = v.out_hi; ms->view.out_cnt = v.out_cnt;
   ms->view.out_cap = v.out_cap; ms->view.stats = v.stats; ms->view.cnt1 = nullptr;
-  ms->view.leaf_off = v.leaf_off; ms->view.leaf_n = v.leaf_n;
+  ms->view.leaf_off = v.leaf_off; ms->view.leaf_n = v.leaf_n; ms->view.seg_bits = v.sub_bits;
   ms->pending = true;
   ms->leaf_form = true;
   ms->list_n_valid = false;

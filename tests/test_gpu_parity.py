@@ -429,11 +429,12 @@ def test_export_partition_and_merge_roundtrip(ctx):
             ctx.free(p)
 
 
-@pytest.mark.parametrize("k", [31, 63])
-def test_leaf_export_and_lds_merge_two_emulated_ranks(ctx, k):
+@pytest.mark.parametrize("k,shared", [(31, False), (63, False), (63, True), (40, True)])
+def test_leaf_export_and_lds_merge_two_emulated_ranks(ctx, k, shared):
     """SURVEY 8e with leaf owners: two shards counted on their own contexts, per-leaf export with
     owner(leaf) = leaf % 2, then each owner adds both incoming lists of its leaves in LDS; the
-    union of the two owners' results equals the single-context result.  k = 63: two-word keys."""
+    union of the two owners' results equals the single-context result.  k = 63: two-word keys;
+    shared: the ranks' leaves are shared by record (their lists sit in one segment per sub-value)."""
     import cfrk_amd
     R, L, G = 40000, 150, 200000
     two = k > 32
@@ -447,7 +448,10 @@ def test_leaf_export_and_lds_merge_two_emulated_ranks(ctx, k):
     for r, c in enumerate(ranks):
         data, _, _ = orc.synth_reads(r * R // 2, R // 2, L, G)
         g = cfrk_amd.GlobalCounter(c, k, cfrk_amd.CFRK_CANONICAL, 2 * G)
+        if shared:
+            g.set_debug_flags(cfrk_amd.lib.CFRK_DEBUG_RECORD_SUBSETS)
         g.add(data)
+        g.set_debug_flags(0)
         n = g.finish()
         lpp = g.leaves_per_part(parts)
         dk, dh, dc, dl = c.alloc(n * 8 + 8), c.alloc(n * 8 + 8), c.alloc(n * 4 + 4), c.alloc(parts * lpp * 4)
