@@ -489,6 +489,19 @@ def test_leaf_export_and_lds_merge_two_emulated_ranks(ctx, k, shared):
     with pytest.raises(cfrk_amd.CfrkError) as e:
         gh.export_leaves_device(0, 0, 0, 2, 0)
     assert e.value.code == -4
+    if shared:
+        # the same context, now a one-word job: its list has one segment per leaf again
+        c = ranks[0]
+        data, _, _ = orc.synth_reads(0, R // 2, L, G)
+        g = cfrk_amd.GlobalCounter(c, 31, cfrk_amd.CFRK_CANONICAL, 2 * G)
+        g.add(data)
+        n = g.finish()
+        lpp = g.leaves_per_part(parts)
+        dk, dc, dl = c.alloc(n * 8 + 8), c.alloc(n * 4 + 4), c.alloc(parts * lpp * 4)
+        pc = g.export_leaves_device(dk, dc, n, parts, dl, 0)
+        cnt = np.empty(n, np.uint32)
+        c.d2h(cnt, dc)
+        assert sum(pc) == n and int(cnt.astype(np.uint64).sum()) == g.digest()[1]
     for c in ranks:
         c.close()
 
