@@ -606,9 +606,34 @@ __device__ __forceinline__ void count_record_v2(unsigned long long *keys, uint32
   uint64_t fwd = hi >> (64 - 2 * k);
   uint64_t rc = CANON ? dev_revcomp64(fwd, k) : 0;
   uint64_t T = (k == 32) ? lo : ((hi << (2 * k)) | (lo >> (64 - 2 * k)));
+  // (canonical counting) the lists are walked ONCE when every lane of the wave has at most 8 k-mers
+  // to expand and at most 127 noted runs: a lane counts its list's entries by d = clamp(length - j0,
+  // 0, 8) in nine 7-bit fields of one 64-bit register; k-mer j0 + q is counted once more for every
+  // entry with d > q, i.e. the fields' suffix sums, kept as eight bytes (msp2.hip: count_record2).
+  // The forward-strand instantiation keeps the loop per k-mer pair: it is out of registers.
+  unsigned long long exq = 0ull;
+  const bool tb_fast = CANON && tb && !__ballot(valid && (nk > 8 || tb_n > 127u));
+  if (tb_fast) {
+    unsigned long long hist = 0ull;
+    for (uint32_t e = 0; __ballot(e < tb_n); ++e) {         // (as many steps as the wave's longest list)
+      if (e < tb_n) {
+        const int d = min(max((int)tb[e] - j0, 0), 8);
+        hist += 1ull << (7 * d);
+      }
+    }
+    uint32_t run = 0;
+#pragma unroll
+    for (int d = 8; d >= 1; --d) {
+      run += (uint32_t)(hist >> (7 * d)) & 127u;
+      exq |= (unsigned long long)run << (8 * (d - 1));
+    }
+  }
   for (int j = 0; __ballot(j < nk); j += 2) {
     uint32_t add0 = add, add1 = add;
-    if (tb) {
+    if (tb_fast) {
+      add0 += (uint32_t)(exq >> (8 * (j & 7))) & 255u;
+      add1 += (uint32_t)(exq >> (8 * ((j + 1) & 7))) & 255u;
+    } else if (tb) {
       const uint32_t J = (uint32_t)(j0 + j);
       for (uint32_t e = 0; __ballot(e < tb_n); ++e) {       // (as many steps as the wave's longest list)
         const uint32_t tv = (e < tb_n) ? (uint32_t)tb[e] : 0u;
