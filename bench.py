@@ -63,8 +63,9 @@ def parse():
                         "runs, counted by the leaf's owner; leaf: counted per-leaf lists; owner: counted keys")
     a = p.parse_args()
     reads, L, k, glen = CONFIGS[a.config]
-    if a.config == "c5" and a.scaling in ("", "both", "strong"):
-        reads *= max(a.gpus, 1)               # configs[4] is strong scaling of gpus x 125 M reads
+    # configs[4] is defined per GPU (125 M reads each: gpus x 125 M reads in all, whatever --scaling
+    # says); every other config names the job's total
+    a.per_gpu = a.config == "c5" and not a.reads
     a.reads = a.reads or reads
     a.L = a.L or L
     a.k = a.k or k
@@ -115,8 +116,11 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(args, glen):
-    """the oracle (a CPU restatement; the reference has no CPU path) on a bounded sample"""
+def cpu_baseline(args, glen, gpu_digest_of_prefix=None):
+    """the oracle (a CPU restatement; the reference has no CPU path) on a bounded sample.
+    gpu_digest_of_prefix(R) -> digest of the same R reads counted by the HIP path (outside the
+    timed region): the oracle's counts are not thrown away but compared, so every default run is
+    also a parity check at 10^7 reads on the box it runs on (`prefix_parity`)."""
     from tests import oracle_lib as orc
     R = min(args.cpu_reads, args.reads)
     try:
@@ -130,10 +134,18 @@ def cpu_baseline(args, glen):
     lo, hi, cnt = orc.global_count(data, args.k, flags, threads=threads)
     dt = time.perf_counter() - t0
     kmers = R * (args.L - args.k + 1)
-    return {"value": kmers / dt, "unit": "k-mers/s", "cores": threads, "kind": "port",
-            "cpu_model": cpu_model(), "host_cpus_online": os.cpu_count(), "host_cpus_usable": avail,
-            "sample": f"first {R} reads of the same generator ({kmers} k-mers, {dt:.2f} s, "
-                      f"{len(lo)} distinct), oracle/cfrk_oracle.c, {threads} threads"}
+    out = {"value": kmers / dt, "unit": "k-mers/s", "cores": threads, "kind": "port",
+           "cpu_model": cpu_model(), "host_cpus_online": os.cpu_count(), "host_cpus_usable": avail,
+           "sample": f"first {R} reads of the same generator ({kmers} k-mers, {dt:.2f} s, "
+                     f"{len(lo)} distinct), oracle/cfrk_oracle.c, {threads} threads"}
+    parity = None
+    if gpu_digest_of_prefix is not None:
+        want = tuple(int(x) for x in orc.digest(lo, hi, cnt))
+        got = tuple(int(x) for x in gpu_digest_of_prefix(R))
+        parity = got == want
+        out["prefix_digest_oracle"] = [f"{x:016x}" for x in want]
+        out["prefix_digest_gpu"] = [f"{x:016x}" for x in got]
+    return out, parity
 
 
 def measured_traffic(R, L, k, canonical, glen):
@@ -155,8 +167,7 @@ def measured_traffic(R, L, k, canonical, glen):
 def config_label(args, world, scaling):
     base = (args.reads, args.L, args.k, args.glen or args.reads, args.uniform, args.no_canonical)
     for name, (reads, L, k, glen) in CONFIGS.items():
-        r = reads * (world if name == "c5" and scaling != "weak" else 1)
-        if base == (r, L, k, glen or r, False, False):
+        if base == (reads, L, k, glen or reads, False, False):
             if name == "c3":
                 if world == 1:
                     return "BASELINE.json configs[2]"
@@ -212,7 +223,8 @@ def main():
 
     def measure(scaling):
         """W warm-up + K timed steps of the job under `scaling`; returns rank 0's result dict"""
-        R = args.reads * world if scaling == "weak" else args.reads   # total reads of the job
+        # total reads of the job (a per-GPU config has the same job under both scalings)
+        R = args.reads * world if (scaling == "weak" or args.per_gpu) else args.reads
         glen = args.glen or args.reads
         r0, r1 = sharded.shard_range(R, rank, world)       # contiguous read ranges (SURVEY 8e)
         Rl = r1 - r0
@@ -378,7 +390,8 @@ def main():
             "metric": "k-mers/sec", "value": kmers_total * args.steps / dt, "unit": "k-mers/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": scaling if world > 1 else "weak",
+            # (N = 1 is the first point of the strong-scaling curve of configs[3]: the job is fixed)
+            "scaling": scaling,
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"{R} synthetic {L} bp reads, k={k}, "
                                    f"{'canonical' if flags else 'forward'}, "
@@ -388,6 +401,8 @@ def main():
                        + (" + owner all-to-all" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_kind": ("committed PMC measurement of this workload (tools/traffic.sh, file named in "
+                                          "traffic_source): NOT taken during this run" if traffic else None),
                          "kernel": "counting kernels of cfrk_global_add_device (HIP events on the context stream)",
                          "kernel_ms": avg_ms, "algorithmic_bytes": b_alg,
                          "timed_bytes": b_timed, "frac_timed_bytes": b_timed / (avg_ms * 1e-3) / 8e12,
@@ -407,20 +422,37 @@ def main():
         return out, ok, kmers_total
 
     scaling = args.scaling or "both"
+    parity = None
     if world == 1:
         out, ok, total = measure("strong")
-    elif scaling == "both":
+    elif scaling == "both" and not args.per_gpu:
         out, ok, total = measure("strong")
-        w, wok, _ = measure("weak")
-        ok = ok and wok
-        out["weak"] = {key: w[key] for key in ("value", "ms_per_step", "config", "distinct", "sum_count_ok",
-                                               "digest", "step_breakdown_ms", "exchange")}
+        # The headline is safe from here on: if the weak pass (N x the per-GPU memory) dies or
+        # hangs, the watchdog / the handler below still print the strong-scaling line.
+        _PENDING["line"] = dict(out, weak={"error": "weak-scaling pass did not finish"}, cpu_baseline=None)
+        _PENDING["ok"] = ok
+        try:
+            w, wok, _ = measure("weak")
+            ok = ok and wok
+            out["weak"] = {key: w[key] for key in ("value", "ms_per_step", "config", "distinct", "sum_count_ok",
+                                                   "digest", "step_breakdown_ms", "exchange")}
+        except Exception as e:            # noqa: BLE001 -- reported in the line, the headline stands
+            out["weak"] = {"error": f"{type(e).__name__}: {e}"}
     else:
-        out, ok, total = measure(scaling)
+        out, ok, total = measure("strong" if scaling == "both" else scaling)
+    _PENDING["line"] = None
 
     if rank == 0:
         if world == 1 and args.cpu_reads > 0:
-            out["cpu_baseline"] = cpu_baseline(args, args.glen or args.reads)
+            def gpu_digest_of_prefix(Rp):
+                nNp = Rp * (L + 1)
+                d = torch.empty(nNp + 64, dtype=torch.int8, device=dev)
+                ctx.synth_reads_device(0, Rp, L, args.glen or args.reads, d.data_ptr(), uniform=args.uniform)
+                g = cfrk_amd.GlobalCounter(ctx, k, flags, min(args.glen or args.reads, Rp * max(L - k + 1, 0)) + 1024)
+                g.add_device(d.data_ptr(), nNp)
+                return g.digest()
+            out["cpu_baseline"], parity = cpu_baseline(args, args.glen or args.reads, gpu_digest_of_prefix)
+            out["prefix_parity"] = parity
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
@@ -429,7 +461,60 @@ def main():
         dist.destroy_process_group()
     if not ok and not os.environ.get("CFRK_DEBUG_FLAGS"):
         raise SystemExit(f"sum(count) != {total}")
+    if parity is False:
+        raise SystemExit("prefix_parity false: the HIP path and the oracle disagree on the cpu_baseline sample")
+
+
+# what rank 0 prints if the process has to give up after the headline measurement finished
+_PENDING = {"line": None, "ok": True}
+
+
+def _watchdog(seconds):
+    """Hard limit for one rank: a rank stuck in a collective (the first RCCL run is the driver's)
+    must not hang the job.  Dumps every thread's stack, prints a finished headline if there is one,
+    and leaves with os._exit -- no destructors, no process-group teardown that could hang again."""
+    import faulthandler
+    import threading
+
+    def fire():
+        r = os.environ.get("RANK", "0")
+        sys.stderr.write(f"[bench rank {r}] hard timeout after {seconds} s; stacks follow\n")
+        faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+        line = _PENDING["line"]
+        if line is not None and r == "0":
+            print(json.dumps(line), flush=True)
+            os._exit(0 if _PENDING["ok"] else 1)
+        os._exit(124)
+
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
+def _rank_entry():
+    """main() with every failure reported per rank on stderr (rank id, traceback, the library's
+    last error text is in the exception) and a non-hanging exit."""
+    limit = float(os.environ.get("CFRK_BENCH_TIMEOUT", "1500"))
+    wd = _watchdog(limit) if limit > 0 else None
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException:             # noqa: BLE001
+        import traceback
+        r, w = os.environ.get("RANK", "0"), os.environ.get("WORLD_SIZE", "1")
+        sys.stderr.write(f"[bench rank {r}/{w}] failed:\n{traceback.format_exc()}\n")
+        sys.stderr.flush()
+        line = _PENDING["line"]
+        if line is not None and r == "0":
+            print(json.dumps(line), flush=True)
+        # other ranks may be inside a collective with this one: leave without teardown
+        os._exit(1)
+    finally:
+        if wd is not None:
+            wd.cancel()
 
 
 if __name__ == "__main__":
-    main()
+    _rank_entry()

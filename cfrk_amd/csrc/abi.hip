@@ -319,17 +319,30 @@ struct LayoutCheck {
     if (nt == 0) nt = 1;
     bad.assign(nt, -1);
     why.assign(nt, 0);
-    for (unsigned t = 0; t < nt; ++t) th.emplace_back([this, t, nt] {
+    auto piece_fn = [this](unsigned t, unsigned nt) {
       const int64_t i0 = nS * t / nt, i1 = nS * (t + 1) / nt;
       for (int64_t i = i0; i < i1; ++i) {
-        const int64_t want = i ? start[i - 1] + (int64_t)length[i - 1] + 1 : 0;
+        // A thread's first read is compared with a predecessor another thread validates: every
+        // term is range-checked before it is used, so a corrupt table (negative starts, sums that
+        // overflow) never turns into an out-of-bounds read of data[].
         int w = 0;
-        if (start[i] != want || length[i] < 0) w = 1;
-        else if (start[i] + (int64_t)length[i] + 1 > nN) w = 2;
+        if (start[i] < 0 || start[i] > nN || length[i] < 0) w = 1;
+        else if (i && (start[i - 1] < 0 || start[i - 1] > nN || length[i - 1] < 0 ||
+                       start[i] != start[i - 1] + (int64_t)length[i - 1] + 1)) w = 1;
+        else if (!i && start[i] != 0) w = 1;
+        else if ((int64_t)length[i] + 1 > nN - start[i]) w = 2;
         else { const int8_t term = data[start[i] + length[i]]; if (term >= 0 && term <= 3) w = 3; }
         if (w) { bad[t] = i; why[t] = w; return; }
       }
-    });
+    };
+    // std::thread may throw (resource exhaustion): nothing may cross the extern "C" boundary, so
+    // the pieces no thread could be started for are checked right here
+    unsigned started = 0;
+    try {
+      for (; started < nt; ++started) th.emplace_back(piece_fn, started, nt);
+    } catch (...) {
+      for (unsigned t = started; t < nt; ++t) piece_fn(t, nt);
+    }
   }
   void join() { for (auto &x : th) if (x.joinable()) x.join(); }
   // true (and the context's error text set) when the layout is not the reference's
@@ -339,7 +352,8 @@ struct LayoutCheck {
     for (size_t t = 0; t < bad.size(); ++t) {
       if (bad[t] < 0) continue;
       const int64_t i = bad[t];
-      const int64_t want = i ? start[i - 1] + (int64_t)length[i - 1] + 1 : 0;
+      // (the predecessor's fields may themselves be garbage: wrap-around arithmetic, text only)
+      const int64_t want = i ? (int64_t)((uint64_t)start[i - 1] + (uint64_t)(int64_t)length[i - 1] + 1u) : 0;
       if (why[t] == 1) cfrk_fail(ctx, CFRK_ERR_LAYOUT, "read %lld: start %lld, expected %lld", (long long)i, (long long)start[i], (long long)want);
       else if (why[t] == 2) cfrk_fail(ctx, CFRK_ERR_LAYOUT, "read %lld runs past nN", (long long)i);
       else cfrk_fail(ctx, CFRK_ERR_LAYOUT, "read %lld has no terminator", (long long)i);

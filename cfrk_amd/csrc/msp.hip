@@ -90,13 +90,17 @@ __host__ __device__ __forceinline__ uint32_t l1_reg(uint32_t bin, uint32_t xg) {
 
 // write record `rec` as entry `dst` of level-1 region `reg`; a full region parks a few records and
 // beyond that raises ST_L1OVF (the cursors keep counting: the host redoes P1 with exact sizes)
+// (EX = false: compiled for the fixed-stride layout only -- the fused pipeline kernel, which never
+// runs on an exact layout, sheds the code and the scalar registers of that case)
+template <bool EX>
 __device__ __forceinline__ void l1_put(const MspView &v, uint32_t reg, uint32_t dst, uint4 rec, int k, bool canon,
                                        const TableView &t) {
-  const uint64_t cap = v.exact1 ? (uint64_t)v.rcap[reg] : v.cap1;
-  const uint64_t at = v.exact1 ? v.rbase[reg] : (uint64_t)reg * v.cap1;
+  const bool exact1 = EX && v.exact1;
+  const uint64_t cap = exact1 ? (uint64_t)v.rcap[reg] : v.cap1;
+  const uint64_t at = exact1 ? v.rbase[reg] : (uint64_t)reg * v.cap1;
   if (dst < cap) {
     v.rec1[at + dst] = rec;
-  } else if (v.exact1) {
+  } else if (exact1) {
     spill_record(rec, k, canon, t);                      // cannot happen: cap is the exact count
   } else if (*(volatile uint64_t *)&v.stats[ST_L1OVF] == 0) {
     const unsigned long long o = atomicAdd((unsigned long long *)&v.stats[ST_OVFN1], 1ull);
@@ -117,17 +121,32 @@ __device__ __forceinline__ void l1_put(const MspView &v, uint32_t reg, uint32_t 
 // allocation.  Runs per wave grow as 2/(W+1): the trips held in registers are a template
 // parameter (4 for W >= 16 ... 12 for W = 4), and so are registers and workgroups per CU.
 // P1B_TR = balanced trips held in registers (64 runs per wave each)
-template <int W, int P1B_TR>
-__global__ __launch_bounds__(P1_THREADS, (P1B_TR <= 6 ? 6 : 4)) void msp_p1b_kernel(const int8_t *__restrict__ data,
-                                                             int64_t nN, int k, int m, int canon,
-                                                             int64_t tile0, MspView v, TableView t) {
+// LDS of one P1 workgroup: per-wave staging (later the bin-sorted records), histogram, offsets
+template <int P1B_TR>
+struct P1Lds {
+  static constexpr int STAGE = 4096 + 3 * 512 + P1B_TR * 128;     // bytes of staging per wave
+  static constexpr int ARENA = P1_WAVES * STAGE;
+  static constexpr int BYTES = ARENA + 2 * B1 * 4 + 32;
+};
+
+// Workgroup-level body of the partition kernel: the tiles tile_first, tile_first + tile_stride, ...
+// < tile_end, appending to sub-region `subreg` of every level-1 bin.  Called by the stand-alone
+// kernel (one tile per workgroup, or a persistent grid) and by the fused kernel msp_p12_kernel,
+// where two workgroups per CU do this while a third runs p2_role on the previous chunk.
+template <int W, int P1B_TR, bool EX>
+__device__ __forceinline__ void p1_role(uint4 *pool, const int8_t *__restrict__ data, int64_t nN, int k, int m, int canon,
+                                        int64_t tile_first, int64_t tile_stride, int64_t tile_end, uint32_t subreg,
+                                        const MspView &v, const TableView &t) {
   constexpr int NH = 32 + W - 1;
-  constexpr int P1B_STAGE = 4096 + 3 * 512 + P1B_TR * 128;     // bytes of staging per wave
+  constexpr int P1B_STAGE = P1Lds<P1B_TR>::STAGE;
   // sorted records share the staging bytes; the last 2.5 KB hold the copy-out table (dabs, plim)
   constexpr int P1B_TAIL = B1 * 10;
   constexpr int P1B_RCAP = (P1_WAVES * P1B_STAGE - P1B_TAIL) / 16;
-  __shared__ uint4 arena[P1_WAVES * P1B_STAGE / 16];   // per-wave staging, later the bin-sorted records (P1B_RCAP of them)
-  __shared__ uint32_t hist[B1], loff[B1];
+  uint4 *const arena = pool;                     // per-wave staging, later the bin-sorted records (P1B_RCAP of them)
+  uint32_t *const hist = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(pool) + P1Lds<P1B_TR>::ARENA);
+  uint32_t *const loff = hist + B1;
+  uint32_t *const wtot = loff + B1;              // 4 words
+  uint32_t *const nrec_p = wtot + 4;
   uint32_t *const gbase = hist;                  // the global bases take the histogram's place once it is scanned
   // copy-out fast path, worked out once per bin and tile by the thread that reserved the segment:
   // arena position p of bin b goes to record dabs[b] + p of the level-1 buffer while p < plim[b]
@@ -135,23 +154,27 @@ __global__ __launch_bounds__(P1_THREADS, (P1B_TR <= 6 ? 6 : 4)) void msp_p1b_ker
   unsigned long long *const dabs = reinterpret_cast<unsigned long long *>(reinterpret_cast<uint8_t *>(arena) + P1B_RCAP * 16);
   uint16_t *const plim = reinterpret_cast<uint16_t *>(dabs + B1);
   static_assert((P1_WAVES * P1B_STAGE - P1B_TAIL) % 16 == 0, "the table starts on a record boundary");
-  __shared__ uint32_t wtot[4];
-  __shared__ uint32_t nrec_s;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nkmax = min(48 - k + 1, 32);
+  for (int64_t tile = tile_first; tile < tile_end; tile += tile_stride) {
+  // The thread index goes through an empty asm at the top of every tile: nothing derived from it
+  // (lane, wave, staging addresses, masks) can be hoisted out of the tile loop, where it would stay
+  // live across the whole body -- hoisted, those values cost 5 VGPRs more than the kernel has at
+  // three workgroups per CU and the compiler spilled them to scratch (16 reloads per tile and thread).
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63, wave = tid >> 6;
   uint8_t *const stage = reinterpret_cast<uint8_t *>(arena) + wave * P1B_STAGE;
   uint16_t *const s_leaf = reinterpret_cast<uint16_t *>(stage);               // [64 lanes][32 positions]
   uint32_t *const s_str = reinterpret_cast<uint32_t *>(stage + 4096);         // 128 dwords of bases
   uint64_t *const s_E = reinterpret_cast<uint64_t *>(stage + 4096 + 512);     // run terminators
   uint64_t *const s_W = reinterpret_cast<uint64_t *>(stage + 4096 + 1024);    // validity of position p-1
   uint16_t *const s_dsc = reinterpret_cast<uint16_t *>(stage + 4096 + 1536);  // (lane << 5) | position
-
   if (tid < B1) hist[tid] = 0;
   __syncthreads();
 
   // ---- A: this lane's chunk, packed 2 bits per base; neighbours' chunks by shuffle ----
-  const int64_t wave_g = (tile0 + blockIdx.x) * P1_WAVES + wave;
+  const int64_t wave_g = tile * P1_WAVES + wave;
   const int64_t chunk = wave_g * P1_OWN + lane - 1;
   const int64_t off = chunk * 32;
   uint32_t b0 = 0, b1 = 0, bad = 0xFFFFFFFFu;
@@ -202,7 +225,8 @@ __global__ __launch_bounds__(P1_THREADS, (P1B_TR <= 6 ? 6 : 4)) void msp_p1b_ker
   }
   if (v.dbg & CFRK_ABL_P1_NO_EMIT) {             // timing ablation: keep the front end alive, emit nothing
     if (S == 0x12345678u && (uint32_t)E == 0x9ABCDEFu) v.stats[ST_AUX0] = 1;
-    return;
+    __syncthreads();
+    continue;
   }
   uint32_t cnt_w;
   uint32_t S2 = 0;                               // run starts beyond the balanced phase's capacity
@@ -266,9 +290,9 @@ __global__ __launch_bounds__(P1_THREADS, (P1B_TR <= 6 ? 6 : 4)) void msp_p1b_ker
     S2 &= ~(0x80000000u >> a);
     const uint4 rec = build(((uint32_t)lane << 5) | (uint32_t)a);
     if (((rec.w >> 8) & v.sel_mask) != v.sel_val) continue;    // not a leaf of this pass
-    const uint32_t reg = l1_reg(rec.w >> 16, blockIdx.x & (v.nxg - 1));
+    const uint32_t reg = l1_reg(rec.w >> 16, subreg);
     const uint32_t dst = atomicAdd(&v.cnt1[reg], 1u);
-    l1_put(v, reg, dst, rec, k, canon != 0, t);
+    l1_put<EX>(v, reg, dst, rec, k, canon != 0, t);
   }
 
   // ---- B2: lane i builds the wave's i-th record ----
@@ -292,10 +316,10 @@ __global__ __launch_bounds__(P1_THREADS, (P1B_TR <= 6 ? 6 : 4)) void msp_p1b_ker
   uint32_t my_base = 0;
   if (tid < B1) {
     const uint32_t c = hist[tid];
-    if (c) my_base = atomicAdd(&v.cnt1[l1_reg(tid, blockIdx.x & (v.nxg - 1))], c);
+    if (c) my_base = atomicAdd(&v.cnt1[l1_reg(tid, subreg)], c);
   }
   block_scan<B1>(hist, loff, wtot);              // ends with a barrier: the staging area is dead
-  if (tid == B1 - 1) nrec_s = loff[tid] + hist[tid];   // (before this thread overwrites hist[tid] below)
+  if (tid == B1 - 1) *nrec_p = loff[tid] + hist[tid];   // (before this thread overwrites hist[tid] below)
 #pragma unroll
   for (int tr = 0; tr < P1B_TR; ++tr) {
     if (rk[tr] != 0xFFFFFFFFu) {
@@ -305,9 +329,10 @@ __global__ __launch_bounds__(P1_THREADS, (P1B_TR <= 6 ? 6 : 4)) void msp_p1b_ker
   }
   if (tid < B1) {
     gbase[tid] = my_base;
-    const uint32_t reg = l1_reg(tid, blockIdx.x & (v.nxg - 1));
-    const uint64_t cap = v.exact1 ? (uint64_t)v.rcap[reg] : v.cap1;
-    const uint64_t at = v.exact1 ? v.rbase[reg] : (uint64_t)reg * v.cap1;
+    const uint32_t reg = l1_reg(tid, subreg);
+    const bool exact1 = EX && v.exact1;
+    const uint64_t cap = exact1 ? (uint64_t)v.rcap[reg] : v.cap1;
+    const uint64_t at = exact1 ? v.rbase[reg] : (uint64_t)reg * v.cap1;
     const uint32_t lo = loff[tid];
     dabs[tid] = at + my_base - lo;
     const uint64_t room = cap > (uint64_t)my_base ? cap - my_base : 0;       // records of this segment that fit the region
@@ -317,12 +342,13 @@ __global__ __launch_bounds__(P1_THREADS, (P1B_TR <= 6 ? 6 : 4)) void msp_p1b_ker
   __syncthreads();
 
   // ---- D: copy out in bin order ----
+  const uint32_t nrec_s = *nrec_p;
   const uint32_t nrec = min(nrec_s, (uint32_t)P1B_RCAP);
   for (uint32_t p = tid; p < nrec; p += P1_THREADS) {
     const uint4 rec = arena[p];
     const uint32_t b = rec.w >> 16;
     if (p < (uint32_t)plim[b]) v.rec1[dabs[b] + p] = rec;
-    else l1_put(v, l1_reg(b, blockIdx.x & (v.nxg - 1)), gbase[b] + (p - loff[b]), rec, k, canon != 0, t);   // region full: park / flag
+    else l1_put<EX>(v, l1_reg(b, subreg), gbase[b] + (p - loff[b]), rec, k, canon != 0, t);   // region full: park / flag
   }
   if (nrec_s > (uint32_t)P1B_RCAP) {             // records beyond the LDS arena go to their reserved places
 #pragma unroll
@@ -330,48 +356,98 @@ __global__ __launch_bounds__(P1_THREADS, (P1B_TR <= 6 ? 6 : 4)) void msp_p1b_ker
       if (rk[tr] != 0xFFFFFFFFu) {
         const uint32_t b = rc[tr].w >> 16;
         if (loff[b] + rk[tr] >= (uint32_t)P1B_RCAP)
-          l1_put(v, l1_reg(b, blockIdx.x & (v.nxg - 1)), gbase[b] + rk[tr], rc[tr], k, canon != 0, t);
+          l1_put<EX>(v, l1_reg(b, subreg), gbase[b] + rk[tr], rc[tr], k, canon != 0, t);
       }
     }
   }
+  __syncthreads();                               // the arena and the tables are the next tile's
+  }  // tile loop
 }
+
+template <int W, int P1B_TR>
+__global__ __launch_bounds__(P1_THREADS, (P1B_TR <= 6 ? 6 : 4)) void msp_p1b_kernel(const int8_t *__restrict__ data,
+                                                             int64_t nN, int k, int m, int canon,
+                                                             int64_t tile0, int64_t tile_end, MspView v, TableView t) {
+  // Workgroup b takes the tiles tile0 + b, tile0 + b + gridDim.x, ... < tile_end: a grid of one
+  // workgroup per tile (small batches) or a persistent grid (the first stage of cfrk_msp_count's pipeline).
+  __shared__ uint4 pool[P1Lds<P1B_TR>::BYTES / 16];
+  p1_role<W, P1B_TR, true>(pool, data, nN, k, m, canon, tile0 + blockIdx.x, gridDim.x, tile_end, blockIdx.x & (v.nxg - 1), v, t);
+}
+
 
 // ---------------------------------------------------------------------------------------- P2
 // sub-bin of a record inside its level-1 bin: leaf low byte x {truncated run, complete run}.
 // Complete runs get a stream of their own so that P3 can count them per RECORD with every lane
 // busy, instead of k-mer by k-mer.
-// Grid = B1 * NXG * tiles_per_sub workgroups.  blockIdx % 8 picks the XCD group, and each group
-// walks ITS bins (b1 = group, group+8, ...) one after the other, so that at any moment the
-// workgroups of one XCD append to the leaf streams of very few level-1 bins: a leaf stream is only
-// ever written from one XCD and its frontier sectors merge in L2 (P2: 11.6 -> 10.0 ms).
+// PERSISTENT grid of nwg workgroups (a multiple of 8).  Workgroup w belongs to XCD group w % 8 and
+// that group walks ITS bins (b1 = group, group + 8, ...) one after the other: the group's work items
+// -- P2_GROUP consecutive tiles of one bin -- are numbered bin after bin from the records the bins
+// really hold (no empty items), and workgroup j of the group takes items j, j + nwg/8, ...  At any
+// moment the workgroups of one XCD append to the leaf streams of one or two level-1 bins: a leaf
+// stream is only ever written from one XCD and its frontier sectors merge in L2 (P2: 11.6 -> 10.0 ms).
 // Two streams per leaf: truncated runs (class 0) and complete runs (class 1).  The leaf kernel
 // sorts records by length itself, so finer classes would only shorten P2's write segments.
 constexpr int NCLS = 2;
 constexpr int NSUB = NCLS * B2;                           // 512 sub-bins of a level-1 bin
 __device__ __forceinline__ uint32_t sub_of(uint32_t w) { return (((w >> 8) & (B2 - 1)) << 1) | ((((w >> 6) & 3u) == 3u) ? 1u : 0u); }
 
-__global__ __launch_bounds__(P2_THREADS, 4) void msp_p2_kernel(int groups_per_bin, int k, int canon,
-                                                            MspView v, TableView t) {
-  __shared__ uint4 sorted[P2_TILE];
-  __shared__ uint32_t hist[NSUB], loff[NSUB], gbase[NSUB];   // hist doubles as the fill cursor
+// LDS of one P2 workgroup with tiles of P2_THREADS * PER records
+template <int PER>
+struct P2Lds {
+  static constexpr int TILE = P2_THREADS * PER;
+  static constexpr int BYTES = TILE * 16 + NSUB * (4 + 4 + 8 + 2) + (P2_THREADS / 64) * 4 + (NXG + 1) * 4 + (B1 / NXCD + 1) * 4 + 28;
+};
+
+// PER = records per thread and tile: 8 stand-alone (two workgroups of 75 KB per CU), 5 in the fused
+// kernel (the LDS of a P1 workgroup, 80 VGPRs)
+template <int PER, bool EX, bool PF>
+__device__ __forceinline__ void p2_role(uint4 *pool, uint32_t wg, uint32_t nwg, int k, int canon, const MspView &v, const TableView &t) {
+  constexpr int TILE = P2_THREADS * PER;
+  static_assert(TILE <= 0xFFFF, "tile positions fit 16 bits");
+  uint4 *const sorted = pool;
   // copy-out fast path, once per stream and tile: sorted position p of sub-bin sb goes to record
   // dabs[sb] + p of the leaf buffer while p < plim[sb]
-  __shared__ unsigned long long dabs[NSUB];
-  __shared__ uint16_t plim[NSUB];
-  static_assert(P2_TILE <= 0xFFFF, "tile positions fit 16 bits");
-  __shared__ uint32_t wtot[P2_THREADS / 64];
-  __shared__ uint32_t rpre[NXG + 1];             // exclusive prefix of the bin's sub-region sizes
+  unsigned long long *const dabs = reinterpret_cast<unsigned long long *>(pool + TILE);
+  uint32_t *const hist = reinterpret_cast<uint32_t *>(dabs + NSUB);   // hist doubles as the fill cursor
+  uint32_t *const loff = hist + NSUB;
+  uint16_t *const plim = reinterpret_cast<uint16_t *>(loff + NSUB);
+  uint32_t *const wtot = reinterpret_cast<uint32_t *>(plim + NSUB);   // P2_THREADS / 64 words
+  uint32_t *const rpre = wtot + P2_THREADS / 64;                      // exclusive prefix of the bin's sub-region sizes (NXG + 1)
+  uint32_t *const gpre = rpre + NXG + 1;                              // exclusive prefix of the group's items per bin (B1 / NXCD + 1)
   static_assert(NSUB <= P2_THREADS && NSUB % 64 == 0, "the scan below gives one thread per sub-bin");
   static_assert(NXG <= 64, "one wave scans the sub-region sizes");
+  constexpr int BPG = B1 / NXCD;                 // bins per XCD group
+  static_assert(P2_THREADS == BPG * 16, "sixteen threads add up a bin's sub-regions");
   const int tid = threadIdx.x;
-  const uint32_t xg = blockIdx.x & (NXCD - 1), seq = blockIdx.x / NXCD;
-  const uint32_t b1 = xg + NXCD * (seq / (uint32_t)groups_per_bin);
-  const uint32_t grp = seq % (uint32_t)groups_per_bin;
+  const bool exact1 = EX && v.exact1, exact2 = EX && v.exact;
+  const uint32_t xg = wg & (NXCD - 1), j0 = wg / NXCD, nj = nwg / NXCD;
+  // items per bin of this group: sixteen threads per bin add the sub-region sizes
+  {
+    const uint32_t i = (uint32_t)tid >> 4, part = (uint32_t)tid & 15u, b = xg + NXCD * i;
+    uint32_t sum = 0;
+    for (uint32_t sr = part; sr < v.nxg; sr += 16u) {
+      const uint32_t reg = l1_reg(b, sr);
+      sum += (uint32_t)min((uint64_t)v.cnt1[reg], exact1 ? (uint64_t)v.rcap[reg] : v.cap1);
+    }
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) sum += __shfl_xor(sum, d);
+    if (part == 0) gpre[i + 1] = (sum + (uint32_t)(TILE * P2_GROUP) - 1u) / (uint32_t)(TILE * P2_GROUP);
+    if (tid == 0) gpre[0] = 0;
+    __syncthreads();
+    if (tid == 0) for (int q = 1; q <= BPG; ++q) gpre[q] += gpre[q - 1];
+    __syncthreads();
+  }
+  const uint32_t nitems = gpre[BPG];
+  uint32_t bi = 0;                               // bin of the current item (items grow: the cursor only moves forward)
+  for (uint32_t item = j0; item < nitems; item += nj) {
+  while (gpre[bi + 1] <= item) ++bi;
+  const uint32_t b1 = xg + NXCD * bi;
+  const uint32_t grp = item - gpre[bi];
   // The bin's sub-regions are read as ONE stream (region after region): tiles are full except the
   // bin's last one, however many cursors P1 spreads its appends over.
   if (tid < 64) {
     const uint32_t c = ((uint32_t)tid < v.nxg) ? (uint32_t)min((uint64_t)v.cnt1[l1_reg(b1, tid)],
-                                                               v.exact1 ? (uint64_t)v.rcap[l1_reg(b1, tid)] : v.cap1) : 0u;
+                                                               exact1 ? (uint64_t)v.rcap[l1_reg(b1, tid)] : v.cap1) : 0u;
     uint32_t incl = c;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -385,8 +461,7 @@ __global__ __launch_bounds__(P2_THREADS, 4) void msp_p2_kernel(int groups_per_bi
   const uint64_t n = rpre[v.nxg];
   // a workgroup takes P2_GROUP consecutive tiles and asks for the next tile's records before it
   // sorts and writes the current one: the load latency hides under the LDS work
-  const uint64_t g0r = (uint64_t)grp * P2_GROUP * P2_TILE;
-  if (g0r >= n) return;
+  const uint64_t g0r = (uint64_t)grp * P2_GROUP * TILE;
   // record `idx` of the bin's stream lies in the sub-region `sr` with rpre[sr] <= idx < rpre[sr + 1]: one
   // binary search for a thread's first record, then the cursor only moves forward (a thread's
   // indices grow from fetch to fetch)
@@ -401,36 +476,50 @@ __global__ __launch_bounds__(P2_THREADS, 4) void msp_p2_kernel(int groups_per_bi
   }
   auto fetch = [&](uint64_t idx) {
     while (sr + 1 < v.nxg && rpre[sr + 1] <= idx) ++sr;
-    if (v.exact1) return v.rec1[v.rbase[l1_reg(b1, sr)] + (idx - rpre[sr])];
+    if (exact1) return v.rec1[v.rbase[l1_reg(b1, sr)] + (idx - rpre[sr])];
     return v.rec1[(uint64_t)l1_reg(b1, sr) * v.cap1 + (idx - rpre[sr])];
   };
   const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
-  uint4 nx[P2_PER];
+  // PF: the next tile's records are asked for before the current tile is sorted and written (PER
+  // more uint4 registers).  The fused kernel's copy of this role goes without: it has 80 VGPRs,
+  // and while it waits for its loads the partitioning workgroups of its CU keep the vector pipe busy.
+  uint4 nx[PF ? PER : 1];
+  if (PF) {
 #pragma unroll
-  for (int i = 0; i < P2_PER; ++i) {
-    const uint64_t idx = g0r + (uint64_t)i * P2_THREADS + tid;
-    nx[i] = zero4;
-    if (idx < n) nx[i] = fetch(idx);
+    for (int i = 0; i < PER; ++i) {
+      const uint64_t idx = g0r + (uint64_t)i * P2_THREADS + tid;
+      nx[PF ? i : 0] = zero4;
+      if (idx < n) nx[PF ? i : 0] = fetch(idx);
+    }
   }
   for (int tt = 0; tt < P2_GROUP; ++tt) {
-    const uint64_t r0 = g0r + (uint64_t)tt * P2_TILE;
+    const uint64_t r0 = g0r + (uint64_t)tt * TILE;
     if (r0 >= n) break;
-    const uint32_t nt = (uint32_t)min((uint64_t)P2_TILE, n - r0);
-    uint4 r[P2_PER];
+    const uint32_t nt = (uint32_t)min((uint64_t)TILE, n - r0);
+    uint4 r[PER];
+    if (PF) {
 #pragma unroll
-    for (int i = 0; i < P2_PER; ++i) r[i] = nx[i];
-    if (tt + 1 < P2_GROUP) {
+      for (int i = 0; i < PER; ++i) r[i] = nx[PF ? i : 0];
+      if (tt + 1 < P2_GROUP) {
 #pragma unroll
-      for (int i = 0; i < P2_PER; ++i) {
-        const uint64_t idx = r0 + P2_TILE + (uint64_t)i * P2_THREADS + tid;
-        nx[i] = zero4;
-        if (idx < n) nx[i] = fetch(idx);
+        for (int i = 0; i < PER; ++i) {
+          const uint64_t idx = r0 + TILE + (uint64_t)i * P2_THREADS + tid;
+          nx[PF ? i : 0] = zero4;
+          if (idx < n) nx[PF ? i : 0] = fetch(idx);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const uint64_t idx = r0 + (uint64_t)i * P2_THREADS + tid;
+        r[i] = zero4;
+        if (idx < n) r[i] = fetch(idx);
       }
     }
     if (tid < NSUB) hist[tid] = 0;
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < P2_PER; ++i) {
+    for (int i = 0; i < PER; ++i) {
       const uint32_t idx = (uint32_t)i * P2_THREADS + tid;
       if (idx < nt) atomicAdd(&hist[sub_of(r[i].w)], 1u);
     }
@@ -461,7 +550,7 @@ __global__ __launch_bounds__(P2_THREADS, 4) void msp_p2_kernel(int groups_per_bi
     }
     // counting sort of the tile by sub-bin, in LDS
 #pragma unroll
-    for (int i = 0; i < P2_PER; ++i) {
+    for (int i = 0; i < PER; ++i) {
       const uint32_t idx = (uint32_t)i * P2_THREADS + tid;
       if (idx < nt) {
         const uint32_t sb = sub_of(r[i].w);
@@ -469,12 +558,11 @@ __global__ __launch_bounds__(P2_THREADS, 4) void msp_p2_kernel(int groups_per_bi
       }
     }
     if (tid < NSUB) {
-      gbase[tid] = g0;
       const uint64_t leaf = ((uint64_t)b1 * NSUB + tid) >> 1;
       const uint32_t cls = tid & 1u;
       uint64_t cap = cls ? v.cap2c : v.cap2t;
       uint64_t at = (leaf >> v.sel_bits) * (v.cap2c + v.cap2t) + (cls ? 0 : v.cap2c);
-      if (v.exact) { cap = v.lcap[b1 * NSUB + tid]; at = v.lbase[b1 * NSUB + tid]; }
+      if (exact2) { cap = v.lcap[b1 * NSUB + tid]; at = v.lbase[b1 * NSUB + tid]; }
       const uint32_t lo = loff[tid];
       dabs[tid] = at + g0 - lo;
       const uint64_t room = cap > (uint64_t)g0 ? cap - g0 : 0;
@@ -487,14 +575,14 @@ __global__ __launch_bounds__(P2_THREADS, 4) void msp_p2_kernel(int groups_per_bi
       const uint32_t sb = sub_of(rec.w);
       if (p < (uint32_t)plim[sb]) { v.rec2[dabs[sb] + p] = rec; continue; }
       // the stream is full: park the record or raise the flag (below)
-      const uint32_t dst = gbase[sb] + (p - loff[sb]);
       const uint64_t leaf = ((uint64_t)b1 * NSUB + sb) >> 1;
       const uint32_t cls = sb & 1u;
       uint64_t cap = cls ? v.cap2c : v.cap2t;
       uint64_t at = (leaf >> v.sel_bits) * (v.cap2c + v.cap2t) + (cls ? 0 : v.cap2c);
-      if (v.exact) { cap = v.lcap[b1 * NSUB + sb]; at = v.lbase[b1 * NSUB + sb]; }
+      if (exact2) { cap = v.lcap[b1 * NSUB + sb]; at = v.lbase[b1 * NSUB + sb]; }
+      const uint64_t dst = dabs[sb] + p - at;              // = the stream's reserved base + rank inside the segment
       if (dst < cap) v.rec2[at + dst] = rec;
-      else if (v.exact) spill_record(rec, k, canon != 0, t);      // cannot happen: cap is the exact count
+      else if (exact2) spill_record(rec, k, canon != 0, t);      // cannot happen: cap is the exact count
       else {
         // too small by a little: park the record (the host counts the parked ones through the
         // HBM table); by a lot: the cursors keep counting and the host redoes P2 with exact sizes
@@ -506,7 +594,43 @@ __global__ __launch_bounds__(P2_THREADS, 4) void msp_p2_kernel(int groups_per_bi
         }
       }
     }
-    __syncthreads();                                       // sorted/loff/gbase are reused by the next tile
+    __syncthreads();                                       // sorted/loff/dabs are reused by the next tile
+  }
+  }  // item loop
+}
+
+__global__ __launch_bounds__(P2_THREADS, 4) void msp_p2_kernel(int k, int canon, MspView v, TableView t) {
+  __shared__ uint4 pool[(P2Lds<P2_PER>::BYTES + 15) / 16];
+  p2_role<P2_PER, true, true>(pool, blockIdx.x, gridDim.x, k, canon, v, t);
+}
+
+// ------------------------------------------------------------------------------------ P1 || P2
+// One launch of a pipeline stage: workgroups [0, n_p1) partition chunk s of the input (p1_role,
+// VALU-issue bound), the others split the level-1 records of chunk s-1 (p2_role, HBM bound).  Exact
+// persistent grid, three workgroups per CU -- two of the first kind, one of the second (blockIdx
+// b, b + CUs, b + 2 CUs share a CU under the observed round-robin dispatch; speed only) -- so the
+// vector pipe and the memory system of every CU are busy at the same time.  Two ordinary grids on
+// two streams do not overlap at all (the first owns every workgroup slot until it drains:
+// profiles/r03/overlap_probe.txt), and with exact grids on two streams the overlap depends on the
+// launch order (profiles/r03/coresidency.txt); one launch with roles does not.  The memory-bound
+// waves run at s_setprio 3: they issue a few instructions and wait, and must not queue behind the
+// arithmetic of their neighbours (12.6 instead of 13.7 ms in the micro-benchmark).
+// The level-1 buffer is a ping-pong pair: v.rec1 / v.cnt1 take chunk s, rec1_prev / cnt1_prev hold
+// chunk s-1; kernel boundaries order the stages.
+constexpr int P2_PER_FUSED = 5;
+template <int W, int P1B_TR>
+__global__ __launch_bounds__(P1_THREADS, 6) void msp_p12_kernel(const int8_t *__restrict__ data, int64_t nN, int k, int m, int canon,
+                                                             int64_t tile0, int64_t tile_end, uint32_t n_p1, MspView v,
+                                                             uint4 *rec1_prev, uint32_t *cnt1_prev, uint64_t cap1_prev, TableView t) {
+  constexpr int BYTES = P1Lds<P1B_TR>::BYTES > P2Lds<P2_PER_FUSED>::BYTES ? P1Lds<P1B_TR>::BYTES : P2Lds<P2_PER_FUSED>::BYTES;
+  static_assert(3 * BYTES <= 160 * 1024, "three workgroups per CU");
+  __shared__ uint4 pool[(BYTES + 15) / 16];
+  if (blockIdx.x < n_p1) {
+    p1_role<W, P1B_TR, false>(pool, data, nN, k, m, canon, tile0 + blockIdx.x, n_p1, tile_end, blockIdx.x & (v.nxg - 1), v, t);
+  } else {
+    __builtin_amdgcn_s_setprio(3);
+    v.rec1 = rec1_prev; v.cnt1 = cnt1_prev; v.cap1 = cap1_prev;
+    p2_role<P2_PER_FUSED, false, false>(pool, blockIdx.x - n_p1, gridDim.x - n_p1, k, canon, v, t);
   }
 }
 
@@ -1838,21 +1962,33 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
   // (a leaf of the pass holds ALL its records: the pass has fewer leaves, not lighter ones)
   const uint64_t cap2c = (uint64_t)(expect_all / NLEAF * 2.1 * slack) + 96;
   const uint64_t cap2t = (uint64_t)(expect_all / NLEAF * 0.6 * slack) + 96;   // truncated runs: ~15 % of the records
-  // P2 reads a bin's sub-regions as one stream: tile groups per BIN, enough for full regions
-  const int64_t tiles_per_sub = (int64_t)(((uint64_t)nxg * cap1 + (uint64_t)P2_TILE * P2_GROUP - 1) /
-                                          ((uint64_t)P2_TILE * P2_GROUP));
-  if (tiles_per_sub * B1 > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
+  // Large batches go through a PIPELINE: the input is cut into chunks of tiles, and stage s runs
+  // P1 on chunk s and P2 on chunk s-1 in ONE launch (msp_p12_kernel), so the level-1 buffer only
+  // ever holds two chunks.  The fused kernel exists for W >= 12 (k >= 24: three workgroups of it
+  // fit a CU); anything that overflows a region falls back to the one-chunk path below.
+  const int ncu = std::max(8, ctx->num_cus / 8 * 8);
+  const bool small_pipe = (ctx->dbg_flags & CFRK_DEBUG_SMALL_PIPELINE) != 0;
+  const int64_t chunk_min = small_pipe ? 3 : 32 * 2 * (int64_t)ncu;   // tiles: 32 per partitioning workgroup
+  int nchunks = (int)std::min<int64_t>(small_pipe ? 5 : 16, ntiles / chunk_min);
+  const bool pipelined = W >= 12 && (nxg == NXG || small_pipe) && nchunks >= 3 && !(ctx->dbg_flags & CFRK_DEBUG_NO_PIPELINE);
+  if (!pipelined) nchunks = 1;
+  const int64_t chunk_tiles = (ntiles + nchunks - 1) / nchunks;
+  // per sub-region of ONE chunk (the cursors of a chunk see 1 / nchunks of the records)
+  const uint64_t cap1c = pipelined ? (uint64_t)(expect * ((double)chunk_tiles / (double)ntiles) / (B1 * nxg) * 1.35) + 2048 : cap1;
 
   void *p;
   MspView &v = ms->view;
-  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L1, (size_t)B1 * nxg * cap1 * sizeof(uint4), &p))) return rc;
+  const size_t nreg = (size_t)B1 * nxg;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L1, pipelined ? 2 * nreg * cap1c * sizeof(uint4) : nreg * cap1 * sizeof(uint4), &p))) return rc;
   v.rec1 = (uint4 *)p; v.cap1 = cap1; v.nxg = (uint32_t)nxg; v.dbg = ctx->dbg_flags;
   v.sel_mask = (1u << sel_bits) - 1u; v.sel_val = sel_val; v.sel_bits = (uint32_t)sel_bits;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)(NLEAF >> sel_bits) * (cap2c + cap2t) * sizeof(uint4), &p))) return rc;
   v.rec2 = (uint4 *)p; v.cap2c = cap2c; v.cap2t = cap2t;
-  if ((rc = cfrk_pool_get(ctx, BUF_MSP_AUX, (size_t)NLEAF * 8 + (size_t)(B1 * nxg + (NCLS + 1) * NLEAF) * sizeof(uint32_t), &p))) return rc;
+  // (the second set of level-1 cursors, for the pipeline's ping-pong buffer, comes last)
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_AUX, (size_t)NLEAF * 8 + (size_t)(2 * B1 * nxg + (NCLS + 1) * NLEAF) * sizeof(uint32_t), &p))) return rc;
   v.leaf_off = (uint64_t *)p;
   v.cnt1 = (uint32_t *)(v.leaf_off + NLEAF); v.cnt2 = v.cnt1 + B1 * nxg; v.leaf_n = v.cnt2 + NCLS * NLEAF;
+  uint32_t *const cnt1_alt = v.leaf_n + NLEAF;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTK, (size_t)ctx->g_cap * 8, &p))) return rc;
   v.out_keys = (uint64_t *)p;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTC, (size_t)ctx->g_cap * 4, &p))) return rc;
@@ -1882,32 +2018,83 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
   if (ctx->g_flags & CFRK_RUNS_ONLY) v.ovf_cap = v.ovf1_cap = 0;
   v.exact = 0; v.lbase = nullptr; v.lcap = nullptr;
   v.exact1 = 0; v.rbase = nullptr; v.rcap = nullptr;
-  const size_t nreg = (size_t)B1 * nxg;
-  int64_t p2_groups = tiles_per_sub;             // tile groups per bin P2 is launched with
-  bool run_p1 = true;
+  // stand-alone P1 over the tiles [t0, t1) with `grid` workgroups (one per tile, or persistent)
+  auto launch_p1 = [&](unsigned grid, int64_t t0, int64_t t1, const MspView &vv) -> int {
+    const dim3 g1(grid), b1(P1_THREADS);
+#define CFRK_P1B_CASE(WW) \
+    case WW: hipLaunchKernelGGL((msp_p1b_kernel<WW, (WW >= 16 ? 4 : WW >= 12 ? 6 : WW >= 8 ? 8 : WW >= 6 ? 10 : 12)>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, t0, t1, vv, t); break;
+    switch (W) {
+      CFRK_P1B_CASE(4) CFRK_P1B_CASE(5) CFRK_P1B_CASE(6) CFRK_P1B_CASE(7) CFRK_P1B_CASE(8) CFRK_P1B_CASE(9)
+      CFRK_P1B_CASE(10) CFRK_P1B_CASE(11) CFRK_P1B_CASE(12) CFRK_P1B_CASE(13) CFRK_P1B_CASE(14)
+      CFRK_P1B_CASE(15) CFRK_P1B_CASE(16) CFRK_P1B_CASE(17) CFRK_P1B_CASE(18)
+      default: return cfrk_fail(ctx, CFRK_ERR_ARG, "no partition kernel for W=%d", W);
+    }
+#undef CFRK_P1B_CASE
+    HIP_TRY(ctx, hipGetLastError());
+    return CFRK_OK;
+  };
+  // one pipeline stage: P1 on [t0, t1) into vv's level-1 buffer, P2 on the previous chunk's
+  auto launch_p12 = [&](int64_t t0, int64_t t1, const MspView &vv, uint4 *rec1_prev, uint32_t *cnt1_prev) -> int {
+    const dim3 g(3u * (unsigned)ncu), b(P1_THREADS);
+    const uint32_t n_p1 = 2u * (uint32_t)ncu;
+#define CFRK_P12_CASE(WW) \
+    case WW: hipLaunchKernelGGL((msp_p12_kernel<WW, (WW >= 16 ? 4 : 6)>), g, b, 0, ctx->stream, d_data, nN, k, m, canon, t0, t1, n_p1, vv, rec1_prev, cnt1_prev, vv.cap1, t); break;
+    switch (W) {
+      CFRK_P12_CASE(12) CFRK_P12_CASE(13) CFRK_P12_CASE(14) CFRK_P12_CASE(15) CFRK_P12_CASE(16) CFRK_P12_CASE(17) CFRK_P12_CASE(18)
+      default: return cfrk_fail(ctx, CFRK_ERR_ARG, "no fused kernel for W=%d", W);
+    }
+#undef CFRK_P12_CASE
+    HIP_TRY(ctx, hipGetLastError());
+    return CFRK_OK;
+  };
+  const unsigned p2_grid = 2u * (unsigned)ncu;   // stand-alone P2: persistent, two workgroups per CU
+  bool run_p1 = true, settled = false, piped = pipelined;
   uint64_t parked1 = 0, parked2 = 0;
-  for (int attempt = 0; attempt < 4; ++attempt) {
+  for (int attempt = 0; attempt < 5; ++attempt) {
+    if (piped) {
+      // ---- pipeline: stage s = P1(chunk s) || P2(chunk s - 1); level-1 halves and cursors alternate
+      HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_L1OVF, 0, 2 * sizeof(uint64_t), ctx->stream));   // ST_L1OVF, ST_OVFN1
+      HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_L2OVF, 0, 2 * sizeof(uint64_t), ctx->stream));   // ST_L2OVF, ST_OVFN
+      MspView half[2] = {v, v};
+      for (int h = 0; h < 2; ++h) {
+        half[h].rec1 = v.rec1 + (size_t)h * nreg * cap1c;
+        half[h].cnt1 = h ? cnt1_alt : v.cnt1;
+        half[h].cap1 = cap1c;
+      }
+      for (int s = 0; s <= nchunks; ++s) {
+        const MspView &cur = half[s & 1], &prev = half[(s & 1) ^ 1];
+        const int64_t t0 = tile0 + (int64_t)s * chunk_tiles, t1 = std::min(tile0 + ntiles, t0 + chunk_tiles);
+        if (s < nchunks && s > 0) HIP_TRY(ctx, hipMemsetAsync(cur.cnt1, 0, nreg * sizeof(uint32_t), ctx->stream));   // (stage 0: cleared above)
+        if (s == 0) { if ((rc = launch_p1(3u * (unsigned)ncu, t0, t1, cur))) return rc; }
+        else if (s < nchunks) { if ((rc = launch_p12(t0, t1, cur, prev.rec1, prev.cnt1))) return rc; }
+        else {
+          hipLaunchKernelGGL(msp_p2_kernel, dim3(p2_grid), dim3(P2_THREADS), 0, ctx->stream, k, canon, prev, t);
+          HIP_TRY(ctx, hipGetLastError());
+        }
+      }
+    } else {
     if (run_p1) {
       HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_L1OVF, 0, 2 * sizeof(uint64_t), ctx->stream));   // ST_L1OVF, ST_OVFN1
-      const dim3 g1((unsigned)ntiles), b1(P1_THREADS);
-#define CFRK_P1B_CASE(WW) \
-      case WW: hipLaunchKernelGGL((msp_p1b_kernel<WW, (WW >= 16 ? 4 : WW >= 12 ? 6 : WW >= 8 ? 8 : WW >= 6 ? 10 : 12)>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, tile0, v, t); break;
-      switch (W) {
-        CFRK_P1B_CASE(4) CFRK_P1B_CASE(5) CFRK_P1B_CASE(6) CFRK_P1B_CASE(7) CFRK_P1B_CASE(8) CFRK_P1B_CASE(9)
-        CFRK_P1B_CASE(10) CFRK_P1B_CASE(11) CFRK_P1B_CASE(12) CFRK_P1B_CASE(13) CFRK_P1B_CASE(14)
-        CFRK_P1B_CASE(15) CFRK_P1B_CASE(16) CFRK_P1B_CASE(17) CFRK_P1B_CASE(18)
-        default: return cfrk_fail(ctx, CFRK_ERR_ARG, "no partition kernel for W=%d", W);
-      }
-#undef CFRK_P1B_CASE
-      HIP_TRY(ctx, hipGetLastError());
+      if ((rc = launch_p1((unsigned)ntiles, tile0, tile0 + ntiles, v))) return rc;
     }
     HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_L2OVF, 0, 2 * sizeof(uint64_t), ctx->stream));   // ST_L2OVF, ST_OVFN
-    hipLaunchKernelGGL(msp_p2_kernel, dim3((unsigned)(p2_groups * B1)), dim3(P2_THREADS), 0, ctx->stream,
-                       (int)p2_groups, k, canon, v, t);
+    hipLaunchKernelGGL(msp_p2_kernel, dim3(p2_grid), dim3(P2_THREADS), 0, ctx->stream, k, canon, v, t);
     HIP_TRY(ctx, hipGetLastError());
+    }
     uint64_t st[ST_NWORDS];
     HIP_TRY(ctx, hipMemcpyAsync(st, ctx->g_stats, sizeof st, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (piped && (st[ST_L1OVF] || st[ST_L2OVF])) {
+      // a region overflowed by more than the parking buffers take: the cursors of a pipeline do not
+      // add up to the batch's demand (the level-1 halves are reused), so the batch starts over on the
+      // one-chunk path, which lays the overflowing level out exactly
+      piped = false;
+      if ((rc = cfrk_pool_get(ctx, BUF_MSP_L1, nreg * cap1 * sizeof(uint4), &p))) return rc;
+      v.rec1 = (uint4 *)p;
+      HIP_TRY(ctx, hipMemsetAsync(v.cnt1, 0, (nreg + (size_t)NCLS * NLEAF) * sizeof(uint32_t), ctx->stream));   // cnt1 and cnt2
+      run_p1 = true;
+      continue;
+    }
     if (st[ST_L1OVF]) {
       // exact level-1 layout; P2 ran on an incomplete level 1 and is redone as well
       if ((rc = cfrk_pool_get(ctx, BUF_MSP_LAYOUT1, nreg * (sizeof(uint64_t) + sizeof(uint32_t)), &p))) return rc;
@@ -1916,18 +2103,22 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
       hipLaunchKernelGGL(msp_layout_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)v.cnt1, (uint32_t)nreg, rbase, rcap);
       HIP_TRY(ctx, hipGetLastError());
       {
-        // the heaviest bin decides how many tile groups per bin P2 needs from now on
+        // all records of the batch: the buffer must hold them back to back
         std::vector<uint32_t> c1(nreg);
         HIP_TRY(ctx, hipMemcpyAsync(c1.data(), v.cnt1, nreg * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        uint64_t maxbin = 0;
+        uint64_t maxbin = 0, all = 0;
         for (int b = 0; b < B1; ++b) {
           uint64_t sum = 0;
           for (int r = 0; r < nxg; ++r) sum += c1[l1_reg((uint32_t)b, (uint32_t)r)];
           maxbin = std::max(maxbin, sum);
+          all += sum;
         }
-        p2_groups = (int64_t)((maxbin + (uint64_t)P2_TILE * P2_GROUP - 1) / ((uint64_t)P2_TILE * P2_GROUP)) + 1;
-        if (p2_groups * B1 > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
+        if (all > (uint64_t)B1 * nxg * cap1) {           // more records than the density estimate allowed for
+          if ((rc = cfrk_pool_get(ctx, BUF_MSP_L1, (size_t)all * sizeof(uint4), &p))) return rc;
+          v.rec1 = (uint4 *)p;
+        }
+        (void)maxbin;                                  // (P2 is persistent: it sizes its work from the cursors)
       }
       HIP_TRY(ctx, hipMemsetAsync(v.cnt1, 0, (nreg + (size_t)NCLS * NLEAF) * sizeof(uint32_t), ctx->stream));   // cnt1 and cnt2
       v.exact1 = 1; v.rbase = rbase; v.rcap = rcap;
@@ -1947,8 +2138,10 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
       continue;
     }
     parked2 = st[ST_OVFN];
+    settled = true;
     break;
   }
+  if (!settled) return cfrk_fail(ctx, CFRK_ERR_STATE, "the record regions did not settle after an exact layout");
   if (parked1 && v.ovf1_cap) {
     const uint32_t n = (uint32_t)std::min<uint64_t>(parked1, v.ovf1_cap);
     hipLaunchKernelGGL(msp_spill_list_kernel, dim3((n + 255u) / 256u), dim3(256), 0, ctx->stream, (const uint4 *)v.ovf1, n, k, canon, t);

@@ -18,6 +18,8 @@ CFRK_DEBUG_FORCE_RT_OVERFLOW = 0x1   # cfrk_debug_set_flags
 CFRK_DEBUG_SMALL_WAVE_CAP = 0x2
 CFRK_DEBUG_NO_ANCHORS = 0x4
 CFRK_DEBUG_RECORD_SUBSETS = 0x8
+CFRK_DEBUG_NO_PIPELINE = 0x10
+CFRK_DEBUG_SMALL_PIPELINE = 0x20
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libcfrk_hip.so")

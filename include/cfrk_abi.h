@@ -217,6 +217,12 @@ int cfrk_debug_last_add_passes(cfrk_ctx *ctx, int *out_passes);
  * whatever the capacity hint (normally only for hints above ~2.7e8 distinct k-mers, 2..32
  * workgroups per leaf): makes that path reachable with small inputs (tests). */
 #define CFRK_DEBUG_RECORD_SUBSETS 0x8
+/* Bit 4: the one-word partitioned path never pipelines (large batches at k >= 24 normally cut the
+ * input into chunks and run the partition kernel on chunk s beside the second-level kernel on chunk
+ * s-1 in one launch); same result, for A/B timing.  Bit 5: pipeline whatever the batch size, in
+ * chunks of a few tiles: makes the fused kernel reachable with small inputs (tests). */
+#define CFRK_DEBUG_NO_PIPELINE 0x10
+#define CFRK_DEBUG_SMALL_PIPELINE 0x20
 int cfrk_debug_set_flags(cfrk_ctx *ctx, uint32_t flags);
 
 /* ---- synthetic reads, generated on device ----------------------------------- */

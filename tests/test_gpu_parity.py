@@ -204,6 +204,33 @@ def test_c2_shape_1m_reads_k15_full_equality(ctx):
     ctx.free(d)
 
 
+def test_c2_full_size_10m_reads_k15_entry_for_entry(ctx):
+    """BASELINE configs[1] AS WRITTEN: 10 M synthetic 150 bp reads (genome 10^7), k=15, canonical,
+    one GPU -- every (key, count) of the HIP path against the oracle's threaded counter (a diff,
+    as /root/reference/test/test.sh:13-19 does it, not a checksum), plus the digest both ways."""
+    import cfrk_amd
+    R, L, G, k = 10_000_000, 150, 10_000_000, 15
+    nN = R * (L + 1)
+    d = ctx.alloc(nN + 64)
+    ctx.synth_reads_device(0, R, L, G, d)
+    g = cfrk_amd.GlobalCounter(ctx, k, cfrk_amd.CFRK_CANONICAL, 2 * G)
+    g.add_device(d, nN)
+    lo, hi, cnt = g.export()
+    gd = g.digest()
+    host = np.empty(nN, np.int8)
+    ctx.d2h(host, d)
+    ctx.free(d)
+    # the device generator is the oracle's generator (read 0 and the last read, byte for byte)
+    w0, _, _ = orc.synth_reads(0, 1, L, G)
+    w1, _, _ = orc.synth_reads(R - 1, 1, L, G)
+    assert (host[:L + 1] == w0).all() and (host[-(L + 1):] == w1).all()
+    threads = max(1, min(64, len(os.sched_getaffinity(0))))
+    wlo, whi, wcnt = orc.global_count(host, k, orc.ORC_CANONICAL, threads=threads)
+    assert int(wcnt.sum()) == R * (L - k + 1)
+    assert len(lo) == len(wlo) and (lo == wlo).all() and (cnt.astype(np.uint64) == wcnt).all()
+    assert gd == orc.digest(wlo, whi, wcnt)
+
+
 def test_c3_shape_properties_k31(ctx):
     """config-3 shape (k=31, 150 bp, canonical) at 4 M reads: size-independent properties --
     sum(count) == R*(L-k+1) exactly (no invalid bases), counting reads twice doubles every
@@ -521,6 +548,22 @@ def test_global_errors(ctx):
     with pytest.raises(cfrk_amd.CfrkError) as e:
         g.add(noterm, start, length)
     assert e.value.code == -5
+    # a corrupt table whose entries are consistent with each other but negative (the threaded
+    # layout check compares a piece's first read with a predecessor another thread validates,
+    # nS > 2^20 makes several pieces) is refused before any byte of data[] is looked at
+    nS = (1 << 20) + 4096
+    ln = np.full(nS, 3, np.int32)
+    st = np.arange(nS, dtype=np.int64) * 4
+    dat = np.tile(np.array([0, 1, 2, -1], np.int8), nS)
+    cut = nS // 2
+    st2 = st.copy(); st2[cut - 1:] -= (1 << 40)           # start[cut-1] < 0 and start[cut] matches it
+    with pytest.raises(cfrk_amd.CfrkError) as e:
+        g.add(dat, st2, ln)
+    assert e.value.code == -5
+    ln2 = ln.copy(); ln2[cut] = -7
+    with pytest.raises(cfrk_amd.CfrkError) as e:
+        g.add(dat, st, ln2)
+    assert e.value.code == -5
     # table overflow is reported, not silently wrong
     rnd = np.random.default_rng(0).integers(0, 4, 200000).astype(np.int8)
     g = cfrk_amd.GlobalCounter(ctx, 31, cfrk_amd.CFRK_FORCE_HASH, 64)
@@ -531,6 +574,75 @@ def test_global_errors(ctx):
 
 
 # ------------------------------------------------------------------ minimizer-partitioned path
+
+@pytest.mark.parametrize("k", [24, 25, 27, 28, 29, 30, 31, 32])
+@pytest.mark.parametrize("canonical", [False, True])
+def test_pipelined_partition_matches_oracle(ctx, k, canonical):
+    """the fused kernel (partition kernel on chunk s beside the second-level kernel on chunk s-1,
+    one launch per stage; k >= 24) forced onto a small input: every (key, count) against the oracle,
+    with ragged reads, invalid bases and low-complexity stretches crossing the chunk boundaries"""
+    import cfrk_amd
+    rng = np.random.default_rng(900 + k)
+    reads = _random_reads(rng, 3000, 1, 400, 0.01)
+    reads.append(np.zeros(3000, np.int8))                    # poly-A across several tiles
+    reads.append(np.tile(np.array([0, 1, 2, 3, 3, 2], np.int8), 800))
+    genome = rng.integers(0, 4, 20000).astype(np.int8)       # deep coverage: complete runs repeat
+    for _ in range(2000):
+        a = int(rng.integers(0, len(genome) - 150))
+        reads.append(genome[a:a + 150])
+    data, start, length = refsem.flatten(reads)
+    flags = cfrk_amd.CFRK_CANONICAL if canonical else 0
+    g = cfrk_amd.GlobalCounter(ctx, k, flags, 0)
+    g.set_debug_flags(cfrk_amd.CFRK_DEBUG_SMALL_PIPELINE)
+    g.add(data, start, length)
+    lo, hi, cnt = g.export()
+    g.set_debug_flags(0)
+    wlo, whi, wcnt = orc.global_count(data, k, orc.ORC_CANONICAL if canonical else 0)
+    assert len(lo) == len(wlo)
+    assert (lo == wlo).all() and (cnt.astype(np.uint64) == wcnt).all()
+    assert g.digest() == orc.digest(wlo, whi, wcnt)
+
+
+def test_pipelined_and_one_chunk_paths_agree_at_20m_reads(ctx):
+    """a batch large enough to pipeline by itself (20 M x 150 bp, k = 31 and 25): digest equal to the
+    one-chunk path's (CFRK_DEBUG_NO_PIPELINE) and sum(count) exact"""
+    import cfrk_amd
+    R, L, G = 20_000_000, 150, 20_000_000
+    nN = R * (L + 1)
+    d = ctx.alloc(nN + 64)
+    ctx.synth_reads_device(0, R, L, G, d)
+    for k in (31, 25):
+        got = []
+        for dbg in (0, cfrk_amd.CFRK_DEBUG_NO_PIPELINE):
+            g = cfrk_amd.GlobalCounter(ctx, k, cfrk_amd.CFRK_CANONICAL, G + 1024)
+            g.set_debug_flags(dbg)
+            g.add_device(d, nN)
+            got.append(g.digest())
+            g.set_debug_flags(0)
+        assert got[0] == got[1]
+        assert got[0][1] == R * (L - k + 1)
+    ctx.free(d)
+
+
+def test_pipelined_overflow_falls_back_to_exact_layout(ctx):
+    """deep coverage of a tiny genome through the pipeline: the leaf streams overflow by far more
+    than the parking buffer takes, the batch starts over on the one-chunk path and is laid out exactly"""
+    import cfrk_amd
+    rng = np.random.default_rng(77)
+    genome = rng.integers(0, 4, 1500).astype(np.int8)
+    reads = []
+    for _ in range(30000):
+        a = int(rng.integers(0, len(genome) - 120))
+        reads.append(genome[a:a + 120])
+    data, start, length = refsem.flatten(reads)
+    g = cfrk_amd.GlobalCounter(ctx, 31, cfrk_amd.CFRK_CANONICAL, 0)
+    g.set_debug_flags(cfrk_amd.CFRK_DEBUG_SMALL_PIPELINE)
+    g.add(data, start, length)
+    lo, hi, cnt = g.export()
+    g.set_debug_flags(0)
+    wlo, whi, wcnt = orc.global_count(data, 31, orc.ORC_CANONICAL)
+    assert len(lo) == len(wlo) and (lo == wlo).all() and (cnt.astype(np.uint64) == wcnt).all()
+
 
 def test_msp_low_complexity_and_many_invalid(ctx):
     """homopolymers / short tandem repeats (runs longer than one record, one minimizer for
