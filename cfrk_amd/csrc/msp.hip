@@ -129,14 +129,15 @@ struct P1Lds {
   static constexpr int BYTES = ARENA + 2 * B1 * 4 + 32;
 };
 
-// Workgroup-level body of the partition kernel: the tiles tile_first, tile_first + tile_stride, ...
-// < tile_end, appending to sub-region `subreg` of every level-1 bin.  Called by the stand-alone
-// kernel (one tile per workgroup, or a persistent grid) and by the fused kernel msp_p12_kernel,
-// where two workgroups per CU do this while a third runs p2_role on the previous chunk.
+// Workgroup-level body of the partition kernel: tile `tile` of the input, appended to sub-region
+// `subreg` of every level-1 bin.  Called by the stand-alone kernel and by the fused kernel
+// msp_p12_kernel, whose grid interleaves these workgroups with second-level ones (p2_item).
+// (One tile per workgroup, not a persistent loop: a looping workgroup waits at the top of every
+// tile for its input loads -- and, vmcnt being one in-order counter, for the previous tile's
+// stores before them; measured 16-28 % slower, profiles/r03/persistent_p1_is_slower.txt.)
 template <int W, int P1B_TR, bool EX>
-__device__ __forceinline__ void p1_role(uint4 *pool, const int8_t *__restrict__ data, int64_t nN, int k, int m, int canon,
-                                        int64_t tile_first, int64_t tile_stride, int64_t tile_end, uint32_t subreg,
-                                        const MspView &v, const TableView &t) {
+__device__ __forceinline__ void p1_tile(uint4 *pool, const int8_t *__restrict__ data, int64_t nN, int k, int m, int canon,
+                                        int64_t tile, uint32_t subreg, const MspView &v, const TableView &t) {
   constexpr int NH = 32 + W - 1;
   constexpr int P1B_STAGE = P1Lds<P1B_TR>::STAGE;
   // sorted records share the staging bytes; the last 2.5 KB hold the copy-out table (dabs, plim)
@@ -156,14 +157,7 @@ __device__ __forceinline__ void p1_role(uint4 *pool, const int8_t *__restrict__ 
   static_assert((P1_WAVES * P1B_STAGE - P1B_TAIL) % 16 == 0, "the table starts on a record boundary");
 
   const int nkmax = min(48 - k + 1, 32);
-  for (int64_t tile = tile_first; tile < tile_end; tile += tile_stride) {
-  // The thread index goes through an empty asm at the top of every tile: nothing derived from it
-  // (lane, wave, staging addresses, masks) can be hoisted out of the tile loop, where it would stay
-  // live across the whole body -- hoisted, those values cost 5 VGPRs more than the kernel has at
-  // three workgroups per CU and the compiler spilled them to scratch (16 reloads per tile and thread).
-  int tid = threadIdx.x;
-  asm volatile("" : "+v"(tid));
-  const int lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   uint8_t *const stage = reinterpret_cast<uint8_t *>(arena) + wave * P1B_STAGE;
   uint16_t *const s_leaf = reinterpret_cast<uint16_t *>(stage);               // [64 lanes][32 positions]
   uint32_t *const s_str = reinterpret_cast<uint32_t *>(stage + 4096);         // 128 dwords of bases
@@ -171,7 +165,7 @@ __device__ __forceinline__ void p1_role(uint4 *pool, const int8_t *__restrict__ 
   uint64_t *const s_W = reinterpret_cast<uint64_t *>(stage + 4096 + 1024);    // validity of position p-1
   uint16_t *const s_dsc = reinterpret_cast<uint16_t *>(stage + 4096 + 1536);  // (lane << 5) | position
   if (tid < B1) hist[tid] = 0;
-  __syncthreads();
+  lds_barrier();
 
   // ---- A: this lane's chunk, packed 2 bits per base; neighbours' chunks by shuffle ----
   const int64_t wave_g = tile * P1_WAVES + wave;
@@ -225,8 +219,7 @@ __device__ __forceinline__ void p1_role(uint4 *pool, const int8_t *__restrict__ 
   }
   if (v.dbg & CFRK_ABL_P1_NO_EMIT) {             // timing ablation: keep the front end alive, emit nothing
     if (S == 0x12345678u && (uint32_t)E == 0x9ABCDEFu) v.stats[ST_AUX0] = 1;
-    __syncthreads();
-    continue;
+    return;
   }
   uint32_t cnt_w;
   uint32_t S2 = 0;                               // run starts beyond the balanced phase's capacity
@@ -252,9 +245,7 @@ __device__ __forceinline__ void p1_role(uint4 *pool, const int8_t *__restrict__ 
       ++widx;
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  lds_wave_sync();                               // the wave's staging is written: lanes read each other's
 
   // record of the run that starts at position d & 31 of lane d >> 5 (d is also the index of its leaf id)
   auto build = [&](uint32_t d) {
@@ -310,7 +301,7 @@ __device__ __forceinline__ void p1_role(uint4 *pool, const int8_t *__restrict__ 
         rk[tr] = atomicAdd(&hist[rc[tr].w >> 16], 1u);
     }
   }
-  __syncthreads();
+  lds_barrier();
 
   // ---- C: one global reservation per non-empty bin; bin offsets ----
   uint32_t my_base = 0;
@@ -318,7 +309,7 @@ __device__ __forceinline__ void p1_role(uint4 *pool, const int8_t *__restrict__ 
     const uint32_t c = hist[tid];
     if (c) my_base = atomicAdd(&v.cnt1[l1_reg(tid, subreg)], c);
   }
-  block_scan<B1>(hist, loff, wtot);              // ends with a barrier: the staging area is dead
+  block_scan<B1, true>(hist, loff, wtot);              // ends with a barrier: the staging area is dead
   if (tid == B1 - 1) *nrec_p = loff[tid] + hist[tid];   // (before this thread overwrites hist[tid] below)
 #pragma unroll
   for (int tr = 0; tr < P1B_TR; ++tr) {
@@ -339,7 +330,7 @@ __device__ __forceinline__ void p1_role(uint4 *pool, const int8_t *__restrict__ 
     plim[tid] = (uint16_t)min((uint64_t)lo + room, (uint64_t)0xFFFFu);
     static_assert(P1B_RCAP <= 0xFFFF, "arena positions fit 16 bits");
   }
-  __syncthreads();
+  lds_barrier();
 
   // ---- D: copy out in bin order ----
   const uint32_t nrec_s = *nrec_p;
@@ -360,20 +351,16 @@ __device__ __forceinline__ void p1_role(uint4 *pool, const int8_t *__restrict__ 
       }
     }
   }
-  __syncthreads();                               // the arena and the tables are the next tile's
-  }  // tile loop
 }
 
 template <int W, int P1B_TR>
 __global__ __launch_bounds__(P1_THREADS, (P1B_TR <= 6 ? 6 : 4)) void msp_p1b_kernel(const int8_t *__restrict__ data,
                                                              int64_t nN, int k, int m, int canon,
-                                                             int64_t tile0, int64_t tile_end, MspView v, TableView t) {
-  // Workgroup b takes the tiles tile0 + b, tile0 + b + gridDim.x, ... < tile_end: a grid of one
-  // workgroup per tile (small batches) or a persistent grid (the first stage of cfrk_msp_count's pipeline).
+                                                             int64_t tile0, MspView v, TableView t) {
   __shared__ uint4 pool[P1Lds<P1B_TR>::BYTES / 16];
-  p1_role<W, P1B_TR, true>(pool, data, nN, k, m, canon, tile0 + blockIdx.x, gridDim.x, tile_end, blockIdx.x & (v.nxg - 1), v, t);
+  const int64_t tile = tile0 + blockIdx.x;
+  p1_tile<W, P1B_TR, true>(pool, data, nN, k, m, canon, tile, (uint32_t)tile & (v.nxg - 1), v, t);
 }
-
 
 // ---------------------------------------------------------------------------------------- P2
 // sub-bin of a record inside its level-1 bin: leaf low byte x {truncated run, complete run}.
@@ -391,58 +378,42 @@ constexpr int NCLS = 2;
 constexpr int NSUB = NCLS * B2;                           // 512 sub-bins of a level-1 bin
 __device__ __forceinline__ uint32_t sub_of(uint32_t w) { return (((w >> 8) & (B2 - 1)) << 1) | ((((w >> 6) & 3u) == 3u) ? 1u : 0u); }
 
-// LDS of one P2 workgroup with tiles of P2_THREADS * PER records
+// LDS of one P2 workgroup with tiles of P2_THREADS * PER records (byte offsets into its pool)
 template <int PER>
 struct P2Lds {
   static constexpr int TILE = P2_THREADS * PER;
-  static constexpr int BYTES = TILE * 16 + NSUB * (4 + 4 + 8 + 2) + (P2_THREADS / 64) * 4 + (NXG + 1) * 4 + (B1 / NXCD + 1) * 4 + 28;
+  static constexpr int DABS = TILE * 16;                   // u64[NSUB]
+  static constexpr int HIST = DABS + NSUB * 8;             // u32[NSUB]
+  static constexpr int LOFF = HIST + NSUB * 4;             // u32[NSUB]
+  static constexpr int PLIM = LOFF + NSUB * 4;             // u16[NSUB]
+  static constexpr int WTOT = PLIM + NSUB * 2;             // u32[P2_THREADS / 64]
+  static constexpr int RPRE = WTOT + (P2_THREADS / 64) * 4;   // u32[NXG + 1]
+  static constexpr int GPRE = RPRE + (NXG + 1) * 4;        // u32[B1 / NXCD + 1] (persistent form only)
+  static constexpr int BYTES = (GPRE + (B1 / NXCD + 1) * 4 + 15) / 16 * 16;
 };
 
+// One work item of the second-level kernel: the tiles [grp * NGRP, (grp + 1) * NGRP) of level-1 bin
+// b1 (all of it that exists; nothing if the bin holds fewer records).
 // PER = records per thread and tile: 8 stand-alone (two workgroups of 75 KB per CU), 5 in the fused
-// kernel (the LDS of a P1 workgroup, 80 VGPRs)
-template <int PER, bool EX, bool PF>
-__device__ __forceinline__ void p2_role(uint4 *pool, uint32_t wg, uint32_t nwg, int k, int canon, const MspView &v, const TableView &t) {
+// kernel (the LDS of a P1 workgroup, 80 VGPRs); NGRP = consecutive tiles per item.
+template <int PER, bool EX, bool PF, int NGRP>
+__device__ __forceinline__ void p2_item(uint4 *pool, uint32_t b1, uint32_t grp, int k, int canon, const MspView &v, const TableView &t) {
   constexpr int TILE = P2_THREADS * PER;
   static_assert(TILE <= 0xFFFF, "tile positions fit 16 bits");
   uint4 *const sorted = pool;
+  uint8_t *const pb = reinterpret_cast<uint8_t *>(pool);
   // copy-out fast path, once per stream and tile: sorted position p of sub-bin sb goes to record
   // dabs[sb] + p of the leaf buffer while p < plim[sb]
-  unsigned long long *const dabs = reinterpret_cast<unsigned long long *>(pool + TILE);
-  uint32_t *const hist = reinterpret_cast<uint32_t *>(dabs + NSUB);   // hist doubles as the fill cursor
-  uint32_t *const loff = hist + NSUB;
-  uint16_t *const plim = reinterpret_cast<uint16_t *>(loff + NSUB);
-  uint32_t *const wtot = reinterpret_cast<uint32_t *>(plim + NSUB);   // P2_THREADS / 64 words
-  uint32_t *const rpre = wtot + P2_THREADS / 64;                      // exclusive prefix of the bin's sub-region sizes (NXG + 1)
-  uint32_t *const gpre = rpre + NXG + 1;                              // exclusive prefix of the group's items per bin (B1 / NXCD + 1)
+  unsigned long long *const dabs = reinterpret_cast<unsigned long long *>(pb + P2Lds<PER>::DABS);
+  uint32_t *const hist = reinterpret_cast<uint32_t *>(pb + P2Lds<PER>::HIST);   // hist doubles as the fill cursor
+  uint32_t *const loff = reinterpret_cast<uint32_t *>(pb + P2Lds<PER>::LOFF);
+  uint16_t *const plim = reinterpret_cast<uint16_t *>(pb + P2Lds<PER>::PLIM);
+  uint32_t *const wtot = reinterpret_cast<uint32_t *>(pb + P2Lds<PER>::WTOT);
+  uint32_t *const rpre = reinterpret_cast<uint32_t *>(pb + P2Lds<PER>::RPRE);   // exclusive prefix of the bin's sub-region sizes
   static_assert(NSUB <= P2_THREADS && NSUB % 64 == 0, "the scan below gives one thread per sub-bin");
   static_assert(NXG <= 64, "one wave scans the sub-region sizes");
-  constexpr int BPG = B1 / NXCD;                 // bins per XCD group
-  static_assert(P2_THREADS == BPG * 16, "sixteen threads add up a bin's sub-regions");
   const int tid = threadIdx.x;
   const bool exact1 = EX && v.exact1, exact2 = EX && v.exact;
-  const uint32_t xg = wg & (NXCD - 1), j0 = wg / NXCD, nj = nwg / NXCD;
-  // items per bin of this group: sixteen threads per bin add the sub-region sizes
-  {
-    const uint32_t i = (uint32_t)tid >> 4, part = (uint32_t)tid & 15u, b = xg + NXCD * i;
-    uint32_t sum = 0;
-    for (uint32_t sr = part; sr < v.nxg; sr += 16u) {
-      const uint32_t reg = l1_reg(b, sr);
-      sum += (uint32_t)min((uint64_t)v.cnt1[reg], exact1 ? (uint64_t)v.rcap[reg] : v.cap1);
-    }
-#pragma unroll
-    for (int d = 1; d < 16; d <<= 1) sum += __shfl_xor(sum, d);
-    if (part == 0) gpre[i + 1] = (sum + (uint32_t)(TILE * P2_GROUP) - 1u) / (uint32_t)(TILE * P2_GROUP);
-    if (tid == 0) gpre[0] = 0;
-    __syncthreads();
-    if (tid == 0) for (int q = 1; q <= BPG; ++q) gpre[q] += gpre[q - 1];
-    __syncthreads();
-  }
-  const uint32_t nitems = gpre[BPG];
-  uint32_t bi = 0;                               // bin of the current item (items grow: the cursor only moves forward)
-  for (uint32_t item = j0; item < nitems; item += nj) {
-  while (gpre[bi + 1] <= item) ++bi;
-  const uint32_t b1 = xg + NXCD * bi;
-  const uint32_t grp = item - gpre[bi];
   // The bin's sub-regions are read as ONE stream (region after region): tiles are full except the
   // bin's last one, however many cursors P1 spreads its appends over.
   if (tid < 64) {
@@ -457,11 +428,12 @@ __device__ __forceinline__ void p2_role(uint4 *pool, uint32_t wg, uint32_t nwg, 
     if ((uint32_t)tid < v.nxg) rpre[tid] = incl - c;
     if (tid == 63) rpre[v.nxg] = incl;
   }
-  __syncthreads();
+  lds_barrier();
   const uint64_t n = rpre[v.nxg];
-  // a workgroup takes P2_GROUP consecutive tiles and asks for the next tile's records before it
+  // a workgroup takes NGRP consecutive tiles and asks for the next tile's records before it
   // sorts and writes the current one: the load latency hides under the LDS work
-  const uint64_t g0r = (uint64_t)grp * P2_GROUP * TILE;
+  const uint64_t g0r = (uint64_t)grp * NGRP * TILE;
+  if (g0r >= n) return;
   // record `idx` of the bin's stream lies in the sub-region `sr` with rpre[sr] <= idx < rpre[sr + 1]: one
   // binary search for a thread's first record, then the cursor only moves forward (a thread's
   // indices grow from fetch to fetch)
@@ -492,7 +464,7 @@ __device__ __forceinline__ void p2_role(uint4 *pool, uint32_t wg, uint32_t nwg, 
       if (idx < n) nx[PF ? i : 0] = fetch(idx);
     }
   }
-  for (int tt = 0; tt < P2_GROUP; ++tt) {
+  for (int tt = 0; tt < NGRP; ++tt) {
     const uint64_t r0 = g0r + (uint64_t)tt * TILE;
     if (r0 >= n) break;
     const uint32_t nt = (uint32_t)min((uint64_t)TILE, n - r0);
@@ -500,7 +472,7 @@ __device__ __forceinline__ void p2_role(uint4 *pool, uint32_t wg, uint32_t nwg, 
     if (PF) {
 #pragma unroll
       for (int i = 0; i < PER; ++i) r[i] = nx[PF ? i : 0];
-      if (tt + 1 < P2_GROUP) {
+      if (tt + 1 < NGRP) {
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
           const uint64_t idx = r0 + TILE + (uint64_t)i * P2_THREADS + tid;
@@ -517,13 +489,13 @@ __device__ __forceinline__ void p2_role(uint4 *pool, uint32_t wg, uint32_t nwg, 
       }
     }
     if (tid < NSUB) hist[tid] = 0;
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const uint32_t idx = (uint32_t)i * P2_THREADS + tid;
       if (idx < nt) atomicAdd(&hist[sub_of(r[i].w)], 1u);
     }
-    __syncthreads();
+    lds_barrier();
     uint32_t g0 = 0;
     {
       // per-stream reservation + exclusive scan of the sub-bin sizes (one per thread, tid < NSUB)
@@ -539,14 +511,14 @@ __device__ __forceinline__ void p2_role(uint4 *pool, uint32_t wg, uint32_t nwg, 
         if (lane >= d) incl += y;
       }
       if (lane == 63) wtot[wave] = incl;
-      __syncthreads();
+      lds_barrier();
       uint32_t bs = 0;
       for (int w = 0; w < wave; ++w) bs += wtot[w];
       if (mine) {
         loff[tid] = bs + incl - x0;
         hist[tid] = 0;                                     // from here on: fill cursor
       }
-      __syncthreads();
+      lds_barrier();
     }
     // counting sort of the tile by sub-bin, in LDS
 #pragma unroll
@@ -568,7 +540,7 @@ __device__ __forceinline__ void p2_role(uint4 *pool, uint32_t wg, uint32_t nwg, 
       const uint64_t room = cap > (uint64_t)g0 ? cap - g0 : 0;
       plim[tid] = (uint16_t)min((uint64_t)lo + room, (uint64_t)0xFFFFu);
     }
-    __syncthreads();
+    lds_barrier();
     // copy out: consecutive lanes -> consecutive records of the same stream
     for (uint32_t p = tid; p < nt; p += P2_THREADS) {
       const uint4 rec = sorted[p];
@@ -594,9 +566,45 @@ __device__ __forceinline__ void p2_role(uint4 *pool, uint32_t wg, uint32_t nwg, 
         }
       }
     }
-    __syncthreads();                                       // sorted/loff/dabs are reused by the next tile
+    lds_barrier();                                       // sorted/loff/dabs are reused by the next tile
   }
-  }  // item loop
+}
+
+// PERSISTENT form (stand-alone kernel): nwg workgroups (a multiple of 8); workgroup w belongs to XCD
+// group w % 8 and that group walks ITS bins one after the other -- the group's items are numbered
+// bin after bin from the records the bins really hold (no empty items), and workgroup j of the group
+// takes items j, j + nwg/8, ...
+template <int PER, bool EX, bool PF>
+__device__ __forceinline__ void p2_role(uint4 *pool, uint32_t wg, uint32_t nwg, int k, int canon, const MspView &v, const TableView &t) {
+  constexpr int TILE = P2_THREADS * PER;
+  uint32_t *const gpre = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(pool) + P2Lds<PER>::GPRE);   // exclusive prefix of the group's items per bin
+  constexpr int BPG = B1 / NXCD;                 // bins per XCD group
+  static_assert(P2_THREADS == BPG * 16, "sixteen threads add up a bin's sub-regions");
+  const int tid = threadIdx.x;
+  const bool exact1 = EX && v.exact1;
+  const uint32_t xg = wg & (NXCD - 1), j0 = wg / NXCD, nj = nwg / NXCD;
+  // items per bin of this group: sixteen threads per bin add the sub-region sizes
+  {
+    const uint32_t i = (uint32_t)tid >> 4, part = (uint32_t)tid & 15u, b = xg + NXCD * i;
+    uint32_t sum = 0;
+    for (uint32_t sr = part; sr < v.nxg; sr += 16u) {
+      const uint32_t reg = l1_reg(b, sr);
+      sum += (uint32_t)min((uint64_t)v.cnt1[reg], exact1 ? (uint64_t)v.rcap[reg] : v.cap1);
+    }
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) sum += __shfl_xor(sum, d);
+    if (part == 0) gpre[i + 1] = (sum + (uint32_t)(TILE * P2_GROUP) - 1u) / (uint32_t)(TILE * P2_GROUP);
+    if (tid == 0) gpre[0] = 0;
+    lds_barrier();
+    if (tid == 0) for (int q = 1; q <= BPG; ++q) gpre[q] += gpre[q - 1];
+    lds_barrier();
+  }
+  const uint32_t nitems = gpre[BPG];
+  uint32_t bi = 0;                               // bin of the current item (items grow: the cursor only moves forward)
+  for (uint32_t item = j0; item < nitems; item += nj) {
+    while (gpre[bi + 1] <= item) ++bi;
+    p2_item<PER, EX, PF, P2_GROUP>(pool, xg + NXCD * bi, item - gpre[bi], k, canon, v, t);
+  }
 }
 
 __global__ __launch_bounds__(P2_THREADS, 4) void msp_p2_kernel(int k, int canon, MspView v, TableView t) {
@@ -605,32 +613,44 @@ __global__ __launch_bounds__(P2_THREADS, 4) void msp_p2_kernel(int k, int canon,
 }
 
 // ------------------------------------------------------------------------------------ P1 || P2
-// One launch of a pipeline stage: workgroups [0, n_p1) partition chunk s of the input (p1_role,
-// VALU-issue bound), the others split the level-1 records of chunk s-1 (p2_role, HBM bound).  Exact
-// persistent grid, three workgroups per CU -- two of the first kind, one of the second (blockIdx
-// b, b + CUs, b + 2 CUs share a CU under the observed round-robin dispatch; speed only) -- so the
-// vector pipe and the memory system of every CU are busy at the same time.  Two ordinary grids on
-// two streams do not overlap at all (the first owns every workgroup slot until it drains:
-// profiles/r03/overlap_probe.txt), and with exact grids on two streams the overlap depends on the
-// launch order (profiles/r03/coresidency.txt); one launch with roles does not.  The memory-bound
-// waves run at s_setprio 3: they issue a few instructions and wait, and must not queue behind the
-// arithmetic of their neighbours (12.6 instead of 13.7 ms in the micro-benchmark).
-// The level-1 buffer is a ping-pong pair: v.rec1 / v.cnt1 take chunk s, rec1_prev / cnt1_prev hold
-// chunk s-1; kernel boundaries order the stages.
-constexpr int P2_PER_FUSED = 5;
+// One launch of a pipeline stage: a grid whose workgroups are, in a fixed interleaved pattern,
+// partition workgroups for chunk s of the input (p1_tile, VALU-issue bound) and second-level
+// workgroups for the level-1 records of chunk s-1 (p2_item, HBM bound).  Every workgroup does ONE
+// unit of work and has the same footprint (three per CU), and the dispatcher hands workgroups out in
+// index order, so at any moment a CU holds a mix of both kinds in the proportion of the pattern:
+// its vector pipe and its memory system are busy at the same time.  What does not work: two ordinary
+// grids on two streams (no overlap at all: the first grid owns every slot until it drains,
+// profiles/r03/overlap_probe_two_jobs_two_streams.txt); persistent exact grids overlap
+// (profiles/r03/coresidency_valu_and_mem_kernels.txt) but a persistent partition workgroup is 16-28 %
+// slower than fresh ones.  The memory-bound waves run at s_setprio 3: they issue a few instructions
+// and wait, and must not queue behind the arithmetic of their neighbours.
+// Pattern: groups of 8 workgroups (one per XCD: blockIdx % 8); group g is a second-level group when
+// floor((g + 1) n2g / (n1g + n2g)) > floor(g n2g / (n1g + n2g)) -- n2g of them spread evenly among
+// n1g partition groups.  Second-level slot q of XCD x is tile group q % slots_per_bin of bin
+// x + 8 (q / slots_per_bin): slots are laid out for full regions, the ones past a bin's records
+// return at once.  The level-1 buffer is a ping-pong pair: v.rec1 / v.cnt1 take chunk s,
+// rec1_prev / cnt1_prev hold chunk s-1; kernel boundaries order the stages.
+constexpr int P2_PER_FUSED = 5, P2_GROUP_FUSED = 2;
 template <int W, int P1B_TR>
 __global__ __launch_bounds__(P1_THREADS, 6) void msp_p12_kernel(const int8_t *__restrict__ data, int64_t nN, int k, int m, int canon,
-                                                             int64_t tile0, int64_t tile_end, uint32_t n_p1, MspView v,
-                                                             uint4 *rec1_prev, uint32_t *cnt1_prev, uint64_t cap1_prev, TableView t) {
+                                                             int64_t tile0, int64_t tile_end, uint32_t n1g, uint32_t n2g,
+                                                             uint32_t slots_per_bin, MspView v,
+                                                             uint4 *rec1_prev, uint32_t *cnt1_prev, TableView t) {
   constexpr int BYTES = P1Lds<P1B_TR>::BYTES > P2Lds<P2_PER_FUSED>::BYTES ? P1Lds<P1B_TR>::BYTES : P2Lds<P2_PER_FUSED>::BYTES;
   static_assert(3 * BYTES <= 160 * 1024, "three workgroups per CU");
   __shared__ uint4 pool[(BYTES + 15) / 16];
-  if (blockIdx.x < n_p1) {
-    p1_role<W, P1B_TR, false>(pool, data, nN, k, m, canon, tile0 + blockIdx.x, n_p1, tile_end, blockIdx.x & (v.nxg - 1), v, t);
+  const uint32_t g = blockIdx.x >> 3, xcd = blockIdx.x & 7u;
+  const uint32_t q0 = (uint32_t)(((uint64_t)g * n2g) / (n1g + n2g)), q1 = (uint32_t)(((uint64_t)(g + 1) * n2g) / (n1g + n2g));
+  if (q1 == q0) {
+    const int64_t tile = tile0 + (int64_t)(g - q0) * 8 + xcd;
+    if (tile >= tile_end) return;
+    p1_tile<W, P1B_TR, false>(pool, data, nN, k, m, canon, tile, (uint32_t)tile & (v.nxg - 1), v, t);
   } else {
+    const uint32_t bi = q0 / slots_per_bin, grp = q0 % slots_per_bin;
+    if (bi >= (uint32_t)(B1 / NXCD)) return;
     __builtin_amdgcn_s_setprio(3);
-    v.rec1 = rec1_prev; v.cnt1 = cnt1_prev; v.cap1 = cap1_prev;
-    p2_role<P2_PER_FUSED, false, false>(pool, blockIdx.x - n_p1, gridDim.x - n_p1, k, canon, v, t);
+    v.rec1 = rec1_prev; v.cnt1 = cnt1_prev;
+    p2_item<P2_PER_FUSED, false, false, P2_GROUP_FUSED>(pool, xcd + NXCD * bi, grp, k, canon, v, t);
   }
 }
 
@@ -2018,11 +2038,11 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
   if (ctx->g_flags & CFRK_RUNS_ONLY) v.ovf_cap = v.ovf1_cap = 0;
   v.exact = 0; v.lbase = nullptr; v.lcap = nullptr;
   v.exact1 = 0; v.rbase = nullptr; v.rcap = nullptr;
-  // stand-alone P1 over the tiles [t0, t1) with `grid` workgroups (one per tile, or persistent)
-  auto launch_p1 = [&](unsigned grid, int64_t t0, int64_t t1, const MspView &vv) -> int {
-    const dim3 g1(grid), b1(P1_THREADS);
+  // stand-alone P1 over the tiles [t0, t1), one workgroup each
+  auto launch_p1 = [&](int64_t t0, int64_t t1, const MspView &vv) -> int {
+    const dim3 g1((unsigned)(t1 - t0)), b1(P1_THREADS);
 #define CFRK_P1B_CASE(WW) \
-    case WW: hipLaunchKernelGGL((msp_p1b_kernel<WW, (WW >= 16 ? 4 : WW >= 12 ? 6 : WW >= 8 ? 8 : WW >= 6 ? 10 : 12)>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, t0, t1, vv, t); break;
+    case WW: hipLaunchKernelGGL((msp_p1b_kernel<WW, (WW >= 16 ? 4 : WW >= 12 ? 6 : WW >= 8 ? 8 : WW >= 6 ? 10 : 12)>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, t0, vv, t); break;
     switch (W) {
       CFRK_P1B_CASE(4) CFRK_P1B_CASE(5) CFRK_P1B_CASE(6) CFRK_P1B_CASE(7) CFRK_P1B_CASE(8) CFRK_P1B_CASE(9)
       CFRK_P1B_CASE(10) CFRK_P1B_CASE(11) CFRK_P1B_CASE(12) CFRK_P1B_CASE(13) CFRK_P1B_CASE(14)
@@ -2033,18 +2053,26 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
     HIP_TRY(ctx, hipGetLastError());
     return CFRK_OK;
   };
-  // one pipeline stage: P1 on [t0, t1) into vv's level-1 buffer, P2 on the previous chunk's
+  // one pipeline stage: P1 on the tiles [t0, t1) into vv's level-1 half, P2 on the previous chunk's
+  // (either range may be empty: CFRK_ABL_P12_SPLIT runs every stage as two launches, one kind each)
+  const uint32_t slots_per_bin = (uint32_t)(((uint64_t)nxg * cap1c + (uint64_t)P2_THREADS * P2_PER_FUSED * P2_GROUP_FUSED - 1) /
+                                            ((uint64_t)P2_THREADS * P2_PER_FUSED * P2_GROUP_FUSED));
   auto launch_p12 = [&](int64_t t0, int64_t t1, const MspView &vv, uint4 *rec1_prev, uint32_t *cnt1_prev) -> int {
-    const dim3 g(3u * (unsigned)ncu), b(P1_THREADS);
-    const uint32_t n_p1 = 2u * (uint32_t)ncu;
+    const bool split = (ctx->dbg_flags & CFRK_ABL_P12_SPLIT) != 0;
+    for (int part = split ? 1 : 0; part <= (split ? 2 : 0); ++part) {      // 0: both kinds; 1: partition only; 2: second level only
+      const uint32_t n1g = part == 2 ? 0u : (uint32_t)((t1 - t0 + 7) / 8);
+      const uint32_t n2g = part == 1 ? 0u : (uint32_t)(B1 / NXCD) * slots_per_bin;
+      if (n1g + n2g == 0) continue;
+      const dim3 g(8u * (n1g + n2g)), b(P1_THREADS);
 #define CFRK_P12_CASE(WW) \
-    case WW: hipLaunchKernelGGL((msp_p12_kernel<WW, (WW >= 16 ? 4 : 6)>), g, b, 0, ctx->stream, d_data, nN, k, m, canon, t0, t1, n_p1, vv, rec1_prev, cnt1_prev, vv.cap1, t); break;
-    switch (W) {
-      CFRK_P12_CASE(12) CFRK_P12_CASE(13) CFRK_P12_CASE(14) CFRK_P12_CASE(15) CFRK_P12_CASE(16) CFRK_P12_CASE(17) CFRK_P12_CASE(18)
-      default: return cfrk_fail(ctx, CFRK_ERR_ARG, "no fused kernel for W=%d", W);
-    }
+      case WW: hipLaunchKernelGGL((msp_p12_kernel<WW, (WW >= 16 ? 4 : 6)>), g, b, 0, ctx->stream, d_data, nN, k, m, canon, t0, part == 2 ? t0 : t1, n1g, n2g, slots_per_bin, vv, rec1_prev, cnt1_prev, t); break;
+      switch (W) {
+        CFRK_P12_CASE(12) CFRK_P12_CASE(13) CFRK_P12_CASE(14) CFRK_P12_CASE(15) CFRK_P12_CASE(16) CFRK_P12_CASE(17) CFRK_P12_CASE(18)
+        default: return cfrk_fail(ctx, CFRK_ERR_ARG, "no fused kernel for W=%d", W);
+      }
 #undef CFRK_P12_CASE
-    HIP_TRY(ctx, hipGetLastError());
+      HIP_TRY(ctx, hipGetLastError());
+    }
     return CFRK_OK;
   };
   const unsigned p2_grid = 2u * (unsigned)ncu;   // stand-alone P2: persistent, two workgroups per CU
@@ -2065,7 +2093,7 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
         const MspView &cur = half[s & 1], &prev = half[(s & 1) ^ 1];
         const int64_t t0 = tile0 + (int64_t)s * chunk_tiles, t1 = std::min(tile0 + ntiles, t0 + chunk_tiles);
         if (s < nchunks && s > 0) HIP_TRY(ctx, hipMemsetAsync(cur.cnt1, 0, nreg * sizeof(uint32_t), ctx->stream));   // (stage 0: cleared above)
-        if (s == 0) { if ((rc = launch_p1(3u * (unsigned)ncu, t0, t1, cur))) return rc; }
+        if (s == 0) { if ((rc = launch_p1(t0, t1, cur))) return rc; }
         else if (s < nchunks) { if ((rc = launch_p12(t0, t1, cur, prev.rec1, prev.cnt1))) return rc; }
         else {
           hipLaunchKernelGGL(msp_p2_kernel, dim3(p2_grid), dim3(P2_THREADS), 0, ctx->stream, k, canon, prev, t);
@@ -2075,7 +2103,7 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
     } else {
     if (run_p1) {
       HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_L1OVF, 0, 2 * sizeof(uint64_t), ctx->stream));   // ST_L1OVF, ST_OVFN1
-      if ((rc = launch_p1((unsigned)ntiles, tile0, tile0 + ntiles, v))) return rc;
+      if ((rc = launch_p1(tile0, tile0 + ntiles, v))) return rc;
     }
     HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_L2OVF, 0, 2 * sizeof(uint64_t), ctx->stream));   // ST_L2OVF, ST_OVFN
     hipLaunchKernelGGL(msp_p2_kernel, dim3(p2_grid), dim3(P2_THREADS), 0, ctx->stream, k, canon, v, t);

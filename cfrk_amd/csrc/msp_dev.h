@@ -57,9 +57,21 @@ __device__ __forceinline__ uint32_t leaf_pick(const LeafPack &L, int a) {
   return (g >> ((a & 1) << 4)) & 0xFFFFu;
 }
 
+// Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() is a full fence: the compiler
+// puts s_waitcnt vmcnt(0) in front of it, so a persistent workgroup would wait at the end of every
+// tile until that tile's global STORES (and returning atomics) have completed -- 2-3 us of a 10 us
+// tile in the partition kernel.  The kernels below exchange data between threads through LDS only;
+// global stores drain in the background.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// the same within one wave (LDS written by some lanes, read by others)
+__device__ __forceinline__ void lds_wave_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
 // exclusive prefix sum of cnt[0..NB) into off[0..NB); every thread of the block must call it
 // (blockDim >= NB, NB a multiple of 64, NB <= 512); wtot is NB/64 words of LDS scratch
-template <int NB>
+template <int NB, bool LDS_ONLY = false>
 __device__ __forceinline__ void block_scan(const uint32_t *cnt, uint32_t *off, uint32_t *wtot) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   uint32_t x = 0, incl = 0;
@@ -73,13 +85,13 @@ __device__ __forceinline__ void block_scan(const uint32_t *cnt, uint32_t *off, u
     }
     if (lane == 63) wtot[wave] = incl;
   }
-  __syncthreads();
+  if (LDS_ONLY) lds_barrier(); else __syncthreads();
   if (tid < NB) {
     uint32_t base = 0;
     for (int w = 0; w < wave; ++w) base += wtot[w];
     off[tid] = base + incl - x;
   }
-  __syncthreads();
+  if (LDS_ONLY) lds_barrier(); else __syncthreads();
 }
 
 // Minimizers of one lane's 32 window starts (shared by msp.hip and msp2.hip).
