@@ -113,6 +113,20 @@ __device__ __forceinline__ uint32_t dev_lane_prev(uint32_t x) {       // value o
   return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x138, 0xF, 0xF, true);   // wave_shr:1
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave in six DPP adds (row_shr 1/2/4/8 inside the
+// rows of 16 lanes, then row_bcast:15 / row_bcast:31 carry the row totals on): no LDS traffic.
+// __shfl_up() compiles to ds_bpermute_b32 + address arithmetic + a select -- five instructions and
+// an LDS round trip per step, six dependent steps per scan.
+__device__ __forceinline__ uint32_t dev_wave_scan_incl(uint32_t x) {
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);   // row_shr:1
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);   // row_shr:2
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);   // row_shr:4
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);   // row_shr:8
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
+  return x;
+}
+
 __device__ __forceinline__ uint64_t dev_splitmix64(uint64_t x) {
   x += 0x9E3779B97F4A7C15ull;
   x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;

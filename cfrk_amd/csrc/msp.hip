@@ -227,12 +227,7 @@ __device__ __forceinline__ void p1_tile(uint4 *pool, const int8_t *__restrict__ 
   const uint32_t wcap = (v.dbg & CFRK_DEBUG_SMALL_WAVE_CAP) ? 64u : (uint32_t)(P1B_TR * 64);
   {
     const uint32_t mine = (uint32_t)__popc(S);
-    uint32_t incl = mine;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t y = __shfl_up(incl, d);
-      if (lane >= d) incl += y;
-    }
+    const uint32_t incl = dev_wave_scan_incl(mine);
     cnt_w = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     uint32_t widx = incl - mine;
     const uint32_t tag = (uint32_t)lane << 5;
@@ -419,12 +414,7 @@ __device__ __forceinline__ void p2_item(uint4 *pool, uint32_t b1, uint32_t grp, 
   if (tid < 64) {
     const uint32_t c = ((uint32_t)tid < v.nxg) ? (uint32_t)min((uint64_t)v.cnt1[l1_reg(b1, tid)],
                                                                exact1 ? (uint64_t)v.rcap[l1_reg(b1, tid)] : v.cap1) : 0u;
-    uint32_t incl = c;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t y = __shfl_up(incl, d);
-      if (tid >= d) incl += y;
-    }
+    const uint32_t incl = dev_wave_scan_incl(c);
     if ((uint32_t)tid < v.nxg) rpre[tid] = incl - c;
     if (tid == 63) rpre[v.nxg] = incl;
   }
@@ -504,12 +494,7 @@ __device__ __forceinline__ void p2_item(uint4 *pool, uint32_t b1, uint32_t grp, 
       const uint32_t x0 = mine ? hist[tid] : 0u;
       // returning atomic: issued here, consumed after the sort (its latency flies under it)
       if (x0 && !(v.dbg & CFRK_ABL_P2_NO_ATOMIC)) g0 = atomicAdd(&v.cnt2[b1 * NSUB + tid], x0);
-      uint32_t incl = x0;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t y = __shfl_up(incl, d);
-        if (lane >= d) incl += y;
-      }
+      const uint32_t incl = dev_wave_scan_incl(x0);
       if (lane == 63) wtot[wave] = incl;
       lds_barrier();
       uint32_t bs = 0;

@@ -77,12 +77,7 @@ __device__ __forceinline__ void block_scan(const uint32_t *cnt, uint32_t *off, u
   uint32_t x = 0, incl = 0;
   if (tid < NB) {
     x = cnt[tid];
-    incl = x;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t y = __shfl_up(incl, d);
-      if (lane >= d) incl += y;
-    }
+    incl = dev_wave_scan_incl(x);
     if (lane == 63) wtot[wave] = incl;
   }
   if (LDS_ONLY) lds_barrier(); else __syncthreads();
@@ -101,6 +96,11 @@ __device__ __forceinline__ void block_scan(const uint32_t *cnt, uint32_t *off, u
 // the own positions (H[32..] is scratch); the result is the change mask:
 // bit(63-p) set when the minimizer OCCURRENCE differs between positions p-1 and p
 // (p = 0: against the previous lane's last position).
+// (Measured in round 3 and not kept, profiles/r03/raw_order_minimizers_ab.txt: ordering the RAW
+// canonical m-mers, top-aligned in their windows -- four instructions per position instead of seven
+// -- makes 9.4 % more records (lexicographic minimizers are denser) and clumps the leaves: P1
+// unchanged, P2 +1.0 ms, P3 +3.0 ms; keeping the multiply but extracting both strands top-aligned
+// (six instructions) makes 2.2 % more records for no gain in P1.)
 template <int W>
 __device__ __forceinline__ uint64_t msp_minimizers(uint64_t hi, uint64_t mid, int64_t chunk, int m,
                                                    uint32_t (&H)[32 + W - 1]) {
