@@ -407,6 +407,9 @@ def main():
                          "kernel_ms": avg_ms, "algorithmic_bytes": b_alg,
                          "timed_bytes": b_timed, "frac_timed_bytes": b_timed / (avg_ms * 1e-3) / 8e12,
                          "frac_of_copy_ceiling_6.29TBs": achieved / 6290.0},
+            # device memory of the job: the library's buffers (level-1 records, leaf streams, result
+            # list, table) + the resident reads
+            "device_bytes": {"library": ctx.device_bytes(), "reads": int(nN + 12 * Rl)},
             "distinct": D, "sum_count_ok": ok,
             "digest": [f"{x:016x}" for x in digest],
         }

@@ -12,7 +12,6 @@ struct TableView;
 #define CFRK_ABL_P3_NO_RTAB  0x400u   // leaf kernel: complete runs are not read / deduplicated
 #define CFRK_ABL_P3_NO_OUT   0x800u   // leaf kernel: no compaction to the result list
 #define CFRK_ABL_P1_NO_EMIT  0x1000u  // partition kernel: front end only, no records built
-#define CFRK_ABL_P12_SPLIT 0x4000u   // pipeline: every fused stage runs as two launches of the fused kernel, one role each (counts stay right): each role's speed in the fused configuration
 #define CFRK_ABL_P2_NO_ATOMIC 0x2000u // second-level kernel: no cursor atomics (every tile's segments land at the stream starts)
 
 bool cfrk_msp_usable(const cfrk_ctx *ctx);                 // fast path applies to this begin()?

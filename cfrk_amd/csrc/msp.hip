@@ -130,8 +130,7 @@ struct P1Lds {
 };
 
 // Workgroup-level body of the partition kernel: tile `tile` of the input, appended to sub-region
-// `subreg` of every level-1 bin.  Called by the stand-alone kernel and by the fused kernel
-// msp_p12_kernel, whose grid interleaves these workgroups with second-level ones (p2_item).
+// `subreg` of every level-1 bin.
 // (One tile per workgroup, not a persistent loop: a looping workgroup waits at the top of every
 // tile for its input loads -- and, vmcnt being one in-order counter, for the previous tile's
 // stores before them; measured 16-28 % slower, profiles/r03/persistent_p1_is_slower.txt.)
@@ -595,48 +594,6 @@ __device__ __forceinline__ void p2_role(uint4 *pool, uint32_t wg, uint32_t nwg, 
 __global__ __launch_bounds__(P2_THREADS, 4) void msp_p2_kernel(int k, int canon, MspView v, TableView t) {
   __shared__ uint4 pool[(P2Lds<P2_PER>::BYTES + 15) / 16];
   p2_role<P2_PER, true, true>(pool, blockIdx.x, gridDim.x, k, canon, v, t);
-}
-
-// ------------------------------------------------------------------------------------ P1 || P2
-// One launch of a pipeline stage: a grid whose workgroups are, in a fixed interleaved pattern,
-// partition workgroups for chunk s of the input (p1_tile, VALU-issue bound) and second-level
-// workgroups for the level-1 records of chunk s-1 (p2_item, HBM bound).  Every workgroup does ONE
-// unit of work and has the same footprint (three per CU), and the dispatcher hands workgroups out in
-// index order, so at any moment a CU holds a mix of both kinds in the proportion of the pattern:
-// its vector pipe and its memory system are busy at the same time.  What does not work: two ordinary
-// grids on two streams (no overlap at all: the first grid owns every slot until it drains,
-// profiles/r03/overlap_probe_two_jobs_two_streams.txt); persistent exact grids overlap
-// (profiles/r03/coresidency_valu_and_mem_kernels.txt) but a persistent partition workgroup is 16-28 %
-// slower than fresh ones.  The memory-bound waves run at s_setprio 3: they issue a few instructions
-// and wait, and must not queue behind the arithmetic of their neighbours.
-// Pattern: groups of 8 workgroups (one per XCD: blockIdx % 8); group g is a second-level group when
-// floor((g + 1) n2g / (n1g + n2g)) > floor(g n2g / (n1g + n2g)) -- n2g of them spread evenly among
-// n1g partition groups.  Second-level slot q of XCD x is tile group q % slots_per_bin of bin
-// x + 8 (q / slots_per_bin): slots are laid out for full regions, the ones past a bin's records
-// return at once.  The level-1 buffer is a ping-pong pair: v.rec1 / v.cnt1 take chunk s,
-// rec1_prev / cnt1_prev hold chunk s-1; kernel boundaries order the stages.
-constexpr int P2_PER_FUSED = 5, P2_GROUP_FUSED = 2;
-template <int W, int P1B_TR>
-__global__ __launch_bounds__(P1_THREADS, 6) void msp_p12_kernel(const int8_t *__restrict__ data, int64_t nN, int k, int m, int canon,
-                                                             int64_t tile0, int64_t tile_end, uint32_t n1g, uint32_t n2g,
-                                                             uint32_t slots_per_bin, MspView v,
-                                                             uint4 *rec1_prev, uint32_t *cnt1_prev, TableView t) {
-  constexpr int BYTES = P1Lds<P1B_TR>::BYTES > P2Lds<P2_PER_FUSED>::BYTES ? P1Lds<P1B_TR>::BYTES : P2Lds<P2_PER_FUSED>::BYTES;
-  static_assert(3 * BYTES <= 160 * 1024, "three workgroups per CU");
-  __shared__ uint4 pool[(BYTES + 15) / 16];
-  const uint32_t g = blockIdx.x >> 3, xcd = blockIdx.x & 7u;
-  const uint32_t q0 = (uint32_t)(((uint64_t)g * n2g) / (n1g + n2g)), q1 = (uint32_t)(((uint64_t)(g + 1) * n2g) / (n1g + n2g));
-  if (q1 == q0) {
-    const int64_t tile = tile0 + (int64_t)(g - q0) * 8 + xcd;
-    if (tile >= tile_end) return;
-    p1_tile<W, P1B_TR, false>(pool, data, nN, k, m, canon, tile, (uint32_t)tile & (v.nxg - 1), v, t);
-  } else {
-    const uint32_t bi = q0 / slots_per_bin, grp = q0 % slots_per_bin;
-    if (bi >= (uint32_t)(B1 / NXCD)) return;
-    __builtin_amdgcn_s_setprio(3);
-    v.rec1 = rec1_prev; v.cnt1 = cnt1_prev;
-    p2_item<P2_PER_FUSED, false, false, P2_GROUP_FUSED>(pool, xcd + NXCD * bi, grp, k, canon, v, t);
-  }
 }
 
 // ---------------------------------------------------------------------------------------- P3
@@ -1863,6 +1820,18 @@ __global__ __launch_bounds__(256) void msp_spill_list_kernel(const uint4 *__rest
   if (i < n) spill_record(recs[i], k, canon != 0, t);
 }
 
+// sum of n cursors (one workgroup): how many records the first chunk of a batch made
+__global__ __launch_bounds__(1024) void msp_sum_kernel(const uint32_t *__restrict__ cnt, uint32_t n, uint64_t *out) {
+  __shared__ unsigned long long tot;
+  if (threadIdx.x == 0) tot = 0;
+  __syncthreads();
+  unsigned long long mine = 0;
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) mine += cnt[i];
+  atomicAdd(&tot, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) *out = tot;
+}
+
 __global__ void msp_info_kernel(MspView v, uint64_t *out) {
   // diagnostics: record totals / maxima per level (single block)
   __shared__ unsigned long long tot1, max1, tot2, max2;
@@ -1967,15 +1936,21 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
   // (a leaf of the pass holds ALL its records: the pass has fewer leaves, not lighter ones)
   const uint64_t cap2c = (uint64_t)(expect_all / NLEAF * 2.1 * slack) + 96;
   const uint64_t cap2t = (uint64_t)(expect_all / NLEAF * 0.6 * slack) + 96;   // truncated runs: ~15 % of the records
-  // Large batches go through a PIPELINE: the input is cut into chunks of tiles, and stage s runs
-  // P1 on chunk s and P2 on chunk s-1 in ONE launch (msp_p12_kernel), so the level-1 buffer only
-  // ever holds two chunks.  The fused kernel exists for W >= 12 (k >= 24: three workgroups of it
-  // fit a CU); anything that overflows a region falls back to the one-chunk path below.
-  const int ncu = std::max(8, ctx->num_cus / 8 * 8);
+  // Large batches are counted in CHUNKS of tiles: P1 on chunk c, then P2 on chunk c, with one
+  // level-1 buffer that only ever holds one chunk (C3: 2.7 GB instead of 40 GB); the leaf streams
+  // accumulate over the chunks.  Same kernels, same work; anything that overflows a region starts
+  // over on the one-chunk path below, whose cursors add up to the batch's exact demand.
+  // (What the chunks were built for did not pay: running P1 on chunk c+1 BESIDE P2 on chunk c in one
+  // launch -- persistent roles or an interleaved grid -- takes as long as the two one after the other,
+  // profiles/r03/persistent_p1_is_slower.txt: a CU is full with three partition workgroups.)
   const bool small_pipe = (ctx->dbg_flags & CFRK_DEBUG_SMALL_PIPELINE) != 0;
-  const int64_t chunk_min = small_pipe ? 3 : 32 * 2 * (int64_t)ncu;   // tiles: 32 per partitioning workgroup
-  int nchunks = (int)std::min<int64_t>(small_pipe ? 5 : 16, ntiles / chunk_min);
-  const bool pipelined = W >= 12 && (nxg == NXG || small_pipe) && nchunks >= 3 && !(ctx->dbg_flags & CFRK_DEBUG_NO_PIPELINE);
+  const int64_t chunk_min = small_pipe ? 3 : 16384;            // tiles (16384 = 256 MB of input)
+  // as many chunks as keep the level-1 buffer under ~6 GB (each costs ~30 us of launches and kernel
+  // tails: 16 chunks +0.5 ms on C3, 64 +2.7 ms -- and nothing comes back from the Infinity Cache
+  // even at 512 chunks of 43 MB, profiles/r03/chunk_count_sweep_c3.txt)
+  int nchunks = (int)std::min<int64_t>(small_pipe ? 5 : std::max<int64_t>(2, (int64_t)((double)B1 * nxg * cap1 * 16.0 / 6e9) + 1), ntiles / chunk_min);
+  if (const char *e = getenv("CFRK_MSP_CHUNKS")) nchunks = std::max(1, std::min(atoi(e), (int)std::min<int64_t>(4096, ntiles / 8)));   // (experiments)
+  const bool pipelined = (nxg == NXG || small_pipe) && nchunks >= 2 && !(ctx->dbg_flags & CFRK_DEBUG_NO_PIPELINE);
   if (!pipelined) nchunks = 1;
   const int64_t chunk_tiles = (ntiles + nchunks - 1) / nchunks;
   // per sub-region of ONE chunk (the cursors of a chunk see 1 / nchunks of the records)
@@ -1984,16 +1959,15 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
   void *p;
   MspView &v = ms->view;
   const size_t nreg = (size_t)B1 * nxg;
-  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L1, pipelined ? 2 * nreg * cap1c * sizeof(uint4) : nreg * cap1 * sizeof(uint4), &p))) return rc;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L1, nreg * (pipelined ? cap1c : cap1) * sizeof(uint4), &p))) return rc;
   v.rec1 = (uint4 *)p; v.cap1 = cap1; v.nxg = (uint32_t)nxg; v.dbg = ctx->dbg_flags;
   v.sel_mask = (1u << sel_bits) - 1u; v.sel_val = sel_val; v.sel_bits = (uint32_t)sel_bits;
-  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)(NLEAF >> sel_bits) * (cap2c + cap2t) * sizeof(uint4), &p))) return rc;
+  // (a chunked batch sizes its leaf streams after the first chunk: whatever the pool already holds will do until then)
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (pipelined && !small_pipe) ? 16 : (size_t)(NLEAF >> sel_bits) * (cap2c + cap2t) * sizeof(uint4), &p))) return rc;
   v.rec2 = (uint4 *)p; v.cap2c = cap2c; v.cap2t = cap2t;
-  // (the second set of level-1 cursors, for the pipeline's ping-pong buffer, comes last)
-  if ((rc = cfrk_pool_get(ctx, BUF_MSP_AUX, (size_t)NLEAF * 8 + (size_t)(2 * B1 * nxg + (NCLS + 1) * NLEAF) * sizeof(uint32_t), &p))) return rc;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_AUX, (size_t)NLEAF * 8 + (size_t)(B1 * nxg + (NCLS + 1) * NLEAF) * sizeof(uint32_t), &p))) return rc;
   v.leaf_off = (uint64_t *)p;
   v.cnt1 = (uint32_t *)(v.leaf_off + NLEAF); v.cnt2 = v.cnt1 + B1 * nxg; v.leaf_n = v.cnt2 + NCLS * NLEAF;
-  uint32_t *const cnt1_alt = v.leaf_n + NLEAF;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTK, (size_t)ctx->g_cap * 8, &p))) return rc;
   v.out_keys = (uint64_t *)p;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTC, (size_t)ctx->g_cap * 4, &p))) return rc;
@@ -2038,52 +2012,45 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
     HIP_TRY(ctx, hipGetLastError());
     return CFRK_OK;
   };
-  // one pipeline stage: P1 on the tiles [t0, t1) into vv's level-1 half, P2 on the previous chunk's
-  // (either range may be empty: CFRK_ABL_P12_SPLIT runs every stage as two launches, one kind each)
-  const uint32_t slots_per_bin = (uint32_t)(((uint64_t)nxg * cap1c + (uint64_t)P2_THREADS * P2_PER_FUSED * P2_GROUP_FUSED - 1) /
-                                            ((uint64_t)P2_THREADS * P2_PER_FUSED * P2_GROUP_FUSED));
-  auto launch_p12 = [&](int64_t t0, int64_t t1, const MspView &vv, uint4 *rec1_prev, uint32_t *cnt1_prev) -> int {
-    const bool split = (ctx->dbg_flags & CFRK_ABL_P12_SPLIT) != 0;
-    for (int part = split ? 1 : 0; part <= (split ? 2 : 0); ++part) {      // 0: both kinds; 1: partition only; 2: second level only
-      const uint32_t n1g = part == 2 ? 0u : (uint32_t)((t1 - t0 + 7) / 8);
-      const uint32_t n2g = part == 1 ? 0u : (uint32_t)(B1 / NXCD) * slots_per_bin;
-      if (n1g + n2g == 0) continue;
-      const dim3 g(8u * (n1g + n2g)), b(P1_THREADS);
-#define CFRK_P12_CASE(WW) \
-      case WW: hipLaunchKernelGGL((msp_p12_kernel<WW, (WW >= 16 ? 4 : 6)>), g, b, 0, ctx->stream, d_data, nN, k, m, canon, t0, part == 2 ? t0 : t1, n1g, n2g, slots_per_bin, vv, rec1_prev, cnt1_prev, t); break;
-      switch (W) {
-        CFRK_P12_CASE(12) CFRK_P12_CASE(13) CFRK_P12_CASE(14) CFRK_P12_CASE(15) CFRK_P12_CASE(16) CFRK_P12_CASE(17) CFRK_P12_CASE(18)
-        default: return cfrk_fail(ctx, CFRK_ERR_ARG, "no fused kernel for W=%d", W);
-      }
-#undef CFRK_P12_CASE
-      HIP_TRY(ctx, hipGetLastError());
-    }
-    return CFRK_OK;
-  };
-  const unsigned p2_grid = 2u * (unsigned)ncu;   // stand-alone P2: persistent, two workgroups per CU
+  const unsigned p2_grid = 2u * (unsigned)std::max(8, ctx->num_cus / 8 * 8);   // P2: persistent, two workgroups per CU, a multiple of 8
   bool run_p1 = true, settled = false, piped = pipelined;
   uint64_t parked1 = 0, parked2 = 0;
   for (int attempt = 0; attempt < 5; ++attempt) {
     if (piped) {
-      // ---- pipeline: stage s = P1(chunk s) || P2(chunk s - 1); level-1 halves and cursors alternate
+      // ---- chunks: P1(c), P2(c) on the one level-1 buffer
       HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_L1OVF, 0, 2 * sizeof(uint64_t), ctx->stream));   // ST_L1OVF, ST_OVFN1
       HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_L2OVF, 0, 2 * sizeof(uint64_t), ctx->stream));   // ST_L2OVF, ST_OVFN
-      MspView half[2] = {v, v};
-      for (int h = 0; h < 2; ++h) {
-        half[h].rec1 = v.rec1 + (size_t)h * nreg * cap1c;
-        half[h].cnt1 = h ? cnt1_alt : v.cnt1;
-        half[h].cap1 = cap1c;
-      }
-      for (int s = 0; s <= nchunks; ++s) {
-        const MspView &cur = half[s & 1], &prev = half[(s & 1) ^ 1];
-        const int64_t t0 = tile0 + (int64_t)s * chunk_tiles, t1 = std::min(tile0 + ntiles, t0 + chunk_tiles);
-        if (s < nchunks && s > 0) HIP_TRY(ctx, hipMemsetAsync(cur.cnt1, 0, nreg * sizeof(uint32_t), ctx->stream));   // (stage 0: cleared above)
-        if (s == 0) { if ((rc = launch_p1(t0, t1, cur))) return rc; }
-        else if (s < nchunks) { if ((rc = launch_p12(t0, t1, cur, prev.rec1, prev.cnt1))) return rc; }
-        else {
-          hipLaunchKernelGGL(msp_p2_kernel, dim3(p2_grid), dim3(P2_THREADS), 0, ctx->stream, k, canon, prev, t);
+      MspView vc = v;
+      vc.cap1 = cap1c;
+      for (int c = 0; c < nchunks; ++c) {
+        const int64_t t0 = tile0 + (int64_t)c * chunk_tiles, t1 = std::min(tile0 + ntiles, t0 + chunk_tiles);
+        if (t0 >= t1) break;
+        if (c > 0) HIP_TRY(ctx, hipMemsetAsync(vc.cnt1, 0, nreg * sizeof(uint32_t), ctx->stream));   // (chunk 0: cleared above)
+        if ((rc = launch_p1(t0, t1, vc))) return rc;
+        if (c == 0 && !small_pipe) {
+          // The leaf streams are sized from what the first chunk really made, not from the worst
+          // density a batch of unknown read length could have (the estimate above allows for reads
+          // as short as 2k: 1.34 x the records 150-base reads make, times 2.7 for lumpy leaves --
+          // 79 GB for C3's 21.9 GB of records).  One 8-byte read-back + sync per add.
+          if ((rc = cfrk_pool_get(ctx, BUF_SCRATCH, 64 * sizeof(uint64_t), &p))) return rc;
+          hipLaunchKernelGGL(msp_sum_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)vc.cnt1, (uint32_t)nreg, (uint64_t *)p);
           HIP_TRY(ctx, hipGetLastError());
+          uint64_t made = 0;
+          HIP_TRY(ctx, hipMemcpyAsync(&made, p, sizeof made, hipMemcpyDeviceToHost, ctx->stream));
+          HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+          // records of this pass's leaves in the whole batch (+3 %: chunks differ a little), per leaf
+          const double per_leaf = (double)made * ((double)ntiles / (double)(t1 - t0)) * 1.03 / (double)(NLEAF >> sel_bits);
+          // complete runs are ~84 % of a deep batch's records, the heaviest stream of a uniform batch
+          // ~1.2 x the mean leaf; truncated runs (two per read + invalid bases) a fifth to a third
+          // (up to 0.7: 50-base reads at k = 31 make as many truncated runs as complete ones)
+          const uint64_t m2c = (uint64_t)(per_leaf * 1.3) + 512, m2t = (uint64_t)(per_leaf * 0.7) + 256;
+          if (m2c + m2t < v.cap2c + v.cap2t) { v.cap2c = m2c; v.cap2t = m2t; }
+          if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)(NLEAF >> sel_bits) * (v.cap2c + v.cap2t) * sizeof(uint4), &p))) return rc;
+          v.rec2 = (uint4 *)p;
+          vc.cap2c = v.cap2c; vc.cap2t = v.cap2t; vc.rec2 = v.rec2;
         }
+        hipLaunchKernelGGL(msp_p2_kernel, dim3(p2_grid), dim3(P2_THREADS), 0, ctx->stream, k, canon, vc, t);
+        HIP_TRY(ctx, hipGetLastError());
       }
     } else {
     if (run_p1) {
@@ -2098,8 +2065,8 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
     HIP_TRY(ctx, hipMemcpyAsync(st, ctx->g_stats, sizeof st, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (piped && (st[ST_L1OVF] || st[ST_L2OVF])) {
-      // a region overflowed by more than the parking buffers take: the cursors of a pipeline do not
-      // add up to the batch's demand (the level-1 halves are reused), so the batch starts over on the
+      // a region overflowed by more than the parking buffers take: the level-1 cursors of a chunk do
+      // not add up to the batch's demand (the buffer is reused), so the batch starts over on the
       // one-chunk path, which lays the overflowing level out exactly
       piped = false;
       if ((rc = cfrk_pool_get(ctx, BUF_MSP_L1, nreg * cap1 * sizeof(uint4), &p))) return rc;
@@ -2294,6 +2261,17 @@ int cfrk_msp_resolve(cfrk_ctx *ctx, ResultSrc *src, bool *use_list) {
   src->lo = ms->view.out_keys; src->hi = ctx->g_two ? ms->view.out_hi : nullptr; src->cnt = ms->view.out_cnt;
   src->n = st[ST_CURSOR]; src->kind = ctx->g_two ? 3 : 2; src->stats = ctx->g_stats;
   *use_list = true;
+  return CFRK_OK;
+}
+
+extern "C" int cfrk_debug_device_bytes(cfrk_ctx *ctx, uint64_t *out_bytes) {
+  if (!ctx || !out_bytes) return CFRK_ERR_ARG;
+  uint64_t n = 0;
+  for (int i = 0; i < BUF_NSLOTS; ++i) n += ctx->pool[i].cap;
+  if (ctx->g_keys_lo) n += ctx->g_cap * 8;
+  if (ctx->g_keys_hi) n += ctx->g_cap * 8;
+  if (ctx->g_counts) n += ctx->g_cap * 4;
+  *out_bytes = n;
   return CFRK_OK;
 }
 

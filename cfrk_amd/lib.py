@@ -86,6 +86,7 @@ def load_library():
         "cfrk_global_merge_runs_device": ([vp, vp, C.POINTER(u64), C.c_int], C.c_int),
         "cfrk_debug_msp_info": ([vp, C.POINTER(u64)], C.c_int),
         "cfrk_debug_set_mem_budget": ([vp, u64], C.c_int),
+        "cfrk_debug_device_bytes": ([vp, C.POINTER(u64)], C.c_int),
         "cfrk_debug_set_flags": ([vp, C.c_uint32], C.c_int),
         "cfrk_debug_last_add_passes": ([vp, C.POINTER(C.c_int)], C.c_int),
         "cfrk_synth_reads_device": ([vp, i64, i64, i32, i64, u64, u64, u64, i32, vp, vp, vp], C.c_int),
@@ -134,6 +135,12 @@ class Context:
 
     def sync(self):
         self.check(self._L.cfrk_ctx_sync(self._h), "cfrk_ctx_sync")
+
+    def device_bytes(self):
+        """device memory the context holds (pool + global table), without the caller's buffers"""
+        n = C.c_uint64()
+        self.check(self._L.cfrk_debug_device_bytes(self._h, C.byref(n)), "cfrk_debug_device_bytes")
+        return n.value
 
     # -- raw device buffers --------------------------------------------------------------
     def alloc(self, nbytes):

@@ -200,6 +200,9 @@ int cfrk_debug_msp_info(cfrk_ctx *ctx, uint64_t out[9]);
  * behaviour reachable with small inputs (tests) and lets a host that shares the GPU hold the
  * library to a budget.  out_passes (may be NULL) receives the passes of the most recent add. */
 int cfrk_debug_set_mem_budget(cfrk_ctx *ctx, uint64_t bytes);
+/* Device memory the context holds right now: its pool (record buffers, result list, staging) plus the
+ * global table.  The caller's own buffers (the reads handed to cfrk_global_add_device) are not in it. */
+int cfrk_debug_device_bytes(cfrk_ctx *ctx, uint64_t *out_bytes);
 int cfrk_debug_last_add_passes(cfrk_ctx *ctx, int *out_passes);
 
 /* Test switches for rarely taken device paths (0 = normal operation).  Bit 0: every leaf of the
