@@ -164,6 +164,26 @@ int cfrk_memcpy_d2h(cfrk_ctx *ctx, void *dst, const void *src, size_t bytes) {
   return CFRK_OK;
 }
 
+int cfrk_memcpy_peer(cfrk_ctx *dst_ctx, void *dst, cfrk_ctx *src_ctx, const void *src, size_t bytes) {
+  if (!dst_ctx || !src_ctx || (bytes && (!dst || !src))) return CFRK_ERR_ARG;
+  if (bytes == 0) return CFRK_OK;
+  HIP_TRY(src_ctx, hipSetDevice(src_ctx->device));
+  HIP_TRY(src_ctx, hipStreamSynchronize(src_ctx->stream));
+  HIP_TRY(dst_ctx, hipSetDevice(dst_ctx->device));
+  if (dst_ctx->device != src_ctx->device) {
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, dst_ctx->device, src_ctx->device) == hipSuccess && can) {
+      const hipError_t e = hipDeviceEnablePeerAccess(src_ctx->device, 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();   // the copy still works, staged by the runtime
+      else (void)hipGetLastError();
+    }
+    HIP_TRY(dst_ctx, hipMemcpyPeerAsync(dst, dst_ctx->device, src, src_ctx->device, bytes, dst_ctx->stream));
+  } else {
+    HIP_TRY(dst_ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, dst_ctx->stream));
+  }
+  return CFRK_OK;
+}
+
 /* ------------------------------------------------------------------ per-read dense */
 
 static int dense_check(cfrk_ctx *ctx, int64_t nN, int64_t nS, int k) {

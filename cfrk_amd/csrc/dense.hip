@@ -142,6 +142,52 @@ __global__ __launch_bounds__(256) void dense_kernel(const int8_t *__restrict__ d
 }
 
 // second pass of the LDS variant: row i-1's last bin += invalid windows of read i
+// CFRK_FLOAT_INDEX (k = 13..15): the index of a window exactly as the reference computes it,
+//   lint index = 0;  for i < k:  index += nuc * powf(4, (k-1)-i);      src/kmer_kernel.cu:30-46
+// i.e. every step converts the running index to float, adds the (exact) product and truncates
+// back.  Partial sums above 2^24 are rounded to the float grid, so for k >= 13 most windows land in
+// a neighbouring bin (51 % wrong at k = 13, 94 % at k = 15) and an all-T window rounds
+// UP to 4^k: the reference then adds to bin 0 of the NEXT row (beyond the last row it writes out of
+// bounds; that one add is dropped here).  Float adds are IEEE round-to-nearest on both sides, the
+// products are exact, so this reproduces the reference bit for bit.  One thread per window, k byte
+// loads each, global atomics: a compatibility curiosity, not a fast path.
+template <bool COMPAT>
+__global__ __launch_bounds__(256) void dense_float_index_kernel(const int8_t *__restrict__ data,
+                                                                const int64_t *__restrict__ start,
+                                                                const int32_t *__restrict__ length, int64_t nN,
+                                                                int64_t nS, int k, int32_t *__restrict__ freq) {
+  const int64_t fourk = (int64_t)1 << (2 * k);
+  const int64_t nF = nS * fourk;
+  for (int64_t i = blockIdx.x; i < nS; i += gridDim.x) {
+    const int64_t st = start[i];
+    const int L = length[i];
+    // compat: thread t < length-1 of a 1024-thread block (src/kmer_kernel.cu:85); native: every
+    // position of the read incl. its terminator, guarded by Index != -1 (src/kmer_kernel.cu:61-68)
+    const int nwin = COMPAT ? min(max(L - 1, 0), 1024) : max(L + 1, 0);
+    for (int t = threadIdx.x; t < nwin; t += blockDim.x) {
+      const int64_t id = st + t;
+      if (id >= nN) continue;
+      long index = 0;
+      for (int j = 0; j < k; ++j) {
+        const int8_t nuc = (id + j < nN) ? data[id + j] : (int8_t)-1;
+        if (nuc != -1) {
+          // 4^n exactly (a power of two: libm's powf returns it exactly on the host; the device's
+          // powf is an exp2/log2 approximation and is not used)
+          const float p4 = (float)(1u << (2 * ((k - 1) - j)));
+          const float f = (float)index + (float)nuc * p4;
+          index = (long)f;
+        } else {
+          index = -1;
+          break;
+        }
+      }
+      if (index == -1 && !COMPAT) continue;             // ComputeFreq's guard; ComputeFreqNew has none
+      const int64_t pos = fourk * i + (int64_t)(int)index;   // Index[] is an int array
+      if (pos >= 0 && pos < nF) atomicAdd(&freq[pos], 1);
+    }
+  }
+}
+
 __global__ void dense_spill_kernel(int32_t *__restrict__ freq, const int32_t *__restrict__ spill,
                                    int64_t nS, int64_t fourk) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1;
@@ -179,6 +225,12 @@ int cfrk_launch_dense(cfrk_ctx *ctx, const int8_t *d_data, const int64_t *d_star
     if (compat && nS > 1)
       hipLaunchKernelGGL(dense_spill_kernel, dim3((unsigned)((nS - 1 + 255) / 256)), dim3(256), 0, ctx->stream,
                          d_freq, (const int32_t *)d_spill, nS, fourk);
+  } else if ((flags & CFRK_FLOAT_INDEX) && k >= 13) {
+    // (k <= 12: the float accumulation is exact, the ordinary kernels already are the reference)
+    const int grid = (int)std::min<int64_t>(nS, (int64_t)ctx->num_cus * 32);
+    HIP_TRY(ctx, hipMemsetAsync(d_freq, 0, (size_t)nS * (size_t)fourk * 4, ctx->stream));
+    if (compat) hipLaunchKernelGGL((dense_float_index_kernel<true>), dim3(grid), dim3(256), 0, ctx->stream, d_data, d_start, d_length, nN, nS, k, d_freq);
+    else hipLaunchKernelGGL((dense_float_index_kernel<false>), dim3(grid), dim3(256), 0, ctx->stream, d_data, d_start, d_length, nN, nS, k, d_freq);
   } else {
     const int grid = (int)std::min<int64_t>((nS + 3) / 4, (int64_t)ctx->num_cus * 16);
     HIP_TRY(ctx, hipMemsetAsync(d_freq, 0, (size_t)nS * (size_t)fourk * 4, ctx->stream));  // SetMatrix(d_Freq, 0)

@@ -13,7 +13,10 @@
 //   k <= 7 (at most 16384 keys): no partition at all, every workgroup counts into a replicated
 //   LDS table and adds it to a dense HBM array once.
 //
-// HBM sees 4 bytes per k-mer per pass; every occurrence is one LDS atomic.  Same semantics and
+// HBM never sees the bits a key's region already implies: level 1 stores the 2k-8 bits below the
+// bin as a 16-bit plane plus (2k-8 > 16) an 8-bit plane -- 3 bytes per k-mer at k = 15 instead of
+// 4 --, the leaves store the low idx <= 13 bits as 16-bit words (round 3: 24.1 -> 15 GB per launch
+// on configs[1]); every occurrence is one LDS atomic.  Same semantics and
 // the same result-list form as msp.hip (which covers 16 <= k <= 32); overflowing regions spill
 // into the HBM table.
 #include "msp.h"
@@ -33,8 +36,9 @@ constexpr int RX3_THREADS = 256;
 constexpr int RX_IDX_MAX = 13;
 
 struct RxView {
-  uint32_t *key1; uint32_t *cnt1; uint64_t cap1;      // 2^b1 x RX_NXG regions
-  uint32_t *key2; uint32_t *cnt2; uint64_t cap2;      // 2^(b1+b2) leaves
+  // level 1: the 2k - b1 bits of a key below its bin, low 16 in k1lo, the rest (if any: hi8) in k1hi
+  uint16_t *k1lo; uint8_t *k1hi; uint32_t hi8; uint32_t *cnt1; uint64_t cap1;      // 2^b1 x RX_NREG regions
+  uint16_t *key2; uint32_t *cnt2; uint64_t cap2;      // 2^(b1+b2) leaves: the low idx bits of their keys
   // exact layout after a leaf stream overflowed the fixed stride (few distinct keys, each seen
   // very often): leaf l starts at key lbase[l] and holds exactly lcap[l] keys
   const uint64_t *lbase; const uint32_t *lcap; uint32_t exact;
@@ -159,10 +163,13 @@ __global__ __launch_bounds__(RX1_THREADS) void rx1_kernel(const int8_t *__restri
     const uint32_t dst = gbase[b] + (p - loff[b]);
     const uint32_t reg = rx_reg(v, b, blockIdx.x & (RX_NREG - 1));
     if (v.exact1) {
-      if (dst < v.rcap[reg]) v.key1[v.rbase[reg] + dst] = key;
-      else { t.stats[ST_SPILLED] = 1; table_add1(t, (uint64_t)rx_unmix(v, key), 1u); }   // cannot happen
+      if (dst < v.rcap[reg]) {
+        v.k1lo[v.rbase[reg] + dst] = (uint16_t)key;
+        if (v.hi8) v.k1hi[v.rbase[reg] + dst] = (uint8_t)((key & ((1u << sh1) - 1u)) >> 16);
+      } else { t.stats[ST_SPILLED] = 1; table_add1(t, (uint64_t)rx_unmix(v, key), 1u); }   // cannot happen
     } else if (dst < v.cap1) {
-      v.key1[(uint64_t)reg * v.cap1 + dst] = key;
+      v.k1lo[(uint64_t)reg * v.cap1 + dst] = (uint16_t)key;
+      if (v.hi8) v.k1hi[(uint64_t)reg * v.cap1 + dst] = (uint8_t)((key & ((1u << sh1) - 1u)) >> 16);
     } else {
       v.stats[ST_L1OVF] = 1;       // the cursor keeps counting: the host redoes RX1 with exact sizes
     }
@@ -193,30 +200,42 @@ __global__ __launch_bounds__(RX2_THREADS) void rx2_kernel(int tiles_per_sub, RxV
   const uint32_t nt = (uint32_t)min((uint64_t)RX2_KEYS, n - r0);
   hist[tid] = 0; fill[tid] = 0;
   __syncthreads();
-  const uint32_t *src = v.key1 + (v.exact1 ? v.rbase[reg] : (uint64_t)reg * v.cap1) + r0;
+  const uint64_t rb = (v.exact1 ? v.rbase[reg] : (uint64_t)reg * v.cap1) + r0;
+  const uint16_t *slo = v.k1lo + rb;
+  const uint8_t *shi = v.k1hi + rb;
   const uint32_t m2 = (1u << v.b2) - 1u;
-  // four 16-byte loads per thread (a region starts on a 16-byte boundary unless the level was laid
-  // out again: cap1 is a multiple of 4 and the buffer has 16 bytes to spare) instead of sixteen
-  // 4-byte ones; which key a thread holds does not matter to a counting sort
-  uint32_t kk[RX2_PER];
-  static_assert(RX2_PER % 4 == 0, "keys are loaded four at a time");
+  // 16-byte loads of the 16-bit plane (eight keys) and 8-byte loads of the 8-bit plane (a region
+  // starts on a 16-element boundary unless the level was laid out again: cap1 is a multiple of 16)
+  // instead of one load per key; which key a thread holds does not matter to a counting sort
+  uint32_t kk[RX2_PER];                          // the 2k - b1 bits below the bin
+  static_assert(RX2_PER % 8 == 0, "keys are loaded eight at a time");
   const bool vec = !v.exact1;
   auto idx_of = [&](int i) {                     // tile position of key i of this thread
-    return vec ? (((uint32_t)(i >> 2) * RX2_THREADS + tid) << 2) + (uint32_t)(i & 3) : (uint32_t)i * RX2_THREADS + tid;
+    return vec ? (((uint32_t)(i >> 3) * RX2_THREADS + tid) << 3) + (uint32_t)(i & 7) : (uint32_t)i * RX2_THREADS + tid;
   };
   if (vec) {
 #pragma unroll
-    for (int q = 0; q < RX2_PER / 4; ++q) {
-      const uint32_t idx4 = ((uint32_t)q * RX2_THREADS + tid) << 2;
+    for (int q = 0; q < RX2_PER / 8; ++q) {
+      const uint32_t idx8 = ((uint32_t)q * RX2_THREADS + tid) << 3;
       uint4 x = make_uint4(0u, 0u, 0u, 0u);
-      if (idx4 < nt) x = *reinterpret_cast<const uint4 *>(src + idx4);
-      kk[4 * q] = x.x; kk[4 * q + 1] = x.y; kk[4 * q + 2] = x.z; kk[4 * q + 3] = x.w;
+      uint2 h = make_uint2(0u, 0u);
+      if (idx8 < nt) {
+        x = *reinterpret_cast<const uint4 *>(slo + idx8);
+        if (v.hi8) h = *reinterpret_cast<const uint2 *>(shi + idx8);
+      }
+      const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const uint32_t lo16 = (w[c >> 1] >> (16 * (c & 1))) & 0xFFFFu;
+        const uint32_t hb = ((c < 4 ? h.x : h.y) >> (8 * (c & 3))) & 0xFFu;
+        kk[8 * q + c] = (hb << 16) | lo16;
+      }
     }
   } else {
 #pragma unroll
     for (int i = 0; i < RX2_PER; ++i) {
       const uint32_t idx = (uint32_t)i * RX2_THREADS + tid;
-      kk[i] = (idx < nt) ? src[idx] : 0u;
+      kk[i] = (idx < nt) ? ((uint32_t)slo[idx] | (v.hi8 ? (uint32_t)shi[idx] << 16 : 0u)) : 0u;
     }
   }
 #pragma unroll
@@ -244,10 +263,10 @@ __global__ __launch_bounds__(RX2_THREADS) void rx2_kernel(int tiles_per_sub, RxV
     const uint32_t dst = gbase[b] + (p - loff[b]);
     const uint64_t leaf = ((uint64_t)bin1 << v.b2) + b;
     if (v.exact) {
-      if (dst < v.lcap[leaf]) v.key2[v.lbase[leaf] + dst] = key;
-      else { t.stats[ST_SPILLED] = 1; table_add1(t, (uint64_t)rx_unmix(v, key), 1u); }   // cannot happen
+      if (dst < v.lcap[leaf]) v.key2[v.lbase[leaf] + dst] = (uint16_t)(key & ((1u << v.idx) - 1u));
+      else { t.stats[ST_SPILLED] = 1; table_add1(t, (uint64_t)rx_unmix(v, (bin1 << (2 * v.k - v.b1)) | key), 1u); }   // cannot happen
     } else if (dst < v.cap2) {
-      v.key2[leaf * v.cap2 + dst] = key;
+      v.key2[leaf * v.cap2 + dst] = (uint16_t)(key & ((1u << v.idx) - 1u));
     } else {
       v.stats[ST_L2OVF] = 1;       // the cursor keeps counting: the host redoes RX2 with exact sizes
     }
@@ -291,14 +310,13 @@ __global__ __launch_bounds__(RX3_THREADS) void rx3_kernel(RxView v) {
   const uint32_t rmask = (1u << rlog) - 1u;
   for (uint32_t s = tid; s < (nidx << rlog); s += RX3_THREADS) cnt[s] = 0;
   __syncthreads();
-  const uint32_t *src = v.exact ? v.key2 + v.lbase[leaf] : v.key2 + (uint64_t)leaf * v.cap2;
+  const uint16_t *src = v.exact ? v.key2 + v.lbase[leaf] : v.key2 + (uint64_t)leaf * v.cap2;
   {
-    // 16-byte loads, four of them in flight per thread (a key per load and iteration left the
-    // workgroup waiting for HBM ~40 times per leaf): the stream is read as uint4 from the
-    // 16-byte boundary below its first key, elements outside [0, n) are skipped
-    const uint32_t head = (uint32_t)((reinterpret_cast<uintptr_t>(src) >> 2) & 3u);
+    // 16-byte loads (eight 16-bit keys), four of them in flight per thread: the stream is read as
+    // uint4 from the 16-byte boundary below its first key, elements outside [0, n) are skipped
+    const uint32_t head = (uint32_t)((reinterpret_cast<uintptr_t>(src) >> 1) & 7u);
     const uint4 *src4 = reinterpret_cast<const uint4 *>(src - head);
-    const uint64_t n4 = (head + n + 3) >> 2;                 // uint4 elements that hold keys
+    const uint64_t n4 = (head + n + 7) >> 3;                 // uint4 elements that hold keys
     const uint64_t lo = head, hi = head + n;                 // valid element range in the aligned view
     constexpr int INFL = 4;
     for (uint64_t q0 = 0; q0 < n4; q0 += (uint64_t)INFL * RX3_THREADS) {
@@ -311,11 +329,13 @@ __global__ __launch_bounds__(RX3_THREADS) void rx3_kernel(RxView v) {
       }
 #pragma unroll
       for (int u = 0; u < INFL; ++u) {
-        const uint64_t e = 4 * (q0 + (uint64_t)u * RX3_THREADS + tid);
+        const uint64_t e = 8 * (q0 + (uint64_t)u * RX3_THREADS + tid);
         const uint32_t w[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-          if (e + c >= lo && e + c < hi) atomicAdd(&cnt[((w[c] & imask) << rlog) | ((uint32_t)tid & rmask)], 1u);
+        for (int c = 0; c < 8; ++c) {
+          const uint32_t key = (w[c >> 1] >> (16 * (c & 1))) & 0xFFFFu;
+          if (e + c >= lo && e + c < hi) atomicAdd(&cnt[((key & imask) << rlog) | ((uint32_t)tid & rmask)], 1u);
+        }
       }
     }
   }
@@ -475,9 +495,11 @@ int cfrk_radix_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   v.mul = 0x9E3779B1u;
   v.inv = inv_odd32(v.mul);
   const uint64_t nb1 = 1ull << v.b1, nleaf = 1ull << (v.b1 + v.b2);
-  const uint64_t cap1 = ((uint64_t)((double)nN / (double)(nb1 * RX_NREG) * 1.3) + 4096 + 3) & ~3ull;   // (RX2 loads 16 bytes at a time)
+  const uint64_t cap1 = ((uint64_t)((double)nN / (double)(nb1 * RX_NREG) * 1.3) + 4096 + 15) & ~15ull;   // (RX2 loads 8 keys at a time)
   const uint64_t cap2 = (uint64_t)((double)nN / (double)nleaf * 1.5) + 1024;
-  const size_t need = (size_t)nb1 * RX_NREG * cap1 * 4 + (size_t)nleaf * cap2 * 4 + (size_t)ctx->g_cap * 12;
+  v.hi8 = (2 * k - v.b1 > 16) ? 1u : 0u;
+  const size_t l1_elems = (size_t)nb1 * RX_NREG * cap1;
+  const size_t need = l1_elems * 3 + (size_t)nleaf * cap2 * 2 + (size_t)ctx->g_cap * 12;
   const size_t have = ctx->pool[BUF_MSP_L1].cap + ctx->pool[BUF_MSP_L2].cap + ctx->pool[BUF_MSP_OUTK].cap + ctx->pool[BUF_MSP_OUTC].cap;
   if (need > have) {
     size_t free_b = 0, total_b = 0;
@@ -485,10 +507,11 @@ int cfrk_radix_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
     if (need > have + free_b) return cfrk_fail(ctx, CFRK_ERR_NOMEM, "radix path needs %zu B, %zu B available", need, have + free_b);
   }
   void *p;
-  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L1, (size_t)nb1 * RX_NREG * cap1 * 4 + 16, &p))) return rc;
-  v.key1 = (uint32_t *)p; v.cap1 = cap1;
-  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)nleaf * cap2 * 4, &p))) return rc;
-  v.key2 = (uint32_t *)p; v.cap2 = cap2;
+  // (the 16-bit plane, then the 8-bit plane; 64 bytes to spare: RX2's last vector loads may read past a region's keys)
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L1, l1_elems * 3 + 64, &p))) return rc;
+  v.k1lo = (uint16_t *)p; v.k1hi = (uint8_t *)(v.k1lo + l1_elems); v.cap1 = cap1;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)nleaf * cap2 * 2 + 64, &p))) return rc;
+  v.key2 = (uint16_t *)p; v.cap2 = cap2;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_AUX, (size_t)(nb1 * RX_NREG + nleaf) * 4, &p))) return rc;
   v.cnt1 = (uint32_t *)p; v.cnt2 = v.cnt1 + nb1 * RX_NREG;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTK, (size_t)ctx->g_cap * 8, &p))) return rc;

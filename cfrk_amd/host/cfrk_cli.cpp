@@ -14,7 +14,10 @@
 // Options:
 //   --all-chunks     write every chunk (what the reference evidently meant to do)
 //   --native         guarded per-read counting (src/kmer_kernel.cu:52-70) + clean FASTA parsing
-//   --global         one sparse table over all reads ("key:count" lines), k up to 32
+//   --global         one sparse table over all reads, k up to 64: "key:count" lines (k <= 32),
+//                    "hi:lo:count" lines (k > 32: key = hi * 2^64 + lo), ascending by key
+//   --binary         (global) the CFRKGLB1 binary form instead of text (cfrk_host.h: 32-byte header,
+//                    then 12-byte (k <= 32) or 20-byte records, ascending)
 //   --canonical      (global) count min(kmer, reverse complement)
 //   --device N       first GPU ordinal (the reference picks the GPU with most memory, src/main.cu:83-108)
 //   --gpus N         chunks (per-read modes) or files (--batch) are dealt round-robin to N devices,
@@ -50,7 +53,7 @@ namespace {
 struct Options {
   int k = 0, threads = 12;
   long chunk_size = 8192;
-  bool all_chunks = false, native = false, global = false, canonical = false, same_device = false;
+  bool all_chunks = false, native = false, global = false, canonical = false, same_device = false, binary = false;
   int device = 0, gpus = 1;
 };
 
@@ -155,6 +158,20 @@ int run_per_read(const Options &o, const cfrk_batch &batch, std::vector<Worker> 
   return failed;
 }
 
+// the global result (ascending keys) as sparse text or in the binary form
+void write_global(const Options &o, const uint64_t *lo, const uint64_t *hi, const uint32_t *cnt, uint64_t n, FILE *out) {
+  const uint64_t *hi2 = (o.k > 32) ? hi : nullptr;
+  std::string buf;
+  if (o.binary) {
+    buf.resize(cfrk_host_write_binary(o.k, o.canonical ? CFRK_BIN_CANONICAL : 0, lo, hi2, cnt, n, nullptr, 0));
+    cfrk_host_write_binary(o.k, o.canonical ? CFRK_BIN_CANONICAL : 0, lo, hi2, cnt, n, &buf[0], buf.size());
+  } else {
+    buf.resize(cfrk_host_format_sparse2(lo, hi2, cnt, n, nullptr, 0));
+    cfrk_host_format_sparse2(lo, hi2, cnt, n, &buf[0], buf.size());
+  }
+  fwrite(buf.data(), 1, buf.size(), out);
+}
+
 int run_global(const Options &o, const cfrk_batch &batch, Worker &w, FILE *out) {
   int rc;
   cfrk_ctx *ctx = w.ctx;
@@ -163,7 +180,6 @@ int run_global(const Options &o, const cfrk_batch &batch, Worker &w, FILE *out) 
   uint64_t hint = (uint64_t)(batch.nN > 0 ? batch.nN : 1);
   if (hint < (1ull << 20)) hint = 1ull << 20;
   if (hint > (1ull << 31)) hint = 1ull << 31;
-  if (o.k > 32) { fprintf(stderr, "cfrk: --global text output supports k <= 32\n"); return 1; }
   if ((rc = cfrk_global_begin(ctx, o.k, o.canonical ? CFRK_CANONICAL : 0, hint))) return die(ctx, rc, "cfrk_global_begin");
   if ((rc = cfrk_global_add(ctx, batch.data, batch.start, batch.length, batch.nN, batch.nS))) return die(ctx, rc, "cfrk_global_add");
   uint64_t n = 0;
@@ -171,9 +187,7 @@ int run_global(const Options &o, const cfrk_batch &batch, Worker &w, FILE *out) 
   std::vector<uint64_t> keys(n), hi(n);
   std::vector<uint32_t> cnt(n);
   if ((rc = cfrk_global_export(ctx, keys.data(), hi.data(), cnt.data(), n, &n))) return die(ctx, rc, "cfrk_global_export");
-  std::string buf(cfrk_host_format_sparse(keys.data(), cnt.data(), n, nullptr, 0), '\0');
-  cfrk_host_format_sparse(keys.data(), cnt.data(), n, &buf[0], buf.size());
-  fwrite(buf.data(), 1, buf.size(), out);
+  write_global(o, keys.data(), hi.data(), cnt.data(), n, out);
   return 0;
 }
 
@@ -187,9 +201,15 @@ int run_global_multi(const Options &o, const cfrk_batch &batch, std::vector<std:
   uint64_t hint = (uint64_t)(batch.nN > 0 ? batch.nN : 1);
   if (hint < (1ull << 20)) hint = 1ull << 20;
   if (hint > (1ull << 31)) hint = 1ull << 31;
-  std::vector<std::vector<uint64_t>> packed((size_t)N);            // shard s: packed rows (two words per row)
+  // shard s: packed rows stay ON ITS DEVICE (16 bytes per row), rows[s][o] = rows of owner o's segment
+  std::vector<void *> d_packed((size_t)N, nullptr);
   std::vector<std::vector<uint64_t>> rows((size_t)N, std::vector<uint64_t>((size_t)N, 0));
   std::vector<int> status((size_t)N, 0);
+  std::vector<char> refused((size_t)N, 0);           // the shard cannot export runs: count on one device instead
+  auto free_packed = [&] {
+    for (int sh = 0; sh < N; ++sh)
+      if (d_packed[(size_t)sh]) { cfrk_device_free(per_dev[(size_t)sh][0].ctx, d_packed[(size_t)sh]); d_packed[(size_t)sh] = nullptr; }
+  };
   {
     std::vector<std::thread> th;
     for (int sh = 0; sh < N; ++sh)
@@ -199,51 +219,68 @@ int run_global_multi(const Options &o, const cfrk_batch &batch, std::vector<std:
         const int64_t b0 = (r0 < batch.nS) ? batch.start[r0] : batch.nN, b1 = (r1 < batch.nS) ? batch.start[r1] : batch.nN;
         int rc;
         if ((rc = cfrk_global_begin(ctx, o.k, flags | CFRK_RUNS_ONLY, hint))) { status[(size_t)sh] = die(ctx, rc, "cfrk_global_begin"); return; }
-        if (b1 > b0 && (rc = cfrk_global_add(ctx, batch.data + b0, nullptr, nullptr, b1 - b0, 0))) { status[(size_t)sh] = die(ctx, rc, "cfrk_global_add"); return; }
-        // distinct runs never exceed the shard's super-k-mers (about one per 8 bases), plus the headers
-        uint64_t cap = (uint64_t)(b1 - b0) / 4 + (uint64_t)N * 70000 + 4096;
-        for (int attempt = 0; attempt < 2; ++attempt) {
-          void *d = nullptr;
-          if ((rc = cfrk_device_alloc(ctx, cap * 16, &d))) { status[(size_t)sh] = die(ctx, rc, "cfrk_device_alloc"); return; }
-          rc = (b1 > b0) ? cfrk_global_export_runs_device(ctx, d, cap, N, rows[(size_t)sh].data()) : 0;
-          if (rc == CFRK_ERR_SMALL_BUF && attempt == 0) { cfrk_device_free(ctx, d); cap *= 4; continue; }
-          if (rc) { cfrk_device_free(ctx, d); status[(size_t)sh] = die(ctx, rc, "cfrk_global_export_runs_device"); return; }
-          uint64_t total = 0;
-          for (uint64_t x : rows[(size_t)sh]) total += x;
-          packed[(size_t)sh].resize(total * 2);
-          if (total && (rc = cfrk_memcpy_d2h(ctx, packed[(size_t)sh].data(), d, total * 16))) status[(size_t)sh] = die(ctx, rc, "cfrk_memcpy_d2h");
-          cfrk_device_free(ctx, d);
+        if (b1 <= b0) return;
+        if ((rc = cfrk_global_add(ctx, batch.data + b0, nullptr, nullptr, b1 - b0, 0))) {
+          if (rc == CFRK_ERR_NOMEM || rc == CFRK_ERR_STATE) { refused[(size_t)sh] = 1; return; }
+          status[(size_t)sh] = die(ctx, rc, "cfrk_global_add");
           return;
         }
+        // distinct runs never exceed the shard's super-k-mers (about one per 8 bases), plus the headers;
+        // a buffer that is too small is retried at four times the size
+        uint64_t cap = (uint64_t)(b1 - b0) / 4 + (uint64_t)N * 70000 + 4096;
+        for (int attempt = 0; attempt < 3; ++attempt) {
+          void *d = nullptr;
+          if ((rc = cfrk_device_alloc(ctx, cap * 16, &d))) { refused[(size_t)sh] = 1; return; }
+          rc = cfrk_global_export_runs_device(ctx, d, cap, N, rows[(size_t)sh].data());
+          if (!rc) { d_packed[(size_t)sh] = d; return; }
+          cfrk_device_free(ctx, d);
+          if (rc == CFRK_ERR_SMALL_BUF) { cap *= 4; continue; }
+          // (CFRK_ERR_STATE: something of this shard spilled into the HBM table -- its runs are not
+          //  all in the leaf streams; the single-device path counts such input as well)
+          if (rc == CFRK_ERR_STATE || rc == CFRK_ERR_NOMEM) { refused[(size_t)sh] = 1; return; }
+          status[(size_t)sh] = die(ctx, rc, "cfrk_global_export_runs_device");
+          return;
+        }
+        refused[(size_t)sh] = 1;
       });
     for (auto &t : th) t.join();
-    for (int r : status) if (r) return r;
+    for (int r : status) if (r) { free_packed(); return r; }
+    for (char r : refused)
+      if (r) {
+        free_packed();
+        fprintf(stderr, "cfrk: a shard could not export its runs; counting on one device\n");
+        return run_global(o, batch, per_dev[0][0], out);
+      }
   }
   std::vector<std::vector<uint64_t>> keys((size_t)N);
   std::vector<std::vector<uint32_t>> cnts((size_t)N);
   {
+    // owner ow gathers its segment of every shard DEVICE TO DEVICE (xGMI peer-to-peer between the
+    // devices of the node; replaces the host staging of round 2), then expands and counts its leaves
     std::vector<std::thread> th;
     for (int ow = 0; ow < N; ++ow)
       th.emplace_back([&, ow] {
         cfrk_ctx *ctx = per_dev[(size_t)ow][1].ctx;
-        std::vector<uint64_t> recv((size_t)N), buf;
-        for (int sh = 0; sh < N; ++sh) {
-          uint64_t off = 0;
-          for (int q = 0; q < ow; ++q) off += rows[(size_t)sh][(size_t)q];
-          recv[(size_t)sh] = rows[(size_t)sh][(size_t)ow];
-          buf.insert(buf.end(), packed[(size_t)sh].begin() + (ptrdiff_t)(off * 2), packed[(size_t)sh].begin() + (ptrdiff_t)((off + recv[(size_t)sh]) * 2));
-        }
+        std::vector<uint64_t> recv((size_t)N);
+        uint64_t total = 0;
+        for (int sh = 0; sh < N; ++sh) { recv[(size_t)sh] = rows[(size_t)sh][(size_t)ow]; total += recv[(size_t)sh]; }
         int rc;
         if ((rc = cfrk_global_begin(ctx, o.k, flags, hint / (uint64_t)N + 1024))) { status[(size_t)ow] = die(ctx, rc, "cfrk_global_begin"); return; }
-        if (!buf.empty()) {
+        if (total) {
           void *d = nullptr;
-          if ((rc = cfrk_device_alloc(ctx, buf.size() * 8, &d))) { status[(size_t)ow] = die(ctx, rc, "cfrk_device_alloc"); return; }
-          if ((rc = cfrk_memcpy_h2d(ctx, d, buf.data(), buf.size() * 8)) || (rc = cfrk_global_merge_runs_device(ctx, d, recv.data(), N))) {
-            cfrk_device_free(ctx, d);
-            status[(size_t)ow] = die(ctx, rc, "cfrk_global_merge_runs_device");
-            return;
+          if ((rc = cfrk_device_alloc(ctx, total * 16, &d))) { status[(size_t)ow] = die(ctx, rc, "cfrk_device_alloc"); return; }
+          uint64_t at = 0;
+          for (int sh = 0; sh < N && !rc; ++sh) {
+            uint64_t off = 0;
+            for (int q = 0; q < ow; ++q) off += rows[(size_t)sh][(size_t)q];
+            if (recv[(size_t)sh])
+              rc = cfrk_memcpy_peer(ctx, (char *)d + at * 16, per_dev[(size_t)sh][0].ctx, (const char *)d_packed[(size_t)sh] + off * 16, recv[(size_t)sh] * 16);
+            at += recv[(size_t)sh];
           }
+          if (!rc) rc = cfrk_global_merge_runs_device(ctx, d, recv.data(), N);
+          if (!rc) rc = cfrk_ctx_sync(ctx);
           cfrk_device_free(ctx, d);
+          if (rc) { status[(size_t)ow] = die(ctx, rc, "cfrk_global_merge_runs_device"); return; }
         }
         uint64_t n = 0;
         if ((rc = cfrk_global_finish(ctx, &n))) { status[(size_t)ow] = die(ctx, rc, "cfrk_global_finish"); return; }
@@ -252,6 +289,7 @@ int run_global_multi(const Options &o, const cfrk_batch &batch, std::vector<std:
         if ((rc = cfrk_global_export(ctx, keys[(size_t)ow].data(), hi.data(), cnts[(size_t)ow].data(), n, &n))) status[(size_t)ow] = die(ctx, rc, "cfrk_global_export");
       });
     for (auto &t : th) t.join();
+    free_packed();
     for (int r : status) if (r) return r;
   }
   // N ascending lists with disjoint keys -> one ascending list
@@ -266,9 +304,7 @@ int run_global_multi(const Options &o, const cfrk_batch &batch, std::vector<std:
       if (at[(size_t)q] < keys[(size_t)q].size() && (best < 0 || keys[(size_t)q][at[(size_t)q]] < keys[(size_t)best][at[(size_t)best]])) best = q;
     mk[i] = keys[(size_t)best][at[(size_t)best]]; mc[i] = cnts[(size_t)best][at[(size_t)best]]; ++at[(size_t)best];
   }
-  std::string text(cfrk_host_format_sparse(mk.data(), mc.data(), total, nullptr, 0), '\0');
-  cfrk_host_format_sparse(mk.data(), mc.data(), total, &text[0], text.size());
-  fwrite(text.data(), 1, text.size(), out);
+  write_global(o, mk.data(), nullptr, mc.data(), total, out);
   return 0;
 }
 
@@ -298,6 +334,7 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[i], "--native")) o.native = true;
     else if (!strcmp(argv[i], "--global")) o.global = true;
     else if (!strcmp(argv[i], "--canonical")) o.canonical = true;
+    else if (!strcmp(argv[i], "--binary")) o.binary = true;
     else if (!strcmp(argv[i], "--same-device")) o.same_device = true;   // rehearsal: every "device" is --device
     else if (!strcmp(argv[i], "--device") && i + 1 < argc) o.device = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) o.gpus = atoi(argv[++i]);

@@ -289,4 +289,78 @@ size_t cfrk_host_format_sparse(const uint64_t *keys, const uint32_t *counts, uin
   return (size_t)(p - buf);
 }
 
+size_t cfrk_host_format_sparse2(const uint64_t *keys_lo, const uint64_t *keys_hi, const uint32_t *counts,
+                                uint64_t n, char *buf, size_t cap) {
+  if (!keys_hi) return cfrk_host_format_sparse(keys_lo, counts, n, buf, cap);
+  if (!buf) {
+    size_t s = 0;
+    for (uint64_t i = 0; i < n; ++i) s += len_u64(keys_hi[i]) + 1 + len_u64(keys_lo[i]) + 1 + len_u64(counts[i]) + 1;
+    return s;
+  }
+  char *p = buf;
+  (void)cap;
+  for (uint64_t i = 0; i < n; ++i) {
+    p = put_u64(p, keys_hi[i]); *p++ = ':';
+    p = put_u64(p, keys_lo[i]); *p++ = ':';
+    p = put_u64(p, counts[i]); *p++ = '\n';
+  }
+  return (size_t)(p - buf);
+}
+
+static void put_le(char *p, uint64_t x, int bytes) { for (int i = 0; i < bytes; ++i) p[i] = (char)(x >> (8 * i)); }
+static uint64_t get_le(const char *p, int bytes) {
+  uint64_t x = 0;
+  for (int i = 0; i < bytes; ++i) x |= (uint64_t)(unsigned char)p[i] << (8 * i);
+  return x;
+}
+
+size_t cfrk_host_write_binary(int k, int flags, const uint64_t *keys_lo, const uint64_t *keys_hi,
+                              const uint32_t *counts, uint64_t n, char *buf, size_t cap) {
+  const bool two = k > 32;
+  const size_t rec = two ? 20 : 12, need = 32 + (size_t)n * rec;
+  if (!buf) return need;
+  if (cap < need) return 0;
+  memcpy(buf, "CFRKGLB1", 8);
+  put_le(buf + 8, (uint64_t)k, 4);
+  put_le(buf + 12, (uint64_t)((flags & CFRK_BIN_CANONICAL) | (two ? CFRK_BIN_TWO_WORD : 0)), 4);
+  put_le(buf + 16, n, 8);
+  uint64_t sum = 0;
+  char *p = buf + 32;
+  for (uint64_t i = 0; i < n; ++i) {
+    if (two) { put_le(p, keys_hi ? keys_hi[i] : 0, 8); p += 8; }
+    put_le(p, keys_lo[i], 8); p += 8;
+    put_le(p, counts[i], 4); p += 4;
+    sum += counts[i];
+  }
+  put_le(buf + 24, sum, 8);
+  return need;
+}
+
+int cfrk_host_read_binary(const char *buf, size_t len, int *k, int *flags, uint64_t *n, uint64_t *keys_lo,
+                          uint64_t *keys_hi, uint32_t *counts) {
+  if (!buf || len < 32 || memcmp(buf, "CFRKGLB1", 8) != 0) return -1;
+  const int kk = (int)get_le(buf + 8, 4), ff = (int)get_le(buf + 12, 4);
+  const uint64_t nn = get_le(buf + 16, 8);
+  const bool two = (ff & CFRK_BIN_TWO_WORD) != 0;
+  if (kk < 1 || kk > 64 || two != (kk > 32)) return -1;
+  const size_t rec = two ? 20 : 12;
+  if (nn > (len - 32) / rec || len != 32 + (size_t)nn * rec) return -1;
+  if (k) *k = kk;
+  if (flags) *flags = ff;
+  if (n) *n = nn;
+  const char *p = buf + 32;
+  uint64_t sum = 0;
+  for (uint64_t i = 0; i < nn; ++i) {
+    uint64_t hi = 0;
+    if (two) { hi = get_le(p, 8); p += 8; }
+    const uint64_t lo = get_le(p, 8); p += 8;
+    const uint32_t c = (uint32_t)get_le(p, 4); p += 4;
+    if (keys_lo) keys_lo[i] = lo;
+    if (keys_hi) keys_hi[i] = hi;
+    if (counts) counts[i] = c;
+    sum += c;
+  }
+  return sum == get_le(buf + 24, 8) ? 0 : -1;
+}
+
 }  // extern "C"

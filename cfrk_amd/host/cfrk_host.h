@@ -48,9 +48,30 @@ int cfrk_host_chunk(const cfrk_batch *b, int64_t first, int64_t count, const int
 size_t cfrk_host_format_dense(const int32_t *freq, int64_t nS, int k, char *buf, size_t cap);
 /* the same text, formatted by `threads` host threads (row ranges) */
 size_t cfrk_host_format_dense_mt(const int32_t *freq, int64_t nS, int k, char *buf, size_t cap, int threads);
-/* Sparse global form: "<key>:<count>\n" per distinct key, ascending (keys < 2^64, k <= 32). */
+/* Sparse global form (what the commented-out `if (Freq[i] != 0)` of src/main.cu:51-56 was heading
+ * for): one line per distinct key, ascending.
+ *   k <= 32:  "<key>:<count>\n"            key = the 2k-bit k-mer value in decimal (as PrintFreq prints indices)
+ *   k  > 32:  "<hi>:<lo>:<count>\n"        key = hi * 2^64 + lo, both words in decimal (keys_hi != NULL) */
 size_t cfrk_host_format_sparse(const uint64_t *keys, const uint32_t *counts, uint64_t n, char *buf,
                                size_t cap);
+size_t cfrk_host_format_sparse2(const uint64_t *keys_lo, const uint64_t *keys_hi, const uint32_t *counts,
+                                uint64_t n, char *buf, size_t cap);
+
+/* Binary global form, little endian, everything in one file:
+ *   header, 32 bytes:  char magic[8] = "CFRKGLB1"; uint32 k; uint32 flags (bit 0: canonical counting,
+ *                      bit 1: two-word keys, i.e. k > 32); uint64 n (records); uint64 sum of counts
+ *   n records, ascending by key:   k <= 32: { uint64 key; uint32 count }            12 bytes, packed
+ *                                   k  > 32: { uint64 hi; uint64 lo; uint32 count }  20 bytes, packed
+ * (12 / 20 bytes are the slot sizes S of the algorithmic-byte budget)
+ * write: returns bytes needed / written (buf may be NULL to size); keys_hi may be NULL for k <= 32.
+ * read:  parses a whole image; on success (0) *k, *flags, *n are set and, when the arrays are not NULL,
+ *        n entries are stored (keys_hi gets zeros for k <= 32).  -1: not a CFRKGLB1 image or truncated. */
+#define CFRK_BIN_CANONICAL 0x1
+#define CFRK_BIN_TWO_WORD 0x2
+size_t cfrk_host_write_binary(int k, int flags, const uint64_t *keys_lo, const uint64_t *keys_hi,
+                              const uint32_t *counts, uint64_t n, char *buf, size_t cap);
+int cfrk_host_read_binary(const char *buf, size_t len, int *k, int *flags, uint64_t *n, uint64_t *keys_lo,
+                          uint64_t *keys_hi, uint32_t *counts);
 
 #ifdef __cplusplus
 }

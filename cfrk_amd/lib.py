@@ -14,6 +14,7 @@ CFRK_COMPAT = 0x1
 CFRK_CANONICAL = 0x2
 CFRK_FORCE_HASH = 0x4
 CFRK_RUNS_ONLY = 0x8
+CFRK_FLOAT_INDEX = 0x10
 CFRK_DEBUG_FORCE_RT_OVERFLOW = 0x1   # cfrk_debug_set_flags
 CFRK_DEBUG_SMALL_WAVE_CAP = 0x2
 CFRK_DEBUG_NO_ANCHORS = 0x4
@@ -68,6 +69,7 @@ def load_library():
         "cfrk_device_free": ([vp, vp], C.c_int),
         "cfrk_memcpy_h2d": ([vp, vp, vp, C.c_size_t], C.c_int),
         "cfrk_memcpy_d2h": ([vp, vp, vp, C.c_size_t], C.c_int),
+        "cfrk_memcpy_peer": ([vp, vp, vp, vp, C.c_size_t], C.c_int),
         "cfrk_per_read_dense": ([vp, vp, vp, vp, i64, i64, i32, i32, vp], C.c_int),
         "cfrk_per_read_dense_device": ([vp, vp, vp, vp, i64, i64, i32, i32, vp], C.c_int),
         "cfrk_global_begin": ([vp, i32, i32, u64], C.c_int),

@@ -62,6 +62,12 @@ extern "C" {
 #define CFRK_RUNS_ONLY  0x8  /* global only, 16 <= k <= 32: the job partitions and deduplicates ONE add
                                 and stops there; its result leaves through
                                 cfrk_global_export_runs_device (multi-GPU strong scaling)            */
+#define CFRK_FLOAT_INDEX 0x10 /* per-read dense only, matters for k = 13..15: the window index is accumulated
+                                through float exactly as ComputeIndex does (index += nuc * powf(4, k-1-i),
+                                src/kmer_kernel.cu:38), rounding errors, the all-T window's carry into the
+                                next row and all -- byte-identical to what the reference computes where the
+                                reference is numerically wrong.  Without it: exact integers (for k <= 12 the
+                                two agree).  Combine with CFRK_COMPAT for ComputeFreqNew's semantics.        */
 
 typedef struct cfrk_ctx cfrk_ctx;
 
@@ -83,6 +89,13 @@ int  cfrk_device_alloc(cfrk_ctx *ctx, size_t bytes, void **dptr);
 int  cfrk_device_free(cfrk_ctx *ctx, void *dptr);
 int  cfrk_memcpy_h2d(cfrk_ctx *ctx, void *dst_device, const void *src_host, size_t bytes);
 int  cfrk_memcpy_d2h(cfrk_ctx *ctx, void *dst_host, const void *src_device, size_t bytes);
+/* Device-to-device copy between two contexts, possibly on different GPUs of the node: over xGMI
+ * peer-to-peer (hipMemcpyPeerAsync; peer access is enabled on first use where the topology allows it),
+ * enqueued on dst_ctx's stream.  src_ctx's stream is drained first, so whatever src_ctx was asked to
+ * write is complete in the copy; the call returns once the copy is enqueued (dst_ctx's later work is
+ * ordered behind it).  This is the exchange step of a one-process multi-GPU host (the `cfrk` CLI);
+ * one process per GPU uses RCCL instead (cfrk_amd/sharded.py). */
+int  cfrk_memcpy_peer(cfrk_ctx *dst_ctx, void *dst_device, cfrk_ctx *src_ctx, const void *src_device, size_t bytes);
 
 /* ---- per-read dense counting: the drop-in for kmer_main ------------------------------- */
 

@@ -88,7 +88,9 @@ int orc_per_read_dense(const int8_t *data, const int64_t *start, const int32_t *
             for (int64_t t = 0; t < nwin; t++) {
                 int64_t w = index[start[i] + t];
                 int64_t pos = fourk * i + w;    /* w == -1 -> previous row's last bin */
-                if (pos >= 0) freq[pos] += 1;   /* pos == -1 is the reference's OOB write: dropped */
+                /* pos == -1 is the reference's OOB write: dropped; so is pos == nS*fourk, which the
+                 * float index of an all-T window in the LAST read produces (it rounds up to 4^k) */
+                if (pos >= 0 && pos < nS * fourk) freq[pos] += 1;
             }
         }
     } else {
@@ -96,7 +98,7 @@ int orc_per_read_dense(const int8_t *data, const int64_t *start, const int32_t *
         for (int64_t i = 0; i < nS; i++) {
             int64_t end = start[i] + length[i] + 1;
             for (int64_t p = start[i]; p < end && p < nN; p++) {
-                if (index[p] != -1) freq[fourk * i + index[p]] += 1;
+                if (index[p] != -1 && fourk * i + index[p] < nS * fourk) freq[fourk * i + index[p]] += 1;
             }
         }
     }

@@ -67,6 +67,32 @@ def test_dense_vs_oracle(ctx, k, compat):
     assert (got == want).all()
 
 
+@pytest.mark.parametrize("k,nreads", [(13, 4), (14, 2), (15, 1), (12, 3)])
+@pytest.mark.parametrize("compat", [True, False])
+def test_dense_float_index_matches_the_reference_arithmetic(ctx, k, nreads, compat):
+    """CFRK_FLOAT_INDEX: the window index accumulated through float exactly like ComputeIndex
+    (/root/reference/src/kmer_kernel.cu:38) -- for k = 13..15 that is NOT the exact integer (most
+    windows land in a neighbouring bin, an all-T window carries into the next row), and the HIP path
+    reproduces it bin for bin against the oracle's ORC_FLOAT_INDEX emulation; for k <= 12 the flag
+    changes nothing"""
+    import cfrk_amd
+    rng = np.random.default_rng(1300 + k)
+    reads = [rng.integers(0, 4, int(L)).astype(np.int8) for L in rng.integers(200, 1500, nreads)]
+    reads[0][50:50 + k + 3] = 3                           # all-T windows: the float index rounds up to 4^k
+    reads[-1][-(k + 2):] = 3                              # ... in the last read too (the reference writes out of bounds there)
+    reads[0][120] = -1                                    # an invalid base
+    data, start, length = refsem.flatten(reads)
+    flags = (cfrk_amd.CFRK_COMPAT if compat else 0) | cfrk_amd.CFRK_FLOAT_INDEX
+    got = ctx.per_read_dense(data, start, length, k, flags)
+    want = orc.per_read_dense(data, start, length, k, (orc.ORC_COMPAT if compat else 0) | orc.ORC_FLOAT_INDEX)
+    assert (got == want).all()
+    exact = orc.per_read_dense(data, start, length, k, orc.ORC_COMPAT if compat else 0)
+    if k >= 13:
+        assert (want != exact).any()                      # the reference really is wrong there
+    else:
+        assert (want == exact).all()
+
+
 def test_dense_single_read_and_empty_batch(ctx):
     import cfrk_amd
     data, start, length = refsem.flatten([np.array([0, 1, 2, 3, 0, 1], np.int8)])
@@ -858,6 +884,67 @@ def test_cli_chunking_quirks_and_modes(tmp_path):
     # usage
     r = subprocess.run([cli, str(fa)], capture_output=True)
     assert r.returncode == 1 and r.stdout.startswith(b"Usage: ./cfrk")
+
+
+def _read_glb1(raw):
+    """parse the CFRKGLB1 binary form (cfrk_host.h) -> k, flags, lo, hi, counts"""
+    assert raw[:8] == b"CFRKGLB1"
+    k, flags = np.frombuffer(raw, "<u4", 2, 8)
+    n, total = np.frombuffer(raw, "<u8", 2, 16)
+    two = bool(flags & 2)
+    dt = np.dtype([("hi", "<u8"), ("lo", "<u8"), ("c", "<u4")] if two else [("lo", "<u8"), ("c", "<u4")])
+    assert dt.itemsize == (20 if two else 12) and len(raw) == 32 + int(n) * dt.itemsize
+    rec = np.frombuffer(raw, dt, int(n), 32)
+    assert int(rec["c"].astype(np.uint64).sum()) == int(total)
+    return int(k), int(flags), rec["lo"].copy(), (rec["hi"].copy() if two else np.zeros(int(n), np.uint64)), rec["c"].copy()
+
+
+@pytest.mark.parametrize("k", [15, 31, 33, 47, 63, 64])
+@pytest.mark.parametrize("canonical", [False, True])
+def test_cli_global_sparse_text_and_binary_for_every_k(ctx, tmp_path, k, canonical):
+    """`cfrk in.fasta out k --global [--canonical] [--binary]` for one- and two-word keys: the text
+    ("key:count" / "hi:lo:count") and the binary form both hold exactly what cfrk_global_export
+    returns for the same reads -- and what the oracle counts"""
+    import subprocess
+    import cfrk_amd
+    cli = _cli()
+    rng = np.random.default_rng(300 + k)
+    genome = rng.integers(0, 4, 6000)
+    seqs = []
+    for _ in range(1500):
+        L = int(rng.integers(10, 220))
+        a = int(rng.integers(0, len(genome) - L))
+        r = genome[a:a + L]
+        if rng.random() < 0.5:
+            r = (3 - r)[::-1]
+        sq = "".join("ACGT"[c] for c in r)
+        if L > 40 and rng.random() < 0.1:
+            sq = sq[:L // 3] + "N" + sq[L // 3 + 1:]
+        seqs.append(sq)
+    fa = tmp_path / "g.fasta"
+    fa.write_text("".join(f">r{i}\n{s}\n" for i, s in enumerate(seqs)))
+    reads = [refsem._CODE[np.frombuffer(s.encode(), np.uint8)] for s in seqs]
+    data, start, length = refsem.flatten(reads)
+    g = cfrk_amd.GlobalCounter(ctx, k, cfrk_amd.CFRK_CANONICAL if canonical else 0, 0)
+    g.add(data, start, length)
+    lo, hi, cnt = g.export()
+    wlo, whi, wcnt = orc.global_count(data, k, orc.ORC_CANONICAL if canonical else 0)
+    assert len(lo) == len(wlo) and (lo == wlo).all() and (hi == whi).all() and (cnt.astype(np.uint64) == wcnt).all()
+    extra = ["--canonical"] if canonical else []
+    txt, binf = tmp_path / "o.txt", tmp_path / "o.bin"
+    subprocess.check_call([cli, str(fa), str(txt), str(k), "--global"] + extra)
+    subprocess.check_call([cli, str(fa), str(binf), str(k), "--global", "--binary"] + extra)
+    if k <= 32:
+        want = b"".join(b"%d:%d\n" % (int(a), int(c)) for a, c in zip(lo, cnt))
+    else:
+        want = b"".join(b"%d:%d:%d\n" % (int(h), int(a), int(c)) for h, a, c in zip(hi, lo, cnt))
+    assert txt.read_bytes() == want
+    bk, bflags, blo, bhi, bcnt = _read_glb1(binf.read_bytes())
+    assert bk == k and (bflags & 1) == int(canonical) and bool(bflags & 2) == (k > 32)
+    assert (blo == lo).all() and (bhi == hi).all() and (bcnt == cnt).all()
+    # ascending by (hi, lo)
+    key = [(int(h) << 64) | int(a) for h, a in zip(bhi, blo)]
+    assert key == sorted(key) and len(set(key)) == len(key)
 
 
 def test_cli_chunksize_is_narrowed_to_ushort_like_the_reference(tmp_path):

@@ -158,6 +158,44 @@ def test_writer_matches_oracle_formatter(host):
     assert buf.raw[:n] == b"0:1\n7:4000000000\n9223372036854775813:9\n"
 
 
+def test_sparse_two_word_text_and_binary_form_round_trip(host):
+    """k > 32 keys as "hi:lo:count" lines; the CFRKGLB1 binary form (12- / 20-byte records) written
+    and parsed back, truncated or foreign images refused"""
+    host.cfrk_host_format_sparse2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_char_p, C.c_size_t]
+    host.cfrk_host_format_sparse2.restype = C.c_size_t
+    host.cfrk_host_write_binary.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_char_p, C.c_size_t]
+    host.cfrk_host_write_binary.restype = C.c_size_t
+    host.cfrk_host_read_binary.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                           C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p, C.c_void_p]
+    lo = np.array([5, 2 ** 64 - 1, 0], np.uint64)
+    hi = np.array([0, 0, 2 ** 61 + 3], np.uint64)
+    cnt = np.array([1, 4000000000, 9], np.uint32)
+    n = host.cfrk_host_format_sparse2(lo.ctypes.data, hi.ctypes.data, cnt.ctypes.data, 3, None, 0)
+    buf = C.create_string_buffer(n)
+    host.cfrk_host_format_sparse2(lo.ctypes.data, hi.ctypes.data, cnt.ctypes.data, 3, buf, n)
+    assert buf.raw[:n] == b"0:5:1\n0:18446744073709551615:4000000000\n2305843009213693955:0:9\n"
+    # keys_hi NULL: the one-word form
+    n1 = host.cfrk_host_format_sparse2(lo.ctypes.data, None, cnt.ctypes.data, 3, None, 0)
+    b1 = C.create_string_buffer(n1)
+    host.cfrk_host_format_sparse2(lo.ctypes.data, None, cnt.ctypes.data, 3, b1, n1)
+    assert b1.raw[:n1] == b"5:1\n18446744073709551615:4000000000\n0:9\n"
+    for k, flags, use_hi in ((63, 1, True), (31, 0, False), (32, 1, False), (33, 0, True)):
+        nb = host.cfrk_host_write_binary(k, flags, lo.ctypes.data, hi.ctypes.data if use_hi else None, cnt.ctypes.data, 3, None, 0)
+        assert nb == 32 + 3 * (20 if k > 32 else 12)
+        img = C.create_string_buffer(nb)
+        assert host.cfrk_host_write_binary(k, flags, lo.ctypes.data, hi.ctypes.data if use_hi else None, cnt.ctypes.data, 3, img, nb) == nb
+        assert img.raw[:8] == b"CFRKGLB1"
+        kk, ff, nn = C.c_int(), C.c_int(), C.c_uint64()
+        rlo, rhi, rc_ = np.zeros(3, np.uint64), np.ones(3, np.uint64), np.zeros(3, np.uint32)
+        assert host.cfrk_host_read_binary(img.raw, nb, C.byref(kk), C.byref(ff), C.byref(nn), rlo.ctypes.data, rhi.ctypes.data, rc_.ctypes.data) == 0
+        assert (kk.value, nn.value) == (k, 3) and (ff.value & 1) == flags and bool(ff.value & 2) == (k > 32)
+        assert (rlo == lo).all() and (rc_ == cnt).all() and (rhi == (hi if k > 32 else 0)).all()
+        assert host.cfrk_host_read_binary(img.raw, nb - 1, None, None, None, None, None, None) == -1     # truncated
+        bad = bytearray(img.raw[:nb]); bad[32 + (16 if k > 32 else 8)] ^= 1                       # a count byte: the sum check
+        assert host.cfrk_host_read_binary(bytes(bad), nb, None, None, None, None, None, None) == -1
+    assert host.cfrk_host_read_binary(b"x" * 64, 64, None, None, None, None, None, None) == -1
+
+
 def test_chunk_views_are_chunk_relative(host):
     raw = b"".join(b">r%d\n%s\n" % (i, b"ACGT" * (i + 1)) for i in range(5))
     b = Batch()
