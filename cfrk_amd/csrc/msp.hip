@@ -1445,7 +1445,7 @@ __global__ __launch_bounds__(P3_THREADS) void msp_merge_kernel(const uint64_t *_
 // is replaced by a 16-bit NOTE, position of that run in the leaf's list << 5 | n-1.  The owner
 // rebuilds the run from its twin.  A noted record is marked in place (w = RUN_NOTED, x = the note);
 // leaf_off[leaf] = how many were noted.
-constexpr int DX_THREADS = 256;
+constexpr int DX_THREADS = 256, DX_INFL = 4;
 constexpr uint32_t RUN_NOTED = 0xFFFFFFFFu;        // (a record's header word has the top 8 bits clear)
 constexpr int NOTES_PER_ROW = 8;
 __global__ __launch_bounds__(DX_THREADS) void msp_dedupe_export_kernel(int k, int canon, MspView v) {
@@ -1472,10 +1472,21 @@ __global__ __launch_bounds__(DX_THREADS) void msp_dedupe_export_kernel(int k, in
       rtab_insert_loop(rtab, L, h, RT - 1, RT_TRIPS);
       if ((int32_t)h >= 0) rt_fail = 1u;
     };
-    for (uint64_t r = tid; r < ((n1 + 63) & ~63ull); r += DX_THREADS) {
+    // DX_INFL records per thread are asked for before the first is looked up: a shard's leaf holds a few
+    // thousand records, i.e. ~10 trips of one dependent load each -- the kernel was waiting for HBM
+    for (uint64_t r0 = 0; r0 < n1; r0 += (uint64_t)DX_INFL * DX_THREADS) {
+      uint4 recs[DX_INFL];
+#pragma unroll
+      for (int u = 0; u < DX_INFL; ++u) {
+        const uint64_t r = r0 + (uint64_t)u * DX_THREADS + tid;
+        recs[u] = zero4;
+        if (r < n1) recs[u] = stream[r];
+      }
+#pragma unroll
+      for (int u = 0; u < DX_INFL; ++u) {
+      const uint64_t r = r0 + (uint64_t)u * DX_THREADS + tid;
       const bool valid = r < n1;
-      uint4 rec = zero4;
-      if (valid) rec = stream[r];
+      const uint4 rec = recs[u];
       const uint32_t h = rtab_slot_k(rec, k, RT_LOG);
       const uint4 e = rtab[h];
       const bool match = valid && rtab_diff(e, rec) == 0u;
@@ -1495,6 +1506,7 @@ __global__ __launch_bounds__(DX_THREADS) void msp_dedupe_export_kernel(int k, in
       L.x = take ? px : L.x; L.y = take ? py : L.y; L.z = take ? pz : L.z; L.w = take ? pw : L.w;
       Lh = take ? ph : Lh;
       c += n;
+      }
     }
     if (c) drain(c);
   }
@@ -1534,10 +1546,19 @@ __global__ __launch_bounds__(DX_THREADS) void msp_dedupe_export_kernel(int k, in
     // truncated runs -> notes (the lookup of the leaf kernel's anchoring, msp_p3_kernel)
     const uint64_t nt = min((uint64_t)v.cnt2[NCLS * leaf + 0], v.exact ? (uint64_t)v.lcap[NCLS * leaf + 0] : v.cap2t);
     uint4 *const trunc = v.exact ? v.rec2 + v.lbase[NCLS * leaf + 0] : stream + v.cap2c;
-    for (uint64_t g = tid; g < ((nt + 63) & ~63ull) && !(v.dbg & CFRK_DEBUG_NO_ANCHORS); g += DX_THREADS) {
+    for (uint64_t g0 = 0; g0 < nt && !(v.dbg & CFRK_DEBUG_NO_ANCHORS); g0 += (uint64_t)DX_INFL * DX_THREADS) {
+      uint4 recs[DX_INFL];
+#pragma unroll
+      for (int u = 0; u < DX_INFL; ++u) {
+        const uint64_t g = g0 + (uint64_t)u * DX_THREADS + tid;
+        recs[u] = zero4;
+        if (g < nt) recs[u] = trunc[g];
+      }
+#pragma unroll
+      for (int u = 0; u < DX_INFL; ++u) {
+      const uint64_t g = g0 + (uint64_t)u * DX_THREADS + tid;
       const bool valid = g < nt;
-      uint4 rec = zero4;
-      if (valid) rec = trunc[g];
+      uint4 rec = recs[u];
       const uint32_t nm1 = rec.w & 31u;
       const bool lc = (rec.w & 64u) != 0u, rc_ = (rec.w & 128u) != 0u;
       const bool suf = canon && valid && !lc && rc_;
@@ -1558,6 +1579,7 @@ __global__ __launch_bounds__(DX_THREADS) void msp_dedupe_export_kernel(int k, in
       if (hit) { trunc[g].x = ((uint32_t)sidx[found] << 5) | nm1; trunc[g].w = RUN_NOTED; }
       const unsigned long long hb = __ballot(hit);
       if (lane == 0 && hb) atomicAdd(&noted, (uint32_t)__popcll(hb));
+      }
     }
     __syncthreads();
   }
@@ -1593,9 +1615,26 @@ __device__ __forceinline__ uint64_t block_scan_u64(uint64_t x, unsigned long lon
   return base + incl - x;
 }
 
+// sender: what every leaf contributes -- n1 distinct complete runs, nt truncated runs as records, na as
+// notes, rows in all -- one thread per leaf, coalesced (the plan kernel below used to gather these
+// four words per leaf itself, three times over, 64 dependent strided loads per thread each time:
+// 0.50 ms of a 5.9 ms critical path at N = 8)
+__global__ __launch_bounds__(256) void msp_runs_sizes_kernel(MspView v, uint4 *__restrict__ sz) {
+  const uint32_t leaf = blockIdx.x * 256u + threadIdx.x;
+  if (leaf >= (uint32_t)NLEAF) return;
+  uint32_t n1 = 0, na = 0;
+  uint32_t nt = (uint32_t)min((uint64_t)v.cnt2[NCLS * leaf + 0], v.exact ? (uint64_t)v.lcap[NCLS * leaf + 0] : v.cap2t);
+  if (v.cnt2[NCLS * leaf + 1]) {                               // (a leaf without complete runs never wrote its counts)
+    n1 = v.leaf_n[leaf];
+    na = min((uint32_t)v.leaf_off[leaf], nt);
+  }
+  nt -= na;
+  sz[leaf] = make_uint4(n1, nt, na, n1 + nt + (na + NOTES_PER_ROW - 1) / NOTES_PER_ROW);
+}
+
 // sender, one workgroup: where every leaf's records go in the packed buffer (owner-major order,
 // a header of hrows rows in front of every owner's segment), the headers themselves, rows per segment
-__global__ __launch_bounds__(1024) void msp_runs_plan_kernel(MspView v, int parts, int lpp, int hrows,
+__global__ __launch_bounds__(1024) void msp_runs_plan_kernel(const uint4 *__restrict__ sz, int parts, int lpp, int hrows,
                                                              uint64_t *__restrict__ dst_off, uint4 *__restrict__ packed,
                                                              uint64_t cap_rows,
                                                              uint64_t *__restrict__ part_rows /* [parts]: rows per segment; [parts]: all rows */) {
@@ -1603,120 +1642,157 @@ __global__ __launch_bounds__(1024) void msp_runs_plan_kernel(MspView v, int part
   __shared__ unsigned long long seg[65];          // first row of every owner's segment
   const int tid = threadIdx.x;
   const int n = parts * lpp, per = (n + 1023) / 1024;
-  // n1 distinct complete runs, nt truncated runs as records, na as notes; rows in all
-  auto sizes = [&](int i, uint32_t &n1, uint32_t &nt, uint32_t &na) -> uint64_t {
-    const int p = i / lpp, j = i - p * lpp, leaf = p + j * parts;
-    n1 = 0; nt = 0; na = 0;
-    if (i < n && leaf < NLEAF) {
-      nt = (uint32_t)min((uint64_t)v.cnt2[NCLS * leaf + 0], v.exact ? (uint64_t)v.lcap[NCLS * leaf + 0] : v.cap2t);
-      if (v.cnt2[NCLS * leaf + 1]) {                           // (a leaf without complete runs never wrote its counts)
-        n1 = v.leaf_n[leaf];
-        na = min((uint32_t)v.leaf_off[leaf], nt);
-      }
-      nt -= na;
-    }
-    return (uint64_t)n1 + nt + (na + NOTES_PER_ROW - 1) / NOTES_PER_ROW;
-  };
+  constexpr int U = 16;                            // independent loads in flight per thread
+  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+  auto leaf_of_item = [&](int i) { const int p = i / lpp, j = i - p * lpp; return p + j * parts; };
   uint64_t mine = 0;
-  for (int q = 0; q < per; ++q) { uint32_t a, b, c; mine += sizes(tid * per + q, a, b, c); }
+  for (int q0 = 0; q0 < per; q0 += U) {
+    uint32_t r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = tid * per + q0 + u;
+      const int leaf = leaf_of_item(i);
+      r[u] = (q0 + u < per && i < n && leaf < NLEAF) ? sz[leaf].w : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) mine += r[u];
+  }
   uint64_t total;
   const uint64_t run0 = block_scan_u64(mine, wtot, &total);
   const uint64_t all_rows = total + (uint64_t)parts * hrows;
   if (tid == 0) { part_rows[parts] = all_rows; seg[parts] = all_rows; }
-  uint64_t run = run0;
-  for (int q = 0; q < per; ++q) {
-    const int i = tid * per + q;
-    if (i >= n) break;
-    const int p = i / lpp, j = i - p * lpp;
-    if (j == 0) seg[p] = run + (uint64_t)p * hrows;
-    uint32_t a, b, c;
-    run += sizes(i, a, b, c);
+  // (a segment starts with the first item of its owner: item p * lpp)
+  {
+    uint64_t run = run0;
+    for (int q0 = 0; q0 < per; q0 += U) {
+      uint32_t r[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = tid * per + q0 + u;
+        const int leaf = leaf_of_item(i);
+        r[u] = (q0 + u < per && i < n && leaf < NLEAF) ? sz[leaf].w : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = tid * per + q0 + u;
+        if (q0 + u < per && i < n) {
+          const int p = i / lpp;
+          if (i == p * lpp) seg[p] = run + (uint64_t)p * hrows;
+        }
+        run += r[u];
+      }
+    }
   }
   __syncthreads();
   if (tid < parts) part_rows[tid] = seg[tid + 1] - seg[tid];
   if (all_rows > cap_rows) return;                 // (the host reports the size the buffer needs)
-  run = run0;
-  for (int q = 0; q < per; ++q) {
-    const int i = tid * per + q;
-    if (i >= n) break;
-    const int p = i / lpp, j = i - p * lpp, leaf = p + j * parts;
-    uint32_t a, b, c;
-    const uint64_t rows = sizes(i, a, b, c);
-    if (leaf < NLEAF) dst_off[leaf] = run + (uint64_t)(p + 1) * hrows;
-    uint32_t *hdr = reinterpret_cast<uint32_t *>(packed + seg[p]);
-    hdr[3 * j] = a; hdr[3 * j + 1] = b; hdr[3 * j + 2] = c;
-    run += rows;
+  uint64_t run = run0;
+  for (int q0 = 0; q0 < per; q0 += U) {
+    uint4 e[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = tid * per + q0 + u;
+      const int leaf = leaf_of_item(i);
+      e[u] = (q0 + u < per && i < n && leaf < NLEAF) ? sz[leaf] : zero4;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = tid * per + q0 + u;
+      if (q0 + u < per && i < n) {
+        const int p = i / lpp, j = i - p * lpp, leaf = p + j * parts;
+        if (leaf < NLEAF) dst_off[leaf] = run + (uint64_t)(p + 1) * hrows;
+        uint32_t *hdr = reinterpret_cast<uint32_t *>(packed + seg[p]);
+        hdr[3 * j] = e[u].x; hdr[3 * j + 1] = e[u].y; hdr[3 * j + 2] = e[u].z;
+        run += e[u].w;
+      }
+    }
   }
 }
 
-// owner, one workgroup: from the received headers, where every (source rank, local leaf) segment
-// starts in the packed buffer and where its two parts go in the leaf's streams; stream bases and
-// sizes (exact layout); err = 1 when a rank's header does not add up to the rows it sent
+// (err = 1 when a rank's header does not add up to the rows it sent)
 struct RunsRecv { uint64_t rstart[64]; uint64_t rows[64]; };
-__global__ __launch_bounds__(1024) void msp_runs_layout_kernel(const uint4 *__restrict__ packed, RunsRecv rr, int parts, int lpp, int hrows,
+// owner: every rank's header says how large its leaves' segments are.  Two kernels: (1) one thread per
+// local leaf reads the `parts` header triples of that leaf (coalesced across threads) and writes, per
+// (rank, leaf), the segment's rows and where it goes INSIDE the leaf's two streams, and per leaf the
+// stream sizes; (2) one workgroup turns those compact arrays into offsets with plain scans.  (One
+// workgroup used to do all of it with dependent header loads: 0.27 ms at N = 8.)
+__global__ __launch_bounds__(256) void msp_runs_layout1_kernel(const uint4 *__restrict__ packed, RunsRecv rr, int parts, int lpp,
+                                                                uint32_t *__restrict__ rows /* [parts][lpp] */,
+                                                                uint64_t *__restrict__ d1 /* relative */, uint64_t *__restrict__ d0 /* relative */,
+                                                                uint32_t *__restrict__ lcap, uint64_t *__restrict__ out) {
+  const int ll = blockIdx.x * 256 + threadIdx.x;
+  if (ll >= lpp) return;
+  uint64_t n1 = 0, n0 = 0;
+  uint32_t err = 0;
+  // (the complete streams of all ranks first, then the truncated ones: rank order inside both)
+  for (int r = 0; r < parts; ++r) {
+    const uint32_t *hdr = reinterpret_cast<const uint32_t *>(packed + rr.rstart[r]);
+    const uint32_t a = hdr[3 * ll], b = hdr[3 * ll + 1], c = hdr[3 * ll + 2];
+    rows[(size_t)r * lpp + ll] = a + b + (c + NOTES_PER_ROW - 1) / NOTES_PER_ROW;
+    if (c && !a) err = 1;                                      // notes without a run they could point at
+    d1[(size_t)r * lpp + ll] = n1;
+    n1 += a;
+  }
+  for (int r = 0; r < parts; ++r) {
+    const uint32_t *hdr = reinterpret_cast<const uint32_t *>(packed + rr.rstart[r]);
+    d0[(size_t)r * lpp + ll] = n1 + n0;
+    n0 += (uint64_t)hdr[3 * ll + 1] + hdr[3 * ll + 2];         // (a note becomes a record again)
+  }
+  if (n1 > 0xFFFFFFFFull || n0 > 0xFFFFFFFFull) err = 1;
+  lcap[(size_t)NCLS * ll + 1] = (uint32_t)n1;
+  lcap[(size_t)NCLS * ll + 0] = (uint32_t)n0;
+  if (err) out[1] = 1;
+}
+
+// parts + 1 workgroups: workgroup r < parts scans rank r's segment sizes, the last one the leaves' stream sizes
+__global__ __launch_bounds__(1024) void msp_runs_layout_kernel(RunsRecv rr, int parts, int lpp, int hrows,
+                                                               const uint32_t *__restrict__ rows,
                                                                uint64_t *__restrict__ src, uint64_t *__restrict__ d1, uint64_t *__restrict__ d0,
-                                                               uint64_t *__restrict__ lbase, uint32_t *__restrict__ lcap, uint32_t *__restrict__ cnt2,
+                                                               uint64_t *__restrict__ lbase, const uint32_t *__restrict__ lcap, uint32_t *__restrict__ cnt2,
                                                                uint64_t *__restrict__ out /* [0]: records in all, [1]: err */) {
   __shared__ unsigned long long wtot[16];
   const int tid = threadIdx.x;
   const int per = (lpp + 1023) / 1024;
-  uint32_t err = 0;
-  // (1) every rank's segments: record offsets inside its part of the buffer
-  for (int r = 0; r < parts; ++r) {
-    const uint32_t *hdr = reinterpret_cast<const uint32_t *>(packed + rr.rstart[r]);
-    auto rows_of = [&](int ll) {
-      return (uint64_t)hdr[3 * ll] + hdr[3 * ll + 1] + ((uint64_t)hdr[3 * ll + 2] + NOTES_PER_ROW - 1) / NOTES_PER_ROW;
-    };
+  if ((int)blockIdx.x < parts) {
+    // (1) rank r's segments: record offsets inside its part of the buffer
+    const int r = (int)blockIdx.x;
     uint64_t mine = 0;
     for (int q = 0; q < per; ++q) {
       const int ll = tid * per + q;
-      if (ll >= lpp) break;
-      mine += rows_of(ll);
-      if (hdr[3 * ll + 2] && !hdr[3 * ll]) err = 1;            // notes without a run they could point at
+      if (ll < lpp) mine += rows[(size_t)r * lpp + ll];
     }
     uint64_t total;
     uint64_t run = block_scan_u64(mine, wtot, &total);
-    if (total + (uint64_t)hrows != rr.rows[r]) err = 1;
+    if (total + (uint64_t)hrows != rr.rows[r]) out[1] = 1;
     for (int q = 0; q < per; ++q) {
       const int ll = tid * per + q;
       if (ll >= lpp) break;
       src[(size_t)r * lpp + ll] = rr.rstart[r] + (uint64_t)hrows + run;
-      run += rows_of(ll);
+      run += rows[(size_t)r * lpp + ll];
     }
+    return;
   }
   // (2) the owner's leaves = local indices: stream (ll, class) = the ranks' parts in rank order, complete stream first
   uint64_t mine = 0;
   for (int q = 0; q < per; ++q) {
     const int ll = tid * per + q;
-    if (ll >= lpp) break;
-    for (int r = 0; r < parts; ++r) {
-      const uint32_t *hdr = reinterpret_cast<const uint32_t *>(packed + rr.rstart[r]);
-      mine += (uint64_t)hdr[3 * ll] + hdr[3 * ll + 1] + hdr[3 * ll + 2];      // (a note becomes a record again)
-    }
+    if (ll < lpp) mine += (uint64_t)lcap[(size_t)NCLS * ll + 0] + lcap[(size_t)NCLS * ll + 1];
   }
   uint64_t total;
   uint64_t run = block_scan_u64(mine, wtot, &total);
   for (int q = 0; q < per; ++q) {
     const int ll = tid * per + q;
     if (ll >= lpp) break;
-    uint64_t n1 = 0, n0 = 0;
-    for (int r = 0; r < parts; ++r) {
-      const uint32_t *hdr = reinterpret_cast<const uint32_t *>(packed + rr.rstart[r]);
-      d1[(size_t)r * lpp + ll] = run + n1;
-      n1 += hdr[3 * ll];
+    const uint32_t n1 = lcap[(size_t)NCLS * ll + 1], n0 = lcap[(size_t)NCLS * ll + 0];
+    for (int r = 0; r < parts; ++r) {              // relative -> absolute
+      d1[(size_t)r * lpp + ll] += run;
+      d0[(size_t)r * lpp + ll] += run;
     }
-    for (int r = 0; r < parts; ++r) {
-      const uint32_t *hdr = reinterpret_cast<const uint32_t *>(packed + rr.rstart[r]);
-      d0[(size_t)r * lpp + ll] = run + n1 + n0;
-      n0 += (uint64_t)hdr[3 * ll + 1] + hdr[3 * ll + 2];
-    }
-    if (n1 > 0xFFFFFFFFull || n0 > 0xFFFFFFFFull) err = 1;
-    lbase[(size_t)NCLS * ll + 1] = run; lcap[(size_t)NCLS * ll + 1] = (uint32_t)n1; cnt2[(size_t)NCLS * ll + 1] = (uint32_t)n1;
-    lbase[(size_t)NCLS * ll + 0] = run + n1; lcap[(size_t)NCLS * ll + 0] = (uint32_t)n0; cnt2[(size_t)NCLS * ll + 0] = (uint32_t)n0;
-    run += n1 + n0;
+    lbase[(size_t)NCLS * ll + 1] = run; cnt2[(size_t)NCLS * ll + 1] = n1;
+    lbase[(size_t)NCLS * ll + 0] = run + n1; cnt2[(size_t)NCLS * ll + 0] = n0;
+    run += (uint64_t)n1 + n0;
   }
   if (tid == 0) out[0] = total;
-  if (err) out[1] = 1;
 }
 
 // sender: leaf -> [nd distinct complete runs][nu truncated runs][na notes, 8 per row] at record
@@ -1948,7 +2024,8 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
   // as many chunks as keep the level-1 buffer under ~6 GB (each costs ~30 us of launches and kernel
   // tails: 16 chunks +0.5 ms on C3, 64 +2.7 ms -- and nothing comes back from the Infinity Cache
   // even at 512 chunks of 43 MB, profiles/r03/chunk_count_sweep_c3.txt)
-  int nchunks = (int)std::min<int64_t>(small_pipe ? 5 : std::max<int64_t>(2, (int64_t)((double)B1 * nxg * cap1 * 16.0 / 6e9) + 1), ntiles / chunk_min);
+  // (a batch whose level-1 records fit ~6 GB anyway -- a shard of a multi-GPU job -- stays in one chunk)
+  int nchunks = (int)std::min<int64_t>(small_pipe ? 5 : (int64_t)((double)B1 * nxg * cap1 * 16.0 / 6e9) + 1, ntiles / chunk_min);
   if (const char *e = getenv("CFRK_MSP_CHUNKS")) nchunks = std::max(1, std::min(atoi(e), (int)std::min<int64_t>(4096, ntiles / 8)));   // (experiments)
   const bool pipelined = (nxg == NXG || small_pipe) && nchunks >= 2 && !(ctx->dbg_flags & CFRK_DEBUG_NO_PIPELINE);
   if (!pipelined) nchunks = 1;
@@ -2458,9 +2535,13 @@ extern "C" int cfrk_global_export_runs_device(cfrk_ctx *ctx, void *d_packed, uin
   void *p;
   // offsets, headers and segment sizes are worked out on the device (one workgroup); the host
   // only learns the segment sizes -- together with the job's flags, in ONE copy
-  if ((rc = cfrk_pool_get(ctx, BUF_SCRATCH, (NLEAF + 65 + ST_NWORDS) * sizeof(uint64_t), &p))) return rc;
+  if ((rc = cfrk_pool_get(ctx, BUF_SCRATCH, (NLEAF + 65 + ST_NWORDS) * sizeof(uint64_t) + (size_t)NLEAF * sizeof(uint4), &p))) return rc;
   uint64_t *d_off = (uint64_t *)p, *d_rows = d_off + NLEAF;
-  hipLaunchKernelGGL(msp_runs_plan_kernel, dim3(1), dim3(1024), 0, ctx->stream, v, parts, lpp, hrows, d_off, (uint4 *)d_packed,
+  uint4 *d_sz = (uint4 *)(d_rows + 65 + ST_NWORDS + 1);      // (16-byte aligned: the pool is, and NLEAF + 65 + ST_NWORDS + 1 is even)
+  static_assert((NLEAF + 65 + ST_NWORDS + 1) % 2 == 0, "d_sz is 16-byte aligned");
+  hipLaunchKernelGGL(msp_runs_sizes_kernel, dim3(NLEAF / 256), dim3(256), 0, ctx->stream, v, d_sz);
+  HIP_TRY(ctx, hipGetLastError());
+  hipLaunchKernelGGL(msp_runs_plan_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint4 *)d_sz, parts, lpp, hrows, d_off, (uint4 *)d_packed,
                      cap_rows, d_rows);
   HIP_TRY(ctx, hipGetLastError());
   hipLaunchKernelGGL(msp_runs_gather_kernel, dim3(NLEAF), dim3(256), 0, ctx->stream, v, (const uint64_t *)d_off, (uint4 *)d_packed,
@@ -2515,14 +2596,18 @@ extern "C" int cfrk_global_merge_runs_device(cfrk_ctx *ctx, const void *d_packed
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTC, (size_t)ctx->g_cap * 4, &p))) return rc;
   v.out_cnt = (uint32_t *)p; v.out_cap = ctx->g_cap;
   v.stats = ctx->g_stats; v.dbg = ctx->dbg_flags;
-  if ((rc = cfrk_pool_get(ctx, BUF_SCRATCH, (nseg * 3 + 2) * sizeof(uint64_t), &p))) return rc;
+  if ((rc = cfrk_pool_get(ctx, BUF_SCRATCH, (nseg * 3 + 2) * sizeof(uint64_t) + nseg * sizeof(uint32_t), &p))) return rc;
   uint64_t *d_src = (uint64_t *)p, *d_d1 = d_src + nseg, *d_d0 = d_d1 + nseg, *d_out = d_d0 + nseg;
+  uint32_t *d_segrows = (uint32_t *)(d_out + 2);
   HIP_TRY(ctx, hipMemsetAsync(d_out, 0, 2 * sizeof(uint64_t), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_CURSOR, 0, sizeof(uint64_t), ctx->stream));
   TableView t = cfrk_table_view(ctx);
   // segment (source rank, local leaf): the ranks' headers say how large; all offsets on the device
-  hipLaunchKernelGGL(msp_runs_layout_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint4 *)d_packed, rr, parts, lpp, hrows,
-                     d_src, d_d1, d_d0, d_lbase, d_lcap, v.cnt2, d_out);
+  hipLaunchKernelGGL(msp_runs_layout1_kernel, dim3((unsigned)(lpp + 255) / 256), dim3(256), 0, ctx->stream, (const uint4 *)d_packed, rr, parts, lpp,
+                     d_segrows, d_d1, d_d0, d_lcap, d_out);
+  HIP_TRY(ctx, hipGetLastError());
+  hipLaunchKernelGGL(msp_runs_layout_kernel, dim3((unsigned)parts + 1u), dim3(1024), 0, ctx->stream, rr, parts, lpp, hrows, (const uint32_t *)d_segrows,
+                     d_src, d_d1, d_d0, d_lbase, (const uint32_t *)d_lcap, v.cnt2, d_out);
   HIP_TRY(ctx, hipGetLastError());
   // the headers are checked before anything is copied by them: sizes that add up to the rows each
   // rank sent keep every segment inside its rank's part of the buffer and every stream inside rec2
