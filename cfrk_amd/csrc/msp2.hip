@@ -223,7 +223,7 @@ __global__ __launch_bounds__(Q1_THREADS, (SUB ? 4 : 6)) void msp2_p1_kernel(cons
   uint8_t *const s_sub = stage + Q1_STAGE_BASE;                                // [64 lanes][32 positions] (SUB only)
 
   if (tid < B1) hist[tid] = 0;
-  __syncthreads();
+  lds_barrier();
 
   // ---- A: own chunk and its neighbours (by shuffle) ----
   const int64_t wave_g = (tile0 + blockIdx.x) * Q1_WAVES + wave;
@@ -303,12 +303,7 @@ __global__ __launch_bounds__(Q1_THREADS, (SUB ? 4 : 6)) void msp2_p1_kernel(cons
   const uint32_t wcap = (v.dbg & CFRK_DEBUG_SMALL_WAVE_CAP) ? 64u : (uint32_t)(Q1_TR * 64);
   {
     const uint32_t mine = (uint32_t)__popc(S);
-    uint32_t incl = mine;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t y = __shfl_up(incl, d);
-      if (lane >= d) incl += y;
-    }
+    const uint32_t incl = dev_wave_scan_incl(mine);
     cnt_w = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     widx = incl - mine;
     const uint32_t tag = (uint32_t)lane << 5;
@@ -321,9 +316,7 @@ __global__ __launch_bounds__(Q1_THREADS, (SUB ? 4 : 6)) void msp2_p1_kernel(cons
       ++widx;
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  lds_wave_sync();
 
   // more runs in this wave than the balanced phase holds (pathological input): append directly
   while (S2) {
@@ -354,7 +347,7 @@ __global__ __launch_bounds__(Q1_THREADS, (SUB ? 4 : 6)) void msp2_p1_kernel(cons
     }
     __builtin_amdgcn_sched_barrier(0);             // one trip at a time: interleaved trips spill registers
   }
-  __syncthreads();
+  lds_barrier();
 
   // ---- C: one global reservation per non-empty bin; bin offsets ----
   uint32_t my_base = 0;
@@ -362,7 +355,7 @@ __global__ __launch_bounds__(Q1_THREADS, (SUB ? 4 : 6)) void msp2_p1_kernel(cons
     const uint32_t cnum = hist[tid];
     if (cnum) my_base = atomicAdd(&v.cnt1[q1_reg(tid, blockIdx.x & (NXG - 1))], cnum);
   }
-  block_scan<B1>(hist, loff, wtot);                // ends with a barrier: the staging area is dead
+  block_scan<B1, true>(hist, loff, wtot);                // ends with a barrier: the staging area is dead
   if (tid == B1 - 1) nrec_s = loff[tid] + hist[tid];
 #pragma unroll
   for (int tr = 0; tr < Q1_TR; ++tr) {
@@ -372,7 +365,7 @@ __global__ __launch_bounds__(Q1_THREADS, (SUB ? 4 : 6)) void msp2_p1_kernel(cons
     }
   }
   if (tid < B1) gbase[tid] = my_base;
-  __syncthreads();
+  lds_barrier();
 
   // ---- D: copy out in bin order ----
   auto put = [&](uint32_t b, uint32_t dst, const Rec2 &rec) {
@@ -423,16 +416,11 @@ __global__ __launch_bounds__(Q2_THREADS) void msp2_p2_kernel(int groups_per_bin,
   // the bin's sub-regions are read as one stream (as in msp.hip's P2)
   if (tid < 64) {
     const uint32_t c = (tid < NXG) ? (uint32_t)min((uint64_t)v.cnt1[q1_reg(b1, tid)], q1_cap(v, q1_reg(b1, tid))) : 0u;
-    uint32_t incl = c;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t y = __shfl_up(incl, d);
-      if (tid >= d) incl += y;
-    }
+    const uint32_t incl = dev_wave_scan_incl(c);
     if (tid < NXG) { rpre[tid] = incl - c; rfirst[tid] = q1_at(v, q1_reg(b1, tid)); }
     if (tid == 63) rpre[NXG] = incl;
   }
-  __syncthreads();
+  lds_barrier();
   const uint64_t n = rpre[NXG];
   // Q2_GROUP consecutive tiles per workgroup, the next tile's records requested before the
   // current tile is sorted and written (as in msp.hip's P2)
@@ -470,13 +458,13 @@ __global__ __launch_bounds__(Q2_THREADS) void msp2_p2_kernel(int groups_per_bin,
       }
     }
     hist[tid] = 0;
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int i = 0; i < Q2_PER; ++i) {
       const uint32_t idx = (uint32_t)i * Q2_THREADS + tid;
       if (idx < nt) atomicAdd(&hist[sub_of(r[i].b.w)], 1u);
     }
-    __syncthreads();
+    lds_barrier();
     uint32_t g0 = 0;
     {
       const int lane = tid & 63, wave = tid >> 6;
@@ -484,20 +472,15 @@ __global__ __launch_bounds__(Q2_THREADS) void msp2_p2_kernel(int groups_per_bin,
       if (x0) g0 = atomicAdd(&v.cnt2[b1 * NSUB + tid], x0);
       // (sizing pass of a batch that would not fit otherwise: the streams are then laid out with
       //  exactly the room they need and the kernel runs again)
-      if (v.count_only) { __syncthreads(); continue; }
-      uint32_t incl = x0;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t y = __shfl_up(incl, d);
-        if (lane >= d) incl += y;
-      }
+      if (v.count_only) { lds_barrier(); continue; }
+      const uint32_t incl = dev_wave_scan_incl(x0);
       if (lane == 63) wtot[wave] = incl;
-      __syncthreads();
+      lds_barrier();
       uint32_t bs = 0;
       for (int w = 0; w < wave; ++w) bs += wtot[w];
       loff[tid] = bs + incl - x0;
       hist[tid] = 0;
-      __syncthreads();
+      lds_barrier();
     }
 #pragma unroll
     for (int i = 0; i < Q2_PER; ++i) {
@@ -508,7 +491,7 @@ __global__ __launch_bounds__(Q2_THREADS) void msp2_p2_kernel(int groups_per_bin,
       }
     }
     gbase[tid] = g0;
-    __syncthreads();
+    lds_barrier();
     for (uint32_t p = tid; p < nt; p += Q2_THREADS) {
       const Rec2 rec = sorted[p];
       const uint32_t sb = sub_of(rec.b.w);
@@ -527,7 +510,7 @@ __global__ __launch_bounds__(Q2_THREADS) void msp2_p2_kernel(int groups_per_bin,
         else v.stats[ST_L2OVF] = 1;
       }
     }
-    __syncthreads();                                       // the LDS buffers are reused by the next tile
+    lds_barrier();                                       // the LDS buffers are reused by the next tile
   }
 }
 
