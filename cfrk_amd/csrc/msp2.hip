@@ -1216,6 +1216,18 @@ __global__ __launch_bounds__(256) void msp2_count_invalid_kernel(const int8_t *_
 }
 
 // (either level: base = exclusive prefix sum of the n cursors, cap = the cursors themselves)
+// sum of n cursors (one workgroup): how many records the first chunk of a batch made
+__global__ __launch_bounds__(1024) void msp2_sum_kernel(const uint32_t *__restrict__ cnt, uint32_t n, uint64_t *out) {
+  __shared__ unsigned long long tot;
+  if (threadIdx.x == 0) tot = 0;
+  __syncthreads();
+  unsigned long long mine = 0;
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) mine += cnt[i];
+  atomicAdd(&tot, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) *out = tot;
+}
+
 __global__ __launch_bounds__(1024) void msp2_layout_kernel(const uint32_t *__restrict__ cnt, uint32_t n, uint64_t *__restrict__ base,
                                                            uint32_t *__restrict__ cap) {
   __shared__ unsigned long long part[1024];
@@ -1329,6 +1341,15 @@ static size_t msp2_need_lean(const cfrk_ctx *ctx, int64_t span) {
   return (size_t)B1 * NXG * cap1 * 32 + (size_t)(expect * 32) + (size_t)ctx->g_cap * 20;
 }
 
+// ... counted in chunks (one level-1 buffer of at most ~6 GB, leaf streams sized from the first chunk's
+// records: at most 2.2 x the records, msp2_count_tiles)
+static size_t msp2_need_chunked(const cfrk_ctx *ctx, int64_t span) {
+  const double expect = (double)span * msp2_density(ctx);
+  const uint64_t cap1 = (uint64_t)(expect / (B1 * NXG) * 1.35) + 2048;
+  const double l1 = std::min((double)B1 * NXG * cap1 * 32.0, 6e9 * 1.35 + (double)B1 * NXG * 2048 * 32.0);
+  return (size_t)l1 + (size_t)(expect * 2.2 * 32) + (size_t)NLEAF * 1280 * 32 + (size_t)ctx->g_cap * 20;
+}
+
 static size_t msp2_need(const cfrk_ctx *ctx, int64_t span) {
   const double expect = (double)span * msp2_density(ctx);
   const uint64_t cap1 = (uint64_t)(expect / (B1 * NXG) * 1.35) + 2048;
@@ -1345,7 +1366,7 @@ static size_t msp2_need(const cfrk_ctx *ctx, int64_t span) {
 // more passes over the input otherwise: one more read of the level-1 records is cheaper than a pass)
 static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, int64_t nN, int64_t tile0,
                             int64_t ntiles, double slack, int sel_bits = 0, uint32_t sel_val = 0, bool first = true,
-                            bool lean = false) {
+                            bool lean = false, bool chunked = false) {
   int rc;
   const int k = ctx->g_k;
   const int W2 = msp2_window(k);
@@ -1363,12 +1384,21 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
   const uint64_t cap2t = lean ? 0 : (uint64_t)(expect_all / NLEAF * 0.4 * slack) + 96;
   const int64_t tiles_per_sub = (int64_t)(((uint64_t)NXG * cap1 + (uint64_t)Q2_TILE * Q2_GROUP - 1) / ((uint64_t)Q2_TILE * Q2_GROUP));   // tile groups per bin
   if (tiles_per_sub * B1 > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
+  // chunked (msp.hip: msp_count_tiles): Q1(c), Q2(c) chunk after chunk on ONE level-1 buffer that holds a
+  // chunk's records, leaf streams sized from what the first chunk really made; any overflow beyond the
+  // parking buffers returns CFRK_ERR_SMALL_BUF and the caller plans the batch the old way
+  const bool small_pipe = (ctx->dbg_flags & CFRK_DEBUG_SMALL_PIPELINE) != 0;
+  int nchunks = 1;
+  if (chunked) nchunks = (int)std::min<int64_t>(small_pipe ? 5 : (int64_t)((double)B1 * NXG * cap1 * 32.0 / 6e9) + 1, ntiles / (small_pipe ? 3 : 8192));
+  if (nchunks < 2) { nchunks = 1; chunked = false; }
+  const int64_t chunk_tiles = (ntiles + nchunks - 1) / nchunks;
+  const uint64_t cap1c = chunked ? (uint64_t)(expect * ((double)chunk_tiles / (double)ntiles) / (B1 * NXG) * 1.35) + 2048 : cap1;
   void *p;
   View2 v;
-  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L1, (size_t)B1 * NXG * cap1 * sizeof(Rec2), &p))) return rc;
-  v.rec1 = (Rec2 *)p; v.cap1 = cap1;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L1, (size_t)B1 * NXG * cap1c * sizeof(Rec2), &p))) return rc;
+  v.rec1 = (Rec2 *)p; v.cap1 = cap1c;
   v.rec2 = nullptr;
-  if (!lean) {
+  if (!lean && !chunked) {
     if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)(NLEAF >> sel_bits) * (cap2c + 3 * cap2t) * sizeof(Rec2), &p))) return rc;
     v.rec2 = (Rec2 *)p;
   }
@@ -1412,24 +1442,63 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
   v.exact = 0; v.lbase = nullptr; v.lcap = nullptr;
   v.exact1 = 0; v.rbase = nullptr; v.rcap = nullptr;
   const size_t nreg = (size_t)B1 * NXG;
-  int64_t q2_groups = tiles_per_sub;             // tile groups per bin Q2 is launched with
+  int64_t q2_groups = chunked ? (int64_t)(((uint64_t)NXG * cap1c + (uint64_t)Q2_TILE * Q2_GROUP - 1) / ((uint64_t)Q2_TILE * Q2_GROUP))
+                              : tiles_per_sub;             // tile groups per bin Q2 is launched with
+  auto launch_q1 = [&](int64_t t0, int64_t t1) -> int {
+    const dim3 g1((unsigned)(t1 - t0)), b1(Q1_THREADS);
+#define CFRK_Q1_CASE(WW) \
+    case WW: \
+      if (sub) hipLaunchKernelGGL((msp2_p1_kernel<WW, true>), g1, b1, 0, ctx->stream, d_data, nN, k, m, c, canon, t0, v, t); \
+      else hipLaunchKernelGGL((msp2_p1_kernel<WW, false>), g1, b1, 0, ctx->stream, d_data, nN, k, m, c, canon, t0, v, t); \
+      break;
+    switch (W2) {
+      CFRK_Q1_CASE(18) CFRK_Q1_CASE(20) CFRK_Q1_CASE(22) CFRK_Q1_CASE(24) CFRK_Q1_CASE(26) CFRK_Q1_CASE(28) CFRK_Q1_CASE(30)
+      default: return cfrk_fail(ctx, CFRK_ERR_ARG, "no partition kernel for a window of %d", W2);
+    }
+#undef CFRK_Q1_CASE
+    HIP_TRY(ctx, hipGetLastError());
+    return CFRK_OK;
+  };
   bool run_q1 = true, settled = false;
   uint64_t parked1 = 0, parked2 = 0;
   for (int attempt = 0; attempt < 4; ++attempt) {
+    if (chunked) {
+      HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_L1OVF, 0, 2 * sizeof(uint64_t), ctx->stream));   // ST_L1OVF, ST_OVFN1
+      HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_L2OVF, 0, 2 * sizeof(uint64_t), ctx->stream));   // ST_L2OVF, ST_OVFN
+      for (int cc = 0; cc < nchunks; ++cc) {
+        const int64_t t0 = tile0 + (int64_t)cc * chunk_tiles, t1 = std::min(tile0 + ntiles, t0 + chunk_tiles);
+        if (t0 >= t1) break;
+        if (cc > 0) HIP_TRY(ctx, hipMemsetAsync(v.cnt1, 0, nreg * sizeof(uint32_t), ctx->stream));
+        if ((rc = launch_q1(t0, t1))) return rc;
+        if (cc == 0) {
+          void *sp;
+          if ((rc = cfrk_pool_get(ctx, BUF_SCRATCH, 64 * sizeof(uint64_t), &sp))) return rc;
+          hipLaunchKernelGGL(msp2_sum_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)v.cnt1, (uint32_t)nreg, (uint64_t *)sp);
+          HIP_TRY(ctx, hipGetLastError());
+          uint64_t made = 0;
+          HIP_TRY(ctx, hipMemcpyAsync(&made, sp, sizeof made, hipMemcpyDeviceToHost, ctx->stream));
+          HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+          // records of this pass's leaves in the whole batch (+3 %), per leaf; complete runs up to
+          // 1.3 x the mean leaf, each of the three classes of truncated runs up to 0.3 x
+          const double per_leaf = (double)made * ((double)ntiles / (double)(t1 - t0)) * 1.03 / (double)(NLEAF >> sel_bits);
+          v.cap2c = (uint64_t)(per_leaf * 1.3) + 512; v.cap2t = (uint64_t)(per_leaf * 0.3) + 256;
+          if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)(NLEAF >> sel_bits) * (v.cap2c + 3 * v.cap2t) * sizeof(Rec2), &p))) return rc;
+          v.rec2 = (Rec2 *)p;
+        }
+        hipLaunchKernelGGL(msp2_p2_kernel, dim3((unsigned)(q2_groups * B1)), dim3(Q2_THREADS), 0, ctx->stream, (int)q2_groups, k, canon, v, t);
+        HIP_TRY(ctx, hipGetLastError());
+      }
+      uint64_t stc[ST_NWORDS];
+      HIP_TRY(ctx, hipMemcpyAsync(stc, ctx->g_stats, sizeof stc, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      if (stc[ST_L1OVF] || stc[ST_L2OVF]) return CFRK_ERR_SMALL_BUF;   // (no error text: the caller starts over, the old way)
+      parked1 = stc[ST_OVFN1]; parked2 = stc[ST_OVFN];
+      settled = true;
+      break;
+    }
     if (run_q1) {
       HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_L1OVF, 0, 2 * sizeof(uint64_t), ctx->stream));   // ST_L1OVF, ST_OVFN1
-      const dim3 g1((unsigned)ntiles), b1(Q1_THREADS);
-#define CFRK_Q1_CASE(WW) \
-      case WW: \
-        if (sub) hipLaunchKernelGGL((msp2_p1_kernel<WW, true>), g1, b1, 0, ctx->stream, d_data, nN, k, m, c, canon, tile0, v, t); \
-        else hipLaunchKernelGGL((msp2_p1_kernel<WW, false>), g1, b1, 0, ctx->stream, d_data, nN, k, m, c, canon, tile0, v, t); \
-        break;
-      switch (W2) {
-        CFRK_Q1_CASE(18) CFRK_Q1_CASE(20) CFRK_Q1_CASE(22) CFRK_Q1_CASE(24) CFRK_Q1_CASE(26) CFRK_Q1_CASE(28) CFRK_Q1_CASE(30)
-        default: return cfrk_fail(ctx, CFRK_ERR_ARG, "no partition kernel for a window of %d", W2);
-      }
-#undef CFRK_Q1_CASE
-      HIP_TRY(ctx, hipGetLastError());
+      if ((rc = launch_q1(tile0, tile0 + ntiles))) return rc;
     }
     HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_L2OVF, 0, 2 * sizeof(uint64_t), ctx->stream));   // ST_L2OVF, ST_OVFN
     hipLaunchKernelGGL(msp2_p2_kernel, dim3((unsigned)(q2_groups * B1)), dim3(Q2_THREADS), 0, ctx->stream,
@@ -1561,6 +1630,20 @@ int cfrk_msp2_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   // sized from a counting pass?  (fewer passes over the input for one more read of the level-1 records)
   bool lean = false;
   ms->dens_scale = 1.0;
+  // a large batch is counted in chunks when that fits in one pass (msp2_count_tiles); a batch that
+  // overflows the sizes measured from its first chunk comes back and is planned as before
+  {
+    int cg = 0;
+    const bool big = (double)(nN + 32) * msp2_density(ctx) * 1.35 * 32.0 > 6e9 || (ctx->dbg_flags & CFRK_DEBUG_SMALL_PIPELINE);
+    if (big && !(ctx->dbg_flags & CFRK_DEBUG_NO_PIPELINE) && !ctx->mem_budget &&
+        !(rc = cfrk_msp_plan_groups(ctx, nN + 32, ntiles, (int64_t)Q1_WAVES * Q1_OWN * 32, msp2_need_chunked, (size_t)ctx->g_cap * 20, have, &cg)) &&
+        cg == 1) {
+      if (ms->pending && (rc = cfrk_msp_flush_to_table(ctx))) return rc;
+      ctx->last_passes = 1;
+      rc = msp2_count_tiles(ctx, ms, d_data, nN, 0, ntiles, 1.0, 0, 0, true, false, true);
+      if (rc != CFRK_ERR_SMALL_BUF) return rc;
+    }
+  }
   if (groups != 1) {
     // first, how many positions start a k-mer at all: reads of a few k make far fewer records than
     // one per 2 / (W + 1) bytes (250-base reads at k = 63: 0.75 of it) -- a 5 TB/s look at the batch

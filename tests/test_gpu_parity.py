@@ -629,6 +629,30 @@ def test_pipelined_partition_matches_oracle(ctx, k, canonical):
     assert g.digest() == orc.digest(wlo, whi, wcnt)
 
 
+@pytest.mark.parametrize("k", [33, 40, 47, 63, 64])
+@pytest.mark.parametrize("canonical", [False, True])
+def test_chunked_two_word_path_matches_oracle(ctx, k, canonical):
+    """the two-word path (33 <= k <= 64) counted in chunks with leaf streams sized from the first chunk
+    (forced onto a small input): every (key, count) against the oracle"""
+    import cfrk_amd
+    rng = np.random.default_rng(950 + k)
+    reads = _random_reads(rng, 2500, 1, 500, 0.01)
+    reads.append(np.zeros(3000, np.int8))
+    genome = rng.integers(0, 4, 20000).astype(np.int8)
+    for _ in range(2000):
+        a = int(rng.integers(0, len(genome) - 250))
+        reads.append(genome[a:a + 250])
+    data, start, length = refsem.flatten(reads)
+    g = cfrk_amd.GlobalCounter(ctx, k, cfrk_amd.CFRK_CANONICAL if canonical else 0, 0)
+    g.set_debug_flags(cfrk_amd.CFRK_DEBUG_SMALL_PIPELINE)
+    g.add(data, start, length)
+    lo, hi, cnt = g.export()
+    g.set_debug_flags(0)
+    wlo, whi, wcnt = orc.global_count(data, k, orc.ORC_CANONICAL if canonical else 0)
+    assert len(lo) == len(wlo)
+    assert (lo == wlo).all() and (hi == whi).all() and (cnt.astype(np.uint64) == wcnt).all()
+
+
 def test_pipelined_and_one_chunk_paths_agree_at_20m_reads(ctx):
     """a batch large enough to pipeline by itself (20 M x 150 bp, k = 31 and 25): digest equal to the
     one-chunk path's (CFRK_DEBUG_NO_PIPELINE) and sum(count) exact"""
