@@ -60,8 +60,10 @@ while time.time() < t_end:
         del gh
         g = cfrk_amd.GlobalCounter(ctx, k, flags, hint)
         shared = k > 32 and rng.random() < 0.4       # leaves shared by record whatever the hint (msp2.hip)
-        if shared:
-            g.set_debug_flags(cfrk_amd.lib.CFRK_DEBUG_RECORD_SUBSETS)
+        chunked = k >= 16 and rng.random() < 0.4      # counted in chunks, leaf streams sized from the first one (round 3)
+        dbg = (cfrk_amd.lib.CFRK_DEBUG_RECORD_SUBSETS if shared else 0) | (cfrk_amd.lib.CFRK_DEBUG_SMALL_PIPELINE if chunked else 0)
+        if dbg:
+            g.set_debug_flags(dbg)
         forced = rng.random() < 0.25 and k >= 16
         if forced:                                   # several leaf-subset passes
             g.set_mem_budget(int(nN * float(rng.choice([4, 8, 14]))) + (64 << 20))
@@ -70,11 +72,11 @@ while time.time() < t_end:
         passes = g.last_add_passes()
         if forced:
             g.set_mem_budget(0)
-        if shared:
+        if dbg:
             g.set_debug_flags(0)
         del g
         ok = got == want and got[1] == nk
-        line = f"{tag} passes={passes}{' shared' if shared else ''} distinct={got[0]} {'ok' if ok else 'MISMATCH ' + str(got) + ' != ' + str(want)}"
+        line = f"{tag} passes={passes}{' shared' if shared else ''}{' chunked' if chunked else ''} distinct={got[0]} {'ok' if ok else 'MISMATCH ' + str(got) + ' != ' + str(want)}"
         if ok and 16 <= k <= 32 and rng.random() < 0.5:
             world = int(rng.integers(2, 6))
             Rl = [R * r // world for r in range(world + 1)]
