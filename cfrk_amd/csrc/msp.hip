@@ -1643,7 +1643,6 @@ __global__ __launch_bounds__(1024) void msp_runs_plan_kernel(const uint4 *__rest
   const int tid = threadIdx.x;
   const int n = parts * lpp, per = (n + 1023) / 1024;
   constexpr int U = 16;                            // independent loads in flight per thread
-  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
   auto leaf_of_item = [&](int i) { const int p = i / lpp, j = i - p * lpp; return p + j * parts; };
   uint64_t mine = 0;
   for (int q0 = 0; q0 < per; q0 += U) {
@@ -1687,16 +1686,18 @@ __global__ __launch_bounds__(1024) void msp_runs_plan_kernel(const uint4 *__rest
   if (tid < parts) part_rows[tid] = seg[tid + 1] - seg[tid];
   if (all_rows > cap_rows) return;                 // (the host reports the size the buffer needs)
   uint64_t run = run0;
-  for (int q0 = 0; q0 < per; q0 += U) {
-    uint4 e[U];
+  constexpr int U4 = 8;                            // (four words per load here: 1024 threads have 128 VGPRs each)
+  for (int q0 = 0; q0 < per; q0 += U4) {
+    uint4 e[U4];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < U4; ++u) {
       const int i = tid * per + q0 + u;
       const int leaf = leaf_of_item(i);
-      e[u] = (q0 + u < per && i < n && leaf < NLEAF) ? sz[leaf] : zero4;
+      e[u] = make_uint4(0u, 0u, 0u, 0u);            // (no `cond ? sz[leaf] : zero4`: a select between addresses parks zero4 in scratch)
+      if (q0 + u < per && i < n && leaf < NLEAF) e[u] = sz[leaf];
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < U4; ++u) {
       const int i = tid * per + q0 + u;
       if (q0 + u < per && i < n) {
         const int p = i / lpp, j = i - p * lpp, leaf = p + j * parts;
