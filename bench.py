@@ -59,7 +59,7 @@ def parse():
     p.add_argument("--owner-hash", action="store_true",
                    help="force the generic hash-owner exchange + HBM-table merge")
     p.add_argument("--exchange", default="auto", choices=["auto", "runs", "leaf", "owner"],
-                   help="N > 1: what the ranks exchange.  runs (auto for 16 <= k <= 32): deduplicated "
+                   help="N > 1: what the ranks exchange.  runs (auto for 16 <= k <= 64 when the job has a fixed size): deduplicated "
                         "runs, counted by the leaf's owner; leaf: counted per-leaf lists; owner: counted keys")
     a = p.parse_args()
     reads, L, k, glen = CONFIGS[a.config]
@@ -268,7 +268,7 @@ def main():
                     # rows of 16 bytes: distinct runs (<= the leaf streams) + truncated runs + headers
                     # (truncated runs: two per read; distinct complete runs: ~2 strands x 2/(W+1) per genome base,
                     #  never more than the shard's super-k-mers; a too small buffer is doubled below)
-                    rows = int(min(14 * Rl, 2.5 * Rl + 0.3 * glen)) + (1 << 17)
+                    rows = int(min(14 * Rl, 2.5 * Rl + 0.3 * glen)) * (2 if k > 32 else 1) + (1 << 17)   # (k > 32: two rows per record)
                     self.rbuf = torch.empty((max(1 << 20, rows), 2), dtype=torch.int64, device=dev)
                 for _ in range(3):
                     try:
@@ -303,7 +303,7 @@ def main():
             # strong scaling (a job of fixed size): ranks ship deduplicated runs, the owners count.
             # weak scaling: every rank has a full-depth shard, whose counted lists (~D entries) are
             # smaller than its runs (two truncated runs per read on top of the distinct ones)
-            exch = "runs" if 16 <= k <= 32 and scaling == "strong" else "leaf"
+            exch = "runs" if 16 <= k <= 64 and scaling == "strong" else "leaf"
         used = {"exchange": exch, "wire_bytes": 0}
 
         def step():

@@ -243,8 +243,8 @@ int cfrk_per_read_dense(cfrk_ctx *ctx, const int8_t *data, const int64_t *start,
 int cfrk_global_begin(cfrk_ctx *ctx, int k, int flags, uint64_t capacity_hint) {
   if (!ctx) return CFRK_ERR_ARG;
   if (k < 1 || k > 64) return cfrk_fail(ctx, CFRK_ERR_ARG, "k=%d outside 1..64", k);
-  if ((flags & CFRK_RUNS_ONLY) && (k < 16 || k > 32 || (flags & CFRK_FORCE_HASH)))
-    return cfrk_fail(ctx, CFRK_ERR_ARG, "CFRK_RUNS_ONLY needs the partitioned one-word path (16 <= k <= 32)");
+  if ((flags & CFRK_RUNS_ONLY) && (k < 16 || k > 64 || (flags & CFRK_FORCE_HASH)))
+    return cfrk_fail(ctx, CFRK_ERR_ARG, "CFRK_RUNS_ONLY needs a partitioned path (16 <= k <= 64)");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   // Was the HBM table left untouched by the previous job (the partitioned path only writes it

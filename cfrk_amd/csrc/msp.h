@@ -63,6 +63,7 @@ struct cfrk_msp {
   uint64_t list_n;     // entries in the list (valid after resolve)
   bool list_n_valid;
   MspView view;
+  alignas(16) unsigned char view2[256];   // msp2.hip: the View2 of a CFRK_RUNS_ONLY job (its leaf streams hold the runs)
 };
 
 cfrk_msp *cfrk_msp_get(cfrk_ctx *ctx);
@@ -81,6 +82,10 @@ int  cfrk_msp2_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN);
 // msp2.hip: add the `parts` lists of every leaf (ll < leaves_per_part) in LDS into the result list
 int  cfrk_msp2_merge_lists(cfrk_ctx *ctx, const uint64_t *d_lo, const uint64_t *d_hi, const uint32_t *d_cnt,
                            const uint64_t *d_seg_off, const uint32_t *d_seg_n, int parts, int leaves_per_part);
+
+// msp2.hip: the exchange by runs (cfrk_global_export_runs_device / cfrk_global_merge_runs_device) for two-word keys
+int  cfrk_msp2_export_runs(cfrk_ctx *ctx, void *d_packed, uint64_t cap_rows, int parts, uint64_t *part_rows);
+int  cfrk_msp2_merge_runs(cfrk_ctx *ctx, const void *d_packed, const uint64_t *recv_rows, int parts);
 
 // radix.hip: k <= 15
 bool cfrk_radix_usable(const cfrk_ctx *ctx);

@@ -22,6 +22,7 @@
 #include <vector>
 
 namespace {
+#include "msp_runs.h"
 
 // Window (m-mers per k-mer the minimizer is taken over = longest run): all but a margin of c = 1 on
 // both sides of the k-mer's k - m + 1 m-mers (m = 13 / 14 for even / odd k, so the count is even),
@@ -653,13 +654,13 @@ __device__ __forceinline__ uint32_t r2_slot(const Rec2 &r) {
 // The record table is keyed by the record's FIRST k-mer (its top 2k bits, 66 .. 128 of them): a
 // truncated run that is a prefix of a complete run finds its twin by probing from the same slot
 // (msp.hip explains the scheme).
-__device__ __forceinline__ uint32_t r2_slot_k(const Rec2 &r, int k) {
+__device__ __forceinline__ uint32_t r2_slot_k(const Rec2 &r, int k, int log = R2_LOG) {
   const int nb = 2 * k - 64;                       // bits of the first k-mer beyond a.x, a.y: 2 .. 64
   const uint32_t z = (nb >= 32) ? r.a.z : (r.a.z & ~(0xFFFFFFFFu >> nb));
   const uint32_t w = (nb <= 32) ? 0u : ((nb >= 64) ? r.a.w : (r.a.w & ~(0xFFFFFFFFu >> (nb - 32))));
   uint32_t h = (r.a.x * 0x9E3779B1u) ^ (r.a.y * 0x85EBCA77u) ^ (z * 0xC2B2AE3Du) ^ (w * 0x27D4EB2Fu);
   h = (h ^ (h >> 15)) * 0x2C1B3C6Du;
-  return h >> (32 - R2_LOG);
+  return h >> (32 - log);
 }
 // do the first `len` bases (33 <= len <= 96) of two records agree?
 __device__ __forceinline__ bool rec2_prefix_equal(const Rec2 &e, const Rec2 &r, int len) {
@@ -695,13 +696,14 @@ __device__ __forceinline__ Rec2 revcomp_record2(const Rec2 &rec, int len) {
 }
 
 // insert-or-count one record per lane; state = slot h with R2_DONE or-ed in once placed.  On
-// return lanes still without R2_DONE found no place.
-__device__ __forceinline__ void r2_insert_loop(Rec2 *rtab, const Rec2 &rec, uint32_t &h) {
+// return lanes still without R2_DONE found no place.  (mask: slots - 1; inc: the record's
+// multiplicity << 6 -- 1 << 6 unless the stream holds deduplicated runs, see "multi-GPU by runs")
+__device__ __forceinline__ void r2_insert_loop(Rec2 *rtab, const Rec2 &rec, uint32_t &h, uint32_t mask = R2 - 1, uint32_t inc = 1u << 6) {
   uint32_t *words = reinterpret_cast<uint32_t *>(rtab);
   const uint32_t nm1 = rec.b.w & 63u;
   for (int it = 0; it < R2_TRIPS && __ballot((int32_t)h >= 0); ++it) {
     const bool p = (int32_t)h >= 0;
-    const uint32_t hh = h & (R2 - 1);
+    const uint32_t hh = h & mask;
     const uint4 eb = rtab[hh].b;                             // state word + bases 64..95
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // bases 0..63 only after the state
     const uint4 ea = rtab[hh].a;
@@ -715,21 +717,24 @@ __device__ __forceinline__ void r2_insert_loop(Rec2 *rtab, const Rec2 &rec, uint
         rtab[hh].a = rec.a;
         words[8 * hh + 4] = rec.b.x; words[8 * hh + 5] = rec.b.y; words[8 * hh + 6] = rec.b.z;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        atomicExch(&words[8 * hh + 7], (1u << 6) | nm1);
+        atomicExch(&words[8 * hh + 7], inc | nm1);
         won = 1u;
       }
     }
-    if (p && match) atomicAdd(&words[8 * hh + 7], 1u << 6);
+    if (p && match) atomicAdd(&words[8 * hh + 7], inc);
     const bool stay = match || empty || eb.w == R2_LOCK;
-    const uint32_t nh = stay ? hh : ((hh + 1) & (R2 - 1));
+    const uint32_t nh = stay ? hh : ((hh + 1) & mask);
     h = (p && !match && won == 0u) ? nh : (h | R2_DONE);
   }
 }
 
 // SHARED: 2^sub_bits workgroups per leaf (an instantiation of its own: the ordinary kernel is short
 // of scalar registers as it is)
+// mode & Q3_WEIGHTED: the complete streams hold DISTINCT runs with multiplicities (header = count << 6 |
+// n-1, what msp2_dedupe_export_kernel leaves behind): an owner counting the runs its ranks sent
+constexpr uint32_t Q3_WEIGHTED = 1u;
 template <bool CANON, bool SHARED>
-__global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, TableView t) {
+__global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, uint32_t mode, View2 v, TableView t) {
   __shared__ ulonglong2 keys[T2];
   __shared__ uint32_t cnts[T2];
   __shared__ Rec2 rtab[R2];
@@ -751,6 +756,7 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
   __shared__ int sp;
   __shared__ uint32_t leaf_total, nseg;
   const int tid = threadIdx.x, lane = tid & 63;
+  const bool weighted = (mode & Q3_WEIGHTED) != 0u;
   // sub_bits > 0: 2^sub_bits workgroups share a leaf, each taking the records whose extra
   // minimizer-hash bits (b.z, written by msp2_p1_kernel<true>) name it -- every occurrence of a
   // k-mer has the same minimizer, so the workgroups' key sets are disjoint.  The workgroups of a
@@ -807,7 +813,7 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
     int c = 0;                         // wave-uniform
     auto drain = [&](int cnt) {
       uint32_t h = Lh | ((lane < cnt) ? 0u : R2_DONE);
-      r2_insert_loop(rtab, Lr, h);
+      r2_insert_loop(rtab, Lr, h, R2 - 1, weighted ? (Lr.b.w & ~63u) : (1u << 6));
       if ((int32_t)h >= 0) rt_fail = 1u;
     };
     auto home = [&](const Rec2 &rec, bool valid) {
@@ -817,7 +823,7 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
       const uint4 ea = rtab[h].a;
       const bool match = valid && ((((eb.w ^ rec.b.w) & 63u) | (eb.x ^ rec.b.x) | (eb.y ^ rec.b.y) | (ea.x ^ rec.a.x) |
                                     (ea.y ^ rec.a.y) | (ea.z ^ rec.a.z) | (ea.w ^ rec.a.w)) == 0u);
-      if (match) atomicAdd(&words[8 * h + 7], 1u << 6);
+      if (match) atomicAdd(&words[8 * h + 7], weighted ? (rec.b.w & ~63u) : (1u << 6));
       const bool left = valid && !match;
       const unsigned long long mask = __ballot(left);
       if (mask == 0ull) return;
@@ -1072,7 +1078,7 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
         const bool valid = r < ns[3];
         Rec2 rec = zrec;
         if (valid) rec = leaf_rec[r];
-        count_record2<CANON>(keys, cnts, rec, 1u, valid, k, t, ss, ovf);
+        count_record2<CANON>(keys, cnts, rec, weighted ? (rec.b.w >> 6) : 1u, valid, k, t, ss, ovf);
       }
     }
     if (!SHARED) {
@@ -1117,6 +1123,16 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, View2 v, Tab
         sc += n;
       };
       for (int cl = big ? 3 : 2; cl >= 0; --cl) {
+        if (cl == 3 && weighted) {
+          // (distinct runs with multiplicities and no room to merge them: rare enough to expand them where they lie)
+          for (uint64_t r = tid; r < ((ns[3] + 63) & ~63ull); r += Q3_THREADS) {
+            const bool valid = r < ns[3];
+            Rec2 rec = zrec;
+            if (valid) rec = leaf_rec[r];
+            count_record2<CANON>(keys, cnts, rec, rec.b.w >> 6, valid && mine(rec), k, t, ss, ovf);
+          }
+          continue;
+        }
         const Rec2 *src = (cl == 3) ? leaf_rec
                           : v.exact ? v.rec2 + v.lbase[NCLS * leaf + cl] : leaf_rec + v.cap2c + (uint64_t)cl * v.cap2t;
         const uint64_t done = (cl == 3) ? 0ull : (uint64_t)cov[cl];   // (the anchored ones are done)
@@ -1320,6 +1336,223 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_merge_kernel(const uint64_t *
   }
 }
 
+// ---------------------------------------------------------------------------- multi-GPU by runs
+// The exchange of msp.hip ("multi-GPU by runs") for two-word keys: a rank that only partitions
+// (CFRK_RUNS_ONLY) deduplicates every leaf's complete runs in place, turns read ends that are a
+// prefix of one of them into 16-bit notes and ships, per leaf, [distinct runs with multiplicities]
+// [truncated runs][notes]; a 32-byte record travels as two 16-byte rows.  The owner lines the ranks'
+// lists up as the streams of its leaves and runs the leaf kernel in Q3_WEIGHTED mode.
+constexpr int DX2_THREADS = 256, DX2_INFL = 2;
+constexpr int RX_LOG = 11, RX = 1 << RX_LOG;       // record-table slots of the export kernel (64 KB; 16-bit notes hold 11 bits of position)
+static_assert(((RX - 1) << 5 | 29) < 0xFFFF, "a note never equals the padding value");
+
+// stream cl (0..2 truncated, 3 complete) of a leaf and how many records it holds (one pass: sel_bits = 0)
+__device__ __forceinline__ Rec2 *x2_stream(const View2 &v, uint32_t leaf, int cl) {
+  if (v.exact) return v.rec2 + v.lbase[NCLS * leaf + cl];
+  return v.rec2 + (uint64_t)leaf * (v.cap2c + 3 * v.cap2t) + (cl == 3 ? 0ull : v.cap2c + (uint64_t)cl * v.cap2t);
+}
+__device__ __forceinline__ uint32_t x2_count(const View2 &v, uint32_t leaf, int cl) {
+  return (uint32_t)min((uint64_t)v.cnt2[NCLS * leaf + cl], v.exact ? (uint64_t)v.lcap[NCLS * leaf + cl] : (cl == 3 ? v.cap2c : v.cap2t));
+}
+
+// One workgroup per leaf.  The leaf's complete stream -> its DISTINCT runs, header = multiplicity << 6 |
+// n-1 (the extra minimizer-hash bits in b.z stay), at the head of the stream; leaf_n[leaf] = how many.
+// A leaf with more distinct runs than the table holds leaves as it is (multiplicity 1 each).
+// Truncated runs that are a prefix of a distinct run of this rank (a suffix, read on the other strand)
+// become notes: marked in place (b.w = RUN_NOTED, a.x = position of the run in the list << 5 | n-1);
+// leaf_off[leaf] = how many.
+__global__ __launch_bounds__(DX2_THREADS) void msp2_dedupe_export_kernel(int k, int canon, View2 v) {
+  __shared__ Rec2 rtab[RX];
+  __shared__ uint16_t sidx[RX];                    // record-table slot -> position in the leaf's list
+  __shared__ uint32_t wsum[DX2_THREADS / 64];
+  __shared__ uint32_t rt_fail, noted;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t leaf = blockIdx.x;
+  const uint32_t n1 = x2_count(v, leaf, 3);
+  if (n1 == 0) return;
+  Rec2 *const stream = x2_stream(v, leaf, 3);
+  const Rec2 zrec = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
+  {
+    Rec2 z = zrec;
+    z.b.w = R2_EMPTY;
+    for (int s = tid; s < RX; s += DX2_THREADS) rtab[s] = z;
+  }
+  if (tid == 0) { rt_fail = (v.dbg & CFRK_DEBUG_FORCE_RT_OVERFLOW) ? 1u : 0u; noted = 0u; }
+  __syncthreads();
+  for (uint32_t r0 = 0; r0 < n1; r0 += (uint32_t)DX2_INFL * DX2_THREADS) {
+    Rec2 recs[DX2_INFL];
+#pragma unroll
+    for (int u = 0; u < DX2_INFL; ++u) {
+      const uint32_t r = r0 + (uint32_t)u * DX2_THREADS + tid;
+      recs[u] = zrec;
+      if (r < n1) recs[u] = stream[r];
+    }
+#pragma unroll
+    for (int u = 0; u < DX2_INFL; ++u) {
+      const uint32_t r = r0 + (uint32_t)u * DX2_THREADS + tid;
+      uint32_t h = r2_slot_k(recs[u], k, RX_LOG) | ((r < n1) ? 0u : R2_DONE);
+      r2_insert_loop(rtab, recs[u], h, RX - 1);
+      if ((int32_t)h >= 0) rt_fail = 1u;
+    }
+  }
+  __syncthreads();
+  uint32_t nd;
+  if (rt_fail) {
+    // (every record was read before the barrier; the rewrite touches the header word only)
+    for (uint32_t i = tid; i < n1; i += DX2_THREADS) stream[i].b.w = (1u << 6) | (stream[i].b.w & 63u);
+    nd = n1;
+  } else {
+    // occupied slots -> head of the stream (eight slots per thread)
+    constexpr int PER = RX / DX2_THREADS;
+    const uint32_t *words = reinterpret_cast<const uint32_t *>(rtab);
+    uint32_t mine = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) mine += (words[8 * (PER * tid + i) + 7] != R2_EMPTY) ? 1u : 0u;
+    const uint32_t incl = dev_wave_scan_incl(mine);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+    for (int w = 0; w < DX2_THREADS / 64; ++w) { const uint32_t x = wsum[w]; base += (w < wave) ? x : 0u; total += x; }
+    uint32_t at = base + incl - mine;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const Rec2 e = rtab[PER * tid + i];
+      sidx[PER * tid + i] = (uint16_t)at;
+      if (e.b.w != R2_EMPTY) stream[at++] = e;
+    }
+    nd = total;
+    __syncthreads();
+    // truncated runs -> notes (the lookup of the leaf kernel's anchoring, msp2_p3_kernel)
+    for (int cl = 0; cl < 3 && !(v.dbg & CFRK_DEBUG_NO_ANCHORS); ++cl) {
+      const uint32_t nt = x2_count(v, leaf, cl);
+      Rec2 *const trunc = x2_stream(v, leaf, cl);
+      for (uint32_t g0 = 0; g0 < nt; g0 += DX2_THREADS) {
+        const uint32_t g = g0 + tid;
+        const bool valid = g < nt;
+        Rec2 rec = zrec;
+        if (valid) rec = trunc[g];
+        const uint32_t nm1 = rec.b.w & 31u;
+        const bool lc = (rec.b.w & 64u) != 0u, rc_ = (rec.b.w & 128u) != 0u;
+        const bool suf = canon && valid && !lc && rc_;
+        if (suf) rec = revcomp_record2(rec, (int)nm1 + k);
+        const bool anchored = suf || (valid && lc && !rc_);
+        uint32_t h = anchored ? r2_slot_k(rec, k, RX_LOG) : R2_DONE;
+        uint32_t found = 0xFFFFFFFFu;
+        for (int it = 0; it < 32 && __ballot((int32_t)h >= 0); ++it) {
+          const bool p = (int32_t)h >= 0;
+          const uint32_t hh = h & (uint32_t)(RX - 1);
+          const Rec2 e2 = rtab[hh];
+          const bool empty = e2.b.w == R2_EMPTY;
+          const bool hit = p && !empty && (e2.b.w & 31u) >= nm1 && rec2_prefix_equal(e2, rec, (int)nm1 + k);
+          found = hit ? hh : found;
+          h = (p && !hit && !empty) ? ((hh + 1u) & (uint32_t)(RX - 1)) : (h | R2_DONE);
+        }
+        const bool hit = found != 0xFFFFFFFFu;
+        if (hit) { trunc[g].a.x = ((uint32_t)sidx[found] << 5) | nm1; trunc[g].b.w = RUN_NOTED; }
+        const unsigned long long hb = __ballot(hit);
+        if (lane == 0 && hb) atomicAdd(&noted, (uint32_t)__popcll(hb));
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) { v.leaf_n[leaf] = nd; v.leaf_off[leaf] = noted; }
+}
+
+// sender: what every leaf contributes -- n1 distinct complete runs, nt truncated runs as records, na as
+// notes, rows in all (two per record) -- one thread per leaf
+__global__ __launch_bounds__(256) void msp2_runs_sizes_kernel(View2 v, uint4 *__restrict__ sz) {
+  const uint32_t leaf = blockIdx.x * 256u + threadIdx.x;
+  if (leaf >= (uint32_t)NLEAF) return;
+  uint32_t n1 = 0, na = 0;
+  uint32_t nt = x2_count(v, leaf, 0) + x2_count(v, leaf, 1) + x2_count(v, leaf, 2);
+  if (v.cnt2[NCLS * leaf + 3]) {                               // (a leaf without complete runs never wrote its counts)
+    n1 = v.leaf_n[leaf];
+    na = min((uint32_t)v.leaf_off[leaf], nt);
+  }
+  nt -= na;
+  sz[leaf] = make_uint4(n1, nt, na, 2u * (n1 + nt) + (na + NOTES_PER_ROW - 1) / NOTES_PER_ROW);
+}
+
+// sender: leaf -> [nd distinct complete runs][nu truncated runs][na notes, 8 per row] at row dst_off[leaf]
+// of the send buffer (the three truncated streams hold records and noted records mixed)
+__global__ __launch_bounds__(256) void msp2_runs_gather_kernel(View2 v, const uint64_t *__restrict__ dst_off, uint4 *__restrict__ out,
+                                                               const uint64_t *__restrict__ plan_rows, int parts, uint64_t cap_rows) {
+  __shared__ uint32_t cu, cn;
+  if (plan_rows[parts] > cap_rows) return;         // the buffer is too small: nothing was planned
+  const uint32_t leaf = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const bool has1 = v.cnt2[NCLS * leaf + 3] != 0u;
+  const uint32_t nd = has1 ? v.leaf_n[leaf] : 0u;
+  const uint32_t t0 = x2_count(v, leaf, 0), t1 = t0 + x2_count(v, leaf, 1), nt = t1 + x2_count(v, leaf, 2);
+  const uint32_t na = has1 ? min((uint32_t)v.leaf_off[leaf], nt) : 0u;
+  const uint32_t nu = nt - na;
+  const Rec2 *c3 = x2_stream(v, leaf, 3);
+  const Rec2 *s0 = x2_stream(v, leaf, 0), *s1 = x2_stream(v, leaf, 1), *s2 = x2_stream(v, leaf, 2);
+  auto trunc_at = [&](uint32_t g) { return (g < t0) ? s0 + g : (g < t1) ? s1 + (g - t0) : s2 + (g - t1); };
+  uint4 *dst = out + dst_off[leaf];
+  for (uint32_t i = threadIdx.x; i < nd; i += blockDim.x) { const Rec2 r = c3[i]; dst[2 * i] = r.a; dst[2 * i + 1] = r.b; }
+  uint4 *dt = dst + 2 * (uint64_t)nd;
+  if (na == 0u) {
+    for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) { const Rec2 r = *trunc_at(i); dt[2 * i] = r.a; dt[2 * i + 1] = r.b; }
+    return;
+  }
+  if (threadIdx.x == 0) { cu = 0u; cn = 0u; }
+  __syncthreads();
+  uint16_t *notes = reinterpret_cast<uint16_t *>(dt + 2 * (uint64_t)nu);
+  for (uint32_t i = threadIdx.x; i < ((nt + 63u) & ~63u); i += blockDim.x) {
+    const bool valid = i < nt;
+    Rec2 rec = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
+    if (valid) rec = *trunc_at(i);
+    const bool isn = valid && rec.b.w == RUN_NOTED;
+    const unsigned long long mn = __ballot(isn), mu = __ballot(valid && !isn);
+    uint32_t bn = 0, bu = 0;
+    if (lane == 0) {
+      if (mn) bn = atomicAdd(&cn, (uint32_t)__popcll(mn));
+      if (mu) bu = atomicAdd(&cu, (uint32_t)__popcll(mu));
+    }
+    bn = __shfl(bn, 0); bu = __shfl(bu, 0);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    // (the counts of the plan bound both: a stream that changed under us cannot write outside the leaf's rows)
+    if (isn) { const uint32_t at = bn + (uint32_t)__popcll(mn & below); if (at < na) notes[at] = (uint16_t)rec.a.x; }
+    else if (valid) { const uint32_t at = bu + (uint32_t)__popcll(mu & below); if (at < nu) { dt[2 * at] = rec.a; dt[2 * at + 1] = rec.b; } }
+  }
+  const uint32_t pad = (NOTES_PER_ROW - na % NOTES_PER_ROW) % NOTES_PER_ROW;
+  if (threadIdx.x < pad) notes[na + threadIdx.x] = 0xFFFFu;
+}
+
+// owner: segment (source rank, local leaf) of the received buffer -> its place in the leaf's complete
+// stream and its (one) stream of truncated runs.  A note becomes the run it stands for: the first n
+// k-mers of its twin, closed on the left only.
+__global__ __launch_bounds__(256) void msp2_runs_scatter_kernel(const uint4 *__restrict__ in, RunsRecv rr, int lpp, int k,
+                                                                const uint64_t *__restrict__ src_off,
+                                                                const uint64_t *__restrict__ dst1, const uint64_t *__restrict__ dst0,
+                                                                Rec2 *__restrict__ rec2) {
+  const uint32_t seg = blockIdx.x;
+  const uint32_t r = seg / (uint32_t)lpp, ll = seg - r * (uint32_t)lpp;
+  const uint32_t *hdr = reinterpret_cast<const uint32_t *>(in + rr.rstart[r]);
+  const uint32_t nd = hdr[3 * ll], nt = hdr[3 * ll + 1], na = hdr[3 * ll + 2];
+  const uint4 *src = in + src_off[seg];
+  for (uint32_t i = threadIdx.x; i < nd; i += blockDim.x) { Rec2 q; q.a = src[2 * i]; q.b = src[2 * i + 1]; rec2[dst1[seg] + i] = q; }
+  const uint4 *st = src + 2 * (uint64_t)nd;
+  for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) { Rec2 q; q.a = st[2 * i]; q.b = st[2 * i + 1]; rec2[dst0[seg] + i] = q; }
+  const uint16_t *notes = reinterpret_cast<const uint16_t *>(st + 2 * (uint64_t)nt);
+  for (uint32_t i = threadIdx.x; i < na; i += blockDim.x) {          // (nd > 0: the layout kernel checked)
+    const uint32_t note = notes[i];
+    const uint32_t ti = min(note >> 5, nd - 1u);                      // a position outside the list is not followed
+    const uint4 ta = src[2 * ti], tb = src[2 * ti + 1];
+    const uint32_t nm1 = min(note & 31u, tb.w & 31u);
+    const int len = (int)nm1 + k;                                     // bases of the run: 33 .. 93
+    auto mk = [&](int w) {                                            // mask of word w: bits 32 w .. 32 w + 31 of the string
+      const int b = 2 * len - 32 * w;
+      return (b >= 32) ? 0xFFFFFFFFu : ((b <= 0) ? 0u : ~(0xFFFFFFFFu >> b));
+    };
+    Rec2 q;
+    q.a = make_uint4(ta.x, ta.y, ta.z & mk(2), ta.w & mk(3));
+    q.b = make_uint4(tb.x & mk(4), tb.y & mk(5), tb.z, 64u | nm1);
+    rec2[dst0[seg] + nt + i] = q;
+  }
+}
+
 }  // namespace
 
 bool cfrk_msp2_usable(const cfrk_ctx *ctx) {
@@ -1439,6 +1672,10 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
   v.ovf = (Rec2 *)p; v.ovf_cap = (uint32_t)std::min<double>((double)OVF_CAP, expect / 256.0);
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_OVF1, (size_t)OVF_CAP * sizeof(Rec2), &p))) return rc;
   v.ovf1 = (Rec2 *)p; v.ovf1_cap = v.ovf_cap;
+  // a job that only partitions (CFRK_RUNS_ONLY) has no table of its own for parked records: any
+  // overflow goes straight to the exact layout
+  const bool runs_only = (ctx->g_flags & CFRK_RUNS_ONLY) != 0;
+  if (runs_only) v.ovf_cap = v.ovf1_cap = 0;
   v.exact = 0; v.lbase = nullptr; v.lcap = nullptr;
   v.exact1 = 0; v.rbase = nullptr; v.rcap = nullptr;
   const size_t nreg = (size_t)B1 * NXG;
@@ -1565,25 +1802,37 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
     break;
   }
   if (!settled) return cfrk_fail(ctx, CFRK_ERR_STATE, "the record regions did not settle after an exact layout");
-  if (parked1) {
+  if (parked1 && v.ovf1_cap) {
     const uint32_t n = (uint32_t)std::min<uint64_t>(parked1, v.ovf1_cap);
     hipLaunchKernelGGL(msp2_spill_list_kernel, dim3((n + 255u) / 256u), dim3(256), 0, ctx->stream, (const Rec2 *)v.ovf1, n, k, canon, t);
     HIP_TRY(ctx, hipGetLastError());
   }
-  if (parked2) {
+  if (parked2 && v.ovf_cap) {
     const uint32_t n = (uint32_t)std::min<uint64_t>(parked2, v.ovf_cap);
     hipLaunchKernelGGL(msp2_spill_list_kernel, dim3((n + 255u) / 256u), dim3(256), 0, ctx->stream, (const Rec2 *)v.ovf, n, k, canon, t);
     HIP_TRY(ctx, hipGetLastError());
+  }
+  if (runs_only) {
+    // deduplicate the leaves where they lie; the streams stay for cfrk_global_export_runs_device
+    hipLaunchKernelGGL(msp2_dedupe_export_kernel, dim3(NLEAF), dim3(DX2_THREADS), 0, ctx->stream, k, canon, v);
+    HIP_TRY(ctx, hipGetLastError());
+    static_assert(sizeof(View2) <= sizeof(ms->view2), "cfrk_msp::view2 holds a View2");
+    memcpy(ms->view2, &v, sizeof v);
+    ms->pending = false;
+    ms->runs_ready = true;
+    ms->leaf_form = false;
+    ms->list_n_valid = false;
+    return CFRK_OK;
   }
   {
     // (a shared leaf: one workgroup per four sub-values)
     const dim3 g3(((unsigned)NLEAF >> sel_bits) << (v.sub_bits - std::min(v.sub_bits, 2u))), b3(Q3_THREADS);
     if (sub) {
-      if (canon) hipLaunchKernelGGL((msp2_p3_kernel<true, true>), g3, b3, 0, ctx->stream, k, v, t);
-      else hipLaunchKernelGGL((msp2_p3_kernel<false, true>), g3, b3, 0, ctx->stream, k, v, t);
+      if (canon) hipLaunchKernelGGL((msp2_p3_kernel<true, true>), g3, b3, 0, ctx->stream, k, 0u, v, t);
+      else hipLaunchKernelGGL((msp2_p3_kernel<false, true>), g3, b3, 0, ctx->stream, k, 0u, v, t);
     } else {
-      if (canon) hipLaunchKernelGGL((msp2_p3_kernel<true, false>), g3, b3, 0, ctx->stream, k, v, t);
-      else hipLaunchKernelGGL((msp2_p3_kernel<false, false>), g3, b3, 0, ctx->stream, k, v, t);
+      if (canon) hipLaunchKernelGGL((msp2_p3_kernel<true, false>), g3, b3, 0, ctx->stream, k, 0u, v, t);
+      else hipLaunchKernelGGL((msp2_p3_kernel<false, false>), g3, b3, 0, ctx->stream, k, 0u, v, t);
     }
   }
   HIP_TRY(ctx, hipGetLastError());
@@ -1613,6 +1862,141 @@ int cfrk_msp2_merge_lists(cfrk_ctx *ctx, const uint64_t *d_lo, const uint64_t *d
   return CFRK_OK;
 }
 
+// ------------------------------------------------------------------ multi-GPU exchange by runs
+// (cfrk_global_export_runs_device / cfrk_global_merge_runs_device of msp.hip for two-word keys;
+// the callers have checked the arguments and the job's state)
+int cfrk_msp2_export_runs(cfrk_ctx *ctx, void *d_packed, uint64_t cap_rows, int parts, uint64_t *part_rows) {
+  cfrk_msp *ms = ctx->msp;
+  View2 v;
+  memcpy(&v, ms->view2, sizeof v);
+  const int lpp = (NLEAF + parts - 1) / parts;           // leaves per part (owner p: leaves p, p+parts, ...)
+  const int hrows = runs_header_rows(lpp);
+  int rc;
+  void *p;
+  if ((rc = cfrk_pool_get(ctx, BUF_SCRATCH, (NLEAF + 65 + ST_NWORDS) * sizeof(uint64_t) + (size_t)NLEAF * sizeof(uint4), &p))) return rc;
+  uint64_t *d_off = (uint64_t *)p, *d_rows = d_off + NLEAF;
+  uint4 *d_sz = (uint4 *)(d_rows + 65 + ST_NWORDS + 1);      // (16-byte aligned: the pool is, and NLEAF + 65 + ST_NWORDS + 1 is even)
+  static_assert((NLEAF + 65 + ST_NWORDS + 1) % 2 == 0, "d_sz is 16-byte aligned");
+  hipLaunchKernelGGL(msp2_runs_sizes_kernel, dim3(NLEAF / 256), dim3(256), 0, ctx->stream, v, d_sz);
+  HIP_TRY(ctx, hipGetLastError());
+  hipLaunchKernelGGL(msp_runs_plan_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint4 *)d_sz, parts, lpp, hrows, d_off, (uint4 *)d_packed,
+                     cap_rows, d_rows);
+  HIP_TRY(ctx, hipGetLastError());
+  hipLaunchKernelGGL(msp2_runs_gather_kernel, dim3(NLEAF), dim3(256), 0, ctx->stream, v, (const uint64_t *)d_off, (uint4 *)d_packed,
+                     (const uint64_t *)d_rows, parts, cap_rows);
+  HIP_TRY(ctx, hipGetLastError());
+  uint64_t h[65 + ST_NWORDS];
+  HIP_TRY(ctx, hipMemcpyAsync(d_rows + 65, ctx->g_stats, ST_NWORDS * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(h, d_rows, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  const uint64_t *st = h + 65;
+  if (st[ST_SPILLED] || st[ST_ONES]) return cfrk_fail(ctx, CFRK_ERR_STATE, "part of the batch was counted in the HBM table");
+  if (h[parts] > cap_rows) return cfrk_fail(ctx, CFRK_ERR_SMALL_BUF, "%llu rows, room for %llu", (unsigned long long)h[parts], (unsigned long long)cap_rows);
+  for (int q = 0; q < parts; ++q) part_rows[q] = h[q];
+  return CFRK_OK;
+}
+
+int cfrk_msp2_merge_runs(cfrk_ctx *ctx, const void *d_packed, const uint64_t *recv_rows, int parts) {
+  cfrk_msp *ms = cfrk_msp_get(ctx);
+  if (!ms) return cfrk_fail(ctx, CFRK_ERR_NOMEM, "host allocation failed");
+  if (ms->pending || ms->table_dirty) return cfrk_fail(ctx, CFRK_ERR_STATE, "merge_runs needs an empty job (call cfrk_global_begin first)");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  const int k = ctx->g_k;
+  const int canon = (ctx->g_flags & CFRK_CANONICAL) ? 1 : 0;
+  const int lpp = (NLEAF + parts - 1) / parts;
+  const int hrows = runs_header_rows(lpp);
+  const size_t nseg = (size_t)parts * lpp;
+  int rc;
+  void *p;
+  RunsRecv rr;
+  memset(&rr, 0, sizeof rr);
+  uint64_t rows_all = 0;
+  for (int r = 0; r < parts; ++r) {
+    if (recv_rows[r] < (uint64_t)hrows) return cfrk_fail(ctx, CFRK_ERR_ARG, "rank %d sent %llu rows, fewer than its header", r, (unsigned long long)recv_rows[r]);
+    rr.rstart[r] = rows_all; rr.rows[r] = recv_rows[r];
+    rows_all += recv_rows[r];
+  }
+  View2 v;
+  memset(&v, 0, sizeof v);
+  // shared leaves (msp2_count_tiles): the owner holds 1 / parts of the leaves, each as heavy as it is in
+  // the whole job -- the capacity hint of an owner is its share of the job's distinct k-mers
+  const uint64_t per_leaf = ctx->g_cap / NLEAF * (uint64_t)parts;
+  uint32_t sub_bits = 0;
+  while (sub_bits < (uint32_t)SUB_BITS && (per_leaf >> sub_bits) > 2048u) ++sub_bits;
+  if (per_leaf <= 4096u) sub_bits = 0;
+  if ((ctx->dbg_flags & CFRK_DEBUG_RECORD_SUBSETS) && sub_bits < 2u) sub_bits = 2u;
+  v.sub_bits = sub_bits;
+  const size_t nsub = (size_t)NLEAF << sub_bits;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_AUX, nsub * 8 + ((size_t)B1 * NXG + (size_t)NCLS * NLEAF + nsub) * sizeof(uint32_t), &p))) return rc;
+  v.leaf_off = (uint64_t *)p;
+  v.cnt1 = (uint32_t *)(v.leaf_off + nsub); v.cnt2 = v.cnt1 + B1 * NXG; v.leaf_n = v.cnt2 + NCLS * NLEAF;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_LAYOUT, (size_t)NCLS * NLEAF * (sizeof(uint64_t) + 2 * sizeof(uint32_t)), &p))) return rc;
+  uint64_t *d_lbase = (uint64_t *)p;
+  uint32_t *d_lcap = (uint32_t *)(d_lbase + NCLS * NLEAF);
+  v.exact = 1; v.lbase = d_lbase; v.lcap = d_lcap;
+  // (streams nobody fills -- truncated classes 1 and 2, leaves of other owners -- hold nothing)
+  HIP_TRY(ctx, hipMemsetAsync(v.cnt2, 0, ((size_t)NCLS * NLEAF + nsub) * sizeof(uint32_t), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(d_lbase, 0, (size_t)NCLS * NLEAF * (sizeof(uint64_t) + sizeof(uint32_t)), ctx->stream));
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTK, (size_t)ctx->g_cap * 8, &p))) return rc;
+  v.out_lo = (uint64_t *)p;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTH, (size_t)ctx->g_cap * 8, &p))) return rc;
+  v.out_hi = (uint64_t *)p;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTC, (size_t)ctx->g_cap * 4, &p))) return rc;
+  v.out_cnt = (uint32_t *)p; v.out_cap = ctx->g_cap;
+  v.stats = ctx->g_stats; v.dbg = ctx->dbg_flags;
+  if ((rc = cfrk_pool_get(ctx, BUF_SCRATCH, (nseg * 3 + 2) * sizeof(uint64_t) + nseg * sizeof(uint32_t), &p))) return rc;
+  uint64_t *d_src = (uint64_t *)p, *d_d1 = d_src + nseg, *d_d0 = d_d1 + nseg, *d_out = d_d0 + nseg;
+  uint32_t *d_segrows = (uint32_t *)(d_out + 2);
+  HIP_TRY(ctx, hipMemsetAsync(d_out, 0, 2 * sizeof(uint64_t), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_CURSOR, 0, sizeof(uint64_t), ctx->stream));
+  TableView t = cfrk_table_view(ctx);
+  // segment (source rank, local leaf): the ranks' headers say how large; all offsets on the device.
+  // Stream 3 of a leaf takes the ranks' distinct runs, stream 0 all their truncated runs.
+  hipLaunchKernelGGL((msp_runs_layout1_kernel<NCLS, 3, 0, 2>), dim3((unsigned)(lpp + 255) / 256), dim3(256), 0, ctx->stream, (const uint4 *)d_packed, rr, parts, lpp,
+                     d_segrows, d_d1, d_d0, d_lcap, d_out);
+  HIP_TRY(ctx, hipGetLastError());
+  hipLaunchKernelGGL((msp_runs_layout_kernel<NCLS, 3, 0>), dim3((unsigned)parts + 1u), dim3(1024), 0, ctx->stream, rr, parts, lpp, hrows, (const uint32_t *)d_segrows,
+                     d_src, d_d1, d_d0, d_lbase, (const uint32_t *)d_lcap, v.cnt2, d_out);
+  HIP_TRY(ctx, hipGetLastError());
+  // the headers are checked before anything is copied by them (msp.hip)
+  uint64_t h[2];
+  HIP_TRY(ctx, hipMemcpyAsync(h, d_out, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (h[1]) return cfrk_fail(ctx, CFRK_ERR_ARG, "a rank's header does not add up to the rows it sent");
+  if (h[0] > rows_all * NOTES_PER_ROW) return cfrk_fail(ctx, CFRK_ERR_ARG, "the headers announce more records than the rows can hold");
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)(h[0] ? h[0] : 1) * sizeof(Rec2), &p))) return rc;
+  v.rec2 = (Rec2 *)p;
+  hipLaunchKernelGGL(msp2_runs_scatter_kernel, dim3((unsigned)nseg), dim3(256), 0, ctx->stream, (const uint4 *)d_packed, rr, lpp, k,
+                     (const uint64_t *)d_src, (const uint64_t *)d_d1, (const uint64_t *)d_d0, v.rec2);
+  HIP_TRY(ctx, hipGetLastError());
+  {
+    // the owner's leaves are local indices 0 .. lpp-1 (a shared leaf: one workgroup per four sub-values,
+    // eight leaves side by side on the XCDs -- leaves beyond lpp hold nothing and leave at once)
+    const unsigned gbits = sub_bits - std::min(sub_bits, 2u);
+    const dim3 g3(sub_bits ? (((unsigned)lpp + 7u) & ~7u) << gbits : (unsigned)lpp), b3(Q3_THREADS);
+    if (sub_bits) {
+      if (canon) hipLaunchKernelGGL((msp2_p3_kernel<true, true>), g3, b3, 0, ctx->stream, k, Q3_WEIGHTED, v, t);
+      else hipLaunchKernelGGL((msp2_p3_kernel<false, true>), g3, b3, 0, ctx->stream, k, Q3_WEIGHTED, v, t);
+    } else {
+      if (canon) hipLaunchKernelGGL((msp2_p3_kernel<true, false>), g3, b3, 0, ctx->stream, k, Q3_WEIGHTED, v, t);
+      else hipLaunchKernelGGL((msp2_p3_kernel<false, false>), g3, b3, 0, ctx->stream, k, Q3_WEIGHTED, v, t);
+    }
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  ctx->ev_valid = true;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->h_stats_valid = false;                          // the leaf kernel may have spilled into the table
+  ms->view.out_keys = v.out_lo; ms->view.out_hi = v.out_hi; ms->view.out_cnt = v.out_cnt;
+  ms->view.out_cap = v.out_cap; ms->view.stats = v.stats; ms->view.cnt1 = nullptr;
+  ms->view.leaf_off = v.leaf_off; ms->view.leaf_n = v.leaf_n; ms->view.seg_bits = v.sub_bits;
+  ms->pending = true;
+  ms->leaf_form = false;
+  ms->list_n_valid = false;
+  return CFRK_OK;
+}
+
 int cfrk_msp2_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   cfrk_msp *ms = cfrk_msp_get(ctx);
   if (!ms) return cfrk_fail(ctx, CFRK_ERR_NOMEM, "host allocation failed");
@@ -1623,6 +2007,8 @@ int cfrk_msp2_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   if (ntiles > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
   const size_t have = ctx->pool[BUF_MSP_L1].cap + ctx->pool[BUF_MSP_L2].cap + ctx->pool[BUF_MSP_OUTK].cap +
                       ctx->pool[BUF_MSP_OUTC].cap + ctx->pool[BUF_MSP_OUTH].cap;
+  const bool runs_only = (ctx->g_flags & CFRK_RUNS_ONLY) != 0;
+  if (runs_only && ms->runs_ready) return cfrk_fail(ctx, CFRK_ERR_STATE, "a CFRK_RUNS_ONLY job takes one add");
   int groups = 1;
   if ((rc = cfrk_msp_plan_groups(ctx, nN + 32, ntiles, (int64_t)Q1_WAVES * Q1_OWN * 32, msp2_need,
                                  (size_t)ctx->g_cap * 20, have, &groups))) return rc;
@@ -1670,6 +2056,7 @@ int cfrk_msp2_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   if (groups == 0) return cfrk_fail(ctx, CFRK_ERR_NOMEM, "partitioned path does not fit device memory");
   const int passes = groups;
   ctx->last_passes = passes;
+  if (runs_only && passes != 1) return cfrk_fail(ctx, CFRK_ERR_STATE, "a CFRK_RUNS_ONLY job must fit device memory in one pass");
   if (ms->pending && (rc = cfrk_msp_flush_to_table(ctx))) return rc;
   if (passes == 1 && lean) return msp2_count_tiles(ctx, ms, d_data, nN, 0, ntiles, 1.0, 0, 0, true, true);
   if (passes == 1) {

@@ -1,0 +1,199 @@
+// msp_runs.h -- the parts of the multi-GPU exchange by runs (msp.hip: "multi-GPU by runs") that do not
+// depend on the record format: where every leaf's rows go in the packed buffer (sender) and where
+// every received segment goes in the owner's leaf streams.  Included by msp.hip (16-byte records,
+// one row each) and msp2.hip (32-byte records, two rows each) inside their anonymous namespaces.
+#pragma once
+
+constexpr uint32_t RUN_NOTED = 0xFFFFFFFFu;        // (a record's header word has the top 8 bits clear)
+constexpr int NOTES_PER_ROW = 8;
+// Packed form, one segment per owner: [header: the owner's leaves_per_part x (distinct, truncated,
+// noted) sizes, uint32 triples, padded to whole 16-byte rows][leaf after leaf: the distinct complete
+// runs, the truncated runs, the notes (16 bits each, eight per row)].
+static inline int runs_header_rows(int lpp) { return (lpp * 3 * (int)sizeof(uint32_t) + 15) / 16; }
+
+// exclusive prefix sum over a block of 1024 threads (wtot: 16 words of LDS); returns the exclusive
+// prefix of x, *total = the block's sum
+__device__ __forceinline__ uint64_t block_scan_u64(uint64_t x, unsigned long long *wtot, uint64_t *total) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint64_t incl = x;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint64_t y = __shfl_up(incl, d);
+    if (lane >= d) incl += y;
+  }
+  __syncthreads();                               // (wtot may still be read from a previous scan)
+  if (lane == 63) wtot[wave] = incl;
+  __syncthreads();
+  uint64_t base = 0, all = 0;
+  for (int w = 0; w < 16; ++w) { const uint64_t t = wtot[w]; base += (w < wave) ? t : 0; all += t; }
+  *total = all;
+  return base + incl - x;
+}
+
+// sender, one workgroup: where every leaf's records go in the packed buffer (owner-major order,
+// a header of hrows rows in front of every owner's segment), the headers themselves, rows per segment
+__global__ __launch_bounds__(1024) void msp_runs_plan_kernel(const uint4 *__restrict__ sz, int parts, int lpp, int hrows,
+                                                             uint64_t *__restrict__ dst_off, uint4 *__restrict__ packed,
+                                                             uint64_t cap_rows,
+                                                             uint64_t *__restrict__ part_rows /* [parts]: rows per segment; [parts]: all rows */) {
+  __shared__ unsigned long long wtot[16];
+  __shared__ unsigned long long seg[65];          // first row of every owner's segment
+  const int tid = threadIdx.x;
+  const int n = parts * lpp, per = (n + 1023) / 1024;
+  constexpr int U = 16;                            // independent loads in flight per thread
+  auto leaf_of_item = [&](int i) { const int p = i / lpp, j = i - p * lpp; return p + j * parts; };
+  uint64_t mine = 0;
+  for (int q0 = 0; q0 < per; q0 += U) {
+    uint32_t r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = tid * per + q0 + u;
+      const int leaf = leaf_of_item(i);
+      r[u] = (q0 + u < per && i < n && leaf < NLEAF) ? sz[leaf].w : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) mine += r[u];
+  }
+  uint64_t total;
+  const uint64_t run0 = block_scan_u64(mine, wtot, &total);
+  const uint64_t all_rows = total + (uint64_t)parts * hrows;
+  if (tid == 0) { part_rows[parts] = all_rows; seg[parts] = all_rows; }
+  // (a segment starts with the first item of its owner: item p * lpp)
+  {
+    uint64_t run = run0;
+    for (int q0 = 0; q0 < per; q0 += U) {
+      uint32_t r[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = tid * per + q0 + u;
+        const int leaf = leaf_of_item(i);
+        r[u] = (q0 + u < per && i < n && leaf < NLEAF) ? sz[leaf].w : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = tid * per + q0 + u;
+        if (q0 + u < per && i < n) {
+          const int p = i / lpp;
+          if (i == p * lpp) seg[p] = run + (uint64_t)p * hrows;
+        }
+        run += r[u];
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < parts) part_rows[tid] = seg[tid + 1] - seg[tid];
+  if (all_rows > cap_rows) return;                 // (the host reports the size the buffer needs)
+  uint64_t run = run0;
+  constexpr int U4 = 8;                            // (four words per load here: 1024 threads have 128 VGPRs each)
+  for (int q0 = 0; q0 < per; q0 += U4) {
+    uint4 e[U4];
+#pragma unroll
+    for (int u = 0; u < U4; ++u) {
+      const int i = tid * per + q0 + u;
+      const int leaf = leaf_of_item(i);
+      e[u] = make_uint4(0u, 0u, 0u, 0u);            // (no `cond ? sz[leaf] : zero4`: a select between addresses parks zero4 in scratch)
+      if (q0 + u < per && i < n && leaf < NLEAF) e[u] = sz[leaf];
+    }
+#pragma unroll
+    for (int u = 0; u < U4; ++u) {
+      const int i = tid * per + q0 + u;
+      if (q0 + u < per && i < n) {
+        const int p = i / lpp, j = i - p * lpp, leaf = p + j * parts;
+        if (leaf < NLEAF) dst_off[leaf] = run + (uint64_t)(p + 1) * hrows;
+        uint32_t *hdr = reinterpret_cast<uint32_t *>(packed + seg[p]);
+        hdr[3 * j] = e[u].x; hdr[3 * j + 1] = e[u].y; hdr[3 * j + 2] = e[u].z;
+        run += e[u].w;
+      }
+    }
+  }
+}
+
+// (err = 1 when a rank's header does not add up to the rows it sent)
+struct RunsRecv { uint64_t rstart[64]; uint64_t rows[64]; };
+// owner: every rank's header says how large its leaves' segments are.  Two kernels: (1) one thread per
+// local leaf reads the `parts` header triples of that leaf (coalesced across threads) and writes, per
+// (rank, leaf), the segment's rows and where it goes INSIDE the leaf's two streams, and per leaf the
+// stream sizes; (2) one workgroup turns those compact arrays into offsets with plain scans.  (One
+// workgroup used to do all of it with dependent header loads: 0.27 ms at N = 8.)
+// NC streams per leaf, CI1 / CI0: which of them take the complete / the truncated runs; RMUL rows per record
+template <int NC, int CI1, int CI0, int RMUL>
+__global__ __launch_bounds__(256) void msp_runs_layout1_kernel(const uint4 *__restrict__ packed, RunsRecv rr, int parts, int lpp,
+                                                                uint32_t *__restrict__ rows /* [parts][lpp] */,
+                                                                uint64_t *__restrict__ d1 /* relative */, uint64_t *__restrict__ d0 /* relative */,
+                                                                uint32_t *__restrict__ lcap, uint64_t *__restrict__ out) {
+  const int ll = blockIdx.x * 256 + threadIdx.x;
+  if (ll >= lpp) return;
+  uint64_t n1 = 0, n0 = 0;
+  uint32_t err = 0;
+  // (the complete streams of all ranks first, then the truncated ones: rank order inside both)
+  for (int r = 0; r < parts; ++r) {
+    const uint32_t *hdr = reinterpret_cast<const uint32_t *>(packed + rr.rstart[r]);
+    const uint32_t a = hdr[3 * ll], b = hdr[3 * ll + 1], c = hdr[3 * ll + 2];
+    rows[(size_t)r * lpp + ll] = (uint32_t)RMUL * (a + b) + (c + NOTES_PER_ROW - 1) / NOTES_PER_ROW;
+    if (c && !a) err = 1;                                      // notes without a run they could point at
+    d1[(size_t)r * lpp + ll] = n1;
+    n1 += a;
+  }
+  for (int r = 0; r < parts; ++r) {
+    const uint32_t *hdr = reinterpret_cast<const uint32_t *>(packed + rr.rstart[r]);
+    d0[(size_t)r * lpp + ll] = n1 + n0;
+    n0 += (uint64_t)hdr[3 * ll + 1] + hdr[3 * ll + 2];         // (a note becomes a record again)
+  }
+  if (n1 > 0xFFFFFFFFull || n0 > 0xFFFFFFFFull) err = 1;
+  lcap[(size_t)NC * ll + CI1] = (uint32_t)n1;
+  lcap[(size_t)NC * ll + CI0] = (uint32_t)n0;
+  if (err) out[1] = 1;
+}
+
+// parts + 1 workgroups: workgroup r < parts scans rank r's segment sizes, the last one the leaves' stream sizes
+template <int NC, int CI1, int CI0>
+__global__ __launch_bounds__(1024) void msp_runs_layout_kernel(RunsRecv rr, int parts, int lpp, int hrows,
+                                                               const uint32_t *__restrict__ rows,
+                                                               uint64_t *__restrict__ src, uint64_t *__restrict__ d1, uint64_t *__restrict__ d0,
+                                                               uint64_t *__restrict__ lbase, const uint32_t *__restrict__ lcap, uint32_t *__restrict__ cnt2,
+                                                               uint64_t *__restrict__ out /* [0]: records in all, [1]: err */) {
+  __shared__ unsigned long long wtot[16];
+  const int tid = threadIdx.x;
+  const int per = (lpp + 1023) / 1024;
+  if ((int)blockIdx.x < parts) {
+    // (1) rank r's segments: record offsets inside its part of the buffer
+    const int r = (int)blockIdx.x;
+    uint64_t mine = 0;
+    for (int q = 0; q < per; ++q) {
+      const int ll = tid * per + q;
+      if (ll < lpp) mine += rows[(size_t)r * lpp + ll];
+    }
+    uint64_t total;
+    uint64_t run = block_scan_u64(mine, wtot, &total);
+    if (total + (uint64_t)hrows != rr.rows[r]) out[1] = 1;
+    for (int q = 0; q < per; ++q) {
+      const int ll = tid * per + q;
+      if (ll >= lpp) break;
+      src[(size_t)r * lpp + ll] = rr.rstart[r] + (uint64_t)hrows + run;
+      run += rows[(size_t)r * lpp + ll];
+    }
+    return;
+  }
+  // (2) the owner's leaves = local indices: stream (ll, class) = the ranks' parts in rank order, complete stream first
+  uint64_t mine = 0;
+  for (int q = 0; q < per; ++q) {
+    const int ll = tid * per + q;
+    if (ll < lpp) mine += (uint64_t)lcap[(size_t)NC * ll + CI0] + lcap[(size_t)NC * ll + CI1];
+  }
+  uint64_t total;
+  uint64_t run = block_scan_u64(mine, wtot, &total);
+  for (int q = 0; q < per; ++q) {
+    const int ll = tid * per + q;
+    if (ll >= lpp) break;
+    const uint32_t n1 = lcap[(size_t)NC * ll + CI1], n0 = lcap[(size_t)NC * ll + CI0];
+    for (int r = 0; r < parts; ++r) {              // relative -> absolute
+      d1[(size_t)r * lpp + ll] += run;
+      d0[(size_t)r * lpp + ll] += run;
+    }
+    lbase[(size_t)NC * ll + CI1] = run; cnt2[(size_t)NC * ll + CI1] = n1;
+    lbase[(size_t)NC * ll + CI0] = run + n1; cnt2[(size_t)NC * ll + CI0] = n0;
+    run += (uint64_t)n1 + n0;
+  }
+  if (tid == 0) out[0] = total;
+}
+

@@ -23,7 +23,7 @@
 //   --gpus N         chunks (per-read modes) or files (--batch) are dealt round-robin to N devices,
 //                    one cfrk_ctx pair per device; replaces the reference's pthread fan-out, whose
 //                    threads all use the same device (src/main.cu:208-230,277-295).  With --global
-//                    (16 <= k <= 32) the reads are range-partitioned over the N devices, every device
+//                    (16 <= k <= 64) the reads are range-partitioned over the N devices, every device
 //                    partitions and deduplicates its shard, and the owner of a leaf counts it (the
 //                    runs exchange of cfrk_abi.h, staged through host memory here)
 //   --batch N        the Swift/T workflow's loop (swift/cfrk.swf:15-20) in one process: for i < N
@@ -227,7 +227,8 @@ int run_global_multi(const Options &o, const cfrk_batch &batch, std::vector<std:
         }
         // distinct runs never exceed the shard's super-k-mers (about one per 8 bases), plus the headers;
         // a buffer that is too small is retried at four times the size
-        uint64_t cap = (uint64_t)(b1 - b0) / 4 + (uint64_t)N * 70000 + 4096;
+        // (k > 32: a record is two rows)
+        uint64_t cap = (uint64_t)(b1 - b0) / 4 * (o.k > 32 ? 2 : 1) + (uint64_t)N * 70000 + 4096;
         for (int attempt = 0; attempt < 3; ++attempt) {
           void *d = nullptr;
           if ((rc = cfrk_device_alloc(ctx, cap * 16, &d))) { refused[(size_t)sh] = 1; return; }
@@ -252,7 +253,7 @@ int run_global_multi(const Options &o, const cfrk_batch &batch, std::vector<std:
         return run_global(o, batch, per_dev[0][0], out);
       }
   }
-  std::vector<std::vector<uint64_t>> keys((size_t)N);
+  std::vector<std::vector<uint64_t>> keys((size_t)N), his((size_t)N);
   std::vector<std::vector<uint32_t>> cnts((size_t)N);
   {
     // owner ow gathers its segment of every shard DEVICE TO DEVICE (xGMI peer-to-peer between the
@@ -284,9 +285,8 @@ int run_global_multi(const Options &o, const cfrk_batch &batch, std::vector<std:
         }
         uint64_t n = 0;
         if ((rc = cfrk_global_finish(ctx, &n))) { status[(size_t)ow] = die(ctx, rc, "cfrk_global_finish"); return; }
-        keys[(size_t)ow].resize(n); cnts[(size_t)ow].resize(n);
-        std::vector<uint64_t> hi(n);
-        if ((rc = cfrk_global_export(ctx, keys[(size_t)ow].data(), hi.data(), cnts[(size_t)ow].data(), n, &n))) status[(size_t)ow] = die(ctx, rc, "cfrk_global_export");
+        keys[(size_t)ow].resize(n); cnts[(size_t)ow].resize(n); his[(size_t)ow].resize(n);
+        if ((rc = cfrk_global_export(ctx, keys[(size_t)ow].data(), his[(size_t)ow].data(), cnts[(size_t)ow].data(), n, &n))) status[(size_t)ow] = die(ctx, rc, "cfrk_global_export");
       });
     for (auto &t : th) t.join();
     free_packed();
@@ -295,16 +295,23 @@ int run_global_multi(const Options &o, const cfrk_batch &batch, std::vector<std:
   // N ascending lists with disjoint keys -> one ascending list
   size_t total = 0;
   for (auto &kk : keys) total += kk.size();
-  std::vector<uint64_t> mk(total);
+  std::vector<uint64_t> mk(total), mh(total);
   std::vector<uint32_t> mc(total);
   std::vector<size_t> at((size_t)N, 0);
+  // (the high words are zero for k <= 32)
+  auto less = [&](int a, int b) {
+    const size_t ia = at[(size_t)a], ib = at[(size_t)b];
+    const uint64_t ha = his[(size_t)a][ia], hb = his[(size_t)b][ib];
+    return ha != hb ? ha < hb : keys[(size_t)a][ia] < keys[(size_t)b][ib];
+  };
   for (size_t i = 0; i < total; ++i) {
     int best = -1;
     for (int q = 0; q < N; ++q)
-      if (at[(size_t)q] < keys[(size_t)q].size() && (best < 0 || keys[(size_t)q][at[(size_t)q]] < keys[(size_t)best][at[(size_t)best]])) best = q;
-    mk[i] = keys[(size_t)best][at[(size_t)best]]; mc[i] = cnts[(size_t)best][at[(size_t)best]]; ++at[(size_t)best];
+      if (at[(size_t)q] < keys[(size_t)q].size() && (best < 0 || less(q, best))) best = q;
+    const size_t ib = at[(size_t)best]++;
+    mk[i] = keys[(size_t)best][ib]; mh[i] = his[(size_t)best][ib]; mc[i] = cnts[(size_t)best][ib];
   }
-  write_global(o, mk.data(), nullptr, mc.data(), total, out);
+  write_global(o, mk.data(), mh.data(), mc.data(), total, out);
   return 0;
 }
 
@@ -316,7 +323,7 @@ int run_file(const Options &o, const char *in, const char *outp, std::vector<Wor
   if (rc) { fprintf(stderr, "cfrk: cannot read %s (error %d)\n", in, rc); return 1; }
   FILE *out = fopen(outp, "wb");                      // PrintFreq opens with "w" even when empty
   if (!out) { fprintf(stderr, "cfrk: cannot write %s\n", outp); cfrk_host_free_batch(&batch); return 1; }
-  if (o.global && per_dev && per_dev->size() > 1 && o.k >= 16 && o.k <= 32 && batch.nS >= (int64_t)per_dev->size()) rc = run_global_multi(o, batch, *per_dev, out);
+  if (o.global && per_dev && per_dev->size() > 1 && o.k >= 16 && o.k <= 64 && batch.nS >= (int64_t)per_dev->size()) rc = run_global_multi(o, batch, *per_dev, out);
   else rc = o.global ? run_global(o, batch, workers[0], out) : run_per_read(o, batch, workers, out);
   fclose(out);
   cfrk_host_free_batch(&batch);

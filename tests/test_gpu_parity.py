@@ -1131,6 +1131,79 @@ def test_runs_exchange_emulated_ranks_equals_one_gpu_and_oracle(ctx, k, canonica
         assert total_rows - world * world * ((lpp * 12 + 15) // 16) < 3 * R
 
 
+@pytest.mark.parametrize("k,canonical,world,G,dbg", [
+    (63, True, 2, 30_000, 0), (40, True, 8, 30_000, 0), (33, False, 3, 30_000, 0), (64, True, 4, 1_200, 0),
+    (47, True, 2, 5_000_000, 0), (55, True, 4, 30_000, "subsets"), (63, True, 2, 30_000, "rt_overflow"),
+    (44, True, 3, 30_000, "chunked"), (63, False, 2, 1_200, "subsets")])
+def test_runs_exchange_two_word_keys_emulated_ranks_equal_the_oracle(ctx, k, canonical, world, G, dbg):
+    """The runs exchange for 33 <= k <= 64 (32-byte records travel as two rows): `world`
+    emulated ranks partition and deduplicate their read range, the owners count what they receive;
+    the union of the owners' results equals the oracle's count of ALL reads, key by key.  Variants:
+    leaves shared by record on ranks and owners, a record table that overflows (no deduplication,
+    multiplicity 1), ranks that partition in chunks."""
+    import cfrk_amd
+    R, L = 16_000, 150
+    data, _, _ = orc.synth_reads(0, R, L, G)
+    data = data.copy()
+    data[::1013] = -1
+    data.reshape(R, L + 1)[:, L] = -1
+    flags = cfrk_amd.CFRK_CANONICAL if canonical else 0
+    dflags = {0: 0, "subsets": cfrk_amd.lib.CFRK_DEBUG_RECORD_SUBSETS, "rt_overflow": cfrk_amd.lib.CFRK_DEBUG_FORCE_RT_OVERFLOW,
+              "chunked": cfrk_amd.lib.CFRK_DEBUG_SMALL_PIPELINE}[dbg]
+    sends = []
+    for r in range(world):
+        r0, r1 = R * r // world, R * (r + 1) // world
+        shard = data[r0 * (L + 1):r1 * (L + 1)]
+        g = cfrk_amd.GlobalCounter(ctx, k, flags | cfrk_amd.CFRK_RUNS_ONLY, 2 * G)
+        g.set_debug_flags(dflags)
+        g.add(shard)
+        with pytest.raises(cfrk_amd.CfrkError):       # a job that holds runs has no counts
+            g.digest()
+        with pytest.raises(cfrk_amd.CfrkError):       # ... and takes one add
+            g.add(shard)
+        cap = 1 << 20
+        d = ctx.alloc(cap * 16)
+        with pytest.raises(cfrk_amd.CfrkError) as ei: # a buffer that is too small is reported, not overrun
+            g.export_runs_device(d, 1000, world)
+        assert ei.value.code == -9
+        rows = g.export_runs_device(d, cap, world)
+        host = np.empty((sum(rows), 2), np.uint64)
+        ctx.d2h(host, d)
+        ctx.free(d)
+        g.set_debug_flags(0)
+        sends.append((host, rows))
+    merged = {}
+    total_rows = 0
+    for owner in range(world):
+        segs, recv = [], []
+        for host, rows in sends:
+            a = sum(rows[:owner])
+            segs.append(host[a:a + rows[owner]])
+            recv.append(rows[owner])
+        buf = np.concatenate(segs)
+        total_rows += len(buf)
+        d = ctx.alloc(max(len(buf), 1) * 16)
+        ctx.h2d(d, buf)
+        og = cfrk_amd.GlobalCounter(ctx, k, flags, 2 * G)
+        og.set_debug_flags(dflags & ~cfrk_amd.lib.CFRK_DEBUG_SMALL_PIPELINE)
+        og.merge_runs_device(d, recv)
+        lo, hi, cnt = og.export()
+        og.set_debug_flags(0)
+        ctx.free(d)
+        for a, b, c in zip(lo, hi, cnt):
+            key = (int(b) << 64) | int(a)
+            assert key not in merged                  # owners hold disjoint key sets
+            merged[key] = int(c)
+    wlo, whi, wcnt = orc.global_count(data, k, orc.ORC_CANONICAL if canonical else 0, threads=4)
+    assert len(merged) == len(wlo)
+    assert all(merged[(int(b) << 64) | int(a)] == int(c) for a, b, c in zip(wlo, whi, wcnt))
+    # deduplication really happened on the ranks, and read ends travel as notes: far fewer rows than the
+    # two per super-k-mer (>= 8 per read at these k) that undeduplicated records would take
+    lpp = (65536 + world - 1) // world
+    if G <= 30_000 and dbg != "rt_overflow":
+        assert total_rows - world * world * ((lpp * 12 + 15) // 16) < 8 * R
+
+
 def test_runs_exchange_notes_outnumber_the_rows_that_carry_them(ctx):
     """300 k reads of a 1200-base genome on two emulated ranks: 600 k read ends travel as 75 k rows of
     notes, so an owner's leaf streams hold several times more records than the rows it received (the
@@ -1168,18 +1241,20 @@ def test_runs_exchange_notes_outnumber_the_rows_that_carry_them(ctx):
     assert len(lo) == len(wlo) and (lo[order] == wlo).all() and (cnt[order].astype(np.uint64) == wcnt).all()
 
 
-def test_runs_exchange_call_sequence_and_malformed_messages(ctx):
-    """error behaviour of the runs exchange: CFRK_RUNS_ONLY outside 16 <= k <= 32, a second add,
+@pytest.mark.parametrize("K", [31, 63])
+def test_runs_exchange_call_sequence_and_malformed_messages(ctx, K):
+    """error behaviour of the runs exchange (one-word and two-word records): CFRK_RUNS_ONLY outside 16 <= k <= 64, a second add,
     counts asked of a job that holds runs, a too small send buffer (the needed size is reported and the
     export can be repeated), an owner that is not fresh, and a received segment whose header does not
     add up to its rows"""
     import cfrk_amd
     data, _, _ = orc.synth_reads(0, 4000, 150, 20_000)
-    for k in (15, 33):
+    for k, fl in ((15, 0), (65, 0), (K, cfrk_amd.CFRK_FORCE_HASH)):
         with pytest.raises(cfrk_amd.CfrkError) as e:
-            cfrk_amd.GlobalCounter(ctx, k, cfrk_amd.CFRK_CANONICAL | cfrk_amd.CFRK_RUNS_ONLY, 1000)
+            cfrk_amd.GlobalCounter(ctx, k, cfrk_amd.CFRK_CANONICAL | cfrk_amd.CFRK_RUNS_ONLY | fl, 1000)
         assert e.value.code == -1
-    g = cfrk_amd.GlobalCounter(ctx, 31, cfrk_amd.CFRK_CANONICAL | cfrk_amd.CFRK_RUNS_ONLY, 100_000)
+    rm = 2 if K > 32 else 1                                    # rows per record
+    g = cfrk_amd.GlobalCounter(ctx, K, cfrk_amd.CFRK_CANONICAL | cfrk_amd.CFRK_RUNS_ONLY, 100_000)
     g.add(data)
     with pytest.raises(cfrk_amd.CfrkError) as e:
         g.add(data)
@@ -1196,7 +1271,7 @@ def test_runs_exchange_call_sequence_and_malformed_messages(ctx):
     host = np.empty((sum(rows), 2), np.uint64)
     ctx.d2h(host, d)
     # a counting job cannot export runs, a runs job cannot be the owner
-    gc = cfrk_amd.GlobalCounter(ctx, 31, cfrk_amd.CFRK_CANONICAL, 100_000)
+    gc = cfrk_amd.GlobalCounter(ctx, K, cfrk_amd.CFRK_CANONICAL, 100_000)
     gc.add(data)
     with pytest.raises(cfrk_amd.CfrkError) as e:
         gc.export_runs_device(d, (1 << 24) // 16, 2)
@@ -1208,12 +1283,12 @@ def test_runs_exchange_call_sequence_and_malformed_messages(ctx):
     seg0 = host[:rows[0]]
     buf = np.concatenate([seg0, seg0])
     ctx.h2d(d, buf)
-    og = cfrk_amd.GlobalCounter(ctx, 31, cfrk_amd.CFRK_CANONICAL, 100_000)
+    og = cfrk_amd.GlobalCounter(ctx, K, cfrk_amd.CFRK_CANONICAL, 100_000)
     og.merge_runs_device(d, [rows[0], rows[0]])
     lo, hi, cnt = og.export()
-    wlo, _, wcnt = orc.global_count(data, 31, orc.ORC_CANONICAL)
+    wlo, _, wcnt = orc.global_count(data, K, orc.ORC_CANONICAL)
     assert 0 < len(lo) < len(wlo) and int(cnt.sum()) % 2 == 0        # owner 0's leaves only, every count doubled
-    og2 = cfrk_amd.GlobalCounter(ctx, 31, cfrk_amd.CFRK_CANONICAL, 100_000)
+    og2 = cfrk_amd.GlobalCounter(ctx, K, cfrk_amd.CFRK_CANONICAL, 100_000)
     with pytest.raises(cfrk_amd.CfrkError) as e:
         og2.merge_runs_device(d, [rows[0] - 1, rows[0] + 1])
     assert e.value.code == -1
@@ -1223,14 +1298,14 @@ def test_runs_exchange_call_sequence_and_malformed_messages(ctx):
     # announces notes for a leaf without runs is refused
     lpp = 65536 // 2
     hdr = seg0.reshape(-1).view(np.uint32)[:3 * lpp].reshape(lpp, 3).copy()
-    rows_of = hdr[:, 0].astype(np.int64) + hdr[:, 1] + (hdr[:, 2].astype(np.int64) + 7) // 8
+    rows_of = rm * (hdr[:, 0].astype(np.int64) + hdr[:, 1]) + (hdr[:, 2].astype(np.int64) + 7) // 8
     first = np.concatenate([[0], np.cumsum(rows_of)[:-1]]) + (lpp * 12 + 15) // 16
     ll = int(np.argmax(hdr[:, 2] > 0))
     assert hdr[ll, 2] > 0 and hdr[:, 2].sum() > 0.5 * (hdr[:, 1].sum() + hdr[:, 2].sum())   # most read ends are notes
     bad = seg0.copy()
-    bad.reshape(-1).view(np.uint16)[8 * int(first[ll] + hdr[ll, 0] + hdr[ll, 1])] = (1023 << 5) | 31
+    bad.reshape(-1).view(np.uint16)[8 * int(first[ll] + rm * (int(hdr[ll, 0]) + int(hdr[ll, 1])))] = (1023 << 5) | 31
     ctx.h2d(d, np.concatenate([bad, seg0]))
-    og3 = cfrk_amd.GlobalCounter(ctx, 31, cfrk_amd.CFRK_CANONICAL, 100_000)
+    og3 = cfrk_amd.GlobalCounter(ctx, K, cfrk_amd.CFRK_CANONICAL, 100_000)
     og3.merge_runs_device(d, [rows[0], rows[0]])
     assert og3.finish() > 0
     bad = seg0.copy()
@@ -1241,7 +1316,7 @@ def test_runs_exchange_call_sequence_and_malformed_messages(ctx):
     bh[3 * one + 2] -= 1                                      # (the rows still add up)
     bh[3 * empty + 2] = 1
     ctx.h2d(d, np.concatenate([bad, seg0]))
-    og4 = cfrk_amd.GlobalCounter(ctx, 31, cfrk_amd.CFRK_CANONICAL, 100_000)
+    og4 = cfrk_amd.GlobalCounter(ctx, K, cfrk_amd.CFRK_CANONICAL, 100_000)
     with pytest.raises(cfrk_amd.CfrkError) as e:
         og4.merge_runs_device(d, [rows[0], rows[0]])
     assert e.value.code == -1
@@ -1271,7 +1346,7 @@ def test_cli_global_over_several_devices_equals_one_device(tmp_path):
     fa = tmp_path / "g.fasta"
     fa.write_text("".join(f">r{i}\n{s}\n" for i, s in enumerate(seqs)))
     one = tmp_path / "one.cfrk"
-    for k, extra in ((31, ["--canonical"]), (21, [])):
+    for k, extra in ((31, ["--canonical"]), (21, []), (63, ["--canonical"]), (40, ["--binary"])):
         subprocess.check_call([cli, str(fa), str(one), str(k), "--global"] + extra)
         for n in (2, 3):
             many = tmp_path / f"many{n}.cfrk"

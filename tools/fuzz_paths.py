@@ -3,7 +3,7 @@
 minutes for: for random (k, read shape, genome size, strand flag, capacity hint, memory budget)
 the partitioned / radix path must give the digest of the general HBM-table path (whose agreement
 with the oracle the parity tests pin key by key) and sum(count) must equal the number of valid
-k-mers; for 16 <= k <= 32 the runs exchange over 2..5 emulated ranks must give the same digest too.
+k-mers; for 16 <= k <= 64 the runs exchange over 2..5 emulated ranks must give the same digest too.
 usage (GPU box): tools/fuzz_paths.py [seconds [seed]]      prints one line per case, exits 1 on a mismatch"""
 import os
 import sys
@@ -77,7 +77,7 @@ while time.time() < t_end:
         del g
         ok = got == want and got[1] == nk
         line = f"{tag} passes={passes}{' shared' if shared else ''}{' chunked' if chunked else ''} distinct={got[0]} {'ok' if ok else 'MISMATCH ' + str(got) + ' != ' + str(want)}"
-        if ok and 16 <= k <= 32 and rng.random() < 0.5:
+        if ok and 16 <= k <= 64 and rng.random() < 0.5:
             world = int(rng.integers(2, 6))
             Rl = [R * r // world for r in range(world + 1)]
             sends = []
@@ -90,7 +90,7 @@ while time.time() < t_end:
                 ctx.sync()
                 gr.add_device(dsh, nsh)
                 ctx.free(dsh)
-                cap = 4 * (Rl[r + 1] - Rl[r]) * max(2, (L - k + 1) // 4) + (1 << 18)
+                cap = (2 if k > 32 else 1) * 4 * (Rl[r + 1] - Rl[r]) * max(2, (L - k + 1) // 4) + (1 << 18)   # (k > 32: two rows per record)
                 buf = ctx.alloc(cap * 16)
                 try:
                     rows = gr.export_runs_device(buf, cap, world)

@@ -34,7 +34,7 @@ d = torch.empty(nN + 64, dtype=torch.int8, device=dev)
 
 t_count, t_export, wire = [], [], []
 segs, rows0 = [], []
-buf = None if leaf_mode else torch.empty((max(1 << 20, int(min(14 * Rl, 2.5 * Rl + 0.3 * R)) + (1 << 17)), 2), dtype=torch.int64, device=dev)   # the send buffer lives across steps
+buf = None if leaf_mode else torch.empty((max(1 << 20, int(min(14 * Rl, 2.5 * Rl + 0.3 * R)) * (2 if k > 32 else 1) + (1 << 17)), 2), dtype=torch.int64, device=dev)   # the send buffer lives across steps
 keys = cnt = lc = None
 for r in range(world):
     ctx.synth_reads_device(r * Rl, Rl, L, R, d.data_ptr())
