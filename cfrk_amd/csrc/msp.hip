@@ -1599,8 +1599,9 @@ __global__ __launch_bounds__(DX_THREADS) void msp_dedupe_export_kernel(int k, in
 // notes, rows in all -- one thread per leaf, coalesced (the plan kernel below used to gather these
 // four words per leaf itself, three times over, 64 dependent strided loads per thread each time:
 // 0.50 ms of a 5.9 ms critical path at N = 8)
-__global__ __launch_bounds__(256) void msp_runs_sizes_kernel(MspView v, uint4 *__restrict__ sz) {
+__global__ __launch_bounds__(256) void msp_runs_sizes_kernel(MspView v, uint4 *__restrict__ sz, unsigned long long *__restrict__ plan_sync) {
   const uint32_t leaf = blockIdx.x * 256u + threadIdx.x;
+  if (leaf < 72u) plan_sync[leaf] = 0ull;                      // (the plan kernel's look-back words)
   if (leaf >= (uint32_t)NLEAF) return;
   uint32_t n1 = 0, na = 0;
   uint32_t nt = (uint32_t)min((uint64_t)v.cnt2[NCLS * leaf + 0], v.exact ? (uint64_t)v.lcap[NCLS * leaf + 0] : v.cap2t);
@@ -1615,7 +1616,7 @@ __global__ __launch_bounds__(256) void msp_runs_sizes_kernel(MspView v, uint4 *_
 // sender: leaf -> [nd distinct complete runs][nu truncated runs][na notes, 8 per row] at record
 // dst_off[leaf] of the send buffer (the truncated stream holds records and noted records mixed)
 __global__ __launch_bounds__(256) void msp_runs_gather_kernel(MspView v, const uint64_t *__restrict__ dst_off, uint4 *__restrict__ out,
-                                                              const uint64_t *__restrict__ plan_rows, int parts, uint64_t cap_rows) {
+                                                              const uint64_t *__restrict__ plan_rows, const uint64_t *__restrict__ seg_start, int parts, uint64_t cap_rows) {
   __shared__ uint32_t cu, cn;
   if (plan_rows[parts] > cap_rows) return;         // the buffer is too small: nothing was planned
   const uint32_t leaf = blockIdx.x;
@@ -1625,6 +1626,7 @@ __global__ __launch_bounds__(256) void msp_runs_gather_kernel(MspView v, const u
   const uint32_t nt = (uint32_t)min((uint64_t)v.cnt2[NCLS * leaf + 0], v.exact ? (uint64_t)v.lcap[NCLS * leaf + 0] : v.cap2t);
   const uint32_t na = has1 ? min((uint32_t)v.leaf_off[leaf], nt) : 0u;
   const uint32_t nu = nt - na;
+  if (threadIdx.x == 0) runs_write_header(out, seg_start, parts, blockIdx.x, nd, nu, na);
   const uint4 *c1 = v.exact ? v.rec2 + v.lbase[NCLS * leaf + 1] : v.rec2 + (uint64_t)(leaf >> v.sel_bits) * (v.cap2c + v.cap2t);
   const uint4 *c0 = v.exact ? v.rec2 + v.lbase[NCLS * leaf + 0] : c1 + v.cap2c;
   uint4 *dst = out + dst_off[leaf];
@@ -2349,26 +2351,29 @@ extern "C" int cfrk_global_export_runs_device(cfrk_ctx *ctx, void *d_packed, uin
   void *p;
   // offsets, headers and segment sizes are worked out on the device (one workgroup); the host
   // only learns the segment sizes -- together with the job's flags, in ONE copy
-  if ((rc = cfrk_pool_get(ctx, BUF_SCRATCH, (NLEAF + 65 + ST_NWORDS) * sizeof(uint64_t) + (size_t)NLEAF * sizeof(uint4), &p))) return rc;
+  if ((rc = cfrk_pool_get(ctx, BUF_SCRATCH, (NLEAF + 65 + ST_NWORDS + 1 + 64 + 72) * sizeof(uint64_t) + (size_t)NLEAF * sizeof(uint4), &p))) return rc;
   uint64_t *d_off = (uint64_t *)p, *d_rows = d_off + NLEAF;
-  uint4 *d_sz = (uint4 *)(d_rows + 65 + ST_NWORDS + 1);      // (16-byte aligned: the pool is, and NLEAF + 65 + ST_NWORDS + 1 is even)
-  static_assert((NLEAF + 65 + ST_NWORDS + 1) % 2 == 0, "d_sz is 16-byte aligned");
-  hipLaunchKernelGGL(msp_runs_sizes_kernel, dim3(NLEAF / 256), dim3(256), 0, ctx->stream, v, d_sz);
+  uint64_t *d_seg = d_rows + 65 + ST_NWORDS + 1;
+  unsigned long long *d_sync = (unsigned long long *)(d_seg + 64);
+  uint4 *d_sz = (uint4 *)(d_sync + 72);      // (16-byte aligned: the pool is, and NLEAF + 65 + ST_NWORDS + 1 is even)
+  static_assert((NLEAF + 65 + ST_NWORDS + 1 + 64 + 72) % 2 == 0, "d_sz is 16-byte aligned");
+  hipLaunchKernelGGL(msp_runs_sizes_kernel, dim3(NLEAF / 256), dim3(256), 0, ctx->stream, v, d_sz, d_sync);
   HIP_TRY(ctx, hipGetLastError());
-  hipLaunchKernelGGL(msp_runs_plan_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint4 *)d_sz, parts, lpp, hrows, d_off, (uint4 *)d_packed,
-                     cap_rows, d_rows);
+  hipLaunchKernelGGL(msp_runs_plan_kernel, dim3(runs_plan_grid(parts, lpp)), dim3(1024), 0, ctx->stream, (const uint4 *)d_sz, parts, lpp, hrows, d_off,
+                     d_rows + parts, d_seg, d_sync);
   HIP_TRY(ctx, hipGetLastError());
   hipLaunchKernelGGL(msp_runs_gather_kernel, dim3(NLEAF), dim3(256), 0, ctx->stream, v, (const uint64_t *)d_off, (uint4 *)d_packed,
-                     (const uint64_t *)d_rows, parts, cap_rows);
+                     (const uint64_t *)d_rows, (const uint64_t *)d_seg, parts, cap_rows);
   HIP_TRY(ctx, hipGetLastError());
-  uint64_t h[65 + ST_NWORDS];
+  // [0, 65): all rows at [parts]; then the job's flags; then the segment starts -- ONE copy
+  uint64_t h[65 + ST_NWORDS + 1 + 64];
   HIP_TRY(ctx, hipMemcpyAsync(d_rows + 65, ctx->g_stats, ST_NWORDS * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(h, d_rows, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  const uint64_t *st = h + 65;
+  const uint64_t *st = h + 65, *seg = h + 65 + ST_NWORDS + 1;
   if (st[ST_SPILLED] || st[ST_ONES]) return cfrk_fail(ctx, CFRK_ERR_STATE, "part of the batch was counted in the HBM table");
   if (h[parts] > cap_rows) return cfrk_fail(ctx, CFRK_ERR_SMALL_BUF, "%llu rows, room for %llu", (unsigned long long)h[parts], (unsigned long long)cap_rows);
-  for (int q = 0; q < parts; ++q) part_rows[q] = h[q];
+  for (int q = 0; q < parts; ++q) part_rows[q] = (q + 1 < parts ? seg[q + 1] : h[parts]) - seg[q];
   return CFRK_OK;
 }
 

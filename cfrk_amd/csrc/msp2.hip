@@ -1460,8 +1460,9 @@ __global__ __launch_bounds__(DX2_THREADS) void msp2_dedupe_export_kernel(int k, 
 
 // sender: what every leaf contributes -- n1 distinct complete runs, nt truncated runs as records, na as
 // notes, rows in all (two per record) -- one thread per leaf
-__global__ __launch_bounds__(256) void msp2_runs_sizes_kernel(View2 v, uint4 *__restrict__ sz) {
+__global__ __launch_bounds__(256) void msp2_runs_sizes_kernel(View2 v, uint4 *__restrict__ sz, unsigned long long *__restrict__ plan_sync) {
   const uint32_t leaf = blockIdx.x * 256u + threadIdx.x;
+  if (leaf < 72u) plan_sync[leaf] = 0ull;                      // (the plan kernel's look-back words)
   if (leaf >= (uint32_t)NLEAF) return;
   uint32_t n1 = 0, na = 0;
   uint32_t nt = x2_count(v, leaf, 0) + x2_count(v, leaf, 1) + x2_count(v, leaf, 2);
@@ -1476,7 +1477,7 @@ __global__ __launch_bounds__(256) void msp2_runs_sizes_kernel(View2 v, uint4 *__
 // sender: leaf -> [nd distinct complete runs][nu truncated runs][na notes, 8 per row] at row dst_off[leaf]
 // of the send buffer (the three truncated streams hold records and noted records mixed)
 __global__ __launch_bounds__(256) void msp2_runs_gather_kernel(View2 v, const uint64_t *__restrict__ dst_off, uint4 *__restrict__ out,
-                                                               const uint64_t *__restrict__ plan_rows, int parts, uint64_t cap_rows) {
+                                                               const uint64_t *__restrict__ plan_rows, const uint64_t *__restrict__ seg_start, int parts, uint64_t cap_rows) {
   __shared__ uint32_t cu, cn;
   if (plan_rows[parts] > cap_rows) return;         // the buffer is too small: nothing was planned
   const uint32_t leaf = blockIdx.x;
@@ -1486,6 +1487,7 @@ __global__ __launch_bounds__(256) void msp2_runs_gather_kernel(View2 v, const ui
   const uint32_t t0 = x2_count(v, leaf, 0), t1 = t0 + x2_count(v, leaf, 1), nt = t1 + x2_count(v, leaf, 2);
   const uint32_t na = has1 ? min((uint32_t)v.leaf_off[leaf], nt) : 0u;
   const uint32_t nu = nt - na;
+  if (threadIdx.x == 0) runs_write_header(out, seg_start, parts, blockIdx.x, nd, nu, na);
   const Rec2 *c3 = x2_stream(v, leaf, 3);
   const Rec2 *s0 = x2_stream(v, leaf, 0), *s1 = x2_stream(v, leaf, 1), *s2 = x2_stream(v, leaf, 2);
   auto trunc_at = [&](uint32_t g) { return (g < t0) ? s0 + g : (g < t1) ? s1 + (g - t0) : s2 + (g - t1); };
@@ -1873,26 +1875,29 @@ int cfrk_msp2_export_runs(cfrk_ctx *ctx, void *d_packed, uint64_t cap_rows, int 
   const int hrows = runs_header_rows(lpp);
   int rc;
   void *p;
-  if ((rc = cfrk_pool_get(ctx, BUF_SCRATCH, (NLEAF + 65 + ST_NWORDS) * sizeof(uint64_t) + (size_t)NLEAF * sizeof(uint4), &p))) return rc;
+  if ((rc = cfrk_pool_get(ctx, BUF_SCRATCH, (NLEAF + 65 + ST_NWORDS + 1 + 64 + 72) * sizeof(uint64_t) + (size_t)NLEAF * sizeof(uint4), &p))) return rc;
   uint64_t *d_off = (uint64_t *)p, *d_rows = d_off + NLEAF;
-  uint4 *d_sz = (uint4 *)(d_rows + 65 + ST_NWORDS + 1);      // (16-byte aligned: the pool is, and NLEAF + 65 + ST_NWORDS + 1 is even)
-  static_assert((NLEAF + 65 + ST_NWORDS + 1) % 2 == 0, "d_sz is 16-byte aligned");
-  hipLaunchKernelGGL(msp2_runs_sizes_kernel, dim3(NLEAF / 256), dim3(256), 0, ctx->stream, v, d_sz);
+  uint64_t *d_seg = d_rows + 65 + ST_NWORDS + 1;
+  unsigned long long *d_sync = (unsigned long long *)(d_seg + 64);
+  uint4 *d_sz = (uint4 *)(d_sync + 72);      // (16-byte aligned: the pool is, and NLEAF + 65 + ST_NWORDS + 1 is even)
+  static_assert((NLEAF + 65 + ST_NWORDS + 1 + 64 + 72) % 2 == 0, "d_sz is 16-byte aligned");
+  hipLaunchKernelGGL(msp2_runs_sizes_kernel, dim3(NLEAF / 256), dim3(256), 0, ctx->stream, v, d_sz, d_sync);
   HIP_TRY(ctx, hipGetLastError());
-  hipLaunchKernelGGL(msp_runs_plan_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint4 *)d_sz, parts, lpp, hrows, d_off, (uint4 *)d_packed,
-                     cap_rows, d_rows);
+  hipLaunchKernelGGL(msp_runs_plan_kernel, dim3(runs_plan_grid(parts, lpp)), dim3(1024), 0, ctx->stream, (const uint4 *)d_sz, parts, lpp, hrows, d_off,
+                     d_rows + parts, d_seg, d_sync);
   HIP_TRY(ctx, hipGetLastError());
   hipLaunchKernelGGL(msp2_runs_gather_kernel, dim3(NLEAF), dim3(256), 0, ctx->stream, v, (const uint64_t *)d_off, (uint4 *)d_packed,
-                     (const uint64_t *)d_rows, parts, cap_rows);
+                     (const uint64_t *)d_rows, (const uint64_t *)d_seg, parts, cap_rows);
   HIP_TRY(ctx, hipGetLastError());
-  uint64_t h[65 + ST_NWORDS];
+  // [0, 65): all rows at [parts]; then the job's flags; then the segment starts -- ONE copy
+  uint64_t h[65 + ST_NWORDS + 1 + 64];
   HIP_TRY(ctx, hipMemcpyAsync(d_rows + 65, ctx->g_stats, ST_NWORDS * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(h, d_rows, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  const uint64_t *st = h + 65;
+  const uint64_t *st = h + 65, *seg = h + 65 + ST_NWORDS + 1;
   if (st[ST_SPILLED] || st[ST_ONES]) return cfrk_fail(ctx, CFRK_ERR_STATE, "part of the batch was counted in the HBM table");
   if (h[parts] > cap_rows) return cfrk_fail(ctx, CFRK_ERR_SMALL_BUF, "%llu rows, room for %llu", (unsigned long long)h[parts], (unsigned long long)cap_rows);
-  for (int q = 0; q < parts; ++q) part_rows[q] = h[q];
+  for (int q = 0; q < parts; ++q) part_rows[q] = (q + 1 < parts ? seg[q + 1] : h[parts]) - seg[q];
   return CFRK_OK;
 }
 
