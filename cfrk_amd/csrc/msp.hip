@@ -1724,7 +1724,21 @@ __global__ __launch_bounds__(1024) void msp_sum_kernel(const uint32_t *__restric
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) mine += cnt[i];
   atomicAdd(&tot, mine);
   __syncthreads();
-  if (threadIdx.x == 0) *out = tot;
+  if (threadIdx.x == 0) { out[0] = tot; out[1] = 0; out[2] = 0; }
+}
+
+// ... and what share of them are truncated runs: the records of sub-region 0 of every level-1 bin (1/64
+// of the chunk, every bin in it) -- out[1] += records looked at, out[2] += truncated ones among them
+__global__ __launch_bounds__(256) void msp_class_sample_kernel(MspView v, unsigned long long *out) {
+  const uint32_t reg = l1_reg(blockIdx.x, 0u);
+  const uint32_t n = (uint32_t)min((uint64_t)v.cnt1[reg], v.cap1);
+  const uint32_t *w = reinterpret_cast<const uint32_t *>(v.rec1 + (uint64_t)reg * v.cap1) + 3;
+  uint32_t tr = 0;
+  for (uint32_t i = threadIdx.x; i < n; i += 256u) tr += ((w[4 * (size_t)i] & 192u) != 192u) ? 1u : 0u;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) tr += __shfl_xor(tr, d);
+  if ((threadIdx.x & 63) == 0 && tr) atomicAdd(&out[2], (unsigned long long)tr);
+  if (threadIdx.x == 0) atomicAdd(&out[1], (unsigned long long)n);
 }
 
 __global__ void msp_info_kernel(MspView v, uint64_t *out) {
@@ -1927,19 +1941,22 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
           // The leaf streams are sized from what the first chunk really made, not from the worst
           // density a batch of unknown read length could have (the estimate above allows for reads
           // as short as 2k: 1.34 x the records 150-base reads make, times 2.7 for lumpy leaves --
-          // 79 GB for C3's 21.9 GB of records).  One 8-byte read-back + sync per add.
+          // 79 GB for C3's 21.9 GB of records).  One 24-byte read-back + sync per add.
           if ((rc = cfrk_pool_get(ctx, BUF_SCRATCH, 64 * sizeof(uint64_t), &p))) return rc;
           hipLaunchKernelGGL(msp_sum_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)vc.cnt1, (uint32_t)nreg, (uint64_t *)p);
           HIP_TRY(ctx, hipGetLastError());
-          uint64_t made = 0;
-          HIP_TRY(ctx, hipMemcpyAsync(&made, p, sizeof made, hipMemcpyDeviceToHost, ctx->stream));
+          hipLaunchKernelGGL(msp_class_sample_kernel, dim3(B1), dim3(256), 0, ctx->stream, vc, (unsigned long long *)p);
+          HIP_TRY(ctx, hipGetLastError());
+          uint64_t made[3] = {0, 0, 0};               // records of the chunk; records sampled, truncated ones among them
+          HIP_TRY(ctx, hipMemcpyAsync(made, p, sizeof made, hipMemcpyDeviceToHost, ctx->stream));
           HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
           // records of this pass's leaves in the whole batch (+3 %: chunks differ a little), per leaf
-          const double per_leaf = (double)made * ((double)ntiles / (double)(t1 - t0)) * 1.03 / (double)(NLEAF >> sel_bits);
-          // complete runs are ~84 % of a deep batch's records, the heaviest stream of a uniform batch
-          // ~1.2 x the mean leaf; truncated runs (two per read + invalid bases) a fifth to a third
-          // (up to 0.7: 50-base reads at k = 31 make as many truncated runs as complete ones)
-          const uint64_t m2c = (uint64_t)(per_leaf * 1.3) + 512, m2t = (uint64_t)(per_leaf * 0.7) + 256;
+          const double per_leaf = (double)made[0] * ((double)ntiles / (double)(t1 - t0)) * 1.03 / (double)(NLEAF >> sel_bits);
+          // ... split into complete and truncated runs by the sample (truncated: two per read + invalid
+          // bases -- 16 % of a deep batch of 150-base reads, half of the records of 50-base reads at
+          // k = 31); the heaviest stream of a uniform batch is ~1.2 x the mean leaf
+          const double ft = made[1] >= 4096 ? std::min(1.0, (double)made[2] / (double)made[1] + 0.01) : 0.5;
+          const uint64_t m2c = (uint64_t)(per_leaf * (1.0 - ft) * 1.3 + per_leaf * 0.02) + 512, m2t = (uint64_t)(per_leaf * ft * 1.6) + 256;
           if (m2c + m2t < v.cap2c + v.cap2t) { v.cap2c = m2c; v.cap2t = m2t; }
           if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)(NLEAF >> sel_bits) * (v.cap2c + v.cap2t) * sizeof(uint4), &p))) return rc;
           v.rec2 = (uint4 *)p;

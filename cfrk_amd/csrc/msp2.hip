@@ -1241,7 +1241,21 @@ __global__ __launch_bounds__(1024) void msp2_sum_kernel(const uint32_t *__restri
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) mine += cnt[i];
   atomicAdd(&tot, mine);
   __syncthreads();
-  if (threadIdx.x == 0) *out = tot;
+  if (threadIdx.x == 0) { out[0] = tot; out[1] = out[2] = out[3] = out[4] = 0; }
+}
+
+// ... and how they split into the four classes of streams: the records of sub-region 0 of every level-1
+// bin (1/64 of the chunk, every bin in it) -- out[1 + class] += records of that class (msp.hip)
+__global__ __launch_bounds__(256) void msp2_class_sample_kernel(View2 v, unsigned long long *out) {
+  __shared__ uint32_t c[NCLS];
+  if (threadIdx.x < NCLS) c[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t reg = q1_reg(blockIdx.x, 0u);
+  const uint32_t n = (uint32_t)min((uint64_t)v.cnt1[reg], v.cap1);
+  const uint32_t *w = reinterpret_cast<const uint32_t *>(v.rec1 + (uint64_t)reg * v.cap1) + 7;
+  for (uint32_t i = threadIdx.x; i < n; i += 256u) atomicAdd(&c[cls_of(w[8 * (size_t)i])], 1u);
+  __syncthreads();
+  if (threadIdx.x < NCLS && c[threadIdx.x]) atomicAdd(&out[1 + threadIdx.x], (unsigned long long)c[threadIdx.x]);
 }
 
 __global__ __launch_bounds__(1024) void msp2_layout_kernel(const uint32_t *__restrict__ cnt, uint32_t n, uint64_t *__restrict__ base,
@@ -1714,13 +1728,21 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
           if ((rc = cfrk_pool_get(ctx, BUF_SCRATCH, 64 * sizeof(uint64_t), &sp))) return rc;
           hipLaunchKernelGGL(msp2_sum_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)v.cnt1, (uint32_t)nreg, (uint64_t *)sp);
           HIP_TRY(ctx, hipGetLastError());
-          uint64_t made = 0;
-          HIP_TRY(ctx, hipMemcpyAsync(&made, sp, sizeof made, hipMemcpyDeviceToHost, ctx->stream));
+          hipLaunchKernelGGL(msp2_class_sample_kernel, dim3(B1), dim3(256), 0, ctx->stream, v, (unsigned long long *)sp);
+          HIP_TRY(ctx, hipGetLastError());
+          uint64_t made[1 + NCLS] = {0, 0, 0, 0, 0};        // records of the chunk; of the sample, by class
+          HIP_TRY(ctx, hipMemcpyAsync(made, sp, sizeof made, hipMemcpyDeviceToHost, ctx->stream));
           HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-          // records of this pass's leaves in the whole batch (+3 %), per leaf; complete runs up to
-          // 1.3 x the mean leaf, each of the three classes of truncated runs up to 0.3 x
-          const double per_leaf = (double)made * ((double)ntiles / (double)(t1 - t0)) * 1.03 / (double)(NLEAF >> sel_bits);
-          v.cap2c = (uint64_t)(per_leaf * 1.3) + 512; v.cap2t = (uint64_t)(per_leaf * 0.3) + 256;
+          // records of this pass's leaves in the whole batch (+3 %), per leaf, split by the sample: complete
+          // runs up to 1.3 x their share of the mean leaf, the largest class of truncated runs up to 1.6 x its share
+          const double per_leaf = (double)made[0] * ((double)ntiles / (double)(t1 - t0)) * 1.03 / (double)(NLEAF >> sel_bits);
+          const uint64_t sampled = made[1] + made[2] + made[3] + made[4];
+          double fc = 0.75, ft = 0.3;
+          if (sampled >= 4096) {
+            fc = (double)made[4] / (double)sampled + 0.02;
+            ft = (double)std::max(made[1], std::max(made[2], made[3])) / (double)sampled + 0.01;
+          }
+          v.cap2c = (uint64_t)(per_leaf * std::min(1.0, fc) * 1.3) + 512; v.cap2t = (uint64_t)(per_leaf * std::min(1.0, ft) * 1.6) + 256;
           if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)(NLEAF >> sel_bits) * (v.cap2c + 3 * v.cap2t) * sizeof(Rec2), &p))) return rc;
           v.rec2 = (Rec2 *)p;
         }
