@@ -13,6 +13,7 @@ struct TableView;
 #define CFRK_ABL_P3_NO_OUT   0x800u   // leaf kernel: no compaction to the result list
 #define CFRK_ABL_P1_NO_EMIT  0x1000u  // partition kernel: front end only, no records built
 #define CFRK_ABL_P2_NO_ATOMIC 0x2000u // second-level kernel: no cursor atomics (every tile's segments land at the stream starts)
+#define CFRK_ABL_P2_LINEAR_OUT 0x4000u // second-level kernel: sorted tiles written back to back (what the scatter into 512 streams per bin costs)
 
 bool cfrk_msp_usable(const cfrk_ctx *ctx);                 // fast path applies to this begin()?
 int  cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN);

@@ -530,6 +530,10 @@ __device__ __forceinline__ void p2_item(uint4 *pool, uint32_t b1, uint32_t grp, 
     for (uint32_t p = tid; p < nt; p += P2_THREADS) {
       const uint4 rec = sorted[p];
       const uint32_t sb = sub_of(rec.w);
+      if (v.dbg & CFRK_ABL_P2_LINEAR_OUT) {                // timing ablation: the tile goes out as it lies in LDS, bin after bin
+        v.rec2[(uint64_t)b1 * (NSUB / 2) * (v.cap2c + v.cap2t) + r0 + p] = rec;
+        continue;
+      }
       if (p < (uint32_t)plim[sb]) { v.rec2[dabs[sb] + p] = rec; continue; }
       // the stream is full: park the record or raise the flag (below)
       const uint64_t leaf = ((uint64_t)b1 * NSUB + sb) >> 1;
