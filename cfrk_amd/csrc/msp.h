@@ -39,6 +39,7 @@ struct MspView {
   uint64_t *out_hi;                           // high key words of the list (two-word keys only)
   uint64_t *leaf_off; uint32_t *leaf_n;        // where each leaf's entries sit in the result list
   uint32_t seg_bits;                             // ... in 2^seg_bits segments, entry (leaf << seg_bits) | j (leaves shared by record, msp2.hip)
+  uint32_t sub_bits;                             // msp.hip: records carry so many sub-value bits in the header's top byte (0: none)
   // exact layout (after a leaf stream overflowed the fixed-stride layout): stream (leaf, class)
   // starts at record lbase[NCLS * leaf + class] and holds exactly lcap[...] records
   const uint64_t *lbase; const uint32_t *lcap; uint32_t exact;

@@ -88,6 +88,9 @@ constexpr int P1_WAVES = P1_THREADS / 64;
 // 256 bins of one sub-region side by side, a workgroup's 256 reservations are 16 requests instead
 // of 256.
 __host__ __device__ __forceinline__ uint32_t l1_reg(uint32_t bin, uint32_t xg) { return xg * (uint32_t)B1 + bin; }
+// level-1 bin of a record: the leaf id's high byte (header bits 16..23; the top byte may hold sub-value bits)
+template <bool SUB>
+__device__ __forceinline__ uint32_t bin_of(uint32_t w) { return SUB ? ((w >> 16) & (uint32_t)(B1 - 1)) : (w >> 16); }
 
 // write record `rec` as entry `dst` of level-1 region `reg`; a full region parks a few records and
 // beyond that raises ST_L1OVF (the cursors keep counting: the host redoes P1 with exact sizes)
@@ -123,9 +126,15 @@ __device__ __forceinline__ void l1_put(const MspView &v, uint32_t reg, uint32_t 
 // parameter (4 for W >= 16 ... 12 for W = 4), and so are registers and workgroups per CU.
 // P1B_TR = balanced trips held in registers (64 runs per wave each)
 // LDS of one P1 workgroup: per-wave staging (later the bin-sorted records), histogram, offsets
-template <int P1B_TR>
+// SUB: a job with far more distinct k-mers than the leaf tables hold (capacity hint > ~2.7e8) also stages
+// five bits of every position's minimizer hash that the leaf id does not use and writes them to the top
+// byte of the record's header word: the leaf kernel then splits an overfull leaf by RECORD, not by key,
+// so that every record is expanded once (msp2.hip does the same).  2 KB more staging per wave: two
+// workgroups per CU instead of three.
+constexpr int SUB_BITS = 5;
+template <int P1B_TR, bool SUB = false>
 struct P1Lds {
-  static constexpr int STAGE = 4096 + 3 * 512 + P1B_TR * 128;     // bytes of staging per wave
+  static constexpr int STAGE = 4096 + 3 * 512 + P1B_TR * 128 + (SUB ? 2048 : 0);     // bytes of staging per wave
   static constexpr int ARENA = P1_WAVES * STAGE;
   static constexpr int BYTES = ARENA + 2 * B1 * 4 + 32;
 };
@@ -135,16 +144,16 @@ struct P1Lds {
 // (One tile per workgroup, not a persistent loop: a looping workgroup waits at the top of every
 // tile for its input loads -- and, vmcnt being one in-order counter, for the previous tile's
 // stores before them; measured 16-28 % slower, profiles/r03/persistent_p1_is_slower.txt.)
-template <int W, int P1B_TR, bool EX>
+template <int W, int P1B_TR, bool EX, bool SUB>
 __device__ __forceinline__ void p1_tile(uint4 *pool, const int8_t *__restrict__ data, int64_t nN, int k, int m, int canon,
                                         int64_t tile, uint32_t subreg, const MspView &v, const TableView &t) {
   constexpr int NH = 32 + W - 1;
-  constexpr int P1B_STAGE = P1Lds<P1B_TR>::STAGE;
+  constexpr int P1B_STAGE = P1Lds<P1B_TR, SUB>::STAGE;
   // sorted records share the staging bytes; the last 2.5 KB hold the copy-out table (dabs, plim)
   constexpr int P1B_TAIL = B1 * 10;
   constexpr int P1B_RCAP = (P1_WAVES * P1B_STAGE - P1B_TAIL) / 16;
   uint4 *const arena = pool;                     // per-wave staging, later the bin-sorted records (P1B_RCAP of them)
-  uint32_t *const hist = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(pool) + P1Lds<P1B_TR>::ARENA);
+  uint32_t *const hist = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(pool) + P1Lds<P1B_TR, SUB>::ARENA);
   uint32_t *const loff = hist + B1;
   uint32_t *const wtot = loff + B1;              // 4 words
   uint32_t *const nrec_p = wtot + 4;
@@ -164,6 +173,7 @@ __device__ __forceinline__ void p1_tile(uint4 *pool, const int8_t *__restrict__ 
   uint64_t *const s_E = reinterpret_cast<uint64_t *>(stage + 4096 + 512);     // run terminators
   uint64_t *const s_W = reinterpret_cast<uint64_t *>(stage + 4096 + 1024);    // validity of position p-1
   uint16_t *const s_dsc = reinterpret_cast<uint16_t *>(stage + 4096 + 1536);  // (lane << 5) | position
+  uint8_t *const s_sub = stage + 4096 + 1536 + P1B_TR * 128;                  // [64 lanes][32 positions] (SUB only)
   if (tid < B1) hist[tid] = 0;
   lds_barrier();
 
@@ -216,6 +226,24 @@ __device__ __forceinline__ void p1_tile(uint4 *pool, const int8_t *__restrict__ 
     reinterpret_cast<uint2 *>(s_str)[lane] = make_uint2(b0, b1);
     s_E[lane] = E;
     s_W[lane] = (Vx >> 1) | ((uint64_t)prevV << 63);
+    if (SUB) {
+      // bits 24..27 and 7 of the packed minimum: hash bits, equal for every occurrence of a k-mer, that
+      // neither the leaf id (bits 8..23) nor the position tag (bits 0..4) uses; bit 7 -- the uniform one -- lowest
+      uint32_t sw[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        uint32_t x = 0;
+#pragma unroll
+        for (int j = 3; j >= 0; --j) {
+          const uint32_t h = H[4 * i + j];
+          x = (x << 8) | (((h >> 24) & 15u) << 1) | ((h >> 7) & 1u);
+        }
+        sw[i] = x;
+      }
+      uint4 *sp = reinterpret_cast<uint4 *>(s_sub + lane * 32);
+      sp[0] = make_uint4(sw[0], sw[1], sw[2], sw[3]);
+      sp[1] = make_uint4(sw[4], sw[5], sw[6], sw[7]);
+    }
   }
   if (v.dbg & CFRK_ABL_P1_NO_EMIT) {             // timing ablation: keep the front end alive, emit nothing
     if (S == 0x12345678u && (uint32_t)E == 0x9ABCDEFu) v.stats[ST_AUX0] = 1;
@@ -267,6 +295,7 @@ __device__ __forceinline__ void p1_tile(uint4 *pool, const int8_t *__restrict__ 
     rec.y = (uint32_t)(r12 >> 32);
     rec.z = (uint32_t)r12;
     rec.w = (leaf << 8) | flags | (uint32_t)(n - 1);
+    if (SUB) rec.w |= (uint32_t)s_sub[d] << 24;
     return rec;
   };
 
@@ -276,7 +305,7 @@ __device__ __forceinline__ void p1_tile(uint4 *pool, const int8_t *__restrict__ 
     S2 &= ~(0x80000000u >> a);
     const uint4 rec = build(((uint32_t)lane << 5) | (uint32_t)a);
     if (((rec.w >> 8) & v.sel_mask) != v.sel_val) continue;    // not a leaf of this pass
-    const uint32_t reg = l1_reg(rec.w >> 16, subreg);
+    const uint32_t reg = l1_reg(bin_of<SUB>(rec.w), subreg);
     const uint32_t dst = atomicAdd(&v.cnt1[reg], 1u);
     l1_put<EX>(v, reg, dst, rec, k, canon != 0, t);
   }
@@ -293,7 +322,7 @@ __device__ __forceinline__ void p1_tile(uint4 *pool, const int8_t *__restrict__ 
     if (i < cnt_w) {
       rc[tr] = build(s_dsc[i]);
       if (((rc[tr].w >> 8) & v.sel_mask) == v.sel_val)       // (all leaves, unless the batch takes several passes)
-        rk[tr] = atomicAdd(&hist[rc[tr].w >> 16], 1u);
+        rk[tr] = atomicAdd(&hist[bin_of<SUB>(rc[tr].w)], 1u);
     }
   }
   lds_barrier();
@@ -309,7 +338,7 @@ __device__ __forceinline__ void p1_tile(uint4 *pool, const int8_t *__restrict__ 
 #pragma unroll
   for (int tr = 0; tr < P1B_TR; ++tr) {
     if (rk[tr] != 0xFFFFFFFFu) {
-      const uint32_t pos = loff[rc[tr].w >> 16] + rk[tr];
+      const uint32_t pos = loff[bin_of<SUB>(rc[tr].w)] + rk[tr];
       if (pos < (uint32_t)P1B_RCAP) arena[pos] = rc[tr];
     }
   }
@@ -332,7 +361,7 @@ __device__ __forceinline__ void p1_tile(uint4 *pool, const int8_t *__restrict__ 
   const uint32_t nrec = min(nrec_s, (uint32_t)P1B_RCAP);
   for (uint32_t p = tid; p < nrec; p += P1_THREADS) {
     const uint4 rec = arena[p];
-    const uint32_t b = rec.w >> 16;
+    const uint32_t b = bin_of<SUB>(rec.w);
     if (p < (uint32_t)plim[b]) v.rec1[dabs[b] + p] = rec;
     else l1_put<EX>(v, l1_reg(b, subreg), gbase[b] + (p - loff[b]), rec, k, canon != 0, t);   // region full: park / flag
   }
@@ -340,7 +369,7 @@ __device__ __forceinline__ void p1_tile(uint4 *pool, const int8_t *__restrict__ 
 #pragma unroll
     for (int tr = 0; tr < P1B_TR; ++tr) {
       if (rk[tr] != 0xFFFFFFFFu) {
-        const uint32_t b = rc[tr].w >> 16;
+        const uint32_t b = bin_of<SUB>(rc[tr].w);
         if (loff[b] + rk[tr] >= (uint32_t)P1B_RCAP)
           l1_put<EX>(v, l1_reg(b, subreg), gbase[b] + rk[tr], rc[tr], k, canon != 0, t);
       }
@@ -348,13 +377,13 @@ __device__ __forceinline__ void p1_tile(uint4 *pool, const int8_t *__restrict__ 
   }
 }
 
-template <int W, int P1B_TR>
-__global__ __launch_bounds__(P1_THREADS, (P1B_TR <= 6 ? 6 : 4)) void msp_p1b_kernel(const int8_t *__restrict__ data,
+template <int W, int P1B_TR, bool SUB>
+__global__ __launch_bounds__(P1_THREADS, ((P1B_TR <= 6 && !SUB) ? 6 : 4)) void msp_p1b_kernel(const int8_t *__restrict__ data,
                                                              int64_t nN, int k, int m, int canon,
                                                              int64_t tile0, MspView v, TableView t) {
-  __shared__ uint4 pool[P1Lds<P1B_TR>::BYTES / 16];
+  __shared__ uint4 pool[P1Lds<P1B_TR, SUB>::BYTES / 16];
   const int64_t tile = tile0 + blockIdx.x;
-  p1_tile<W, P1B_TR, true>(pool, data, nN, k, m, canon, tile, (uint32_t)tile & (v.nxg - 1), v, t);
+  p1_tile<W, P1B_TR, true, SUB>(pool, data, nN, k, m, canon, tile, (uint32_t)tile & (v.nxg - 1), v, t);
 }
 
 // ---------------------------------------------------------------------------------------- P2
@@ -949,11 +978,21 @@ __device__ __noinline__ uint32_t p3_big_dedupe(uint4 *pool, uint4 *stream, uint6
   return p3_compact(pool, stream, wsum);
 }
 
-// mode: P3_EXPORT = stop after the deduplication and leave the leaf's distinct complete runs, header
-// word = multiplicity << 6 | n-1, at the head of its stream (leaf_n = their number): what a rank
-// ships to the leaf's owner; P3_WEIGHTED = the complete stream holds such entries (from several ranks).
+// mode: P3_WEIGHTED = the complete stream holds DISTINCT runs, header word = multiplicity << 6 | n-1
+// (what msp_dedupe_export_kernel leaves behind; from several ranks): an owner counting the runs it received.
+// SHARED: 2^sub_bits workgroups per leaf, each taking the records whose sub-value -- the extra
+// minimizer-hash bits in the header's top byte, written by msp_p1b_kernel<.., true> -- names it.  Every
+// occurrence of a k-mer has the same minimizer, so the workgroups' key sets are disjoint and every record
+// is expanded once, where key-subset passes expand every record in every pass (the c5 shape at k = 31:
+// 15 000 distinct k-mers per leaf).  The workgroups of a leaf run next to each other on one XCD, whose L2
+// serves all but the first read of the leaf's streams (msp2.hip: msp2_p3_kernel<.., true>).
+// P3_EXPORT = stop after the deduplication and leave the leaf's distinct complete runs at the head of its
+// stream (leaf_n = their number).  The host no longer asks for it (msp_dedupe_export_kernel does that job
+// with eight workgroups per CU), but the compiler allocates the hot loops' registers better with the
+// branch in place: without it the canonical kernel spills six dwords instead of two and P3 takes 7.10
+// instead of 6.80 ms on C3.
 constexpr uint32_t P3_EXPORT = 1u, P3_WEIGHTED = 2u;
-template <bool CANON>
+template <bool CANON, bool SHARED>
 __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void msp_p3_kernel(int k, uint32_t mode, MspView v, TableView t) {
   // k-mer table (keys, counts) and record table in one allocation: p3_big_dedupe uses all of it
   __shared__ uint4 pool[BT];
@@ -985,7 +1024,11 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
   const int tid = threadIdx.x, lane = tid & 63;
   // (the grid holds the leaves of this pass only: were the others launched and left at once, the
   //  pass's leaves -- equal low bits -- would all sit on 8 / 2^sel_bits of the 8 XCDs)
-  const uint32_t leaf = (blockIdx.x << v.sel_bits) | v.sel_val;
+  // (shared leaves: workgroup b goes to XCD b % 8 -- eight leaves side by side, a leaf's workgroups one after the other)
+  const uint32_t sub_bits = SHARED ? v.sub_bits : 0u, smask = (1u << sub_bits) - 1u;
+  const uint32_t vq = blockIdx.x >> 3, rsel = vq & smask;
+  const uint32_t leaf = ((SHARED ? (((vq >> sub_bits) << 3) | (blockIdx.x & 7u)) : blockIdx.x) << v.sel_bits) | v.sel_val;
+  auto mine = [&](uint32_t w) { return !SHARED || ((w >> 24) & smask) == rsel; };
   const uint64_t nt = min((uint64_t)v.cnt2[NCLS * leaf + 0], v.exact ? (uint64_t)v.lcap[NCLS * leaf + 0] : v.cap2t);  // truncated runs
   const uint64_t n1 = min((uint64_t)v.cnt2[NCLS * leaf + 1], v.exact ? (uint64_t)v.lcap[NCLS * leaf + 1] : v.cap2c);  // complete runs
   const uint4 *leaf_rec = v.exact ? v.rec2 + v.lbase[NCLS * leaf + 1] : v.rec2 + (uint64_t)(leaf >> v.sel_bits) * (v.cap2c + v.cap2t);
@@ -996,16 +1039,17 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
   // Both uses of the pool-wide table need duplicates to pay for the extra pass: a leaf with
   // fewer than BT_MIN_RUNS complete runs cannot hold many copies of more than ~10^3 distinct ones
   // (low coverage of a large genome: the stream path is the better fallback there).
-  const bool big_first = k < 28 && n1 >= (uint64_t)BT_MIN_RUNS;
+  // (a shared leaf never rewrites its stream: the other workgroups are reading it)
+  const bool big_first = !SHARED && k < 28 && n1 >= (uint64_t)BT_MIN_RUNS;
   uint4 *const tab = big_first ? pool : rtab;
   const int tab_log = big_first ? BT_LOG : RT_LOG;
   const uint32_t tab_mask = (1u << tab_log) - 1u;
   const int tab_trips = big_first ? BT_TRIPS : RT_TRIPS;
-  if ((mode & P3_EXPORT) && n1 == 0) return;      // nothing to deduplicate: the truncated runs leave as they are
+  if (!SHARED && (mode & P3_EXPORT) && n1 == 0) return;      // nothing to deduplicate: the truncated runs leave as they are
   if (big_first) {
     for (int s = tid; s < BT; s += P3_THREADS) pool[s] = make_uint4(0u, 0u, 0u, RT_EMPTY);
   } else {
-    if (!(mode & P3_EXPORT))                       // (an exporting leaf never touches its k-mer table)
+    if (SHARED || !(mode & P3_EXPORT))             // (an exporting leaf never touches its k-mer table)
       for (int s = tid; s < TS; s += P3_THREADS) { keys[s] = CFRK_EMPTY_KEY; cnts[s] = 0; }
     for (int s = tid; s < RT; s += P3_THREADS) rtab[s] = make_uint4(0u, 0u, 0u, RT_EMPTY);
   }
@@ -1033,7 +1077,7 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     uint4 L = zero4;                 // leftover records, lanes [0, c)
     uint32_t Lh = 0;
     int c = 0;                       // wave-uniform
-    const bool weighted = (mode & P3_WEIGHTED) != 0u;
+    const bool weighted = !SHARED && (mode & P3_WEIGHTED) != 0u;   // (an owner's leaves are never shared)
     auto drain = [&](int cnt) {
       uint32_t h = Lh | ((lane < cnt) ? 0u : RT_DONE);
       rtab_insert_loop(tab, L, h, tab_mask, tab_trips, weighted ? ((L.w >> 6) << 6) : (1u << 6));
@@ -1062,14 +1106,46 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
       Lh = take ? ph : Lh;
       c += n;
     };
-    for (uint64_t r = tid; r < ((n1a + 63) & ~63ull) && !(v.dbg & CFRK_ABL_P3_NO_RTAB); r += 2ull * P3_THREADS) {
-      const uint64_t r1 = r + P3_THREADS;
-      const bool v0 = r < n1a, v1 = r1 < n1a;
-      uint4 rec0 = zero4, rec1 = zero4;
-      if (v0) rec0 = src[r];
-      if (v1) rec1 = src[r1];
-      home(rec0, v0);
-      home(rec1, v1);
+    if (!SHARED) {
+      for (uint64_t r = tid; r < ((n1a + 63) & ~63ull) && !(v.dbg & CFRK_ABL_P3_NO_RTAB); r += 2ull * P3_THREADS) {
+        const uint64_t r1 = r + P3_THREADS;
+        const bool v0 = r < n1a, v1 = r1 < n1a;
+        uint4 rec0 = zero4, rec1 = zero4;
+        if (v0) rec0 = src[r];
+        if (v1) rec1 = src[r1];
+        home(rec0, v0);
+        home(rec1, v1);
+      }
+    } else {
+      // a shared leaf: most records read here are another workgroup's.  The one lane in 2^sub_bits that
+      // holds a record of this workgroup is gathered into full sets of 64 before the table look-up:
+      // home() costs the wave ~100 instructions however few lanes take part (msp2.hip)
+      uint4 Cr = zero4;
+      int cc = 0;                        // wave-uniform
+      auto cfeed = [&](const uint4 rec, bool keep) {
+        const unsigned long long mask = __ballot(keep);
+        if (mask == 0ull) return;
+        const int n = __popcll(mask);
+        if (cc + n > 64) { home(Cr, lane < cc); cc = 0; }
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        const int dst = keep ? (cc + rank) : ((cc + n) & 63);      // the others aim at a lane nobody keeps
+        const int da = dst << 2;
+        const uint32_t px = __builtin_amdgcn_ds_permute(da, rec.x), py = __builtin_amdgcn_ds_permute(da, rec.y);
+        const uint32_t pz = __builtin_amdgcn_ds_permute(da, rec.z), pw = __builtin_amdgcn_ds_permute(da, rec.w);
+        const bool take = lane >= cc && lane < cc + n;
+        Cr.x = take ? px : Cr.x; Cr.y = take ? py : Cr.y; Cr.z = take ? pz : Cr.z; Cr.w = take ? pw : Cr.w;
+        cc += n;
+      };
+      for (uint64_t r = tid; r < ((n1a + 63) & ~63ull); r += 2ull * P3_THREADS) {
+        const uint64_t r1 = r + P3_THREADS;
+        const bool v0 = r < n1a, v1 = r1 < n1a;
+        uint4 rec0 = zero4, rec1 = zero4;
+        if (v0) rec0 = src[r];
+        if (v1) rec1 = src[r1];
+        cfeed(rec0, v0 && mine(rec0.w));
+        if (r1 < ((n1a + 63) & ~63ull)) cfeed(rec1, v1 && mine(rec1.w));       // (wave-uniform)
+      }
+      if (cc) home(Cr, lane < cc);
     }
     if (c) drain(c);
     if ((v.dbg & CFRK_DEBUG_FORCE_RT_OVERFLOW) && !big_first) rt_fail = 1u;
@@ -1080,7 +1156,7 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
   //      LENGTH (counting sort of 16-bit indices in LDS): a wave expands 64 records in lock-step
   //      for as many steps as its longest one, so equal lengths keep every lane busy.
   uint32_t nd = 0xFFFFFFFFu;                     // distinct runs listed in the stream (second chance), ~0: none
-  if (mode & P3_EXPORT) {
+  if (!SHARED && (mode & P3_EXPORT)) {
     uint4 *const stream = const_cast<uint4 *>(leaf_rec);
     const bool weighted = (mode & P3_WEIGHTED) != 0u;
     if (big_first) { if (rt_fail == 0u) nd = p3_compact(pool, stream, wsum); }
@@ -1096,7 +1172,7 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     return;
   }
   if (big_first || rt_fail != 0u) {              // (rt_fail read after the barrier above: uniform)
-    if (!big_first && (n1 >= (uint64_t)BT_MIN_RUNS || (v.dbg & CFRK_DEBUG_FORCE_RT_OVERFLOW))) nd = p3_big_dedupe(pool, const_cast<uint4 *>(leaf_rec), n1, wsum, &rt_fail, (mode & P3_WEIGHTED) != 0u);
+    if (!SHARED && !big_first && (n1 >= (uint64_t)BT_MIN_RUNS || (v.dbg & CFRK_DEBUG_FORCE_RT_OVERFLOW))) nd = p3_big_dedupe(pool, const_cast<uint4 *>(leaf_rec), n1, wsum, &rt_fail, (mode & P3_WEIGHTED) != 0u);
     else if (!big_first) __syncthreads();        // (as below)
     else if (rt_fail == 0u) nd = p3_compact(pool, const_cast<uint4 *>(leaf_rec), wsum);
     else __syncthreads();                        // (the pool is cleared below: everybody has read rt_fail and the table)
@@ -1126,10 +1202,11 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
 #pragma unroll
     for (int i = 0; i < TL_PER; ++i) {
       const uint32_t g = (uint32_t)(i * P3_THREADS + tid);
-      const bool valid = g < tl;
+      bool valid = g < tl;
       tw[i] = TW_NONE; trank[i] = 0u;
       uint4 rec = make_uint4(0u, 0u, 0u, 0u);
       if (valid) rec = trunc[g];
+      if (SHARED) valid = valid && mine(rec.w);
       const uint32_t nm1 = rec.w & 31u;
       if (valid) tw[i] = nm1;
       if (anchors_on && __ballot(valid)) {
@@ -1184,6 +1261,7 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
       }
       if (tid < 32) nhist[31 - tid] = incl - own; else thist[63 - tid] = incl - own;
       if (tid == 31) nocc = incl;
+      if (tid == 63 && !use_anchors) nfl = incl;       // entries of the length-sorted list (a shared leaf: this workgroup's only)
     }
     uint32_t goff = 0;
     if (use_anchors) {
@@ -1281,11 +1359,11 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
           const bool valid = i < n1;
           uint4 rec = make_uint4(0u, 0u, 0u, 0u);
           if (valid) rec = leaf_rec[i];
-          count_record_v2<CANON>(keys, cnts, rec, (mode & P3_WEIGHTED) ? (rec.w >> 6) : 1u, valid, k, kmask, rcsh, t, ss, ovf);
+          count_record_v2<CANON>(keys, cnts, rec, (!SHARED && (mode & P3_WEIGHTED)) ? (rec.w >> 6) : 1u, valid && mine(rec.w), k, kmask, rcsh, t, ss, ovf);
         }
       }
       // truncated runs: those without a twin (anchored leaf), or all of the sorted list
-      const uint32_t ntr = use_anchors ? nfl : tl;
+      const uint32_t ntr = nfl;
       for (uint32_t i = tid; i < ((ntr + 63u) & ~63u) && !(v.dbg & CFRK_ABL_P3_NO_TRUNC); i += P3_THREADS) {
         const bool valid = i < ntr;
         uint4 rec = make_uint4(0u, 0u, 0u, 0u);
@@ -1297,7 +1375,7 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         const bool valid = i < nt;
         uint4 rec = make_uint4(0u, 0u, 0u, 0u);
         if (valid) rec = trunc[i];
-        count_record_v2<CANON>(keys, cnts, rec, 1u, valid, k, kmask, rcsh, t, ss, ovf);
+        count_record_v2<CANON>(keys, cnts, rec, 1u, valid && mine(rec.w), k, kmask, rcsh, t, ss, ovf);
       }
     }
     __syncthreads();
@@ -1329,11 +1407,14 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     if (tid == 0) {
       wg_base = atomicAdd((unsigned long long *)&v.stats[ST_CURSOR], (unsigned long long)wg_total);
       // a leaf counted in several passes has several segments in the list: no per-leaf index then
-      if (nseg == 0) v.leaf_off[leaf] = wg_base;
+      // (a shared leaf: one index entry per sub-value, (leaf << sub_bits) | sub-value)
+      uint32_t sg = leaf;
+      if (SHARED) sg = (leaf << sub_bits) | rsel;
+      if (nseg == 0) v.leaf_off[sg] = wg_base;
       else if (wg_total) v.stats[ST_MULTISEG] = 1;
       if (wg_total) nseg = nseg + 1;
       leaf_total += wg_total;
-      v.leaf_n[leaf] = leaf_total;
+      v.leaf_n[sg] = leaf_total;
     }
     __syncthreads();
     const unsigned long long gb = wg_base;
@@ -1879,9 +1960,20 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
   // (a chunked batch sizes its leaf streams after the first chunk: whatever the pool already holds will do until then)
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (pipelined && !small_pipe) ? 16 : (size_t)(NLEAF >> sel_bits) * (cap2c + cap2t) * sizeof(uint4), &p))) return rc;
   v.rec2 = (uint4 *)p; v.cap2c = cap2c; v.cap2t = cap2t;
-  if ((rc = cfrk_pool_get(ctx, BUF_MSP_AUX, (size_t)NLEAF * 8 + (size_t)(B1 * nxg + (NCLS + 1) * NLEAF) * sizeof(uint32_t), &p))) return rc;
+  // far more distinct k-mers expected than the leaf tables hold (65536 x ~2500): records carry extra
+  // minimizer-hash bits and 2^sub_bits workgroups share a leaf (~2000 distinct k-mers each; msp2.hip)
+  uint32_t sub_bits = 0;
+  while (sub_bits < (uint32_t)SUB_BITS && ((ctx->g_cap / NLEAF) >> sub_bits) > 2048u) ++sub_bits;
+  if (ctx->g_cap / NLEAF <= 4096u) sub_bits = 0;
+  if ((ctx->dbg_flags & CFRK_DEBUG_RECORD_SUBSETS) && sub_bits < 2u) sub_bits = 2u;
+  if (ctx->g_flags & CFRK_RUNS_ONLY) sub_bits = 0;       // (the exchange by runs has no room for the bits in a distinct run's header)
+  const bool sub = sub_bits != 0u;
+  v.sub_bits = sub_bits; v.seg_bits = sub_bits;
+  // (leaf index: one entry per leaf, or per (leaf, sub-value) when leaves are shared)
+  const size_t nseg = (size_t)NLEAF << sub_bits;
+  if ((rc = cfrk_pool_get(ctx, BUF_MSP_AUX, nseg * 8 + ((size_t)B1 * nxg + (size_t)NCLS * NLEAF + nseg) * sizeof(uint32_t), &p))) return rc;
   v.leaf_off = (uint64_t *)p;
-  v.cnt1 = (uint32_t *)(v.leaf_off + NLEAF); v.cnt2 = v.cnt1 + B1 * nxg; v.leaf_n = v.cnt2 + NCLS * NLEAF;
+  v.cnt1 = (uint32_t *)(v.leaf_off + nseg); v.cnt2 = v.cnt1 + B1 * nxg; v.leaf_n = v.cnt2 + NCLS * NLEAF;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTK, (size_t)ctx->g_cap * 8, &p))) return rc;
   v.out_keys = (uint64_t *)p;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTC, (size_t)ctx->g_cap * 4, &p))) return rc;
@@ -1890,7 +1982,7 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
   TableView t = cfrk_table_view(ctx);
 
   // (cnt1, cnt2 and -- first pass only -- the leaf index and the list cursor)
-  HIP_TRY(ctx, hipMemsetAsync(v.cnt1, 0, (size_t)(B1 * nxg + (NCLS + (first ? 1 : 0)) * NLEAF) * sizeof(uint32_t), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(v.cnt1, 0, ((size_t)B1 * nxg + (size_t)NCLS * NLEAF + (first ? nseg : 0)) * sizeof(uint32_t), ctx->stream));
   if (first) HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_CURSOR, 0, sizeof(uint64_t), ctx->stream));
 
   // Both levels are laid out for an input that spreads evenly over the minimizer space.  One that
@@ -1915,7 +2007,10 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
   auto launch_p1 = [&](int64_t t0, int64_t t1, const MspView &vv) -> int {
     const dim3 g1((unsigned)(t1 - t0)), b1(P1_THREADS);
 #define CFRK_P1B_CASE(WW) \
-    case WW: hipLaunchKernelGGL((msp_p1b_kernel<WW, (WW >= 16 ? 4 : WW >= 12 ? 6 : WW >= 8 ? 8 : WW >= 6 ? 10 : 12)>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, t0, vv, t); break;
+    case WW: \
+      if (sub) hipLaunchKernelGGL((msp_p1b_kernel<WW, (WW >= 16 ? 4 : WW >= 12 ? 6 : WW >= 8 ? 8 : WW >= 6 ? 10 : 12), true>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, t0, vv, t); \
+      else hipLaunchKernelGGL((msp_p1b_kernel<WW, (WW >= 16 ? 4 : WW >= 12 ? 6 : WW >= 8 ? 8 : WW >= 6 ? 10 : 12), false>), g1, b1, 0, ctx->stream, d_data, nN, k, m, canon, t0, vv, t); \
+      break;
     switch (W) {
       CFRK_P1B_CASE(4) CFRK_P1B_CASE(5) CFRK_P1B_CASE(6) CFRK_P1B_CASE(7) CFRK_P1B_CASE(8) CFRK_P1B_CASE(9)
       CFRK_P1B_CASE(10) CFRK_P1B_CASE(11) CFRK_P1B_CASE(12) CFRK_P1B_CASE(13) CFRK_P1B_CASE(14)
@@ -2051,8 +2146,13 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
   }
   const bool runs_only = (ctx->g_flags & CFRK_RUNS_ONLY) != 0;
   if (runs_only) hipLaunchKernelGGL(msp_dedupe_export_kernel, dim3(NLEAF), dim3(DX_THREADS), 0, ctx->stream, k, canon, v);
-  else if (canon) hipLaunchKernelGGL((msp_p3_kernel<true>), dim3((unsigned)NLEAF >> sel_bits), dim3(P3_THREADS), 0, ctx->stream, k, 0u, v, t);
-  else hipLaunchKernelGGL((msp_p3_kernel<false>), dim3((unsigned)NLEAF >> sel_bits), dim3(P3_THREADS), 0, ctx->stream, k, 0u, v, t);
+  else if (sub) {
+    const dim3 g3(((unsigned)NLEAF >> sel_bits) << v.sub_bits);
+    if (canon) hipLaunchKernelGGL((msp_p3_kernel<true, true>), g3, dim3(P3_THREADS), 0, ctx->stream, k, 0u, v, t);
+    else hipLaunchKernelGGL((msp_p3_kernel<false, true>), g3, dim3(P3_THREADS), 0, ctx->stream, k, 0u, v, t);
+  }
+  else if (canon) hipLaunchKernelGGL((msp_p3_kernel<true, false>), dim3((unsigned)NLEAF >> sel_bits), dim3(P3_THREADS), 0, ctx->stream, k, 0u, v, t);
+  else hipLaunchKernelGGL((msp_p3_kernel<false, false>), dim3((unsigned)NLEAF >> sel_bits), dim3(P3_THREADS), 0, ctx->stream, k, 0u, v, t);
   HIP_TRY(ctx, hipGetLastError());
   ms->pending = !runs_only;
   ms->runs_ready = runs_only;
@@ -2463,8 +2563,8 @@ extern "C" int cfrk_global_merge_runs_device(cfrk_ctx *ctx, const void *d_packed
   hipLaunchKernelGGL(msp_runs_scatter_kernel, dim3((unsigned)nseg), dim3(256), 0, ctx->stream, (const uint4 *)d_packed, rr, lpp, k,
                      (const uint64_t *)d_src, (const uint64_t *)d_d1, (const uint64_t *)d_d0, v.rec2);
   HIP_TRY(ctx, hipGetLastError());
-  if (canon) hipLaunchKernelGGL((msp_p3_kernel<true>), dim3(lpp), dim3(P3_THREADS), 0, ctx->stream, k, P3_WEIGHTED, v, t);
-  else hipLaunchKernelGGL((msp_p3_kernel<false>), dim3(lpp), dim3(P3_THREADS), 0, ctx->stream, k, P3_WEIGHTED, v, t);
+  if (canon) hipLaunchKernelGGL((msp_p3_kernel<true, false>), dim3(lpp), dim3(P3_THREADS), 0, ctx->stream, k, P3_WEIGHTED, v, t);
+  else hipLaunchKernelGGL((msp_p3_kernel<false, false>), dim3(lpp), dim3(P3_THREADS), 0, ctx->stream, k, P3_WEIGHTED, v, t);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   ctx->ev_valid = true;

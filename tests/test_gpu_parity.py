@@ -1355,6 +1355,48 @@ def test_cli_global_over_several_devices_equals_one_device(tmp_path):
         assert one.stat().st_size > 100_000
 
 
+@pytest.mark.parametrize("k,canonical", [(31, True), (28, False), (21, True), (32, True)])
+def test_one_word_leaves_with_more_keys_than_their_table_are_split_by_record(ctx, k, canonical):
+    """The one-word path (16 <= k <= 32) shares an overfull leaf by RECORD too: with a capacity hint above
+    2.7e8 the partition kernel writes five more minimizer-hash bits into the header's top byte and 2^s
+    workgroups take a leaf, each the records its bits name -- every record expanded once, where key-subset
+    passes expand every record in every pass.  All-distinct input (~4000 distinct k-mers per leaf), hint
+    above / below the switch: both give the digest of the general HBM-table path; and the same switch
+    forced on a small deep input (anchored truncated runs, record table in use, exact re-layout, chunked
+    counting, export by leaf) gives the oracle's list."""
+    import cfrk_amd
+    flags = cfrk_amd.CFRK_CANONICAL if canonical else 0
+    L = 150
+    R = 250_000_000 // (L - k + 1)                                     # 2.5e8 k-mers, ~all distinct (the list of the smaller hint holds 2.68e8)
+    data, _, _ = orc.synth_reads(0, R, L, 0, uniform=True)
+    K = R * (L - k + 1)
+    digests = []
+    for hint in (300_000_000, 134_000_000):                            # record subsets on / off
+        g = cfrk_amd.GlobalCounter(ctx, k, flags, hint)
+        g.add(data)
+        d = g.digest()
+        assert d[1] == K and d[0] > 0.99 * K
+        digests.append(d)
+        del g
+    gh = cfrk_amd.GlobalCounter(ctx, k, flags | cfrk_amd.CFRK_FORCE_HASH, 300_000_000)
+    gh.add(data)
+    assert digests[0] == digests[1] == gh.digest()
+    del gh
+    for G, dbg in ((30_000, 0), (1_200, 0), (30_000, cfrk_amd.lib.CFRK_DEBUG_SMALL_PIPELINE), (5_000_000, cfrk_amd.lib.CFRK_DEBUG_FORCE_RT_OVERFLOW)):
+        small, _, _ = orc.synth_reads(0, 40_000, 150, G)
+        small = small.copy()
+        small[::1013] = -1
+        want = orc.global_count(small, k, orc.ORC_CANONICAL if canonical else 0, threads=4)
+        g = cfrk_amd.GlobalCounter(ctx, k, flags, 8_000_000)
+        g.set_debug_flags(cfrk_amd.lib.CFRK_DEBUG_RECORD_SUBSETS | dbg)
+        g.add(small)
+        lo, hi, cnt = g.export()
+        g.set_debug_flags(0)
+        assert len(lo) == len(want[0])
+        assert (lo == want[0]).all() and (cnt.astype(np.uint64) == want[2]).all()
+        del g
+
+
 def test_two_word_leaves_with_more_keys_than_their_table_are_split_by_record(ctx):
     """k = 63, all-distinct input with ~4000 distinct k-mers per leaf (the LDS table has 4096 slots):
     with a capacity hint above 2.7e8 the records carry more minimizer-hash bits and several workgroups

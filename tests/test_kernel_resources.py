@@ -19,9 +19,12 @@ CSRC = os.path.join(ROOT, "cfrk_amd", "csrc")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 # (file, {symbol fragment: allowed scratch instructions}); everything else must have none.
-# msp_p3_kernel<true> spills two dwords per thread once per workgroup (64 VGPRs at 8 waves/SIMD);
-# p3_big_dedupe / p3_dump_rtab are out-of-line, once-per-workgroup paths and save callee-saved registers.
-FILES = [("msp.hip", {"msp_p3_kernelILb1E": 6, "msp_p3_kernelILb0E": 6, "p3_big_dedupe": 4, "p3_dump_rtab": 4}),
+# msp_p3_kernel<true, false> spills two dwords per thread once per workgroup (64 VGPRs at 8 waves/SIMD), the
+# instantiations for leaves shared by record (<.., true>: D > 2.7e8 per GPU only) a few more, all at phase
+# boundaries -- none inside the scan, probe or expansion loops; p3_big_dedupe is an out-of-line,
+# once-per-workgroup path and saves callee-saved registers, and so does p3_dump_rtab.
+FILES = [("msp.hip", {"msp_p3_kernelILb1ELb0E": 6, "msp_p3_kernelILb0ELb0E": 6, "msp_p3_kernelILb1ELb1E": 16, "msp_p3_kernelILb0ELb1E": 16,
+                      "p3_big_dedupe": 4, "p3_dump_rtab": 4}),
          ("msp2.hip", {}),
          ("radix.hip", {}),
          ("dense.hip", {}),

@@ -59,7 +59,7 @@ while time.time() < t_end:
         want = gh.digest()
         del gh
         g = cfrk_amd.GlobalCounter(ctx, k, flags, hint)
-        shared = k > 32 and rng.random() < 0.4       # leaves shared by record whatever the hint (msp2.hip)
+        shared = k >= 16 and rng.random() < 0.4      # leaves shared by record whatever the hint (msp.hip / msp2.hip)
         chunked = k >= 16 and rng.random() < 0.4      # counted in chunks, leaf streams sized from the first one (round 3)
         dbg = (cfrk_amd.lib.CFRK_DEBUG_RECORD_SUBSETS if shared else 0) | (cfrk_amd.lib.CFRK_DEBUG_SMALL_PIPELINE if chunked else 0)
         if dbg:
