@@ -733,21 +733,7 @@ __device__ __forceinline__ void count_record_v2(unsigned long long *keys, uint32
   // The forward-strand instantiation keeps the loop per k-mer pair: it is out of registers.
   unsigned long long exq = 0ull;
   const bool tb_fast = CANON && tb && !__ballot(valid && (nk > 8 || tb_n > 127u));
-  if (tb_fast) {
-    unsigned long long hist = 0ull;
-    for (uint32_t e = 0; __ballot(e < tb_n); ++e) {         // (as many steps as the wave's longest list)
-      if (e < tb_n) {
-        const int d = min(max((int)tb[e] - j0, 0), 8);
-        hist += 1ull << (7 * d);
-      }
-    }
-    uint32_t run = 0;
-#pragma unroll
-    for (int d = 8; d >= 1; --d) {
-      run += (uint32_t)(hist >> (7 * d)) & 127u;
-      exq |= (unsigned long long)run << (8 * (d - 1));
-    }
-  }
+  if (tb_fast) exq = noted_counts8(tb, tb_n, j0);
   for (int j = 0; __ballot(j < nk); j += 2) {
     uint32_t add0 = add, add1 = add;
     if (tb_fast) {
@@ -1095,15 +1081,10 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
       if (mask == 0ull) return;
       const int n = __popcll(mask);
       if (c + n > 64) { drain(c); c = 0; }
-      const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-      const int dst = left ? (c + rank) : ((c + n) & 63);      // the others aim at a lane nobody keeps
-      const int da = dst << 2;
-      const uint32_t px = __builtin_amdgcn_ds_permute(da, rec.x), py = __builtin_amdgcn_ds_permute(da, rec.y);
-      const uint32_t pz = __builtin_amdgcn_ds_permute(da, rec.z), pw = __builtin_amdgcn_ds_permute(da, rec.w);
-      const uint32_t ph = __builtin_amdgcn_ds_permute(da, h);
-      const bool take = lane >= c && lane < c + n;
-      L.x = take ? px : L.x; L.y = take ? py : L.y; L.z = take ? pz : L.z; L.w = take ? pw : L.w;
-      Lh = take ? ph : Lh;
+      uint32_t set[5] = {L.x, L.y, L.z, L.w, Lh};
+      const uint32_t mine_[5] = {rec.x, rec.y, rec.z, rec.w, h};
+      wave_append<5>(set, mine_, left, mask, c, n);
+      L = make_uint4(set[0], set[1], set[2], set[3]); Lh = set[4];
       c += n;
     };
     if (!SHARED) {
@@ -1127,13 +1108,10 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         if (mask == 0ull) return;
         const int n = __popcll(mask);
         if (cc + n > 64) { home(Cr, lane < cc); cc = 0; }
-        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-        const int dst = keep ? (cc + rank) : ((cc + n) & 63);      // the others aim at a lane nobody keeps
-        const int da = dst << 2;
-        const uint32_t px = __builtin_amdgcn_ds_permute(da, rec.x), py = __builtin_amdgcn_ds_permute(da, rec.y);
-        const uint32_t pz = __builtin_amdgcn_ds_permute(da, rec.z), pw = __builtin_amdgcn_ds_permute(da, rec.w);
-        const bool take = lane >= cc && lane < cc + n;
-        Cr.x = take ? px : Cr.x; Cr.y = take ? py : Cr.y; Cr.z = take ? pz : Cr.z; Cr.w = take ? pw : Cr.w;
+        uint32_t set[4] = {Cr.x, Cr.y, Cr.z, Cr.w};
+        const uint32_t mine_[4] = {rec.x, rec.y, rec.z, rec.w};
+        wave_append<4>(set, mine_, keep, mask, cc, n);
+        Cr = make_uint4(set[0], set[1], set[2], set[3]);
         cc += n;
       };
       for (uint64_t r = tid; r < ((n1a + 63) & ~63ull); r += 2ull * P3_THREADS) {
@@ -1396,13 +1374,8 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     constexpr int NIT = TS / P3_THREADS;
     uint32_t wbase[NIT];
     if (v.dbg & CFRK_ABL_P3_NO_OUT) continue;
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      const unsigned long long m = __ballot(keys[i * P3_THREADS + tid] != CFRK_EMPTY_KEY);
-      uint32_t b = 0;
-      if (lane == 0 && m) b = atomicAdd(&wg_total, (uint32_t)__popcll(m));
-      wbase[i] = __shfl(b, 0);
-    }
+    auto occupied = [&](int s) { return keys[s] != CFRK_EMPTY_KEY; };
+    wg_rank_slots<NIT, P3_THREADS>(wbase, &wg_total, occupied);
     __syncthreads();
     if (tid == 0) {
       wg_base = atomicAdd((unsigned long long *)&v.stats[ST_CURSOR], (unsigned long long)wg_total);
@@ -1417,19 +1390,10 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
       v.leaf_n[sg] = leaf_total;
     }
     __syncthreads();
-    const unsigned long long gb = wg_base;
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      const int s = i * P3_THREADS + tid;
-      const unsigned long long key = keys[s];
-      const bool occ = key != CFRK_EMPTY_KEY;
-      const unsigned long long m = __ballot(occ);
-      if (occ) {
-        const unsigned long long dst = gb + wbase[i] + __popcll(m & ((1ull << lane) - 1ull));
-        if (dst < v.out_cap) { v.out_keys[dst] = key; v.out_cnt[dst] = cnts[s]; }
-        else v.stats[ST_OVERFLOW] = 1;
-      }
-    }
+    wg_emit_slots<NIT, P3_THREADS>(wbase, wg_base, occupied, [&](int s, unsigned long long dst) {
+      if (dst < v.out_cap) { v.out_keys[dst] = keys[s]; v.out_cnt[dst] = cnts[s]; }
+      else v.stats[ST_OVERFLOW] = 1;
+    });
     __syncthreads();
   }
 }
@@ -1472,7 +1436,7 @@ __global__ __launch_bounds__(P3_THREADS) void msp_merge_kernel(const uint64_t *_
   __shared__ uint32_t cnts[TS];
   __shared__ uint32_t wg_total;
   __shared__ unsigned long long wg_base;
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x;
   const uint32_t ll = blockIdx.x;                       // local leaf index on this owner
   uint32_t total = 0;
   for (int p = 0; p < parts; ++p) total += seg_n[(size_t)p * leaves_per_part + ll];
@@ -1493,29 +1457,15 @@ __global__ __launch_bounds__(P3_THREADS) void msp_merge_kernel(const uint64_t *_
   __syncthreads();
   constexpr int NIT = TS / P3_THREADS;
   uint32_t wbase[NIT];
-#pragma unroll
-  for (int i = 0; i < NIT; ++i) {
-    const unsigned long long m = __ballot(keys[i * P3_THREADS + tid] != CFRK_EMPTY_KEY);
-    uint32_t b = 0;
-    if (lane == 0 && m) b = atomicAdd(&wg_total, (uint32_t)__popcll(m));
-    wbase[i] = __shfl(b, 0);
-  }
+  auto occupied = [&](int s) { return keys[s] != CFRK_EMPTY_KEY; };
+  wg_rank_slots<NIT, P3_THREADS>(wbase, &wg_total, occupied);
   __syncthreads();
   if (tid == 0) wg_base = atomicAdd((unsigned long long *)&v.stats[ST_CURSOR], (unsigned long long)wg_total);
   __syncthreads();
-  const unsigned long long gb = wg_base;
-#pragma unroll
-  for (int i = 0; i < NIT; ++i) {
-    const int s = i * P3_THREADS + tid;
-    const unsigned long long key = keys[s];
-    const bool occ = key != CFRK_EMPTY_KEY;
-    const unsigned long long m = __ballot(occ);
-    if (occ) {
-      const unsigned long long dst = gb + wbase[i] + __popcll(m & ((1ull << lane) - 1ull));
-      if (dst < v.out_cap) { v.out_keys[dst] = key; v.out_cnt[dst] = cnts[s]; }
-      else v.stats[ST_OVERFLOW] = 1;
-    }
-  }
+  wg_emit_slots<NIT, P3_THREADS>(wbase, wg_base, occupied, [&](int s, unsigned long long dst) {
+    if (dst < v.out_cap) { v.out_keys[dst] = keys[s]; v.out_cnt[dst] = cnts[s]; }
+    else v.stats[ST_OVERFLOW] = 1;
+  });
 }
 
 // The exporting side of the runs exchange needs none of the leaf kernel's k-mer machinery: a small
@@ -1580,15 +1530,10 @@ __global__ __launch_bounds__(DX_THREADS) void msp_dedupe_export_kernel(int k, in
       if (mask == 0ull) continue;
       const int n = __popcll(mask);
       if (c + n > 64) { drain(c); c = 0; }
-      const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-      const int dst = left ? (c + rank) : ((c + n) & 63);      // the others aim at a lane nobody keeps
-      const int da = dst << 2;
-      const uint32_t px = __builtin_amdgcn_ds_permute(da, rec.x), py = __builtin_amdgcn_ds_permute(da, rec.y);
-      const uint32_t pz = __builtin_amdgcn_ds_permute(da, rec.z), pw = __builtin_amdgcn_ds_permute(da, rec.w);
-      const uint32_t ph = __builtin_amdgcn_ds_permute(da, h);
-      const bool take = lane >= c && lane < c + n;
-      L.x = take ? px : L.x; L.y = take ? py : L.y; L.z = take ? pz : L.z; L.w = take ? pw : L.w;
-      Lh = take ? ph : Lh;
+      uint32_t set[5] = {L.x, L.y, L.z, L.w, Lh};
+      const uint32_t mine_[5] = {rec.x, rec.y, rec.z, rec.w, h};
+      wave_append<5>(set, mine_, left, mask, c, n);
+      L = make_uint4(set[0], set[1], set[2], set[3]); Lh = set[4];
       c += n;
       }
     }

@@ -587,21 +587,7 @@ __device__ __forceinline__ void count_record2(ulonglong2 *keys, uint32_t *cnts, 
   // (One pass over the list per K-MER was a third of the expansion's instructions at k = 63.)
   unsigned long long exq = 0ull;
   const bool tb_fast = tb && !__ballot(valid && (nk - j0 > 8 || tb_n > 127u));
-  if (tb_fast) {
-    unsigned long long hist = 0ull;
-    for (uint32_t e = 0; __ballot(e < tb_n); ++e) {         // (as many steps as the wave's longest list)
-      if (e < tb_n) {
-        const int d = min(max((int)tb[e] - j0, 0), 8);
-        hist += 1ull << (7 * d);
-      }
-    }
-    uint32_t run = 0;
-#pragma unroll
-    for (int d = 8; d >= 1; --d) {
-      run += (uint32_t)(hist >> (7 * d)) & 127u;
-      exq |= (unsigned long long)run << (8 * (d - 1));
-    }
-  }
+  if (tb_fast) exq = noted_counts8(tb, tb_n, j0);
   Roll2 roll;
   roll.init(rec, k, j0);
   for (int j = j0; __ballot(j < nk); ++j) {
@@ -829,18 +815,18 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, uint32_t mod
       if (mask == 0ull) return;
       const int n = __popcll(mask);
       if (c + n > 64) { drain(c); c = 0; }
-      const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-      const int dst = left ? (c + rank) : ((c + n) & 63);      // the others aim at a lane nobody keeps
-      const int da = dst << 2;
-      const uint32_t p0 = __builtin_amdgcn_ds_permute(da, rec.a.x), p1 = __builtin_amdgcn_ds_permute(da, rec.a.y);
-      const uint32_t p2 = __builtin_amdgcn_ds_permute(da, rec.a.z), p3 = __builtin_amdgcn_ds_permute(da, rec.a.w);
-      const uint32_t p4 = __builtin_amdgcn_ds_permute(da, rec.b.x), p5 = __builtin_amdgcn_ds_permute(da, rec.b.y);
-      const uint32_t p6 = SHARED ? __builtin_amdgcn_ds_permute(da, rec.b.z) : 0u;
-      const uint32_t p7 = __builtin_amdgcn_ds_permute(da, rec.b.w), ph = __builtin_amdgcn_ds_permute(da, h);
-      const bool take = lane >= c && lane < c + n;
-      Lr.a.x = take ? p0 : Lr.a.x; Lr.a.y = take ? p1 : Lr.a.y; Lr.a.z = take ? p2 : Lr.a.z; Lr.a.w = take ? p3 : Lr.a.w;
-      Lr.b.x = take ? p4 : Lr.b.x; Lr.b.y = take ? p5 : Lr.b.y; Lr.b.z = take ? p6 : Lr.b.z; Lr.b.w = take ? p7 : Lr.b.w;
-      Lh = take ? ph : Lh;
+      // (the spare word travels only when leaves are shared: it holds the sub-value then)
+      if (SHARED) {
+        uint32_t set[9] = {Lr.a.x, Lr.a.y, Lr.a.z, Lr.a.w, Lr.b.x, Lr.b.y, Lr.b.z, Lr.b.w, Lh};
+        const uint32_t mine_[9] = {rec.a.x, rec.a.y, rec.a.z, rec.a.w, rec.b.x, rec.b.y, rec.b.z, rec.b.w, h};
+        wave_append<9>(set, mine_, left, mask, c, n);
+        Lr.a = make_uint4(set[0], set[1], set[2], set[3]); Lr.b = make_uint4(set[4], set[5], set[6], set[7]); Lh = set[8];
+      } else {
+        uint32_t set[8] = {Lr.a.x, Lr.a.y, Lr.a.z, Lr.a.w, Lr.b.x, Lr.b.y, Lr.b.w, Lh};
+        const uint32_t mine_[8] = {rec.a.x, rec.a.y, rec.a.z, rec.a.w, rec.b.x, rec.b.y, rec.b.w, h};
+        wave_append<8>(set, mine_, left, mask, c, n);
+        Lr.a = make_uint4(set[0], set[1], set[2], set[3]); Lr.b = make_uint4(set[4], set[5], 0u, set[6]); Lh = set[7];
+      }
       c += n;
     };
     if (!SHARED) {
@@ -865,16 +851,10 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, uint32_t mod
         if (mask == 0ull) return;
         const int n = __popcll(mask);
         if (cc + n > 64) { home(Cr, lane < cc); cc = 0; }
-        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-        const int dst = keep ? (cc + rank) : ((cc + n) & 63);    // the others aim at a lane nobody keeps
-        const int da = dst << 2;
-        const uint32_t p0 = __builtin_amdgcn_ds_permute(da, rec.a.x), p1 = __builtin_amdgcn_ds_permute(da, rec.a.y);
-        const uint32_t p2 = __builtin_amdgcn_ds_permute(da, rec.a.z), p3 = __builtin_amdgcn_ds_permute(da, rec.a.w);
-        const uint32_t p4 = __builtin_amdgcn_ds_permute(da, rec.b.x), p5 = __builtin_amdgcn_ds_permute(da, rec.b.y);
-        const uint32_t p6 = __builtin_amdgcn_ds_permute(da, rec.b.z), p7 = __builtin_amdgcn_ds_permute(da, rec.b.w);
-        const bool take = lane >= cc && lane < cc + n;
-        Cr.a.x = take ? p0 : Cr.a.x; Cr.a.y = take ? p1 : Cr.a.y; Cr.a.z = take ? p2 : Cr.a.z; Cr.a.w = take ? p3 : Cr.a.w;
-        Cr.b.x = take ? p4 : Cr.b.x; Cr.b.y = take ? p5 : Cr.b.y; Cr.b.z = take ? p6 : Cr.b.z; Cr.b.w = take ? p7 : Cr.b.w;
+        uint32_t set[8] = {Cr.a.x, Cr.a.y, Cr.a.z, Cr.a.w, Cr.b.x, Cr.b.y, Cr.b.z, Cr.b.w};
+        const uint32_t mine_[8] = {rec.a.x, rec.a.y, rec.a.z, rec.a.w, rec.b.x, rec.b.y, rec.b.z, rec.b.w};
+        wave_append<8>(set, mine_, keep, mask, cc, n);
+        Cr.a = make_uint4(set[0], set[1], set[2], set[3]); Cr.b = make_uint4(set[4], set[5], set[6], set[7]);
         cc += n;
       };
       for (uint64_t r = tid; r < ((ns[3] + 63) & ~63ull); r += 4 * Q3_THREADS) {
@@ -1110,16 +1090,10 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, uint32_t mod
         if (mask == 0ull) return;
         const int n = __popcll(mask);
         if (sc + n > 64) sflush();
-        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-        const int dst = keep ? (sc + rank) : ((sc + n) & 63);    // the others aim at a lane nobody keeps
-        const int da = dst << 2;
-        const uint32_t p0 = __builtin_amdgcn_ds_permute(da, rec.a.x), p1 = __builtin_amdgcn_ds_permute(da, rec.a.y);
-        const uint32_t p2 = __builtin_amdgcn_ds_permute(da, rec.a.z), p3 = __builtin_amdgcn_ds_permute(da, rec.a.w);
-        const uint32_t p4 = __builtin_amdgcn_ds_permute(da, rec.b.x), p5 = __builtin_amdgcn_ds_permute(da, rec.b.y);
-        const uint32_t p7 = __builtin_amdgcn_ds_permute(da, rec.b.w);
-        const bool take = lane >= sc && lane < sc + n;
-        Sr.a.x = take ? p0 : Sr.a.x; Sr.a.y = take ? p1 : Sr.a.y; Sr.a.z = take ? p2 : Sr.a.z; Sr.a.w = take ? p3 : Sr.a.w;
-        Sr.b.x = take ? p4 : Sr.b.x; Sr.b.y = take ? p5 : Sr.b.y; Sr.b.w = take ? p7 : Sr.b.w;
+        uint32_t set[7] = {Sr.a.x, Sr.a.y, Sr.a.z, Sr.a.w, Sr.b.x, Sr.b.y, Sr.b.w};
+        const uint32_t mine_[7] = {rec.a.x, rec.a.y, rec.a.z, rec.a.w, rec.b.x, rec.b.y, rec.b.w};
+        wave_append<7>(set, mine_, keep, mask, sc, n);
+        Sr.a = make_uint4(set[0], set[1], set[2], set[3]); Sr.b = make_uint4(set[4], set[5], 0u, set[6]);
         sc += n;
       };
       for (int cl = big ? 3 : 2; cl >= 0; --cl) {
@@ -1164,13 +1138,8 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, uint32_t mod
     // compaction to the two-word result list: one cursor atomic per workgroup and pass
     constexpr int NIT = T2 / Q3_THREADS;
     uint32_t wbase[NIT];
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      const unsigned long long mm = __ballot(cnts[i * Q3_THREADS + tid] != 0u);
-      uint32_t b = 0;
-      if (lane == 0 && mm) b = atomicAdd(&wg_total, (uint32_t)__popcll(mm));
-      wbase[i] = __shfl(b, 0);
-    }
+    auto occupied = [&](int s) { return cnts[s] != 0u; };
+    wg_rank_slots<NIT, Q3_THREADS>(wbase, &wg_total, occupied);
     __syncthreads();
     if (tid == 0) {
       wg_base = atomicAdd((unsigned long long *)&v.stats[ST_CURSOR], (unsigned long long)wg_total);
@@ -1188,19 +1157,10 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, uint32_t mod
       }
     }
     __syncthreads();
-    const unsigned long long gb = wg_base;
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      const int s = i * Q3_THREADS + tid;
-      const uint32_t cval = cnts[s];
-      const bool occ = cval != 0u;
-      const unsigned long long mm = __ballot(occ);
-      if (occ) {
-        const unsigned long long dst = gb + wbase[i] + __popcll(mm & ((1ull << lane) - 1ull));
-        if (dst < v.out_cap) { v.out_lo[dst] = keys[s].x; v.out_hi[dst] = keys[s].y; v.out_cnt[dst] = cval; }
-        else v.stats[ST_OVERFLOW] = 1;
-      }
-    }
+    wg_emit_slots<NIT, Q3_THREADS>(wbase, wg_base, occupied, [&](int s, unsigned long long dst) {
+      if (dst < v.out_cap) { v.out_lo[dst] = keys[s].x; v.out_hi[dst] = keys[s].y; v.out_cnt[dst] = cnts[s]; }
+      else v.stats[ST_OVERFLOW] = 1;
+    });
     __syncthreads();
   }
 }
@@ -1298,7 +1258,7 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_merge_kernel(const uint64_t *
   __shared__ uint32_t cnts[T2];
   __shared__ uint32_t wg_total;
   __shared__ unsigned long long wg_base;
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x;
   const uint32_t ll = blockIdx.x;
   uint32_t total = 0;
   for (int p = 0; p < parts; ++p) total += seg_n[(size_t)p * leaves_per_part + ll];
@@ -1325,29 +1285,15 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_merge_kernel(const uint64_t *
   __syncthreads();
   constexpr int NIT = T2 / Q3_THREADS;
   uint32_t wbase[NIT];
-#pragma unroll
-  for (int i = 0; i < NIT; ++i) {
-    const unsigned long long mm = __ballot(cnts[i * Q3_THREADS + tid] != 0u);
-    uint32_t b = 0;
-    if (lane == 0 && mm) b = atomicAdd(&wg_total, (uint32_t)__popcll(mm));
-    wbase[i] = __shfl(b, 0);
-  }
+  auto occupied = [&](int s) { return cnts[s] != 0u; };
+  wg_rank_slots<NIT, Q3_THREADS>(wbase, &wg_total, occupied);
   __syncthreads();
   if (tid == 0) wg_base = atomicAdd((unsigned long long *)&v.stats[ST_CURSOR], (unsigned long long)wg_total);
   __syncthreads();
-  const unsigned long long gb = wg_base;
-#pragma unroll
-  for (int i = 0; i < NIT; ++i) {
-    const int s = i * Q3_THREADS + tid;
-    const uint32_t cval = cnts[s];
-    const bool occ = cval != 0u;
-    const unsigned long long mm = __ballot(occ);
-    if (occ) {
-      const unsigned long long dst = gb + wbase[i] + __popcll(mm & ((1ull << lane) - 1ull));
-      if (dst < v.out_cap) { v.out_lo[dst] = keys[s].x; v.out_hi[dst] = keys[s].y; v.out_cnt[dst] = cval; }
-      else v.stats[ST_OVERFLOW] = 1;
-    }
-  }
+  wg_emit_slots<NIT, Q3_THREADS>(wbase, wg_base, occupied, [&](int s, unsigned long long dst) {
+    if (dst < v.out_cap) { v.out_lo[dst] = keys[s].x; v.out_hi[dst] = keys[s].y; v.out_cnt[dst] = cnts[s]; }
+    else v.stats[ST_OVERFLOW] = 1;
+  });
 }
 
 // ---------------------------------------------------------------------------- multi-GPU by runs

@@ -69,6 +69,76 @@ __device__ __forceinline__ void lds_wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// Wave-level compaction, used wherever the leaf kernels collect the few lanes that hold work into full
+// sets of 64 (records that missed their home slot, a shared leaf's own records, ...): the lanes with
+// `keep` set hand their NW words, in lane order, to the lanes [c, c + n) of the wave's set, n = the number
+// of set bits in mask = __ballot(keep).  The caller empties a set that would overflow (c + n > 64) first.
+template <int NW>
+__device__ __forceinline__ void wave_append(uint32_t (&set)[NW], const uint32_t (&mine)[NW], bool keep, unsigned long long mask, int c, int n) {
+  const int lane = threadIdx.x & 63;
+  const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+  const int dst = keep ? (c + rank) : ((c + n) & 63);      // the others aim at a lane nobody keeps
+  const int da = dst << 2;
+  const bool take = lane >= c && lane < c + n;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    const uint32_t p = __builtin_amdgcn_ds_permute(da, mine[i]);
+    set[i] = take ? p : set[i];
+  }
+}
+
+// Noted truncated runs of a record (leaf kernels: the lengths, in k-mers, of the truncated runs that are a
+// prefix of the record a lane expands).  k-mer j0 + q of the record is counted once more for every noted
+// length > j0 + q; for q = 0..7 those eight counts come back as the bytes of the result.  One walk over the
+// list: a lane counts its entries by d = clamp(length - j0, 0, 8) in nine 7-bit fields of one 64-bit
+// register, the counts are the fields' suffix sums.  Every lane of the wave must call (the walk takes as
+// many steps as the wave's longest list); needs tb_n <= 127.
+__device__ __forceinline__ unsigned long long noted_counts8(const uint8_t *tb, uint32_t tb_n, int j0) {
+  unsigned long long hist = 0ull;
+  for (uint32_t e = 0; __ballot(e < tb_n); ++e) {
+    if (e < tb_n) {
+      const int d = min(max((int)tb[e] - j0, 0), 8);
+      hist += 1ull << (7 * d);
+    }
+  }
+  unsigned long long exq = 0ull;
+  uint32_t run = 0;
+#pragma unroll
+  for (int d = 8; d >= 1; --d) {
+    run += (uint32_t)(hist >> (7 * d)) & 127u;
+    exq |= (unsigned long long)run << (8 * (d - 1));
+  }
+  return exq;
+}
+
+// Epilogue of the leaf and merge kernels: the occupied slots of a workgroup's LDS table (slot s = i * NT +
+// tid, i < NIT, per thread) go to consecutive places of the result list with ONE cursor atomic per
+// workgroup (an atomic per wave on the single cursor word serialises the grid).  Part 1 ranks the waves'
+// occupied slots inside the workgroup (*wg_total must be 0; barrier afterwards); between the parts one
+// thread takes `*wg_total` places from the list's cursor; part 2 writes: emit(slot, place in the list).
+template <int NIT, int NT, class Occ>
+__device__ __forceinline__ void wg_rank_slots(uint32_t (&wbase)[NIT], uint32_t *wg_total, Occ occupied) {
+  const int tid = threadIdx.x, lane = tid & 63;
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const unsigned long long m = __ballot(occupied(i * NT + tid));
+    uint32_t b = 0;
+    if (lane == 0 && m) b = atomicAdd(wg_total, (uint32_t)__popcll(m));
+    wbase[i] = __shfl(b, 0);
+  }
+}
+template <int NIT, int NT, class Occ, class Emit>
+__device__ __forceinline__ void wg_emit_slots(const uint32_t (&wbase)[NIT], unsigned long long list_base, Occ occupied, Emit emit) {
+  const int tid = threadIdx.x, lane = tid & 63;
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int s = i * NT + tid;
+    const bool occ = occupied(s);
+    const unsigned long long m = __ballot(occ);
+    if (occ) emit(s, list_base + wbase[i] + __popcll(m & ((1ull << lane) - 1ull)));
+  }
+}
+
 // exclusive prefix sum of cnt[0..NB) into off[0..NB); every thread of the block must call it
 // (blockDim >= NB, NB a multiple of 64, NB <= 512); wtot is NB/64 words of LDS scratch
 template <int NB, bool LDS_ONLY = false>

@@ -393,6 +393,29 @@ def test_bench_self_launches_two_ranks_and_matches_the_one_gpu_digest():
     assert both["weak"]["config"]["reads"] == 4_000_000 and both["weak"]["sum_count_ok"]
 
 
+def test_bench_two_ranks_exchange_runs_of_two_word_keys():
+    """the same rehearsal at k = 63: strong scaling takes the runs exchange of msp2.hip (round 3) and
+    gives the 1-GPU digest"""
+    common = ["--steps", "1", "--warmup", "0", "--reads", "2000000", "--k", "63", "--cpu-reads", "0"]
+    one = _bench_line(["--gpus", "1"] + common)
+    two = _bench_line(["--gpus", "2", "--same-gpu", "--dist-backend", "gloo", "--scaling", "strong"] + common)
+    assert one["sum_count_ok"] and two["sum_count_ok"] and two["digest"] == one["digest"]
+    assert two["exchange"]["exchange"] == "runs" and two["exchange"]["wire_bytes"] > 0
+
+
+def test_bench_two_ranks_over_rccl_on_two_gpus():
+    """`bench.py --gpus 2` on two REAL devices over RCCL (backend "nccl"): skipped on the one-GPU boxes the
+    suite usually runs on -- the collectives of cfrk_amd/sharded.py are otherwise only exercised over gloo"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    for k in ("31", "63"):
+        common = ["--steps", "1", "--warmup", "0", "--reads", "2000000", "--k", k, "--cpu-reads", "0"]
+        one = _bench_line(["--gpus", "1"] + common)
+        two = _bench_line(["--gpus", "2", "--dist-backend", "nccl", "--scaling", "strong"] + common)
+        assert one["sum_count_ok"] and two["sum_count_ok"] and two["digest"] == one["digest"]
+
+
 @pytest.mark.parametrize("k", [15, 21, 31, 63])
 def test_c5_high_collision_variant_small_genome(ctx, k):
     """SURVEY 8d's high-collision variant at reduced size: a tiny genome, so every key is hit
