@@ -1536,13 +1536,14 @@ static size_t msp2_need_lean(const cfrk_ctx *ctx, int64_t span) {
   return (size_t)B1 * NXG * cap1 * 32 + (size_t)(expect * 32) + (size_t)ctx->g_cap * 20;
 }
 
-// ... counted in chunks (one level-1 buffer of at most ~6 GB, leaf streams sized from the first chunk's
-// records: at most 2.2 x the records, msp2_count_tiles)
+// ... counted in chunks (one level-1 buffer of at most ~6 GB, leaf streams sized by class from the first
+// chunk's records: ~1.4 x the records the batch really makes, msp2_count_tiles; the density estimate behind
+// `expect` is itself an upper bound, and an attempt that runs out of memory is planned again the old way)
 static size_t msp2_need_chunked(const cfrk_ctx *ctx, int64_t span) {
   const double expect = (double)span * msp2_density(ctx);
   const uint64_t cap1 = (uint64_t)(expect / (B1 * NXG) * 1.35) + 2048;
   const double l1 = std::min((double)B1 * NXG * cap1 * 32.0, 6e9 * 1.35 + (double)B1 * NXG * 2048 * 32.0);
-  return (size_t)l1 + (size_t)(expect * 2.2 * 32) + (size_t)NLEAF * 1280 * 32 + (size_t)ctx->g_cap * 20;
+  return (size_t)l1 + (size_t)(expect * 1.6 * 32) + (size_t)NLEAF * 1280 * 32 + (size_t)ctx->g_cap * 20;
 }
 
 static size_t msp2_need(const cfrk_ctx *ctx, int64_t span) {
@@ -2000,7 +2001,9 @@ int cfrk_msp2_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
       if (ms->pending && (rc = cfrk_msp_flush_to_table(ctx))) return rc;
       ctx->last_passes = 1;
       rc = msp2_count_tiles(ctx, ms, d_data, nN, 0, ntiles, 1.0, 0, 0, true, false, true);
-      if (rc != CFRK_ERR_SMALL_BUF) return rc;
+      // (nothing has been counted when the leaf streams do not fit or overflow: the batch starts over)
+      if (rc != CFRK_ERR_SMALL_BUF && rc != CFRK_ERR_NOMEM) return rc;
+      if (rc == CFRK_ERR_NOMEM) (void)hipGetLastError();
     }
   }
   if (groups != 1) {
