@@ -1681,7 +1681,7 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
           HIP_TRY(ctx, hipMemcpyAsync(made, sp, sizeof made, hipMemcpyDeviceToHost, ctx->stream));
           HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
           // records of this pass's leaves in the whole batch (+3 %), per leaf, split by the sample: complete
-          // runs up to 1.3 x their share of the mean leaf, the largest class of truncated runs up to 1.6 x its share
+          // runs up to 1.45 x their share of the mean leaf (1.3 x parks records of a few leaves, msp.hip), the largest class of truncated runs up to 1.6 x its share
           const double per_leaf = (double)made[0] * ((double)ntiles / (double)(t1 - t0)) * 1.03 / (double)(NLEAF >> sel_bits);
           const uint64_t sampled = made[1] + made[2] + made[3] + made[4];
           double fc = 0.75, ft = 0.3;
@@ -1689,7 +1689,7 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
             fc = (double)made[4] / (double)sampled + 0.02;
             ft = (double)std::max(made[1], std::max(made[2], made[3])) / (double)sampled + 0.01;
           }
-          v.cap2c = (uint64_t)(per_leaf * std::min(1.0, fc) * 1.3) + 512; v.cap2t = (uint64_t)(per_leaf * std::min(1.0, ft) * 1.6) + 256;
+          v.cap2c = (uint64_t)(per_leaf * std::min(1.0, fc) * 1.45) + 512; v.cap2t = (uint64_t)(per_leaf * std::min(1.0, ft) * 1.6) + 256;
           if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)(NLEAF >> sel_bits) * (v.cap2c + 3 * v.cap2t) * sizeof(Rec2), &p))) return rc;
           v.rec2 = (Rec2 *)p;
         }
