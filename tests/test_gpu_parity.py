@@ -393,6 +393,35 @@ def test_bench_self_launches_two_ranks_and_matches_the_one_gpu_digest():
     assert both["weak"]["config"]["reads"] == 4_000_000 and both["weak"]["sum_count_ok"]
 
 
+def test_bench_under_torchrun_as_the_driver_launches_it():
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P
+    bench.py --gpus 2 ...` (RANK / WORLD_SIZE / MASTER_* come from the launcher): rank 0 prints the ONE line,
+    same digest as one GPU (rehearsal: both ranks on cuda:0, collectives over gloo)"""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "1", "--warmup", "0", "--reads", "2000000", "--cpu-reads", "0"]
+    one = _bench_line(["--gpus", "1"] + common)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    for v in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(v, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--same-gpu", "--dist-backend", "gloo"] + common,
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    two = json.loads(lines[0])
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["sum_count_ok"]
+    assert two["digest"] == one["digest"] and two["exchange"]["exchange"] == "runs"
+
+
 def test_bench_two_ranks_exchange_runs_of_two_word_keys():
     """the same rehearsal at k = 63: strong scaling takes the runs exchange of msp2.hip (round 3) and
     gives the 1-GPU digest"""
