@@ -302,6 +302,27 @@ int cfrk_global_add_device(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   if (cfrk_msp_usable(ctx)) rc = cfrk_msp_count(ctx, d_data, nN);
   else if (cfrk_radix_usable(ctx)) rc = cfrk_radix_count(ctx, d_data, nN);
   else if (cfrk_msp2_usable(ctx)) rc = cfrk_msp2_count(ctx, d_data, nN);
+  if (rc == CFRK_ERR_NOMEM && (cfrk_msp_usable(ctx) || cfrk_radix_usable(ctx) || cfrk_msp2_usable(ctx)) &&
+      !(ctx->msp && ctx->msp->pending)) {
+    // The pool only grows: buffers sized by earlier jobs of this context (another k, a larger batch) may be
+    // what stands in the way.  Nothing of the partitioned paths is live between adds unless a result list is
+    // pending: give their buffers back and plan the batch once more before giving the fast path up.
+    static const int trim[] = {BUF_SCRATCH, BUF_MSP_L1, BUF_MSP_L2, BUF_MSP_OUTK, BUF_MSP_OUTC, BUF_MSP_AUX, BUF_MSP_OUTH,
+                               BUF_MSP_ACCK, BUF_MSP_ACCH, BUF_MSP_ACCC, BUF_MSP_LAYOUT, BUF_MSP_OVF, BUF_MSP_OVF1,
+                               BUF_MSP_LAYOUT1, BUF_EXPORT_LO, BUF_EXPORT_HI, BUF_EXPORT_CNT};
+    size_t freed = 0;
+    (void)hipGetLastError();
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int slot : trim) {
+      cfrk_buf &b = ctx->pool[slot];
+      if (b.p) { freed += b.cap; (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    }
+    if (freed) {
+      if (cfrk_msp_usable(ctx)) rc = cfrk_msp_count(ctx, d_data, nN);
+      else if (cfrk_radix_usable(ctx)) rc = cfrk_radix_count(ctx, d_data, nN);
+      else rc = cfrk_msp2_count(ctx, d_data, nN);
+    }
+  }
   if (rc == CFRK_ERR_NOMEM && (ctx->g_flags & CFRK_RUNS_ONLY))
     return cfrk_fail(ctx, CFRK_ERR_NOMEM, "the shard's record buffers do not fit device memory");
   if (rc == CFRK_ERR_NOMEM) {

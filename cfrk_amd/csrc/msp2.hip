@@ -63,6 +63,7 @@ struct View2 {
   uint32_t dbg;                                          // cfrk_debug_set_flags
   uint32_t sel_mask, sel_val, sel_bits;                  // leaf subset of this pass (msp.h: MspView)
   uint32_t sub_bits;                                     // records carry so many more minimizer-hash bits in b.z (0: none)
+  uint32_t hbits;                                        // a workgroup of a shared leaf counts 2^hbits sub-values, one after the other
   uint64_t *stats;
 };
 
@@ -754,7 +755,7 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, uint32_t mod
   // workgroups per leaf: every one of them reads the whole leaf, and that was most of the kernel's
   // time with eight of them.
   const uint32_t sub_bits = SHARED ? v.sub_bits : 0u;
-  const uint32_t hbits = SHARED ? min(sub_bits, 2u) : 0u, hmask = (1u << hbits) - 1u;
+  const uint32_t hbits = SHARED ? v.hbits : 0u, hmask = (1u << hbits) - 1u;
   const uint32_t gbits = sub_bits - hbits;
   const uint32_t rmask = (1u << gbits) - 1u;
   const uint32_t vq = blockIdx.x >> 3;
@@ -1554,6 +1555,25 @@ static size_t msp2_need(const cfrk_ctx *ctx, int64_t span) {
   return (size_t)B1 * NXG * cap1 * 32 + (size_t)NLEAF * (cap2c + 3 * cap2t) * 32 + (size_t)ctx->g_cap * 20;
 }
 
+// Sub-values per workgroup of a shared leaf, as a power of two: four (one pass over the leaf's streams for
+// four sub-values: the leaf is read by 2^(sub_bits - 2) workgroups only) unless the distinct runs of four
+// sub-values would crowd the 1024-entry record table -- short windows make more runs per k-mer: at k = 33
+// (window 18) a leaf of configs[4]'s shape holds ~3400 distinct runs, 860 per four of its sixteen
+// sub-values, the table overflowed in most workgroups and the leaf was counted without deduplication in
+// key-subset passes (1.15 s for the shard that takes 0.17 s at k = 63).
+static uint32_t msp2_hbits(const cfrk_ctx *ctx, uint32_t sub_bits, uint64_t per_leaf_cap) {
+  double runs_per_leaf = (double)per_leaf_cap / 2.0 * 4.0 / (double)(msp2_window(ctx->g_k) + 1);   // (table load 0.5; both strands)
+  // even k takes its minimizers from 13-mers: 3.4e7 canonical values, each at ~30 loci of a 10^9-base genome,
+  // all of them in one (leaf, sub-value) -- the loads of the sub-values scatter twice as much as with 14-mers
+  // (measured on configs[4]'s shape, four / two / one sub-values per workgroup: k = 63 169 / 172 / 210 ms,
+  //  k = 48 366 / 215 / 248, k = 40 581 / 220 / 257, k = 33 1133 / 283 / 335)
+  if (!(ctx->g_k & 1)) runs_per_leaf *= 1.3;
+  uint32_t hbits = std::min(sub_bits, 2u);
+  while (hbits > 0 && runs_per_leaf * (double)(1u << hbits) / (double)(1u << sub_bits) > 640.0) --hbits;
+  if (const char *e = getenv("CFRK_MSP2_HBITS")) hbits = std::min<uint32_t>(sub_bits, (uint32_t)atoi(e));   // (experiments)
+  return hbits;
+}
+
 // one pass of Q1 -> Q2 -> Q3 over the Q1 tiles [tile0, tile0 + ntiles)
 // slack >= 1 widens the per-leaf streams beyond what msp2_need() accounts for (memory permitting)
 // sel_bits / sel_val / first: the leaf subset of this pass (msp.hip: msp_count_tiles)
@@ -1608,6 +1628,7 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
   if ((ctx->dbg_flags & CFRK_DEBUG_RECORD_SUBSETS) && sub_bits < 2u) sub_bits = 2u;
   const bool sub = sub_bits != 0u;
   v.sub_bits = sub_bits;
+  v.hbits = msp2_hbits(ctx, sub_bits, ctx->g_cap / NLEAF);
   // (leaf index: one entry per leaf, or per (leaf, sub-value) when leaves are shared)
   const size_t nseg = (size_t)NLEAF << sub_bits;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_AUX, nseg * 8 + ((size_t)B1 * NXG + (size_t)NCLS * NLEAF + nseg) * sizeof(uint32_t), &p))) return rc;
@@ -1797,7 +1818,7 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
   }
   {
     // (a shared leaf: one workgroup per four sub-values)
-    const dim3 g3(((unsigned)NLEAF >> sel_bits) << (v.sub_bits - std::min(v.sub_bits, 2u))), b3(Q3_THREADS);
+    const dim3 g3(((unsigned)NLEAF >> sel_bits) << (v.sub_bits - v.hbits)), b3(Q3_THREADS);
     if (sub) {
       if (canon) hipLaunchKernelGGL((msp2_p3_kernel<true, true>), g3, b3, 0, ctx->stream, k, 0u, v, t);
       else hipLaunchKernelGGL((msp2_p3_kernel<false, true>), g3, b3, 0, ctx->stream, k, 0u, v, t);
@@ -1825,7 +1846,7 @@ int cfrk_msp2_merge_lists(cfrk_ctx *ctx, const uint64_t *d_lo, const uint64_t *d
   v.rec1 = nullptr; v.cnt1 = nullptr; v.cap1 = 0; v.rec2 = nullptr; v.cnt2 = nullptr; v.cap2c = v.cap2t = 0;
   v.out_lo = ms->view.out_keys; v.out_hi = ms->view.out_hi; v.out_cnt = ms->view.out_cnt; v.out_cap = ms->view.out_cap;
   v.leaf_off = nullptr; v.leaf_n = nullptr; v.stats = ctx->g_stats;
-  v.exact = 0; v.lbase = nullptr; v.lcap = nullptr; v.ovf = nullptr; v.ovf_cap = 0; v.sel_mask = v.sel_val = v.sel_bits = 0; v.sub_bits = 0; v.dbg = 0;
+  v.exact = 0; v.lbase = nullptr; v.lcap = nullptr; v.ovf = nullptr; v.ovf_cap = 0; v.sel_mask = v.sel_val = v.sel_bits = 0; v.sub_bits = 0; v.hbits = 0; v.dbg = 0;
   v.exact1 = 0; v.rbase = nullptr; v.rcap = nullptr; v.ovf1 = nullptr; v.ovf1_cap = 0; v.count_only = 0;
   hipLaunchKernelGGL(msp2_merge_kernel, dim3(leaves_per_part), dim3(Q3_THREADS), 0, ctx->stream, d_lo, d_hi, d_cnt,
                      d_seg_off, d_seg_n, parts, leaves_per_part, v, cfrk_table_view(ctx));
@@ -1901,6 +1922,7 @@ int cfrk_msp2_merge_runs(cfrk_ctx *ctx, const void *d_packed, const uint64_t *re
   if (per_leaf <= 4096u) sub_bits = 0;
   if ((ctx->dbg_flags & CFRK_DEBUG_RECORD_SUBSETS) && sub_bits < 2u) sub_bits = 2u;
   v.sub_bits = sub_bits;
+  v.hbits = msp2_hbits(ctx, sub_bits, per_leaf);
   const size_t nsub = (size_t)NLEAF << sub_bits;
   if ((rc = cfrk_pool_get(ctx, BUF_MSP_AUX, nsub * 8 + ((size_t)B1 * NXG + (size_t)NCLS * NLEAF + nsub) * sizeof(uint32_t), &p))) return rc;
   v.leaf_off = (uint64_t *)p;
@@ -1947,7 +1969,7 @@ int cfrk_msp2_merge_runs(cfrk_ctx *ctx, const void *d_packed, const uint64_t *re
   {
     // the owner's leaves are local indices 0 .. lpp-1 (a shared leaf: one workgroup per four sub-values,
     // eight leaves side by side on the XCDs -- leaves beyond lpp hold nothing and leave at once)
-    const unsigned gbits = sub_bits - std::min(sub_bits, 2u);
+    const unsigned gbits = sub_bits - v.hbits;
     const dim3 g3(sub_bits ? (((unsigned)lpp + 7u) & ~7u) << gbits : (unsigned)lpp), b3(Q3_THREADS);
     if (sub_bits) {
       if (canon) hipLaunchKernelGGL((msp2_p3_kernel<true, true>), g3, b3, 0, ctx->stream, k, Q3_WEIGHTED, v, t);

@@ -1469,12 +1469,21 @@ def test_two_word_leaves_with_more_keys_than_their_table_are_split_by_record(ctx
     gh = cfrk_amd.GlobalCounter(ctx, k, cfrk_amd.CFRK_CANONICAL | cfrk_amd.CFRK_FORCE_HASH, 300_000_000)
     gh.add(data)
     assert digests[0] == digests[1] == gh.digest()
-    # the same switch on a small, deep input (anchored truncated runs, record table in use)
+    # the same switch on a small, deep input (anchored truncated runs, record table in use), with four, two
+    # and one sub-values per workgroup (the library picks from the expected runs per leaf; the knob is for tests)
     small, _, _ = orc.synth_reads(0, 40_000, 150, 30_000)
     want = orc.global_count(small, k, orc.ORC_CANONICAL, threads=4)
-    g = cfrk_amd.GlobalCounter(ctx, k, cfrk_amd.CFRK_CANONICAL, 100_000)
-    g.set_debug_flags(cfrk_amd.lib.CFRK_DEBUG_RECORD_SUBSETS)
-    g.add(small)
-    lo, hi, cnt = g.export()
-    g.set_debug_flags(0)
-    assert (lo == want[0]).all() and (hi == want[1]).all() and (cnt.astype(np.uint64) == want[2]).all()
+    for hb in (None, "1", "0"):
+        if hb is None:
+            os.environ.pop("CFRK_MSP2_HBITS", None)
+        else:
+            os.environ["CFRK_MSP2_HBITS"] = hb
+        try:
+            g = cfrk_amd.GlobalCounter(ctx, k, cfrk_amd.CFRK_CANONICAL, 100_000)
+            g.set_debug_flags(cfrk_amd.lib.CFRK_DEBUG_RECORD_SUBSETS)
+            g.add(small)
+            lo, hi, cnt = g.export()
+            g.set_debug_flags(0)
+        finally:
+            os.environ.pop("CFRK_MSP2_HBITS", None)
+        assert (lo == want[0]).all() and (hi == want[1]).all() and (cnt.astype(np.uint64) == want[2]).all()
