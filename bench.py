@@ -59,7 +59,7 @@ def parse():
     p.add_argument("--owner-hash", action="store_true",
                    help="force the generic hash-owner exchange + HBM-table merge")
     p.add_argument("--exchange", default="auto", choices=["auto", "runs", "leaf", "owner"],
-                   help="N > 1: what the ranks exchange.  runs (auto for 16 <= k <= 64 when the job has a fixed size): deduplicated "
+                   help="N > 1: what the ranks exchange.  runs (auto for 16 <= k <= 64): deduplicated "
                         "runs, counted by the leaf's owner; leaf: counted per-leaf lists; owner: counted keys")
     a = p.parse_args()
     reads, L, k, glen = CONFIGS[a.config]
@@ -300,10 +300,12 @@ def main():
 
         exch = "owner" if args.owner_hash else args.exchange
         if exch == "auto":
-            # strong scaling (a job of fixed size): ranks ship deduplicated runs, the owners count.
-            # weak scaling: every rank has a full-depth shard, whose counted lists (~D entries) are
-            # smaller than its runs (two truncated runs per read on top of the distinct ones)
-            exch = "runs" if 16 <= k <= 64 and scaling == "strong" else "leaf"
+            # ranks ship deduplicated runs (read ends as 16-bit notes), the owners count -- for a job of fixed
+            # size (strong scaling) and for full-depth shards alike: rehearsed at N = 8, a C3-sized shard
+            # ships 0.65 GB of runs against 1.2 GB of counted k-mers and skips its leaf kernel, configs[4]'s
+            # shard 4.1 GB against 17.5 GB.  A rank that cannot export runs makes all take the
+            # leaf exchange (counted per-leaf lists), k <= 15 always does.
+            exch = "runs" if 16 <= k <= 64 else "leaf"
         used = {"exchange": exch, "wire_bytes": 0}
 
         def step():
@@ -390,8 +392,9 @@ def main():
             "metric": "k-mers/sec", "value": kmers_total * args.steps / dt, "unit": "k-mers/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            # (N = 1 is the first point of the strong-scaling curve of configs[3]: the job is fixed)
-            "scaling": scaling,
+            # (N = 1 is the first point of the strong-scaling curve of configs[3]: the job is fixed;
+            #  a per-GPU config -- configs[4]: 125 M reads on every GPU -- grows with N whatever was asked)
+            "scaling": "weak" if (args.per_gpu and world > 1) else scaling,
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"{R} synthetic {L} bp reads, k={k}, "
                                    f"{'canonical' if flags else 'forward'}, "

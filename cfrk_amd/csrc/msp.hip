@@ -766,7 +766,10 @@ __device__ __forceinline__ void count_record_v2(unsigned long long *keys, uint32
     uint32_t b0 = lds_bucket(key0) | (p0 ? 0u : KT_DONE), b1 = lds_bucket(key1) | (p1 ? 0u : KT_DONE);
     // (a pass that may still be split gives up early: probing a nearly full table is the slow way
     //  to find out that it is full)
-    const int trips = ovf ? KT_TRIPS_SPLIT : KT_TRIPS;
+    // (... but not the pass over the WHOLE leaf: an unlucky cluster in a table that is a third full must not
+    //  split a leaf that fits -- a split leaf has two segments in the result list and no entry in the leaf
+    //  index, which the export by leaf needs: at C3's size a handful of the 65 536 leaves were split)
+    const int trips = ovf ? (ss.mask == 0u ? KT_TRIPS : KT_TRIPS_SPLIT) : KT_TRIPS;
     for (int it = 0; it < trips && __ballot((int32_t)(b0 & b1) >= 0); ++it) {
       kt_try(keys, cnts, key0, b0, add0);
       kt_try(keys, cnts, key1, b1, add1);

@@ -604,7 +604,8 @@ __device__ __forceinline__ void count_record2(ulonglong2 *keys, uint32_t *cnts, 
     uint32_t h = t2_slot(lo, hi) | ((j < nk && in_subset2(lo, hi, ss)) ? 0u : T2_DONE);
     // (a pass that may still be split gives up early: probing a nearly full table is the slow way
     //  to find out that it is full)
-    const int trips = ovf ? T2_TRIPS_SPLIT : T2_TRIPS;
+    // (the pass over the whole leaf or sub-value probes on: see msp.hip)
+    const int trips = ovf ? (ss.mask == 0u ? T2_TRIPS : T2_TRIPS_SPLIT) : T2_TRIPS;
     for (int it = 0; it < trips && __ballot((int32_t)h >= 0); ++it) t2_step(keys, cnts, lo, hi, addj, h);
     if ((int32_t)h >= 0) {
       if (ovf) {
@@ -1303,9 +1304,10 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_merge_kernel(const uint64_t *
 // prefix of one of them into 16-bit notes and ships, per leaf, [distinct runs with multiplicities]
 // [truncated runs][notes]; a 32-byte record travels as two 16-byte rows.  The owner lines the ranks'
 // lists up as the streams of its leaves and runs the leaf kernel in Q3_WEIGHTED mode.
-constexpr int DX2_THREADS = 256, DX2_INFL = 2;
-constexpr int RX_LOG = 11, RX = 1 << RX_LOG;       // record-table slots of the export kernel (64 KB; 16-bit notes hold 11 bits of position)
-static_assert(((RX - 1) << 5 | 29) < 0xFFFF, "a note never equals the padding value");
+constexpr int DX2_INFL = 2;
+// A note is 16 bits: position of the twin in the leaf's list << 5 | n-1 -- 11 bits of position
+constexpr uint32_t NOTE_POS_MAX = 2047u;
+static_assert((NOTE_POS_MAX << 5 | 29u) < 0xFFFFu, "a note never equals the padding value");
 
 // stream cl (0..2 truncated, 3 complete) of a leaf and how many records it holds (one pass: sel_bits = 0)
 __device__ __forceinline__ Rec2 *x2_stream(const View2 &v, uint32_t leaf, int cl) {
@@ -1322,7 +1324,13 @@ __device__ __forceinline__ uint32_t x2_count(const View2 &v, uint32_t leaf, int 
 // Truncated runs that are a prefix of a distinct run of this rank (a suffix, read on the other strand)
 // become notes: marked in place (b.w = RUN_NOTED, a.x = position of the run in the list << 5 | n-1);
 // leaf_off[leaf] = how many.
+// RX_LOG / DX2_THREADS: 2048 slots (64 KB of LDS) and 256 threads, two workgroups per CU, for leaves of a few
+// hundred distinct runs; 4096 slots (128 KB) and 1024 threads, one per CU, for the leaves of a job with far
+// more distinct k-mers than its leaf tables hold (configs[4]: ~2000 distinct runs per leaf and rank) --
+// with the small table those leaves left undeduplicated: 53 GB per rank instead of 5.
+template <int RX_LOG, int DX2_THREADS>
 __global__ __launch_bounds__(DX2_THREADS) void msp2_dedupe_export_kernel(int k, int canon, View2 v) {
+  constexpr int RX = 1 << RX_LOG;
   __shared__ Rec2 rtab[RX];
   __shared__ uint16_t sidx[RX];                    // record-table slot -> position in the leaf's list
   __shared__ uint32_t wsum[DX2_THREADS / 64];
@@ -1408,7 +1416,8 @@ __global__ __launch_bounds__(DX2_THREADS) void msp2_dedupe_export_kernel(int k, 
           found = hit ? hh : found;
           h = (p && !hit && !empty) ? ((hh + 1u) & (uint32_t)(RX - 1)) : (h | R2_DONE);
         }
-        const bool hit = found != 0xFFFFFFFFu;
+        // (a twin beyond position 2047 of a long list cannot be named by a note: the run travels as a record)
+        const bool hit = found != 0xFFFFFFFFu && (uint32_t)sidx[found] <= NOTE_POS_MAX;
         if (hit) { trunc[g].a.x = ((uint32_t)sidx[found] << 5) | nm1; trunc[g].b.w = RUN_NOTED; }
         const unsigned long long hb = __ballot(hit);
         if (lane == 0 && hb) atomicAdd(&noted, (uint32_t)__popcll(hb));
@@ -1806,7 +1815,12 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
   }
   if (runs_only) {
     // deduplicate the leaves where they lie; the streams stay for cfrk_global_export_runs_device
-    hipLaunchKernelGGL(msp2_dedupe_export_kernel, dim3(NLEAF), dim3(DX2_THREADS), 0, ctx->stream, k, canon, v);
+    // (the table's size from the expected distinct runs per leaf, as in msp2_hbits)
+    const double runs_per_leaf = (double)(ctx->g_cap / NLEAF) / 2.0 * 4.0 / (double)(W2 + 1);
+    if (runs_per_leaf > 700.0 || (ctx->dbg_flags & CFRK_DEBUG_RECORD_SUBSETS))
+      hipLaunchKernelGGL((msp2_dedupe_export_kernel<12, 1024>), dim3(NLEAF), dim3(1024), 0, ctx->stream, k, canon, v);
+    else
+      hipLaunchKernelGGL((msp2_dedupe_export_kernel<11, 256>), dim3(NLEAF), dim3(256), 0, ctx->stream, k, canon, v);
     HIP_TRY(ctx, hipGetLastError());
     static_assert(sizeof(View2) <= sizeof(ms->view2), "cfrk_msp::view2 holds a View2");
     memcpy(ms->view2, &v, sizeof v);

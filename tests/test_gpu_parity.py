@@ -726,6 +726,34 @@ def test_pipelined_and_one_chunk_paths_agree_at_20m_reads(ctx):
     ctx.free(d)
 
 
+def test_c3_full_size_result_keeps_its_leaf_index_and_parks_nothing(ctx):
+    """BASELINE configs[2] at full size (100 M x 150 bp, k = 31): the result is the known digest, no record was
+    parked or spilled (the leaf streams sized from the first chunk hold every leaf), and every leaf has ONE
+    segment in the result list, so the export by leaf -- what a multi-GPU job of this size takes -- works
+    (until round 3 an unlucky probe chain split a handful of the 65 536 leaves by key and the export refused)"""
+    import cfrk_amd
+    R, L, k, G = 100_000_000, 150, 31, 100_000_000
+    nN = R * (L + 1)
+    d = ctx.alloc(nN + 64)
+    ctx.synth_reads_device(0, R, L, G, d)
+    g = cfrk_amd.GlobalCounter(ctx, k, cfrk_amd.CFRK_CANONICAL, G + 1024)
+    g.add_device(d, nN)
+    info = g.msp_info()
+    assert info["spilled_records"] == 0 and info["spilled_kmers"] == 0 and info["list_entries"] == 99_999_970
+    assert g.last_add_passes() == 1
+    world = 8
+    lpp = g.leaves_per_part(world)
+    cap = G + 1024
+    keys, cnt, lc = ctx.alloc(cap * 8), ctx.alloc(cap * 4), ctx.alloc(world * lpp * 4)
+    pc = g.export_leaves_device(keys, cnt, cap, world, lc, 0)
+    assert sum(pc) == 99_999_970 and min(pc) > 0.12 * 99_999_970
+    dg = g.digest()
+    assert dg[0] == 99_999_970 and dg[1] == R * (L - k + 1)
+    assert [f"{x:016x}" for x in dg] == ["0000000005f5e0e2", "00000002cb417800", "416f1fcc3ea9fc63", "b9ea15c642f30d8b"]
+    for p in (keys, cnt, lc, d):
+        ctx.free(p)
+
+
 def test_chunked_batch_sizes_leaf_streams_from_first_chunk_and_survives_a_lumpy_batch(ctx):
     """a batch large enough to be counted in chunks by itself (4 M x 150 bp): (a) uniform coverage of a
     4 Mb genome -- the leaf streams are sized from the first chunk's records; (b) the same reads from

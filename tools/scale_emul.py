@@ -5,7 +5,8 @@
       receives its segment from every rank and counts its leaves (cfrk_global_merge_runs_device);
   --leaf: the counted-list exchange of round 1 for comparison (count, export by leaf, LDS merge).
 Prints per phase the slowest rank's time, the bytes a rank puts on the wire, and checks that owner 0's
-sum of counts is its share of the job.   usage: scale_emul.py [world [reads [k]]] [--leaf]"""
+sum of counts is its share of the job.   usage: scale_emul.py [world [reads [k]]] [--leaf] [--L=n] [--glen=n] [--weak]
+--weak: `reads` is what EVERY rank holds (the job has world x reads reads: BASELINE configs[4] is 8 x 125 M x 250 bp)."""
 import json
 import os
 import sys
@@ -16,28 +17,31 @@ import torch  # noqa: E402
 import cfrk_amd  # noqa: E402
 
 pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+opt = dict(a[2:].split("=", 1) for a in sys.argv[1:] if a.startswith("--") and "=" in a)
 leaf_mode = "--leaf" in sys.argv
+weak = "--weak" in sys.argv
 world = int(pos[0]) if len(pos) > 0 else 8
 R = int(pos[1]) if len(pos) > 1 else 100_000_000
 k = int(pos[2]) if len(pos) > 2 else 31
-L = 150
+L = int(opt.get("L", 150))
 dev = torch.device("cuda:0")
 stream = torch.cuda.Stream(dev)
 torch.cuda.set_stream(stream)
 ctx = cfrk_amd.Context(0, stream.cuda_stream)
 octx = cfrk_amd.Context(0, stream.cuda_stream)
 flags = cfrk_amd.CFRK_CANONICAL
-hint = R + 1024
-Rl = R // world
+G = int(opt.get("glen", R))
+hint = G + 1024
+Rl = R if weak else R // world
 nN = Rl * (L + 1)
 d = torch.empty(nN + 64, dtype=torch.int8, device=dev)
 
 t_count, t_export, wire = [], [], []
 segs, rows0 = [], []
-buf = None if leaf_mode else torch.empty((max(1 << 20, int(min(14 * Rl, 2.5 * Rl + 0.3 * R)) * (2 if k > 32 else 1) + (1 << 17)), 2), dtype=torch.int64, device=dev)   # the send buffer lives across steps
+buf = None if leaf_mode else torch.empty((max(1 << 20, int(min(14 * Rl, 2.5 * Rl + 0.3 * G)) * (2 if k > 32 else 1) + (1 << 17)), 2), dtype=torch.int64, device=dev)   # the send buffer lives across steps
 keys = cnt = lc = None
 for r in range(world):
-    ctx.synth_reads_device(r * Rl, Rl, L, R, d.data_ptr())
+    ctx.synth_reads_device(r * Rl, Rl, L, G, d.data_ptr())
     ctx.sync()
     best = None
     for it in range(2):                                   # second run: pools and code objects are warm
@@ -50,15 +54,16 @@ for r in range(world):
             lpp = g.leaves_per_part(world)
             if keys is None:
                 keys = torch.empty(hint, dtype=torch.int64, device=dev)
+                khi = torch.empty(hint, dtype=torch.int64, device=dev) if k > 32 else None
                 cnt = torch.empty(hint, dtype=torch.int32, device=dev)
                 lc = torch.empty(world * lpp, dtype=torch.int32, device=dev)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-            pc = g.export_leaves_device(keys.data_ptr(), cnt.data_ptr(), hint, world, lc.data_ptr(), 0)
+            pc = g.export_leaves_device(keys.data_ptr(), cnt.data_ptr(), hint, world, lc.data_ptr(), khi.data_ptr() if k > 32 else 0)
             ctx.sync()
             t2 = time.perf_counter()
-            out = (keys[:pc[0]].clone(), cnt[:pc[0]].clone(), lc[:lpp].clone(), pc[0])
-            w = 12 * (sum(pc) - pc[r]) + 4 * lpp * (world - 1)
+            out = (keys[:pc[0]].clone(), cnt[:pc[0]].clone(), lc[:lpp].clone(), pc[0], khi[:pc[0]].clone() if k > 32 else None)
+            w = (20 if k > 32 else 12) * (sum(pc) - pc[r]) + 4 * lpp * (world - 1)
         else:
             pr = g.export_runs_device(buf.data_ptr(), buf.shape[0], world)
             ctx.sync()
@@ -75,9 +80,10 @@ for it in range(2):
     og = cfrk_amd.GlobalCounter(octx, k, flags, hint // world + 1024)
     if leaf_mode:
         rkeys = torch.cat([s[0] for s in segs]); rcnt = torch.cat([s[1] for s in segs]); rlc = torch.cat([s[2] for s in segs])
+        rhi = torch.cat([s[4] for s in segs]) if k > 32 else None
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        og.merge_leaves_device(rkeys.data_ptr(), rcnt.data_ptr(), [int(s[3]) for s in segs], rlc.data_ptr(), 0)
+        og.merge_leaves_device(rkeys.data_ptr(), rcnt.data_ptr(), [int(s[3]) for s in segs], rlc.data_ptr(), rhi.data_ptr() if k > 32 else 0)
     else:
         packed = torch.cat([s[0] for s in segs])
         torch.cuda.synchronize()
@@ -87,8 +93,8 @@ for it in range(2):
     t_owner = ((time.perf_counter() - t0) * 1e3, og.last_add_ms() if not leaf_mode else None)
 dg = og.digest()
 res = {
-    "what": "strong-scaling step rehearsed on one GPU (%s exchange), wire time excluded" % ("leaf" if leaf_mode else "runs"),
-    "world": world, "reads": R, "k": k,
+    "what": "%s-scaling step rehearsed on one GPU (%s exchange), wire time excluded" % ("weak" if weak else "strong", "leaf" if leaf_mode else "runs"),
+    "world": world, "reads": R * world if weak else R, "read_len": L, "genome": G, "k": k,
     "rank_count_kernels_ms_max": max(t[0] for t in t_count), "rank_count_wall_ms_max": max(t[1] for t in t_count),
     "rank_export_ms_max": max(t_export), "owner_merge_wall_ms": t_owner[0], "owner_kernels_ms": t_owner[1],
     "critical_path_ms": max(t[1] for t in t_count) + max(t_export) + t_owner[0],
