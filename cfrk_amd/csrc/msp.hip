@@ -41,6 +41,7 @@
 #include "msp_dev.h"
 
 #include <algorithm>
+#include <cmath>
 #include <new>
 #include <vector>
 
@@ -2006,6 +2007,15 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
           // (measured on C3: with 1.3 x a few leaves' complete streams overflow and their records are parked --
           //  counted through the HBM table, +0.5 ms and a merge at finish; 1.4 x has none)
           double fc_slack = 1.45, ft_slack = 1.6;
+          {
+            // ... and a leaf's load scatters with the number of distinct runs it holds (the copies of a run come
+            // and go together): lambda = distinct k-mers per leaf x 4 / (W + 1) -- 320 for C3, 64 for 20 M reads
+            // of a 20 Mb genome, whose heaviest complete stream is 2.0 x the mean one (5448 records parked at 1.45 x)
+            // (the table holds 2 .. 4 x the announced distinct k-mers: a third of it stands for the hint)
+            const double lambda = std::max(4.0, (double)ctx->g_cap / 3.0 / (double)NLEAF * 4.0 / (double)(W + 1));
+            fc_slack = std::min(4.0, std::max(fc_slack, 1.2 + 6.5 / std::sqrt(lambda)));
+            ft_slack = std::min(4.0, std::max(ft_slack, 1.3 + 6.5 / std::sqrt(lambda)));
+          }
           if (const char *e = getenv("CFRK_L2_SLACK")) sscanf(e, "%lf,%lf", &fc_slack, &ft_slack);   // (experiments)
           const uint64_t m2c = (uint64_t)(per_leaf * (1.0 - ft) * fc_slack + per_leaf * 0.02) + 512, m2t = (uint64_t)(per_leaf * ft * ft_slack) + 256;
           if (m2c + m2t < v.cap2c + v.cap2t) { v.cap2c = m2c; v.cap2t = m2t; }

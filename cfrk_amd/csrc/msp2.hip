@@ -19,6 +19,7 @@
 #include "msp_dev.h"
 
 #include <algorithm>
+#include <cmath>
 #include <vector>
 
 namespace {
@@ -1719,7 +1720,11 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
             fc = (double)made[4] / (double)sampled + 0.02;
             ft = (double)std::max(made[1], std::max(made[2], made[3])) / (double)sampled + 0.01;
           }
-          v.cap2c = (uint64_t)(per_leaf * std::min(1.0, fc) * 1.45) + 512; v.cap2t = (uint64_t)(per_leaf * std::min(1.0, ft) * 1.6) + 256;
+          // (the slack grows with how few distinct runs a leaf holds, msp.hip)
+          const double lambda = std::max(4.0, (double)ctx->g_cap / 3.0 / (double)NLEAF * 4.0 / (double)(W2 + 1));
+          const double fc_slack = std::min(4.0, std::max(1.45, 1.2 + 6.5 / std::sqrt(lambda)));
+          const double ft_slack = std::min(4.0, std::max(1.6, 1.3 + 6.5 / std::sqrt(lambda)));
+          v.cap2c = (uint64_t)(per_leaf * std::min(1.0, fc) * fc_slack) + 512; v.cap2t = (uint64_t)(per_leaf * std::min(1.0, ft) * ft_slack) + 256;
           if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)(NLEAF >> sel_bits) * (v.cap2c + 3 * v.cap2t) * sizeof(Rec2), &p))) return rc;
           v.rec2 = (Rec2 *)p;
         }
