@@ -1036,11 +1036,21 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
   const uint32_t tab_mask = (1u << tab_log) - 1u;
   const int tab_trips = big_first ? BT_TRIPS : RT_TRIPS;
   if (!SHARED && (mode & P3_EXPORT) && n1 == 0) return;      // nothing to deduplicate: the truncated runs leave as they are
+  // DISPLACED-RUN CACHE.  At load 0.3 a sixth of the distinct runs do not sit in their home slot of the
+  // record table, and every copy of such a run (~50 each at C3's depth) took the slow path: compaction
+  // across the wave plus the probe loop -- there is such a record in nearly every wave-step.  While the
+  // stream is scanned the k-mer table's memory is idle: it holds a direct-mapped cache of DC entries
+  // (same entry format, own hash) in which a displaced run is installed by the probe loop that placed or
+  // found it.  A record that misses its home slot looks there next (one more LDS read) and counts in the
+  // cache entry; after the scan the cache's counts are added to the table's entries and the memory
+  // becomes the k-mer table.  Only first sightings and cache conflicts still take the slow path.
+  constexpr int DC = TS / 2 + TS / 4;            // uint4 entries in the k-mer table's memory (3072)
+  const bool use_cache = !big_first;
+  uint4 *const dcache = pool;
   if (big_first) {
     for (int s = tid; s < BT; s += P3_THREADS) pool[s] = make_uint4(0u, 0u, 0u, RT_EMPTY);
   } else {
-    if (SHARED || !(mode & P3_EXPORT))             // (an exporting leaf never touches its k-mer table)
-      for (int s = tid; s < TS; s += P3_THREADS) { keys[s] = CFRK_EMPTY_KEY; cnts[s] = 0; }
+    for (int s = tid; s < DC; s += P3_THREADS) dcache[s] = make_uint4(0u, 0u, 0u, RT_EMPTY);
     for (int s = tid; s < RT; s += P3_THREADS) rtab[s] = make_uint4(0u, 0u, 0u, RT_EMPTY);
   }
   if (tid == 0) { wg_total = 0; nocc = 0; rt_fail = 0; kovf = 0; sp = 0; leaf_total = 0; nseg = 0; nfb = 0; nfl = 0; }
@@ -1068,19 +1078,42 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     uint32_t Lh = 0;
     int c = 0;                       // wave-uniform
     const bool weighted = !SHARED && (mode & P3_WEIGHTED) != 0u;   // (an owner's leaves are never shared)
+    auto dc_slot = [&](const uint4 rec) {
+      const uint32_t t_ = rec.y ^ __builtin_amdgcn_alignbit(rec.x, rec.x, 7) ^ __builtin_amdgcn_alignbit(rec.z, rec.z, 19) ^ ((rec.w & 63u) << 25);
+      return __umulhi(t_ * 0x85EBCA77u, (uint32_t)DC);
+    };
     auto drain = [&](int cnt) {
       uint32_t h = Lh | ((lane < cnt) ? 0u : RT_DONE);
       rtab_insert_loop(tab, L, h, tab_mask, tab_trips, weighted ? ((L.w >> 6) << 6) : (1u << 6));
       // no room in the record table: a leaf with more distinct runs than it holds (low coverage
       // of a large genome).  Dedupe is pointless there: the whole leaf is counted from its streams.
       if ((int32_t)h >= 0) rt_fail = 1u;
+      // a record that ended up away from its home slot goes into the cache (count 0: what the table's entry
+      // holds stays there), so that its next copies find it with one look instead of coming through here
+      if (use_cache && lane < cnt && (int32_t)h < 0 && ((h ^ Lh) & tab_mask) != 0u) {
+        uint32_t *dmeta = reinterpret_cast<uint32_t *>(dcache);
+        const uint32_t cs = dc_slot(L);
+        if (atomicCAS(&dmeta[4 * cs + 3], RT_EMPTY, RT_LOCK) == RT_EMPTY) {
+          dmeta[4 * cs + 0] = L.x; dmeta[4 * cs + 1] = L.y; dmeta[4 * cs + 2] = L.z;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          atomicExch(&dmeta[4 * cs + 3], L.w & 63u);
+        }
+      }
     };
     auto home = [&](const uint4 rec, bool valid) {
       const uint32_t h = big_first ? rtab_slot(rec, tab_log) : rtab_slot_k(rec, k, tab_log);
       const uint4 e = tab[h];
       const bool match = valid && rtab_diff(e, rec) == 0u;
       if (match) atomicAdd(&rmeta[4 * h + 3], weighted ? ((rec.w >> 6) << 6) : (1u << 6));
-      const bool left = valid && !match;
+      bool left = valid && !match;
+      if (use_cache && __ballot(left)) {
+        uint32_t *dmeta = reinterpret_cast<uint32_t *>(dcache);
+        const uint32_t cs = dc_slot(rec);
+        const uint4 ce = dcache[cs];
+        const bool chit = left && rtab_diff(ce, rec) == 0u;
+        if (chit) atomicAdd(&dmeta[4 * cs + 3], weighted ? ((rec.w >> 6) << 6) : (1u << 6));
+        left = left && !chit;
+      }
       const unsigned long long mask = __ballot(left);
       if (mask == 0ull) return;
       const int n = __popcll(mask);
@@ -1133,6 +1166,26 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     if ((v.dbg & CFRK_DEBUG_FORCE_RT_OVERFLOW) && !big_first) rt_fail = 1u;
   }
   __syncthreads();
+  if (use_cache) {
+    // the cache's counts go to the table's entries (the run is there: it was placed before it was cached;
+    // a table that overflowed is not used at all), then the memory becomes the k-mer table
+    uint32_t *rmeta = reinterpret_cast<uint32_t *>(rtab);
+    for (int s = tid; s < DC && rt_fail == 0u; s += P3_THREADS) {
+      const uint4 ce = dcache[s];
+      if (ce.w == RT_EMPTY || (ce.w >> 6) == 0u) continue;
+      uint32_t hh = rtab_slot_k(ce, k, RT_LOG);
+      for (int it = 0; it < RT; ++it) {
+        const uint4 e = rtab[hh];
+        if (rtab_diff(e, ce) == 0u) { atomicAdd(&rmeta[4 * hh + 3], (ce.w >> 6) << 6); break; }
+        if (e.w == RT_EMPTY) break;                // (cannot happen)
+        hh = (hh + 1u) & (uint32_t)(RT - 1);
+      }
+    }
+    __syncthreads();
+    if (SHARED || !(mode & P3_EXPORT))             // (an exporting leaf never touches its k-mer table)
+      for (int s = tid; s < TS; s += P3_THREADS) { keys[s] = CFRK_EMPTY_KEY; cnts[s] = 0; }
+    __syncthreads();
+  }
   // ---- phase 2: k-mer by k-mer -- every distinct complete record of the record table (weight =
   //      its multiplicity) and the truncated runs (weight 1).  Both are first listed SORTED BY
   //      LENGTH (counting sort of 16-bit indices in LDS): a wave expands 64 records in lock-step
