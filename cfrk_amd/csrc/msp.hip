@@ -1234,13 +1234,21 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     // (b) truncated runs: the first TL_CAP of the stream, by position
     constexpr uint32_t TW_NONE = 0xFFFFFFFFu, TW_TWIN = 0x80000000u;
     uint32_t tw[TL_PER], trank[TL_PER];              // n-1, or TW_TWIN | twin slot << 8 | n
+    // (all of a thread's records are asked for before the first is looked up: one HBM round trip instead of
+    //  TL_PER -- the compiler put a full wait behind every load, 4 x ~1.5 us per leaf with two leaves per CU)
+    uint4 trec[TL_PER];
+#pragma unroll
+    for (int i = 0; i < TL_PER; ++i) trec[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (tl) {                                        // (uniform; lanes past the end load the last record again: no
+#pragma unroll                                       //  per-lane branch, so the four loads are in flight together)
+      for (int i = 0; i < TL_PER; ++i) trec[i] = trunc[min((uint32_t)(i * P3_THREADS + tid), tl - 1u)];
+    }
 #pragma unroll
     for (int i = 0; i < TL_PER; ++i) {
       const uint32_t g = (uint32_t)(i * P3_THREADS + tid);
       bool valid = g < tl;
       tw[i] = TW_NONE; trank[i] = 0u;
-      uint4 rec = make_uint4(0u, 0u, 0u, 0u);
-      if (valid) rec = trunc[g];
+      uint4 rec = trec[i];
       if (SHARED) valid = valid && mine(rec.w);
       const uint32_t nm1 = rec.w & 31u;
       if (valid) tw[i] = nm1;
