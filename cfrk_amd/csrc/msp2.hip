@@ -1417,8 +1417,10 @@ __global__ __launch_bounds__(DX2_THREADS) void msp2_dedupe_export_kernel(int k, 
           found = hit ? hh : found;
           h = (p && !hit && !empty) ? ((hh + 1u) & (uint32_t)(RX - 1)) : (h | R2_DONE);
         }
-        // (a twin beyond position 2047 of a long list cannot be named by a note: the run travels as a record)
-        const bool hit = found != 0xFFFFFFFFu && (uint32_t)sidx[found] <= NOTE_POS_MAX;
+        // (a twin beyond position 2047 of a long list cannot be named by a note: the run travels as a record;
+        //  CFRK_DEBUG_SMALL_WAVE_CAP lowers the limit to 15 so that tests reach this at small sizes)
+        const uint32_t pos_max = (v.dbg & CFRK_DEBUG_SMALL_WAVE_CAP) ? 15u : NOTE_POS_MAX;
+        const bool hit = found != 0xFFFFFFFFu && (uint32_t)sidx[found] <= pos_max;
         if (hit) { trunc[g].a.x = ((uint32_t)sidx[found] << 5) | nm1; trunc[g].b.w = RUN_NOTED; }
         const unsigned long long hb = __ballot(hit);
         if (lane == 0 && hb) atomicAdd(&noted, (uint32_t)__popcll(hb));
