@@ -58,6 +58,8 @@ def parse():
                         "headline and the weak measurement is reported under \"weak\"")
     p.add_argument("--owner-hash", action="store_true",
                    help="force the generic hash-owner exchange + HBM-table merge")
+    p.add_argument("--debug-runs-budget", default="", metavar="RANK:BYTES",
+                   help="(tests) cap rank RANK's record buffers at BYTES during its CFRK_RUNS_ONLY add")
     p.add_argument("--exchange", default="auto", choices=["auto", "runs", "leaf", "owner"],
                    help="N > 1: what the ranks exchange.  runs (auto for 16 <= k <= 64): deduplicated "
                         "runs, counted by the leaf's owner; leaf: counted per-leaf lists; owner: counted keys")
@@ -244,6 +246,7 @@ def main():
                 self.g = None
                 self.bufs = None
                 self.lbufs = None
+                self.runs_refused = False
 
             def export_leaves(self, parts):
                 lpp = self.g.leaves_per_part(parts)
@@ -264,6 +267,8 @@ def main():
                 return keys, hi, cnt, pc, lc
 
             def export_runs(self, parts):
+                if self.runs_refused:      # the CFRK_RUNS_ONLY add itself was refused (shard needs several passes)
+                    return None
                 if getattr(self, "rbuf", None) is None:
                     # rows of 16 bytes: distinct runs (<= the leaf streams) + truncated runs + headers
                     # (truncated runs: two per read; distinct complete runs: ~2 strands x 2/(W+1) per genome base,
@@ -313,7 +318,23 @@ def main():
             eng.g = cfrk_amd.GlobalCounter(ctx, k, flags | (cfrk_amd.CFRK_RUNS_ONLY if runs else 0), hint)
             if os.environ.get("CFRK_DEBUG_FLAGS"):       # timing ablations (tools/ablate.sh): wrong counts
                 eng.g.set_debug_flags(int(os.environ["CFRK_DEBUG_FLAGS"], 0))
-            eng.g.add_device(d_data.data_ptr(), nN)
+            for kv in filter(None, os.environ.get("CFRK_BENCH_PARAMS", "").split(",")):   # sizing experiments
+                eng.g.set_debug_param(int(kv.split(":")[0]), float(kv.split(":")[1]))
+            budget = runs and args.debug_runs_budget and int(args.debug_runs_budget.split(":")[0]) == rank
+            if budget:                                   # (tests) this rank's shard does not fit one pass
+                eng.g.set_mem_budget(int(args.debug_runs_budget.split(":")[1]))
+            eng.runs_refused = False
+            try:
+                eng.g.add_device(d_data.data_ptr(), nN)
+            except cfrk_amd.CfrkError as e:
+                # a CFRK_RUNS_ONLY job must fit device memory in one pass (CFRK_ERR_NOMEM / CFRK_ERR_STATE):
+                # this rank votes "no runs" in the size exchange and every rank takes the leaf exchange together
+                if not (runs and e.code in (-2, -4)):
+                    raise
+                eng.runs_refused = True
+            finally:
+                if budget:
+                    eng.g.set_mem_budget(0)
             if world == 1:
                 ctx.sync()
                 return eng.g

@@ -6,7 +6,7 @@ Python callers.  There is NO CPU fallback: if the HIP library is missing or no g
 is present, every compute entry point raises.
 """
 from .lib import (CFRK_CANONICAL, CFRK_COMPAT, CFRK_DEBUG_FORCE_RT_OVERFLOW, CFRK_DEBUG_NO_PIPELINE, CFRK_DEBUG_SMALL_PIPELINE, CFRK_DEBUG_SMALL_WAVE_CAP, CFRK_FLOAT_INDEX, CFRK_FORCE_HASH, CFRK_RUNS_ONLY, CfrkError, Context, GlobalCounter, Read,
-                  abi_symbols, kmer_main, load_library, library_path)
+                  abi_symbols, device_count, kmer_main, load_library, library_path)
 
 __all__ = ["CFRK_CANONICAL", "CFRK_COMPAT", "CFRK_DEBUG_FORCE_RT_OVERFLOW", "CFRK_DEBUG_NO_PIPELINE", "CFRK_DEBUG_SMALL_PIPELINE", "CFRK_DEBUG_SMALL_WAVE_CAP", "CFRK_FLOAT_INDEX", "CFRK_FORCE_HASH", "CFRK_RUNS_ONLY", "CfrkError", "Context", "GlobalCounter", "Read",
-           "abi_symbols", "kmer_main", "load_library", "library_path"]
+           "abi_symbols", "device_count", "kmer_main", "load_library", "library_path"]

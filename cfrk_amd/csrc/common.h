@@ -62,6 +62,7 @@ struct cfrk_ctx {
   int last_passes;       // passes the most recent add took on a partitioned path (1 unless memory was short)
   uint32_t dbg_flags;    // cfrk_debug_set_flags
   size_t mem_budget;     // 0 = what the device has free; else a cap on the partitioned paths' buffers (diagnostics)
+  double dbg_param[4];   // cfrk_debug_set_param (0 = the library's own choice)
 };
 
 int cfrk_fail(cfrk_ctx *ctx, int code, const char *fmt, ...);

@@ -1954,7 +1954,7 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
   // even at 512 chunks of 43 MB, profiles/r03/chunk_count_sweep_c3.txt)
   // (a batch whose level-1 records fit ~6 GB anyway -- a shard of a multi-GPU job -- stays in one chunk)
   int nchunks = (int)std::min<int64_t>(small_pipe ? 5 : (int64_t)((double)B1 * nxg * cap1 * 16.0 / 6e9) + 1, ntiles / chunk_min);
-  if (const char *e = getenv("CFRK_MSP_CHUNKS")) nchunks = std::max(1, std::min(atoi(e), (int)std::min<int64_t>(4096, ntiles / 8)));   // (experiments)
+  if (ctx->dbg_param[CFRK_PARAM_MSP_CHUNKS] > 0) nchunks = std::max(1, std::min((int)ctx->dbg_param[CFRK_PARAM_MSP_CHUNKS], (int)std::min<int64_t>(4096, ntiles / 8)));   // (experiments)
   const bool pipelined = (nxg == NXG || small_pipe) && nchunks >= 2 && !(ctx->dbg_flags & CFRK_DEBUG_NO_PIPELINE);
   if (!pipelined) nchunks = 1;
   const int64_t chunk_tiles = (ntiles + nchunks - 1) / nchunks;
@@ -2031,6 +2031,32 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
     HIP_TRY(ctx, hipGetLastError());
     return CFRK_OK;
   };
+  // exact layout of the leaf streams from the demand their cursors counted (they count on past a
+  // stream's capacity): streams back to back, each with exactly the room it needs; the buffer grows
+  // when the batch holds more records than it was sized for (a chunked batch's streams were sized from
+  // its first chunk)
+  auto layout_l2 = [&]() -> int {
+    int rc2;
+    void *q;
+    if ((rc2 = cfrk_pool_get(ctx, BUF_MSP_LAYOUT, (size_t)NCLS * NLEAF * (sizeof(uint64_t) + sizeof(uint32_t)), &q))) return rc2;
+    uint64_t *lbase = (uint64_t *)q;
+    uint32_t *lcap = (uint32_t *)(lbase + NCLS * NLEAF);
+    hipLaunchKernelGGL(msp_layout_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)v.cnt2, (uint32_t)(NCLS * NLEAF), lbase, lcap);
+    HIP_TRY(ctx, hipGetLastError());
+    if ((rc2 = cfrk_pool_get(ctx, BUF_SCRATCH, 64 * sizeof(uint64_t), &q))) return rc2;
+    hipLaunchKernelGGL(msp_sum_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)v.cnt2, (uint32_t)(NCLS * NLEAF), (uint64_t *)q);
+    HIP_TRY(ctx, hipGetLastError());
+    uint64_t all = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&all, q, sizeof all, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if ((size_t)all * sizeof(uint4) > ctx->pool[BUF_MSP_L2].cap) {
+      if ((rc2 = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)all * sizeof(uint4), &q))) return rc2;
+      v.rec2 = (uint4 *)q;
+    }
+    HIP_TRY(ctx, hipMemsetAsync(v.cnt2, 0, (size_t)NCLS * NLEAF * sizeof(uint32_t), ctx->stream));
+    v.exact = 1; v.lbase = lbase; v.lcap = lcap;
+    return CFRK_OK;
+  };
   const unsigned p2_grid = 2u * (unsigned)std::max(8, ctx->num_cus / 8 * 8);   // P2: persistent, two workgroups per CU, a multiple of 8
   bool run_p1 = true, settled = false, piped = pipelined;
   uint64_t parked1 = 0, parked2 = 0;
@@ -2044,9 +2070,9 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
       for (int c = 0; c < nchunks; ++c) {
         const int64_t t0 = tile0 + (int64_t)c * chunk_tiles, t1 = std::min(tile0 + ntiles, t0 + chunk_tiles);
         if (t0 >= t1) break;
-        if (c > 0) HIP_TRY(ctx, hipMemsetAsync(vc.cnt1, 0, nreg * sizeof(uint32_t), ctx->stream));   // (chunk 0: cleared above)
+        if (c > 0 || attempt > 0) HIP_TRY(ctx, hipMemsetAsync(vc.cnt1, 0, nreg * sizeof(uint32_t), ctx->stream));   // (chunk 0 of the first attempt: cleared above)
         if ((rc = launch_p1(t0, t1, vc))) return rc;
-        if (c == 0 && !small_pipe) {
+        if (c == 0 && !small_pipe && !v.exact) {
           // The leaf streams are sized from what the first chunk really made, not from the worst
           // density a batch of unknown read length could have (the estimate above allows for reads
           // as short as 2k: 1.34 x the records 150-base reads make, times 2.7 for lumpy leaves --
@@ -2077,7 +2103,8 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
             fc_slack = std::min(4.0, std::max(fc_slack, 1.2 + 6.5 / std::sqrt(lambda)));
             ft_slack = std::min(4.0, std::max(ft_slack, 1.3 + 6.5 / std::sqrt(lambda)));
           }
-          if (const char *e = getenv("CFRK_L2_SLACK")) sscanf(e, "%lf,%lf", &fc_slack, &ft_slack);   // (experiments)
+          if (ctx->dbg_param[CFRK_PARAM_L2_SLACK_COMPLETE] > 0) fc_slack = ctx->dbg_param[CFRK_PARAM_L2_SLACK_COMPLETE];   // (experiments)
+          if (ctx->dbg_param[CFRK_PARAM_L2_SLACK_TRUNCATED] > 0) ft_slack = ctx->dbg_param[CFRK_PARAM_L2_SLACK_TRUNCATED];
           const uint64_t m2c = (uint64_t)(per_leaf * (1.0 - ft) * fc_slack + per_leaf * 0.02) + 512, m2t = (uint64_t)(per_leaf * ft * ft_slack) + 256;
           if (m2c + m2t < v.cap2c + v.cap2t) { v.cap2c = m2c; v.cap2t = m2t; }
           if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)(NLEAF >> sel_bits) * (v.cap2c + v.cap2t) * sizeof(uint4), &p))) return rc;
@@ -2099,15 +2126,27 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
     uint64_t st[ST_NWORDS];
     HIP_TRY(ctx, hipMemcpyAsync(st, ctx->g_stats, sizeof st, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (piped && (st[ST_L1OVF] || st[ST_L2OVF])) {
-      // a region overflowed by more than the parking buffers take: the level-1 cursors of a chunk do
-      // not add up to the batch's demand (the buffer is reused), so the batch starts over on the
-      // one-chunk path, which lays the overflowing level out exactly
+    if (piped && st[ST_L1OVF]) {
+      // a level-1 region overflowed by more than the parking buffer takes: the level-1 cursors of a chunk
+      // do not add up to the batch's demand (the buffer is reused), so the batch starts over on the
+      // one-chunk path, which lays the overflowing level out exactly -- with the leaf streams the
+      // density estimate gives (what the first chunk suggested is void)
       piped = false;
       if ((rc = cfrk_pool_get(ctx, BUF_MSP_L1, nreg * cap1 * sizeof(uint4), &p))) return rc;
       v.rec1 = (uint4 *)p;
+      v.cap2c = cap2c; v.cap2t = cap2t;
+      if ((rc = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)(NLEAF >> sel_bits) * (cap2c + cap2t) * sizeof(uint4), &p))) return rc;
+      v.rec2 = (uint4 *)p;
       HIP_TRY(ctx, hipMemsetAsync(v.cnt1, 0, (nreg + (size_t)NCLS * NLEAF) * sizeof(uint32_t), ctx->stream));   // cnt1 and cnt2
       run_p1 = true;
+      continue;
+    }
+    if (piped && st[ST_L2OVF]) {
+      // only leaf streams overflowed (the first chunk was no measure of the batch: reads sorted or
+      // clustered, a short-read or N-rich prefix, concatenated libraries).  Their cursors counted on
+      // over ALL chunks, so the batch's exact demand is known: lay the streams out back to back and
+      // run the chunks again (one more P1 + P2 over the input; the level-1 buffer stays one chunk).
+      if ((rc = layout_l2())) return rc;
       continue;
     }
     if (st[ST_L1OVF]) {
@@ -2142,13 +2181,7 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
     }
     parked1 = st[ST_OVFN1];
     if (st[ST_L2OVF]) {
-      if ((rc = cfrk_pool_get(ctx, BUF_MSP_LAYOUT, (size_t)NCLS * NLEAF * (sizeof(uint64_t) + sizeof(uint32_t)), &p))) return rc;
-      uint64_t *lbase = (uint64_t *)p;
-      uint32_t *lcap = (uint32_t *)(lbase + NCLS * NLEAF);
-      hipLaunchKernelGGL(msp_layout_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)v.cnt2, (uint32_t)(NCLS * NLEAF), lbase, lcap);
-      HIP_TRY(ctx, hipGetLastError());
-      HIP_TRY(ctx, hipMemsetAsync(v.cnt2, 0, (size_t)NCLS * NLEAF * sizeof(uint32_t), ctx->stream));
-      v.exact = 1; v.lbase = lbase; v.lcap = lcap;
+      if ((rc = layout_l2())) return rc;
       run_p1 = false;
       continue;
     }
@@ -2321,6 +2354,18 @@ extern "C" int cfrk_debug_set_mem_budget(cfrk_ctx *ctx, uint64_t bytes) {
   return CFRK_OK;
 }
 
+extern "C" int cfrk_debug_set_param(cfrk_ctx *ctx, int which, double value) {
+  if (!ctx) return CFRK_ERR_ARG;
+  if (which < 0 || which >= 4 || !(value >= 0)) return cfrk_fail(ctx, CFRK_ERR_ARG, "cfrk_debug_set_param: no such parameter / negative value");
+  if (value != 0) {
+    if (which == CFRK_PARAM_MSP_CHUNKS && !(value >= 1 && value <= 4096)) return cfrk_fail(ctx, CFRK_ERR_ARG, "chunks: 1 .. 4096");
+    if ((which == CFRK_PARAM_L2_SLACK_COMPLETE || which == CFRK_PARAM_L2_SLACK_TRUNCATED) && !(value >= 1.0 && value <= 16.0))
+      return cfrk_fail(ctx, CFRK_ERR_ARG, "leaf-stream slack: 1 .. 16");
+    if (which == CFRK_PARAM_MSP2_SUBVALUE_BITS && !(value >= 1 && value <= 3)) return cfrk_fail(ctx, CFRK_ERR_ARG, "sub-value bits + 1: 1 .. 3");
+  }
+  ctx->dbg_param[which] = value;
+  return CFRK_OK;
+}
 extern "C" int cfrk_debug_set_flags(cfrk_ctx *ctx, uint32_t flags) {
   if (!ctx) return CFRK_ERR_ARG;
   ctx->dbg_flags = flags;

@@ -1582,7 +1582,7 @@ static uint32_t msp2_hbits(const cfrk_ctx *ctx, uint32_t sub_bits, uint64_t per_
   if (!(ctx->g_k & 1)) runs_per_leaf *= 1.3;
   uint32_t hbits = std::min(sub_bits, 2u);
   while (hbits > 0 && runs_per_leaf * (double)(1u << hbits) / (double)(1u << sub_bits) > 640.0) --hbits;
-  if (const char *e = getenv("CFRK_MSP2_HBITS")) hbits = std::min<uint32_t>(sub_bits, (uint32_t)atoi(e));   // (experiments)
+  if (ctx->dbg_param[CFRK_PARAM_MSP2_SUBVALUE_BITS] > 0) hbits = std::min<uint32_t>(sub_bits, (uint32_t)ctx->dbg_param[CFRK_PARAM_MSP2_SUBVALUE_BITS] - 1u);   // (tests)
   return hbits;
 }
 

@@ -21,6 +21,7 @@ CFRK_DEBUG_NO_ANCHORS = 0x4
 CFRK_DEBUG_RECORD_SUBSETS = 0x8
 CFRK_DEBUG_NO_PIPELINE = 0x10
 CFRK_DEBUG_SMALL_PIPELINE = 0x20
+CFRK_PARAM_MSP_CHUNKS, CFRK_PARAM_L2_SLACK_COMPLETE, CFRK_PARAM_L2_SLACK_TRUNCATED, CFRK_PARAM_MSP2_SUBVALUE_BITS = 0, 1, 2, 3   # cfrk_debug_set_param
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libcfrk_hip.so")
@@ -90,6 +91,7 @@ def load_library():
         "cfrk_debug_set_mem_budget": ([vp, u64], C.c_int),
         "cfrk_debug_device_bytes": ([vp, C.POINTER(u64)], C.c_int),
         "cfrk_debug_set_flags": ([vp, C.c_uint32], C.c_int),
+        "cfrk_debug_set_param": ([vp, C.c_int, C.c_double], C.c_int),
         "cfrk_debug_last_add_passes": ([vp, C.POINTER(C.c_int)], C.c_int),
         "cfrk_synth_reads_device": ([vp, i64, i64, i32, i64, u64, u64, u64, i32, vp, vp, vp], C.c_int),
     }
@@ -99,6 +101,16 @@ def load_library():
         f.restype = res
     _lib = L
     return L
+
+
+def device_count():
+    """usable devices (hipGetDeviceCount through the C ABI); raises when the library is missing"""
+    n = C.c_int(0)
+    L = load_library()
+    rc = L.cfrk_device_count(C.byref(n))
+    if rc != 0:
+        raise CfrkError(rc, "cfrk_device_count", L.cfrk_strerror(rc).decode())
+    return n.value
 
 
 def _ptr(a):
@@ -269,6 +281,9 @@ class GlobalCounter:
 
     def set_debug_flags(self, flags):
         self.ctx.check(self._L.cfrk_debug_set_flags(self.ctx._h, int(flags)), "cfrk_debug_set_flags")
+
+    def set_debug_param(self, which, value):
+        self.ctx.check(self._L.cfrk_debug_set_param(self.ctx._h, int(which), float(value)), "cfrk_debug_set_param")
 
     def last_add_passes(self):
         n = C.c_int()

@@ -59,9 +59,9 @@ extern "C" {
 #define CFRK_CANONICAL  0x2  /* global only: key = min(kmer, reverse complement)                     */
 #define CFRK_FORCE_HASH 0x4  /* global only: count with one HBM atomic per occurrence (the general
                                 path) even where the minimizer-partitioned LDS path applies          */
-#define CFRK_RUNS_ONLY  0x8  /* global only, 16 <= k <= 32: the job partitions and deduplicates ONE add
-                                and stops there; its result leaves through
-                                cfrk_global_export_runs_device (multi-GPU strong scaling)            */
+#define CFRK_RUNS_ONLY  0x8  /* global only, 16 <= k <= 64: the job partitions and deduplicates ONE add
+                                (which must fit device memory in one pass) and stops there; its result
+                                leaves through cfrk_global_export_runs_device (multi-GPU exchange)   */
 #define CFRK_FLOAT_INDEX 0x10 /* per-read dense only, matters for k = 13..15: the window index is accumulated
                                 through float exactly as ComputeIndex does (index += nuc * powf(4, k-1-i),
                                 src/kmer_kernel.cu:38), rounding errors, the all-T window's carry into the
@@ -120,8 +120,10 @@ int cfrk_per_read_dense_device(cfrk_ctx *ctx, const int8_t *d_data, const int64_
  * cfrk_global_add calls since begin; a window counts iff its k codes are all valid, so no
  * window crosses a terminator.  Result = set of (key, count), count < 2^32.
  * capacity_hint = expected number of DISTINCT keys (0: library default).  It sizes the result list
- * and the HBM table; a hint above ~2.7e8 also makes the two-word path (33 <= k <= 64) share its
- * leaves between several workgroups (~2000 distinct k-mers each) -- a job that holds far more
+ * and the HBM table, and the partitioned paths (k >= 16) read it as the job's shape: a hint above
+ * ~2.7e8 makes them share every leaf between several workgroups (~2000 distinct k-mers each; one-
+ * and two-word keys alike), and the room a chunked batch's leaf streams get beyond their measured
+ * mean grows when the hint says that a leaf holds few distinct runs.  A job that holds far more
  * distinct k-mers than it announced still counts exactly, but splits overfull leaves by key. */
 int cfrk_global_begin(cfrk_ctx *ctx, int k, int flags, uint64_t capacity_hint);
 
@@ -233,13 +235,23 @@ int cfrk_debug_last_add_passes(cfrk_ctx *ctx, int *out_passes);
  * whatever the capacity hint (normally only for hints above ~2.7e8 distinct k-mers, 2..32
  * workgroups per leaf): makes that path reachable with small inputs (tests). */
 #define CFRK_DEBUG_RECORD_SUBSETS 0x8
-/* Bit 4: the one-word partitioned path never pipelines (large batches at k >= 24 normally cut the
- * input into chunks and run the partition kernel on chunk s beside the second-level kernel on chunk
- * s-1 in one launch); same result, for A/B timing.  Bit 5: pipeline whatever the batch size, in
- * chunks of a few tiles: makes the fused kernel reachable with small inputs (tests). */
+/* Bit 4: the partitioned paths (k >= 16) never count in chunks (a large batch is normally cut into
+ * chunks of tiles -- partition kernel on chunk c, then second-level kernel on chunk c -- so that the
+ * level-1 buffer holds one chunk and the leaf streams are sized from the first chunk's records); same
+ * result, for A/B timing.  Bit 5: count in chunks of a few tiles whatever the batch size: makes the
+ * chunked path reachable with small inputs (tests). */
 #define CFRK_DEBUG_NO_PIPELINE 0x10
 #define CFRK_DEBUG_SMALL_PIPELINE 0x20
 int cfrk_debug_set_flags(cfrk_ctx *ctx, uint32_t flags);
+
+/* Sizing knobs of the partitioned paths for experiments and tests (value 0 = the library's own choice;
+ * out-of-range values are refused with CFRK_ERR_ARG).  The library reads NO environment variables. */
+#define CFRK_PARAM_MSP_CHUNKS          0  /* 1 .. 4096: chunks a large batch is counted in (16 <= k <= 32)            */
+#define CFRK_PARAM_L2_SLACK_COMPLETE   1  /* 1 .. 16: leaf-stream room for complete runs, x the measured mean share   */
+#define CFRK_PARAM_L2_SLACK_TRUNCATED  2  /* 1 .. 16: the same for truncated runs                                     */
+#define CFRK_PARAM_MSP2_SUBVALUE_BITS  3  /* 1 .. 3: log2(sub-values one workgroup of a shared leaf counts) + 1
+                                             (33 <= k <= 64; normally chosen from the expected runs per leaf)         */
+int cfrk_debug_set_param(cfrk_ctx *ctx, int which, double value);
 
 /* ---- synthetic reads, generated on device ----------------------------------- */
 

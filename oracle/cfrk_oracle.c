@@ -257,6 +257,15 @@ typedef struct {
     uint64_t maxpart;
     int phase, oom;
     pthread_barrier_t bar;
+    /* bounded-memory mode (orc_synth_digest): only the keys of slice `slice` of `nslices` are kept,
+     * and the input is not a buffer but the generator of orc_synth_reads, block by block */
+    int slice, nslices;
+    int synth, L, uniform;
+    int64_t R, Glen;
+    uint64_t seedG, seedR, seedS;
+    const int8_t *genome;         /* g[j] = splitmix64(seedG + j) & 3, cached (NULL for uniform reads) */
+    int64_t *r0, *r1;             /* per thread: reads [r0, r1) */
+    uint64_t *dig;                /* [nthreads][4] digest terms of the partitions a thread finished */
 } ps_job;
 
 typedef struct { ps_job *j; int t; } ps_arg;
@@ -267,30 +276,35 @@ static inline uint32_t ps_part(const ps_job *j, u128 key)
     return (uint32_t)(key >> sh);
 }
 
-/* windows that start in [s0, s1): pass 0 counts per partition, pass 1 writes the keys
- * (one-word arithmetic for k <= 32, the same loop on 128-bit values above) */
-static void ps_scan(ps_job *j, int t, int pass)
+/* which slice of the key space a key belongs to (bounded-memory mode); any fixed function of the
+ * key will do: every occurrence of a key lands in the same slice */
+static inline int ps_slice(const ps_job *j, uint64_t lo, uint64_t hi)
+{
+    uint64_t h = (lo ^ (hi * 0xD6E8FEB86659FD93ULL)) * 0x9E3779B97F4A7C15ULL;
+    return (int)(((h >> 32) * (uint64_t)j->nslices) >> 32);
+}
+
+/* every window inside d[0, n), the scan starting with no base seen: pass 0 counts per partition,
+ * pass 1 writes the keys (one-word arithmetic for k <= 32, the same loop on 128-bit values above) */
+static void ps_scan_span(ps_job *j, uint64_t *cur, const int8_t *d, int64_t n, int pass)
 {
     const int k = j->k;
-    uint64_t *cur = j->tcnt + (size_t)t * j->nparts;
-    const int64_t s0 = j->s0[t], s1 = j->s1[t];
     const int sh = 2 * k - j->pbits;
     const int canonical = j->canonical;
+    const int sliced = j->nslices > 1;
     int run = 0;
-    int64_t end = s1 + k - 1;
-    if (end > j->nN) end = j->nN;
-    /* a window starts in [s0, s1) iff it ENDS in [s0 + k - 1, s1 + k - 1) */
     if (!j->two) {
         const uint64_t mask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
         uint64_t fwd = 0, rc = 0;
         uint64_t *out = j->k1;
-        for (int64_t p = s0; p < end; p++) {
-            int8_t c = j->data[p];
+        for (int64_t p = 0; p < n; p++) {
+            int8_t c = d[p];
             if (c < 0 || c > 3) { run = 0; fwd = 0; rc = 0; continue; }
             fwd = ((fwd << 2) | (uint64_t)c) & mask;
             rc = (rc >> 2) | ((uint64_t)(3 - c) << (2 * (k - 1)));
             if (++run >= k) {
                 uint64_t key = (canonical && rc < fwd) ? rc : fwd;
+                if (sliced && ps_slice(j, key, 0) != j->slice) continue;
                 uint32_t q = (uint32_t)(key >> sh);
                 if (pass == 0) cur[q]++;
                 else out[cur[q]++] = key;
@@ -300,18 +314,60 @@ static void ps_scan(ps_job *j, int t, int pass)
     }
     const u128 mask = (k == 64) ? ~(u128)0 : (((u128)1 << (2 * k)) - 1);
     u128 fwd = 0, rc = 0;
-    for (int64_t p = s0; p < end; p++) {
-        int8_t c = j->data[p];
+    for (int64_t p = 0; p < n; p++) {
+        int8_t c = d[p];
         if (c < 0 || c > 3) { run = 0; fwd = 0; rc = 0; continue; }
         fwd = ((fwd << 2) | (u128)c) & mask;
         rc = (rc >> 2) | ((u128)(3 - c) << (2 * (k - 1)));
         if (++run >= k) {
             u128 key = (canonical && rc < fwd) ? rc : fwd;
+            if (sliced && ps_slice(j, (uint64_t)key, (uint64_t)(key >> 64)) != j->slice) continue;
             uint32_t q = ps_part(j, key);
             if (pass == 0) cur[q]++;
             else { key2 v; v.hi = (uint64_t)(key >> 64); v.lo = (uint64_t)key; j->k2[cur[q]++] = v; }
         }
     }
+}
+
+/* reads [r, r + n) of the generator into buf, n * (L + 1) bytes: the same values as orc_synth_reads,
+ * with the genome taken from the cached copy */
+static void ps_synth_block(const ps_job *j, int64_t r, int64_t n, int8_t *buf)
+{
+    const int L = j->L;
+    if (j->uniform) { orc_synth_reads(r, n, L, j->Glen, j->seedG, j->seedR, j->seedS, 1, buf, NULL, NULL); return; }
+    for (int64_t i = 0; i < n; i++) {
+        uint64_t rr = (uint64_t)(r + i);
+        int8_t *d = buf + i * (int64_t)(L + 1);
+        uint64_t pos = orc_splitmix64(j->seedR ^ rr) % (uint64_t)(j->Glen - L + 1);
+        const int8_t *g = j->genome + pos;
+        if (!(orc_splitmix64(j->seedS ^ rr) & 1)) memcpy(d, g, (size_t)L);
+        else for (int q = 0; q < L; q++) d[q] = (int8_t)(3 - g[L - 1 - q]);
+        d[L] = -1;
+    }
+}
+
+#define PS_SYNTH_BLOCK 4096   /* reads generated at a time by a thread of the bounded-memory mode */
+
+/* windows that start in [s0, s1) of the buffer (a window starts there iff it ENDS in
+ * [s0 + k - 1, s1 + k - 1)), or -- bounded-memory mode -- every window of the thread's reads */
+static void ps_scan(ps_job *j, int t, int pass)
+{
+    uint64_t *cur = j->tcnt + (size_t)t * j->nparts;
+    if (j->synth) {
+        int8_t *buf = (int8_t *)malloc((size_t)PS_SYNTH_BLOCK * (size_t)(j->L + 1));
+        if (!buf) { j->oom = 1; return; }
+        for (int64_t r = j->r0[t]; r < j->r1[t]; r += PS_SYNTH_BLOCK) {
+            int64_t n = j->r1[t] - r < PS_SYNTH_BLOCK ? j->r1[t] - r : PS_SYNTH_BLOCK;
+            ps_synth_block(j, r, n, buf);
+            ps_scan_span(j, cur, buf, n * (int64_t)(j->L + 1), pass);
+        }
+        free(buf);
+        return;
+    }
+    const int64_t s0 = j->s0[t], s1 = j->s1[t];
+    int64_t end = s1 + j->k - 1;
+    if (end > j->nN) end = j->nN;
+    if (end > s0) ps_scan_span(j, cur, j->data + s0, end - s0, pass);
 }
 
 #define PS_RB 11
@@ -417,10 +473,20 @@ static void *ps_worker(void *p)
                 }
             }
             j->pdist[q] = d;
+            if (j->dig) {   /* bounded-memory mode: only the digest terms of the partition are kept */
+                uint64_t *g = j->dig + 4 * (size_t)t;
+                for (uint64_t i = 0; i < d; i++) {
+                    uint64_t c = j->rle[b + i];
+                    uint64_t kh = j->two ? j->k2[b + i].lo + orc_splitmix64(j->k2[b + i].hi) : j->k1[b + i];
+                    g[1] += c; g[2] += c * orc_splitmix64(kh); g[3] ^= orc_splitmix64(kh ^ c);
+                }
+                g[0] += d;
+            }
         }
         free(tmp);
     }
     pthread_barrier_wait(&j->bar);
+    if (j->dig) return NULL;
     if (t == 0 && !j->oom) {
         uint64_t run = 0;
         for (int q = 0; q < P; q++) { j->ostart[q] = run; run += j->pdist[q]; }
@@ -479,6 +545,92 @@ int64_t orc_global_count_sorted(const int8_t *data, int64_t nN, int k, int flags
     *keys_lo = j.out_lo; *counts = j.out_cnt;
     if (keys_hi) *keys_hi = j.out_hi; else free(j.out_hi);
     return n;
+}
+
+/* Bounded-memory count of a whole synthetic job, for the full-size parity cases: the reads of the
+ * generator (orc_synth_reads) are never held in memory -- every thread makes its share of them block by
+ * block -- and the key space is counted in `nslices` rounds, each keeping only the keys of its slice
+ * (partition, sort, run-length encode exactly as orc_global_count_sorted does) and adding the slice's
+ * digest terms.  Slices are disjoint in key space, so the sums and the xor over them are the digest of
+ * the whole count.  Memory: the genome (Glen bytes) + 12 B per k-mer occurrence of one slice (28 B for
+ * k > 32).  Same semantics as everything above: src/kmer_kernel.cu:36-46 window validity, the guarded
+ * ComputeFreq of src/kmer_kernel.cu:52-70 summed over reads.  Returns 0, -1 bad argument, -2 memory. */
+typedef struct { int8_t *g; int64_t a, b; uint64_t seedG; } gen_arg;
+static void *gen_worker(void *p)
+{
+    gen_arg *a = (gen_arg *)p;
+    for (int64_t q = a->a; q < a->b; q++) a->g[q] = (int8_t)(orc_splitmix64(a->seedG + (uint64_t)q) & 3);
+    return NULL;
+}
+
+/* slices [slice0, slice1) of nslices */
+int orc_synth_digest_slices(int64_t R, int L, int64_t Glen, uint64_t seedG, uint64_t seedR, uint64_t seedS,
+                            int uniform, int k, int flags, int nthreads, int slice0, int slice1, int nslices,
+                            uint64_t out[4])
+{
+    if (k < 1 || k > 64 || R < 0 || L < 1 || nslices < 1 || (!uniform && Glen < L)) return -1;
+    if (slice0 < 0 || slice1 > nslices || slice0 > slice1) return -1;
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 1024) nthreads = 1024;
+    int rc = 0;
+    int8_t *genome = NULL;
+    pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
+    if (!th) return -2;
+    if (!uniform) {
+        genome = (int8_t *)malloc((size_t)Glen);
+        gen_arg *ga = (gen_arg *)calloc((size_t)nthreads, sizeof(gen_arg));
+        if (!genome || !ga) { free(genome); free(ga); free(th); return -2; }
+        for (int t = 0; t < nthreads; t++) {
+            ga[t].g = genome; ga[t].a = Glen * t / nthreads; ga[t].b = Glen * (t + 1) / nthreads; ga[t].seedG = seedG;
+            pthread_create(&th[t], NULL, gen_worker, &ga[t]);
+        }
+        for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+        free(ga);
+    }
+    out[0] = out[1] = out[2] = out[3] = 0;
+    for (int s = slice0; s < slice1 && rc == 0; s++) {
+        ps_job j;
+        memset(&j, 0, sizeof j);
+        j.k = k; j.canonical = (flags & ORC_CANONICAL) != 0; j.two = k > 32;
+        j.pbits = 2 * k < 12 ? 2 * k : 12;
+        j.nparts = 1 << j.pbits;
+        j.nthreads = nthreads;
+        j.slice = s; j.nslices = nslices;
+        j.synth = 1; j.L = L; j.uniform = uniform; j.R = R; j.Glen = Glen;
+        j.seedG = seedG; j.seedR = seedR; j.seedS = seedS; j.genome = genome;
+        j.r0 = (int64_t *)malloc(sizeof(int64_t) * (size_t)nthreads);
+        j.r1 = (int64_t *)malloc(sizeof(int64_t) * (size_t)nthreads);
+        j.tcnt = (uint64_t *)calloc((size_t)nthreads * j.nparts, 8);
+        j.pstart = (uint64_t *)calloc((size_t)j.nparts + 1, 8);
+        j.pdist = (uint64_t *)calloc((size_t)j.nparts, 8);
+        j.dig = (uint64_t *)calloc((size_t)nthreads * 4, 8);
+        ps_arg *args = (ps_arg *)calloc((size_t)nthreads, sizeof(ps_arg));
+        if (!j.r0 || !j.r1 || !j.tcnt || !j.pstart || !j.pdist || !j.dig || !args) rc = -2;
+        else {
+            pthread_barrier_init(&j.bar, NULL, (unsigned)nthreads);
+            for (int t = 0; t < nthreads; t++) {
+                j.r0[t] = R * t / nthreads; j.r1[t] = R * (t + 1) / nthreads;
+                args[t].j = &j; args[t].t = t;
+                pthread_create(&th[t], NULL, ps_worker, &args[t]);
+            }
+            for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+            pthread_barrier_destroy(&j.bar);
+            if (j.oom) rc = -2;
+            else for (int t = 0; t < nthreads; t++) {
+                out[0] += j.dig[4 * t]; out[1] += j.dig[4 * t + 1]; out[2] += j.dig[4 * t + 2]; out[3] ^= j.dig[4 * t + 3];
+            }
+        }
+        free(j.k1); free(j.k2); free(j.rle);
+        free(j.r0); free(j.r1); free(j.tcnt); free(j.pstart); free(j.pdist); free(j.dig); free(args);
+    }
+    free(genome); free(th);
+    return rc;
+}
+
+int orc_synth_digest(int64_t R, int L, int64_t Glen, uint64_t seedG, uint64_t seedR, uint64_t seedS,
+                     int uniform, int k, int flags, int nthreads, int nslices, uint64_t out[4])
+{
+    return orc_synth_digest_slices(R, L, Glen, seedG, seedR, seedS, uniform, k, flags, nthreads, 0, nslices, nslices, out);
 }
 
 /* ------------------------------------------------------------------ digest */

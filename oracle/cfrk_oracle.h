@@ -60,6 +60,19 @@ void orc_free(void *p);
 int64_t orc_global_count_sorted(const int8_t *data, int64_t nN, int k, int flags, int nthreads,
                                 uint64_t **keys_lo, uint64_t **keys_hi, uint64_t **counts);
 
+/* Bounded-memory digest of the global count of a WHOLE synthetic job (reads [0, R) of orc_synth_reads'
+ * generator), for the full-size parity cases (BASELINE configs[2] and one GPU's share of configs[4]):
+ * the reads are generated block by block by the scanning threads and the key space is counted in
+ * `nslices` rounds of 1/nslices of the keys each, so memory is the genome + one slice's occurrences.
+ * out = the digest orc_digest would give for orc_global_count of the same reads.  0, or <0 on error. */
+int orc_synth_digest(int64_t R, int L, int64_t Glen, uint64_t seedG, uint64_t seedR, uint64_t seedS,
+                     int uniform, int k, int flags, int nthreads, int nslices, uint64_t out[4]);
+/* the digest terms of slices [slice0, slice1) only (sums and xor of these over a cover of [0, nslices) give
+ * orc_synth_digest; lets a driver report progress between slices) */
+int orc_synth_digest_slices(int64_t R, int L, int64_t Glen, uint64_t seedG, uint64_t seedR, uint64_t seedS,
+                            int uniform, int k, int flags, int nthreads, int slice0, int slice1, int nslices,
+                            uint64_t out[4]);
+
 /* Order-independent digest (SURVEY 8d "Parity at scale").
  * out[0]=D, out[1]=sum count, out[2]=sum count*splitmix64(kh), out[3]=xor splitmix64(kh ^ count)
  * with kh = lo for k <= 32 and lo + splitmix64(hi) otherwise. */

@@ -50,6 +50,12 @@ def lib():
         L.orc_splitmix64.restype = C.c_uint64
         L.orc_synth_reads.argtypes = [C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_uint64,
                                       C.c_uint64, C.c_uint64, C.c_int, p8, p64, p32]
+        L.orc_synth_digest.argtypes = [C.c_int64, C.c_int, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint64,
+                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, pu64]
+        L.orc_synth_digest.restype = C.c_int
+        L.orc_synth_digest_slices.argtypes = [C.c_int64, C.c_int, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint64,
+                                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, pu64]
+        L.orc_synth_digest_slices.restype = C.c_int
         L.orc_format_cfrk.argtypes = [p32, C.c_int64, C.c_int, C.c_char_p, C.c_size_t]
         L.orc_format_cfrk.restype = C.c_size_t
         L.orc_encode_base.argtypes = [C.c_int]
@@ -122,6 +128,32 @@ def synth_reads(r0, R, L, Glen, seedG=1, seedR=2, seedS=3, uniform=False):
     lib().orc_synth_reads(r0, R, L, Glen, seedG, seedR, seedS, int(uniform),
                           _p(data, C.c_int8), _p(start, C.c_int64), _p(length, C.c_int32))
     return data, start, length
+
+
+def synth_digest(R, L, Glen, k, flags=0, threads=1, slices=1, seedG=1, seedR=2, seedS=3, uniform=False,
+                 progress=None):
+    """Digest of the global count of reads [0, R) of the generator, in bounded memory (the reads are
+    never materialised; the key space is counted in `slices` rounds).  progress(slice_done, slices):
+    called between slices (the digest terms of the slices are added / xored here)."""
+    if progress is None:
+        out = np.zeros(4, np.uint64)
+        rc = lib().orc_synth_digest(R, L, Glen, seedG, seedR, seedS, int(uniform), k, flags, threads, slices,
+                                    _p(out, C.c_uint64))
+        if rc != 0:
+            raise ValueError(f"orc_synth_digest rc={rc}")
+        return tuple(int(x) for x in out)
+    M = (1 << 64) - 1
+    acc = [0, 0, 0, 0]
+    for s in range(slices):
+        out = np.zeros(4, np.uint64)
+        rc = lib().orc_synth_digest_slices(R, L, Glen, seedG, seedR, seedS, int(uniform), k, flags, threads,
+                                           s, s + 1, slices, _p(out, C.c_uint64))
+        if rc != 0:
+            raise ValueError(f"orc_synth_digest_slices rc={rc}")
+        o = [int(x) for x in out]
+        acc = [(acc[0] + o[0]) & M, (acc[1] + o[1]) & M, (acc[2] + o[2]) & M, acc[3] ^ o[3]]
+        progress(s + 1, slices)
+    return tuple(acc)
 
 
 def format_cfrk(freq, k):

@@ -361,6 +361,15 @@ def test_global_equals_column_sum_of_per_read_dense_on_gpu(ctx, k):
     assert int(dense.sum()) > 0
 
 
+def _oracle_full_digest(name):
+    """tests/golden/oracle_digest_<name>_full.json: written by tools/oracle_full_digest.py from the ORACLE's
+    bounded-memory count (orc_synth_digest) of the whole config"""
+    import json
+    rec = json.load(open(os.path.join(GOLDEN, f"oracle_digest_{name}_full.json")))
+    assert rec["counter"].startswith("oracle/cfrk_oracle.c") and rec["occurrences"] == rec["expected_occurrences"]
+    return rec["digest_hex"]
+
+
 def _bench_line(args, timeout=600):
     """run bench.py as a child process (it starts its own ranks for --gpus N) and parse its line"""
     import json
@@ -391,6 +400,18 @@ def test_bench_self_launches_two_ranks_and_matches_the_one_gpu_digest():
     both = _bench_line(["--gpus", "2", "--same-gpu", "--dist-backend", "gloo"] + common)
     assert both["scaling"] == "strong" and both["digest"] == one["digest"]
     assert both["weak"]["config"]["reads"] == 4_000_000 and both["weak"]["sum_count_ok"]
+
+
+def test_bench_rank_whose_runs_only_add_is_refused_makes_all_ranks_take_the_leaf_exchange():
+    """a rank whose shard does not fit one pass cannot run a CFRK_RUNS_ONLY job (CFRK_ERR_NOMEM / CFRK_ERR_STATE
+    from the add itself, not from the export): it votes "no runs" and BOTH ranks count their shards and exchange
+    per-leaf lists -- nobody is left waiting in the all-to-all.  Forced on rank 1 with a 50 MB budget."""
+    common = ["--steps", "1", "--warmup", "0", "--reads", "2000000", "--cpu-reads", "0"]
+    one = _bench_line(["--gpus", "1"] + common)
+    two = _bench_line(["--gpus", "2", "--same-gpu", "--dist-backend", "gloo", "--scaling", "strong",
+                       "--debug-runs-budget", "1:50000000"] + common)
+    assert two["sum_count_ok"] and two["digest"] == one["digest"]
+    assert two["exchange"]["exchange"].startswith("leaf")
 
 
 def test_bench_under_torchrun_as_the_driver_launches_it():
@@ -749,9 +770,32 @@ def test_c3_full_size_result_keeps_its_leaf_index_and_parks_nothing(ctx):
     assert sum(pc) == 99_999_970 and min(pc) > 0.12 * 99_999_970
     dg = g.digest()
     assert dg[0] == 99_999_970 and dg[1] == R * (L - k + 1)
-    assert [f"{x:016x}" for x in dg] == ["0000000005f5e0e2", "00000002cb417800", "416f1fcc3ea9fc63", "b9ea15c642f30d8b"]
+    # the digest of the ORACLE's count of the same 10^8 reads (tools/oracle_full_digest.py c3, run once on the GPU
+    # box's host cores; BASELINE.md section 4: C3 - C5 are gated on oracle digest equality, as the reference's own
+    # test diffs against an independent result, test/test.sh:13-19) -- not a digest this GPU path produced
+    assert [f"{x:016x}" for x in dg] == _oracle_full_digest("c3")
     for p in (keys, cnt, lc, d):
         ctx.free(p)
+
+
+def test_c5_shard_full_size_against_the_oracle_digest(ctx):
+    """one GPU's share of BASELINE configs[4] at full size (125 M x 250 bp, k = 63, genome 10^9: ~10^9 distinct
+    two-word keys, leaves shared by record, counted in chunks): digest equal to the ORACLE's count of the same
+    reads (tools/oracle_full_digest.py c5shard), one pass, nothing spilled"""
+    import cfrk_amd
+    R, L, k, G = 125_000_000, 250, 63, 1_000_000_000
+    nN = R * (L + 1)
+    d = ctx.alloc(nN + 64)
+    ctx.synth_reads_device(0, R, L, G, d)
+    g = cfrk_amd.GlobalCounter(ctx, k, cfrk_amd.CFRK_CANONICAL, min(G, R * (L - k + 1)) + 1024)
+    g.add_device(d, nN)
+    dg = g.digest()
+    info = g.msp_info()
+    assert g.last_add_passes() == 1 and info["spilled_records"] == 0 and info["spilled_kmers"] == 0
+    assert dg[1] == R * (L - k + 1)
+    assert [f"{x:016x}" for x in dg] == _oracle_full_digest("c5shard")
+    del g
+    ctx.free(d)
 
 
 def test_chunked_batch_sizes_leaf_streams_from_first_chunk_and_survives_a_lumpy_batch(ctx):
@@ -772,6 +816,35 @@ def test_chunked_batch_sizes_leaf_streams_from_first_chunk_and_survives_a_lumpy_
         g.add_device(d, nN)
         assert got == g.digest()
         assert got[1] == R * (L - k + 1)
+    ctx.free(d)
+
+
+def test_chunked_batch_whose_first_chunk_is_no_measure_of_the_rest(ctx):
+    """the leaf streams of a chunked batch are sized from its FIRST chunk.  Here the first quarter of
+    a 4 M-read batch is invalid bytes only (an N-rich prefix: no records at all), so the streams are sized for
+    nothing and every leaf overflows in the later chunks.  The cursors count on over all chunks, the streams are
+    laid out exactly -- in a buffer that grows to what the batch really holds -- and the chunks run again:
+    same digest as the HBM-table path, exact sum, nothing counted through the spill path."""
+    import cfrk_amd
+    R, L, k, G = 4_000_000, 150, 31, 4_000_000
+    nN = R * (L + 1)
+    d = ctx.alloc(nN + 64)
+    ctx.synth_reads_device(0, R, L, G, d)
+    bad = R // 4
+    ctx.h2d(d, np.full(bad * (L + 1), -1, np.int8))
+    g = cfrk_amd.GlobalCounter(ctx, k, cfrk_amd.CFRK_CANONICAL, 2 * G)
+    g.set_debug_param(cfrk_amd.lib.CFRK_PARAM_MSP_CHUNKS, 4)
+    try:
+        g.add_device(d, nN)
+        got = g.digest()
+        info = g.msp_info()
+    finally:
+        g.set_debug_param(cfrk_amd.lib.CFRK_PARAM_MSP_CHUNKS, 0)
+    assert info["spilled_records"] == 0 and info["spilled_kmers"] == 0
+    gh = cfrk_amd.GlobalCounter(ctx, k, cfrk_amd.CFRK_CANONICAL | cfrk_amd.CFRK_FORCE_HASH, 2 * G)
+    gh.add_device(d, nN)
+    assert got == gh.digest()
+    assert got[1] == (R - bad) * (L - k + 1)
     ctx.free(d)
 
 
@@ -1438,6 +1511,133 @@ def test_cli_global_over_several_devices_equals_one_device(tmp_path):
         assert one.stat().st_size > 100_000
 
 
+def test_cli_global_over_two_real_devices(tmp_path):
+    """the same without --same-device: hipMemcpyPeerAsync / hipDeviceEnablePeerAccess between two real
+    devices (cfrk_memcpy_peer).  Skipped on a one-GPU box."""
+    import subprocess
+    import cfrk_amd
+    if cfrk_amd.device_count() < 2:
+        pytest.skip("needs two devices")
+    cli = _cli()
+    rng = np.random.default_rng(22)
+    genome = rng.integers(0, 4, 20_000)
+    seqs = []
+    for _ in range(6000):
+        L = int(rng.integers(20, 200))
+        a = int(rng.integers(0, len(genome) - L))
+        seqs.append("".join("ACGT"[c] for c in genome[a:a + L]))
+    fa = tmp_path / "g.fasta"
+    fa.write_text("".join(f">r{i}\n{s}\n" for i, s in enumerate(seqs)))
+    for k in (31, 63):
+        one, two = tmp_path / "one.cfrk", tmp_path / "two.cfrk"
+        subprocess.check_call([cli, str(fa), str(one), str(k), "--global", "--canonical"])
+        subprocess.check_call([cli, str(fa), str(two), str(k), "--global", "--canonical", "--gpus", "2"])
+        assert two.read_bytes() == one.read_bytes()
+
+
+# src/tipos.h:5,8-10,23-30 -- the reference's types, declared (the same restatement as
+# tests/test_integration_stub_cpu.py)
+_TIPOS_H = """
+#ifndef _tipos_h
+#define _tipos_h
+#define POW(k) (1U << 2*(k))
+typedef unsigned short ushort;
+typedef long int lint;
+typedef unsigned int uint;
+struct read { char *data; int *length; lint *start; int *Freq; struct read *next; };
+#endif
+"""
+
+# A caller in the shape of src/main.cu:233-305 (written for this test, nothing copied): parse the FASTA with
+# the reference's ingest rules, cut it into chunks of chunkSize reads with chunk-relative start[] as
+# SelectChunk / SelectChunkRemain do (main.cu:110-206), call kmer_main(&chunk, nN, nS, k, device) for every
+# full chunk and for the remainder exactly as main.cu:222,294,300 do, and print what PrintFreq prints
+# (main.cu:26-62; the file is opened with "w" for the chunks and again for the remainder, main.cu:303-305).
+_MAIN_SHAPED_CALLER = r"""
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "tipos.h"
+#include "cfrk_host.h"
+void kmer_main(struct read *rd, lint nN, lint nS, int k, ushort device);   /* src/kmer.cuh:6 */
+
+static void make_chunk(const cfrk_batch &b, lint first, lint count, struct read *rd, lint *nN)
+{
+   rd->data = (char *)(b.data + b.start[first]);
+   rd->length = (int *)(b.length + first);
+   rd->start = (lint *)malloc(sizeof(lint) * (count ? count : 1));
+   lint len = 0;
+   for (lint i = 0; i < count; i++) { rd->start[i] = len; len += b.length[first + i] + 1; }
+   rd->Freq = NULL; rd->next = NULL;
+   *nN = len;
+}
+
+static void print_freq(const char *path, struct read *chunks, const lint *nS, int n, int k)
+{
+   FILE *out = fopen(path, "w");
+   lint fourk = POW(k);
+   int first = 1;
+   for (int j = 0; j < n; j++)
+      for (lint i = 0; i < nS[j]; i++) {
+         if (!first) fputc('\n', out);
+         first = 0;
+         for (lint c = 0; c < fourk; c++) fprintf(out, "%ld:%d ", c, chunks[j].Freq[i * fourk + c]);
+      }
+   fclose(out);
+}
+
+int main(int argc, char **argv)
+{
+   if (argc < 4) return 1;
+   int k = atoi(argv[3]);
+   lint chunkSize = argc == 6 ? atoi(argv[5]) : 8192;
+   ushort device = 0;
+   cfrk_batch b;
+   if (cfrk_host_read_fasta(argv[1], CFRK_INGEST_COMPAT, &b)) return 2;
+   lint gnS = b.nS;
+   int nChunk = (int)(gnS / chunkSize);
+   std::vector<struct read> chunk(nChunk ? nChunk : 1);
+   std::vector<lint> nS(nChunk ? nChunk : 1), nN(nChunk ? nChunk : 1);
+   for (int i = 0; i < nChunk; i++) { make_chunk(b, (lint)i * chunkSize, chunkSize, &chunk[i], &nN[i]); nS[i] = chunkSize; }
+   for (int i = 0; i < nChunk; i++) kmer_main(&chunk[i], nN[i], nS[i], k, device);          /* main.cu:222 */
+   struct read remain; lint rnS = gnS - (lint)nChunk * chunkSize, rnN;
+   make_chunk(b, (lint)nChunk * chunkSize, rnS, &remain, &rnN);
+   kmer_main(&remain, rnN, rnS, k, device);                                                 /* main.cu:300 */
+   print_freq(argv[2], chunk.data(), nS.data(), nChunk, k);                                 /* main.cu:303 */
+   print_freq(argv[2], &remain, &rnS, 1, k);                                                /* main.cu:305 */
+   return 0;
+}
+"""
+
+
+@pytest.mark.parametrize("name", ["seq1", "seq2"])
+def test_kmer_main_shim_executed_by_a_main_shaped_caller_reproduces_the_goldens(derived_fasta, tmp_path, name):
+    """The boundary RUN, not only linked: INTEGRATION.md's kmer_main() (cfrk_amd/host/kmer_main_shim.cpp) is
+    compiled with a caller shaped like the reference's main() and this repo's host parser into an executable,
+    which is fed the golden-derived FASTA; kmer_main(&rd, nN, nS, 2, 0) is called as src/main.cu:222,300 call it
+    and the PrintFreq-format output must be the reference's golden byte for byte (test/test.sh:13-19)."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gxx = shutil.which("g++")
+    assert gxx, "g++ is part of the image"
+    (tmp_path / "tipos.h").write_text(_TIPOS_H)
+    (tmp_path / "caller.cpp").write_text(_MAIN_SHAPED_CALLER)
+    exe = tmp_path / "refmain"
+    lib = os.path.join(root, "cfrk_amd")
+    subprocess.check_call([gxx, "-O1", "-std=c++17", "-pthread", "-I" + str(tmp_path), "-I" + os.path.join(root, "include"),
+                           "-I" + os.path.join(lib, "host"), str(tmp_path / "caller.cpp"),
+                           os.path.join(lib, "host", "kmer_main_shim.cpp"), os.path.join(lib, "host", "cfrk_host.cpp"),
+                           "-L" + lib, "-lcfrk_hip", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
+    out = tmp_path / "out.cfrk"
+    subprocess.check_call([str(exe), derived_fasta[name], str(out), "2", "12", "8192"])
+    assert out.read_bytes() == open(os.path.join(GOLDEN, f"out-{name}.cfrk"), "rb").read()
+    # several full chunks + remainder: only the remainder reaches the file (main.cu:303-305), as refsem restates
+    subprocess.check_call([str(exe), derived_fasta[name], str(out), "3", "12", "300"])
+    assert out.read_bytes() == refsem.reference_cfrk_bytes(open(derived_fasta[name], "rb").read(), 3, 300)
+
+
 @pytest.mark.parametrize("k,canonical", [(31, True), (28, False), (21, True), (32, True)])
 def test_one_word_leaves_with_more_keys_than_their_table_are_split_by_record(ctx, k, canonical):
     """The one-word path (16 <= k <= 32) shares an overfull leaf by RECORD too: with a capacity hint above
@@ -1504,17 +1704,14 @@ def test_two_word_leaves_with_more_keys_than_their_table_are_split_by_record(ctx
     # and one sub-values per workgroup (the library picks from the expected runs per leaf; the knob is for tests)
     small, _, _ = orc.synth_reads(0, 40_000, 150, 30_000)
     want = orc.global_count(small, k, orc.ORC_CANONICAL, threads=4)
-    for hb in (None, "1", "0"):
-        if hb is None:
-            os.environ.pop("CFRK_MSP2_HBITS", None)
-        else:
-            os.environ["CFRK_MSP2_HBITS"] = hb
+    for hb in (0, 2, 1):                                               # library's choice, two, one sub-values
+        g = cfrk_amd.GlobalCounter(ctx, k, cfrk_amd.CFRK_CANONICAL, 100_000)
+        g.set_debug_flags(cfrk_amd.lib.CFRK_DEBUG_RECORD_SUBSETS)
+        g.set_debug_param(cfrk_amd.lib.CFRK_PARAM_MSP2_SUBVALUE_BITS, hb)
         try:
-            g = cfrk_amd.GlobalCounter(ctx, k, cfrk_amd.CFRK_CANONICAL, 100_000)
-            g.set_debug_flags(cfrk_amd.lib.CFRK_DEBUG_RECORD_SUBSETS)
             g.add(small)
             lo, hi, cnt = g.export()
-            g.set_debug_flags(0)
         finally:
-            os.environ.pop("CFRK_MSP2_HBITS", None)
+            g.set_debug_flags(0)
+            g.set_debug_param(cfrk_amd.lib.CFRK_PARAM_MSP2_SUBVALUE_BITS, 0)
         assert (lo == want[0]).all() and (hi == want[1]).all() and (cnt.astype(np.uint64) == want[2]).all()

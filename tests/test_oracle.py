@@ -191,6 +191,23 @@ def test_sorted_variant_equals_hash_variant_on_synthetic_reads(k):
     assert orc.digest(*a, two_word=k > 32) == orc.digest(*b, two_word=k > 32)
 
 
+@pytest.mark.parametrize("R,L,G,k,canonical,uniform", [
+    (3000, 150, 20000, 31, True, False), (3000, 150, 20000, 31, False, False),
+    (2000, 250, 50000, 63, True, False), (1500, 100, 9000, 15, True, False),
+    (700, 60, 60, 40, True, True), (5000, 151, 4000, 33, False, False),
+    (1, 150, 150, 31, True, False), (0, 150, 150, 31, True, False)])
+def test_bounded_memory_digest_equals_the_plain_count(R, L, G, k, canonical, uniform):
+    """orc_synth_digest (reads generated block by block, key space counted in slices: what counts the
+    full-size configs on the GPU box's host) gives the digest of orc_global_count on the materialised
+    reads, for any number of threads and slices"""
+    fl = orc.ORC_CANONICAL if canonical else 0
+    d, _, _ = orc.synth_reads(0, R, L, G, uniform=uniform)
+    want = orc.digest(*orc.global_count(d, k, fl), two_word=k > 32)
+    for threads, slices in [(1, 1), (3, 1), (4, 5), (7, 16)]:
+        assert orc.synth_digest(R, L, G, k, fl, threads, slices, uniform=uniform) == want, (threads, slices)
+    assert orc.synth_digest(R, L, G, k, fl, 2, 3, uniform=uniform, progress=lambda i, n: None) == want
+
+
 @pytest.mark.parametrize("name", ["seq1", "seq2"])
 def test_float_index_equals_exact_index_on_the_golden_preimages_up_to_k12(derived_fasta, name):
     """The reference accumulates the index through float (src/kmer_kernel.cu:38).  On the inputs
