@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--slices", type=int, default=0, help="0: from the free host memory")
     ap.add_argument("--reads", type=int, default=0, help="count only the first N reads (rehearsal)")
     ap.add_argument("--out", default="")
+    ap.add_argument("--git", default="", help="commit the oracle was built from (the GPU box has no .git)")
     a = ap.parse_args()
     R, L, G, k = CONFIGS[a.config]
     if a.reads:
@@ -56,7 +57,7 @@ def main():
            "seeds": [1, 2, 3], "digest_hex": [f"{x:016x}" for x in dg], "distinct": dg[0], "occurrences": dg[1],
            "expected_occurrences": occ, "threads": a.threads, "slices": slices, "seconds": round(dt, 2),
            "host_mem_available_bytes": free, "counter": "oracle/cfrk_oracle.c: orc_synth_digest",
-           "command": "python " + " ".join(sys.argv), "git": sha or None}
+           "command": "python " + " ".join(sys.argv), "git": a.git or sha or None}
     line = json.dumps(rec)
     print(line, flush=True)
     if a.out:

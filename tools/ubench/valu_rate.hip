@@ -11,7 +11,8 @@
 #define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 
 enum Op { ADD, MUL_LO, MUL_U24, MAD_U24, MUL_HI, MIN_U, XOR, AND_OR, LSHL_OR, ALIGNBIT, PERM, BFE, CNDMASK, CMP_ADDC,
-          DPP_SHR, LSHL64, ADD64, MIN3, XAD, FMA, DS_READ128, DS_ADD, DS_BPERM, NOPS };
+          DPP_SHR, LSHL64, ADD64, MIN3, XAD, FMA, DS_READ128, DS_ADD, DS_BPERM, NOPS,
+          PK_MIN_U16, PK_MUL_LO_U16, PK_ADD_U16, PK_LSHL_B16, PK_MAD_U16, PK_MAX_U16, PK_SUB_U16, MIN_DPP };
 
 template <int OP>
 __global__ __launch_bounds__(512) void k(uint32_t *out, uint32_t seed, unsigned long long *clk) {
@@ -49,6 +50,14 @@ __global__ __launch_bounds__(512) void k(uint32_t *out, uint32_t seed, unsigned 
     if (OP == FMA) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b[i]), "v"(c));                      \
     if (OP == DS_ADD) asm volatile("ds_add_u32 %0, %1" : : "v"(la), "v"(c) : "memory");                            \
     if (OP == DS_BPERM) asm volatile("ds_bpermute_b32 %0, %1, %0\n\ts_waitcnt lgkmcnt(0)" : "+v"(a[i]) : "v"(la)); \
+    if (OP == PK_MIN_U16) asm volatile("v_pk_min_u16 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));                        \
+    if (OP == PK_MAX_U16) asm volatile("v_pk_max_u16 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));                        \
+    if (OP == PK_MUL_LO_U16) asm volatile("v_pk_mul_lo_u16 %0, %0, %1" : "+v"(a[i]) : "v"(c));                     \
+    if (OP == PK_ADD_U16) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));                        \
+    if (OP == PK_SUB_U16) asm volatile("v_pk_sub_u16 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));                        \
+    if (OP == PK_LSHL_B16) asm volatile("v_pk_lshlrev_b16 %0, 2, %0" : "+v"(a[i]));                                \
+    if (OP == PK_MAD_U16) asm volatile("v_pk_mad_u16 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c), "v"(b[i]));            \
+    if (OP == MIN_DPP) asm volatile("v_min_u32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(b[i])); \
     if (OP == NOPS) asm volatile("s_nop 0");
     REP8(ONE) REP8(ONE) REP8(ONE) REP8(ONE)
 #undef ONE
@@ -117,5 +126,9 @@ int main() {
   run<XAD>("v_xad_u32", d, dclk); run<FMA>("v_fma_f32 (reference)", d, dclk);
   run<DS_READ128>("ds_read_b128 (4 + wait per iter)", d, dclk, 4); run<DS_ADD>("ds_add_u32 (no return)", d, dclk);
   run<DS_BPERM>("ds_bpermute_b32 + wait", d, dclk); run<NOPS>("s_nop 0", d, dclk);
+  // round 4: the packed 16-bit forms a two-positions-per-instruction minimizer front end would need
+  run<PK_MIN_U16>("v_pk_min_u16", d, dclk); run<PK_MAX_U16>("v_pk_max_u16", d, dclk); run<PK_MUL_LO_U16>("v_pk_mul_lo_u16", d, dclk);
+  run<PK_ADD_U16>("v_pk_add_u16", d, dclk); run<PK_SUB_U16>("v_pk_sub_u16", d, dclk); run<PK_LSHL_B16>("v_pk_lshlrev_b16", d, dclk);
+  run<PK_MAD_U16>("v_pk_mad_u16", d, dclk); run<MIN_DPP>("v_min_u32_dpp row_shr:1", d, dclk);
   return 0;
 }
