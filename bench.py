@@ -48,6 +48,7 @@ def parse():
     p.add_argument("--cpu-reads", type=int, default=10_000_000,
                    help="reads of the same generator timed on the host cores (0: skip)")
     p.add_argument("--cpu-threads", type=int, default=0)
+    p.add_argument("--cpu-runs", type=int, default=3, help="runs of the cpu_baseline sample (the median is reported)")
     p.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                    help="gloo: rehearsal mode -- collectives staged through host memory, every "
                         "rank may sit on the same GPU (--same-gpu)")
@@ -132,13 +133,18 @@ def cpu_baseline(args, glen, gpu_digest_of_prefix=None):
     threads = args.cpu_threads or avail
     data, _, _ = orc.synth_reads(0, R, args.L, glen, uniform=args.uniform)
     flags = 0 if args.no_canonical else orc.ORC_CANONICAL
-    t0 = time.perf_counter()
-    lo, hi, cnt = orc.global_count(data, args.k, flags, threads=threads)
-    dt = time.perf_counter() - t0
+    # median of three runs of the same sample (BASELINE.md 3.4 asks for a median; ~8 s each on the GPU box's host)
+    dts = []
+    for _ in range(max(1, args.cpu_runs)):
+        t0 = time.perf_counter()
+        lo, hi, cnt = orc.global_count(data, args.k, flags, threads=threads)
+        dts.append(time.perf_counter() - t0)
+    dt = sorted(dts)[len(dts) // 2]
     kmers = R * (args.L - args.k + 1)
     out = {"value": kmers / dt, "unit": "k-mers/s", "cores": threads, "kind": "port",
            "cpu_model": cpu_model(), "host_cpus_online": os.cpu_count(), "host_cpus_usable": avail,
-           "sample": f"first {R} reads of the same generator ({kmers} k-mers, {dt:.2f} s, "
+           "runs_s": [round(x, 2) for x in dts],
+           "sample": f"first {R} reads of the same generator ({kmers} k-mers, median of {len(dts)} runs: {dt:.2f} s, "
                      f"{len(lo)} distinct), oracle/cfrk_oracle.c, {threads} threads"}
     parity = None
     if gpu_digest_of_prefix is not None:
@@ -162,7 +168,7 @@ def measured_traffic(R, L, k, canonical, glen):
         w = t.get("workload", {})
         if (w.get("reads"), w.get("read_len"), w.get("k"), w.get("canonical")) == (R, L, k, canonical) and \
                 w.get("genome", glen) == glen:
-            return t.get("hbm_bytes_per_launch"), os.path.relpath(f, ROOT)
+            return t.get("hbm_bytes_per_launch"), os.path.relpath(f, ROOT) + (f" @ {t['git']}" if t.get("git") else " @ (commit not recorded)")
     return None, None
 
 

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """tools/traffic.sh summary -> the traffic_*.json bench.py reads (roofline.traffic).
-usage: traffic_json.py <summary.txt> <reads> <read_len> <k> <canonical 0|1> [genome] > profiles/rNN/traffic_xx.json
+usage: traffic_json.py <summary.txt> <reads> <read_len> <k> <canonical 0|1> [genome [git-sha]] > profiles/rNN/traffic_xx.json
+(git-sha: the commit the measured library was built from -- bench.py echoes it in roofline.traffic_source, so a
+constant that is older than the kernels it describes is visible in the bench line)
 FETCH_SIZE / WRITE_SIZE are reported in KiB; FETCH_SIZE is doubled as MI355X_MICROARCH.md ('HBM')
 prescribes for wide coalesced reads on gfx950; WRITE_SIZE is taken as reported."""
 import json
@@ -33,4 +35,6 @@ out = {"workload": {"reads": int(sys.argv[2]), "read_len": int(sys.argv[3]), "k"
        "hbm_bytes_per_launch": sum(v["fetch_bytes"] + v["write_bytes"] for v in kern.values())}
 if len(sys.argv) > 6:
     out["workload"]["genome"] = int(sys.argv[6])
+if len(sys.argv) > 7:
+    out["git"] = sys.argv[7]
 print(json.dumps(out, indent=1))
