@@ -13,6 +13,12 @@ struct TableView;
 #define CFRK_ABL_P3_NO_OUT   0x800u   // leaf kernel: no compaction to the result list
 #define CFRK_ABL_P1_NO_EMIT  0x1000u  // partition kernel: front end only, no records built
 #define CFRK_ABL_P2_NO_ATOMIC 0x2000u // second-level kernel: no cursor atomics (every tile's segments land at the stream starts)
+#define CFRK_ABL_RX3_NO_CURSOR 0x10000u // radix leaf kernel: no atomic on the result cursor (every leaf writes to leaf * 64)
+#define CFRK_ABL_RX3_NO_COUNT  0x20000u // radix leaf kernel: keys are loaded but not counted
+#define CFRK_ABL_RX2_NO_OUT    0x40000u // radix second-level kernel: the sorted tile is not written out
+#define CFRK_ABL_RX1_NO_OUT    0x80000u // radix first-level kernel: the sorted tile is not written out
+#define CFRK_ABL_RX1_LINEAR    0x100000u // radix first-level kernel: the sorted tile goes out back to back (no scatter into regions)
+#define CFRK_ABL_RX1_NO_HI     0x200000u // radix first-level kernel: the 8-bit plane is not written
 #define CFRK_ABL_P2_LINEAR_OUT 0x4000u // second-level kernel: sorted tiles written back to back (what the scatter into 512 streams per bin costs)
 
 bool cfrk_msp_usable(const cfrk_ctx *ctx);                 // fast path applies to this begin()?

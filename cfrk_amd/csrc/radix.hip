@@ -1,26 +1,28 @@
 // radix.hip -- global k-mer counting for k <= 15 on gfx950: keys fit 30 bits, so instead of
 // hashing the key is radix-partitioned and counted by DIRECT ADDRESS in LDS.
 //
-//   keys are first scrambled by an invertible mix of the 2k-bit value (odd multiply, xorshift by
-//   k) -- canonical k-mers are skewed low and real genomes are not uniform, scrambled keys are;
+//   keys are first scrambled by one odd multiply mod 4^k (a bijection) -- canonical k-mers are skewed low and
+//   real genomes are not uniform, the product's top bits are;
 //   RX1  extract (canonical) k-mers (2 x dwordx4 per lane, 2-bit packing in registers), counting
-//        sort a tile of 8192 keys by the top b1 bits in LDS, one HBM atomic per bin per tile,
-//        coalesced copy-out of 4-byte keys;
+//        sort a tile of 8192 keys by the top b1 bits in LDS (one returning LDS atomic per key), one HBM
+//        atomic per bin per tile;
 //   RX2  split every region by the next b2 bits the same way;
-//   RX3  one workgroup per leaf: an LDS array of 2^idx counters, ds_add_u32 by the low idx bits,
-//        then the non-zero counters are un-scrambled and appended to the result list.
+//   RX3  persistent workgroups walk the leaves: an LDS array of 2^idx counters, ds_add_u32 by the low idx
+//        bits, then the non-zero counters are un-scrambled and appended to the result list through an LDS
+//        buffer (one cursor atomic per ~10 leaves).
 //   8 <= k <= 15: b1 = 8, idx = min(13, 2k - 11), b2 = 2k - 8 - idx (3..9): >= 2048 leaves.
 //   k <= 7 (at most 16384 keys): no partition at all, every workgroup counts into a replicated
 //   LDS table and adds it to a dense HBM array once.
 //
 // HBM never sees the bits a key's region already implies: level 1 stores the 2k-8 bits below the
-// bin as a 16-bit plane plus (2k-8 > 16) an 8-bit plane -- 3 bytes per k-mer at k = 15 instead of
-// 4 --, the leaves store the low idx <= 13 bits as 16-bit words (round 3: 24.1 -> 15 GB per launch
-// on configs[1]); every occurrence is one LDS atomic.  Same semantics and
-// the same result-list form as msp.hip (which covers 16 <= k <= 32); overflowing regions spill
-// into the HBM table.
+// bin as a 16-bit plane plus (2k-8 >= 16) an 8-bit plane -- 3 bytes per k-mer at k = 15 instead of
+// 4 --, the leaves store the low idx <= 13 bits as 16-bit words; everything moves in groups of eight
+// elements (16- and 8-byte vectors; segments are padded, see RX_PAD); every occurrence is one LDS atomic.
+// Same semantics and the same result-list form as msp.hip (which covers 16 <= k <= 32); a level that
+// overflows its regions is laid out again with exact sizes.
 #include "msp.h"
 #include "table.h"
+#include "msp_dev.h"
 
 #include <algorithm>
 #include <vector>
@@ -48,55 +50,58 @@ struct RxView {
   uint64_t *out_keys; uint32_t *out_cnt; uint64_t out_cap;
   uint64_t *stats;
   int k, b1, b2, idx;
-  uint32_t mul, inv, kmask;                           // scramble: x * mul mod 4^k, x ^= x >> k
+  uint32_t mul, inv, kmask;                           // scramble: x * mul mod 4^k
+  uint32_t dbg;                                       // cfrk_debug_set_flags (timing ablations)
 };
 
 // level-1 region / cursor of (bin, sub-region): sub-region major -- the cursors a workgroup reserves
 // from lie side by side (memory-side atomics: one request per touched 64 bytes, see msp.hip l1_reg)
 __device__ __forceinline__ uint32_t rx_reg(const RxView &v, uint32_t bin, uint32_t sub) { return (sub << v.b1) | bin; }
-__device__ __forceinline__ uint32_t rx_mix(const RxView &v, uint32_t key) {
-  uint32_t x = (key * v.mul) & v.kmask;
-  return x ^ (x >> v.k);
-}
-__device__ __forceinline__ uint32_t rx_unmix(const RxView &v, uint32_t x) {
-  x ^= x >> v.k;                                       // k = half the width: an involution
-  return (x * v.inv) & v.kmask;
-}
+// The scramble is one odd multiply mod 4^k (a bijection): the level-1 bin is the product's TOP bits, which
+// mix every bit of the key -- canonical k-mers are skewed low, the product's top bits are not.  (Until round 4
+// an xorshift by k followed: two more instructions per position in RX1 for bits whose balance nothing needs --
+// the low idx bits only address a leaf's counters, and an unbalanced level is laid out again anyway.)
+__device__ __forceinline__ uint32_t rx_mix(const RxView &v, uint32_t key) { return (key * v.mul) & v.kmask; }
+__device__ __forceinline__ uint32_t rx_unmix(const RxView &v, uint32_t x) { return (x * v.inv) & v.kmask; }
 
-template <int NB>
-__device__ __forceinline__ void rx_scan(const uint32_t *cnt, uint32_t *off, uint32_t *wtot) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  uint32_t x = 0, incl = 0;
-  if (tid < NB) {
-    x = cnt[tid];
-    incl = x;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t y = __shfl_up(incl, d);
-      if (lane >= d) incl += y;
-    }
-    if (lane == 63) wtot[wave] = incl;
-  }
-  __syncthreads();
-  if (tid < NB) {
-    uint32_t base = 0;
-    for (int w = 0; w < wave; ++w) base += wtot[w];
-    off[tid] = base + incl - x;
-  }
-  __syncthreads();
-}
+// WIDE STORES (round 4).  What the two partition kernels cost was their copy-out, and not the scatter: a
+// wave-wide 2-byte (or 1-byte) store occupies the CU's address path for ~20 clocks whatever it carries, 128 bytes or
+// 1024 (profiles/r04/c2_radix_ablations.txt: RX1 2.17 ms, 1.16 without its copy-out, 1.95 with the 16-bit plane written
+// back to back instead of scattered).  So everything that reaches HBM moves in groups of EIGHT keys: a bin's segment of
+// a tile is rounded up to a multiple of eight with pad elements (all ones: no key of the level looks like that), every
+// cursor therefore advances in multiples of eight and every region starts on one, and a LANE copies its bin's groups
+// as whole 16-byte (16-bit plane, leaf streams) and 8-byte (8-bit plane) vectors.  The readers drop the pads: the
+// second-level kernel by value (a key of the level is below 2^(2k-b1)), the leaf kernel sends them to a spare counter.
+constexpr uint32_t RX_PAD = 0xFFFFFFFFu;
+constexpr int RX_GROUP = 8;
 
 // ------------------------------------------------------------------------------------------ RX1
+// Instruction count is what bounds the rest of this kernel (the vector pipe issued 76 % of the time), so: ONE
+// returning LDS atomic per key (its rank inside the bin; the rank waits in a register for the scan -- no second
+// "fill" atomic), window starts that are no k-mer go to a dummy bin of their lane and to spare slots instead of
+// around the atomics in branches, LDS-only barriers and DPP scans (msp_dev.h), 32-bit arithmetic throughout.
 template <bool CANON>
 __global__ __launch_bounds__(RX1_THREADS) void rx1_kernel(const int8_t *__restrict__ data, int64_t nN,
                                                           RxView v, TableView t) {
-  __shared__ uint32_t sorted[RX1_KEYS];
-  __shared__ uint32_t hist[256], loff[256], gbase[256], fill[256];
+  constexpr int SLOTS = RX1_KEYS + 256 * (RX_GROUP - 1) + 8;   // the bin-sorted tile with every bin rounded up to 8
+  constexpr int TRASH = SLOTS;                                 // + 64 spare slots for the dummy bins
+  static_assert((SLOTS + 64) % 8 == 0, "whole vectors");
+  __shared__ uint4 slo4[(SLOTS + 64) / 8];                     // 16-bit plane
+  __shared__ uint2 shi2[(SLOTS + 64) / 8];                     // 8-bit plane
+  __shared__ uint32_t hist[320], hp[256], loff[320];           // (bins 256 .. 319: one dummy bin per lane)
   __shared__ uint32_t wtot[4];
+  (void)t;
+  uint16_t *const slo = reinterpret_cast<uint16_t *>(slo4);
+  uint8_t *const shi = reinterpret_cast<uint8_t *>(shi2);
   const int tid = threadIdx.x, lane = tid & 63;
   const int k = v.k;
-  hist[tid] = 0; fill[tid] = 0;
-  __syncthreads();
+  hist[tid] = 0;
+  if (tid < 64) { hist[256 + tid] = 0; loff[256 + tid] = (uint32_t)TRASH; }
+  for (int s = tid; s < (SLOTS + 64) / 8; s += RX1_THREADS) {  // pads everywhere; the keys overwrite their slots
+    slo4[s] = make_uint4(RX_PAD, RX_PAD, RX_PAD, RX_PAD);
+    shi2[s] = make_uint2(RX_PAD, RX_PAD);
+  }
+  lds_barrier();
 
   const int64_t off = ((int64_t)blockIdx.x * RX1_THREADS + tid) * 32;
   uint32_t b0, b1w, bad;
@@ -108,8 +113,7 @@ __global__ __launch_bounds__(RX1_THREADS) void rx1_kernel(const int8_t *__restri
   // The k-mer at position i is the top 2k bits of the 32-bit window of the base string that starts
   // there (one v_alignbit with a static shift), its reverse complement the low 2k bits of a window
   // of the reverse-complemented string that ENDS where the k-mer starts (msp_dev.h: msp_minimizers),
-  // its validity the top k bits of a window of the invalid-base mask: 32-bit work throughout
-  // (64-bit shifts and a bit reversal per position took twice the instructions).
+  // its validity the top k bits of a window of the invalid-base mask: 32-bit work throughout.
   const uint32_t D[3] = {b0, b1w, n0};
   uint32_t R[4];
 #pragma unroll
@@ -121,9 +125,10 @@ __global__ __launch_bounds__(RX1_THREADS) void rx1_kernel(const int8_t *__restri
   R[0] = 0;
   const int fsh = 32 - 2 * k;
   const uint32_t vlim = 1u << (32 - k);            // a window whose top k mask bits are clear is below this
+  const uint32_t mul = v.mul, kmask = v.kmask;
 
-  uint32_t keys[32];
-  uint32_t V = 0;
+  uint32_t keys[32], rk[32];
+  const uint32_t inval = (256u + (uint32_t)lane) << sh1;      // "key" of this lane's dummy bin (sh1 <= 22: fits)
 #pragma unroll
   for (int i = 0; i < 32; ++i) {
     const int o = 2 * i, q = o >> 5, r = o & 31;
@@ -132,56 +137,66 @@ __global__ __launch_bounds__(RX1_THREADS) void rx1_kernel(const int8_t *__restri
     if (CANON) {
       const int o2 = 96 - 2 * i, q2 = o2 >> 5, r2 = o2 & 31;
       const uint32_t Y = r2 ? __builtin_amdgcn_alignbit(R[q2], R[q2 + 1], 32 - r2) : R[q2];
-      key = min(key, Y & v.kmask);
+      key = min(key, Y & kmask);
     }
     const uint32_t Wm = i ? __builtin_amdgcn_alignbit(bad, nbad, 32 - i) : bad;
-    const bool ok = Wm < vlim;
-    key = rx_mix(v, key);
+    key = (key * mul) & kmask;
+    key = (Wm < vlim) ? key : inval;
     keys[i] = key;
-    if (ok) { V |= 1u << i; atomicAdd(&hist[key >> sh1], 1u); }
+    rk[i] = atomicAdd(&hist[key >> sh1], 1u);
   }
-  __syncthreads();
+  lds_barrier();
+  // ---- thread b owns bin b: one reservation (a multiple of eight), padded offsets ----
+  const uint32_t subreg = blockIdx.x & (RX_NREG - 1);
+  const uint32_t reg = rx_reg(v, tid, subreg);
+  const uint32_t c = hist[tid];
+  const uint32_t cp = (c + (RX_GROUP - 1)) & ~(uint32_t)(RX_GROUP - 1);
+  hp[tid] = cp;
   uint32_t my_base = 0;
-  {
-    const uint32_t c = hist[tid];
-    if (c) my_base = atomicAdd(&v.cnt1[rx_reg(v, tid, blockIdx.x & (RX_NREG - 1))], c);
-  }
-  rx_scan<256>(hist, loff, wtot);
+  if (cp) my_base = atomicAdd(&v.cnt1[reg], cp);
+  block_scan<256, true>(hp, loff, wtot);
+  const uint32_t lowmask = (1u << sh1) - 1u;
 #pragma unroll
   for (int i = 0; i < 32; ++i) {
-    if (V & (1u << i)) {
-      const uint32_t b = keys[i] >> sh1;
-      sorted[loff[b] + atomicAdd(&fill[b], 1u)] = keys[i];
-    }
+    const uint32_t pos = min(loff[keys[i] >> sh1] + rk[i], (uint32_t)TRASH + 63u);
+    slo[pos] = (uint16_t)(keys[i] & lowmask);          // (below 16 bits per key the bin's bits would read as a pad)
+    if (v.hi8) shi[pos] = (uint8_t)((keys[i] & lowmask) >> 16);
   }
-  gbase[tid] = my_base;
-  __syncthreads();
-  const uint32_t total = loff[255] + hist[255];
-  for (uint32_t p = tid; p < total; p += RX1_THREADS) {
-    const uint32_t key = sorted[p];
-    const uint32_t b = key >> sh1;
-    const uint32_t dst = gbase[b] + (p - loff[b]);
-    const uint32_t reg = rx_reg(v, b, blockIdx.x & (RX_NREG - 1));
-    if (v.exact1) {
-      if (dst < v.rcap[reg]) {
-        v.k1lo[v.rbase[reg] + dst] = (uint16_t)key;
-        if (v.hi8) v.k1hi[v.rbase[reg] + dst] = (uint8_t)((key & ((1u << sh1) - 1u)) >> 16);
-      } else { t.stats[ST_SPILLED] = 1; table_add1(t, (uint64_t)rx_unmix(v, key), 1u); }   // cannot happen
-    } else if (dst < v.cap1) {
-      v.k1lo[(uint64_t)reg * v.cap1 + dst] = (uint16_t)key;
-      if (v.hi8) v.k1hi[(uint64_t)reg * v.cap1 + dst] = (uint8_t)((key & ((1u << sh1) - 1u)) >> 16);
-    } else {
-      v.stats[ST_L1OVF] = 1;       // the cursor keeps counting: the host redoes RX1 with exact sizes
+  lds_barrier();
+  if (v.dbg & CFRK_ABL_RX1_NO_OUT) return;
+  // ---- copy out: thread b writes its bin's groups, 16 + 8 bytes at a time ----
+  {
+    const uint64_t cap = v.exact1 ? (uint64_t)v.rcap[reg] : v.cap1;
+    uint64_t at = (v.exact1 ? v.rbase[reg] : (uint64_t)reg * v.cap1) + my_base;
+    if (v.dbg & CFRK_ABL_RX1_LINEAR) at = (uint64_t)(blockIdx.x & 255u) * 16384u + loff[tid];   // (timing: the tile stays in its XCD's L2)
+    const uint64_t room = cap > (uint64_t)my_base ? cap - my_base : 0;          // (a multiple of eight)
+    // the cursor keeps counting past the region: the host then redoes RX1 with exact sizes
+    if ((uint64_t)cp > room) v.stats[ST_L1OVF] = 1;
+    const uint32_t nv = (uint32_t)min((uint64_t)cp, room) / RX_GROUP;
+    const uint32_t src = loff[tid] / RX_GROUP;
+    uint4 *const dlo = reinterpret_cast<uint4 *>(v.k1lo + at);
+    uint2 *const dhi = reinterpret_cast<uint2 *>(v.k1hi + at);
+    for (uint32_t j = 0; j < nv; ++j) {
+      dlo[j] = slo4[src + j];
+      if (v.hi8) dhi[j] = shi2[src + j];
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------ RX2
+// One tile of RX2_KEYS elements of one level-1 region, split by the next b2 bits (<= 512 sub-bins) into the
+// leaves' 16-bit streams.  Same economy as RX1: one returning LDS atomic per key, pads and the elements beyond
+// the tile's end go to a dummy bin of their lane, thread b writes sub-bin b's groups as 16-byte vectors.
 __global__ __launch_bounds__(RX2_THREADS) void rx2_kernel(int tiles_per_sub, RxView v, TableView t) {
-  __shared__ uint32_t sorted[RX2_KEYS];
-  __shared__ uint32_t hist[512], loff[512], gbase[512], fill[512];
+  constexpr int SLOTS = RX2_KEYS + 512 * (RX_GROUP - 1) + 8;
+  constexpr int TRASH = SLOTS;
+  static_assert((SLOTS + 64) % 8 == 0, "whole vectors");
+  __shared__ uint4 s4[(SLOTS + 64) / 8];
+  __shared__ uint32_t hist[576], hp[512], loff[576];
   __shared__ uint32_t wtot[8];
-  const int tid = threadIdx.x;
+  (void)t;
+  uint16_t *const s16 = reinterpret_cast<uint16_t *>(s4);
+  const int tid = threadIdx.x, lane = tid & 63;
   const uint32_t nb1 = 1u << v.b1;
   const uint32_t xg = blockIdx.x & (RX_NXG - 1), seq = blockIdx.x / RX_NXG;
   const uint32_t per_bin = (uint32_t)RX_NREG * (uint32_t)tiles_per_sub;
@@ -194,82 +209,70 @@ __global__ __launch_bounds__(RX2_THREADS) void rx2_kernel(int tiles_per_sub, RxV
   const uint32_t sub = (seq % per_bin) / (uint32_t)tiles_per_sub;
   const uint32_t tile = (seq % per_bin) % (uint32_t)tiles_per_sub;
   const uint32_t reg = rx_reg(v, bin1, sub);
-  const uint64_t n = min((uint64_t)v.cnt1[reg], v.exact1 ? (uint64_t)v.rcap[reg] : v.cap1);
+  const uint64_t n = min((uint64_t)v.cnt1[reg], v.exact1 ? (uint64_t)v.rcap[reg] : v.cap1);   // (a multiple of eight)
   const uint64_t r0 = (uint64_t)tile * RX2_KEYS;
   if (r0 >= n) return;
   const uint32_t nt = (uint32_t)min((uint64_t)RX2_KEYS, n - r0);
-  hist[tid] = 0; fill[tid] = 0;
-  __syncthreads();
+  hist[tid] = 0;
+  if (tid < 64) { hist[512 + tid] = 0; loff[512 + tid] = (uint32_t)TRASH; }
+  for (int s = tid; s < (SLOTS + 64) / 8; s += RX2_THREADS) s4[s] = make_uint4(RX_PAD, RX_PAD, RX_PAD, RX_PAD);
+  lds_barrier();
   const uint64_t rb = (v.exact1 ? v.rbase[reg] : (uint64_t)reg * v.cap1) + r0;
-  const uint16_t *slo = v.k1lo + rb;
-  const uint8_t *shi = v.k1hi + rb;
-  const uint32_t m2 = (1u << v.b2) - 1u;
-  // 16-byte loads of the 16-bit plane (eight keys) and 8-byte loads of the 8-bit plane (a region
-  // starts on a 16-element boundary unless the level was laid out again: cap1 is a multiple of 16)
-  // instead of one load per key; which key a thread holds does not matter to a counting sort
-  uint32_t kk[RX2_PER];                          // the 2k - b1 bits below the bin
+  const uint4 *slo = reinterpret_cast<const uint4 *>(v.k1lo + rb);       // (regions start on a multiple of eight)
+  const uint2 *shi = reinterpret_cast<const uint2 *>(v.k1hi + rb);
+  const uint32_t idxb = (uint32_t)v.idx, m2 = (1u << v.b2) - 1u;
+  const uint32_t klim = 1u << (2 * v.k - v.b1);              // a key of this level is below it, a pad is not
+  uint32_t kk[RX2_PER], rk[RX2_PER];             // the 2k - b1 bits below the bin; rank inside the sub-bin
   static_assert(RX2_PER % 8 == 0, "keys are loaded eight at a time");
-  const bool vec = !v.exact1;
-  auto idx_of = [&](int i) {                     // tile position of key i of this thread
-    return vec ? (((uint32_t)(i >> 3) * RX2_THREADS + tid) << 3) + (uint32_t)(i & 7) : (uint32_t)i * RX2_THREADS + tid;
-  };
-  if (vec) {
 #pragma unroll
-    for (int q = 0; q < RX2_PER / 8; ++q) {
-      const uint32_t idx8 = ((uint32_t)q * RX2_THREADS + tid) << 3;
-      uint4 x = make_uint4(0u, 0u, 0u, 0u);
-      uint2 h = make_uint2(0u, 0u);
-      if (idx8 < nt) {
-        x = *reinterpret_cast<const uint4 *>(slo + idx8);
-        if (v.hi8) h = *reinterpret_cast<const uint2 *>(shi + idx8);
-      }
-      const uint32_t w[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const uint32_t lo16 = (w[c >> 1] >> (16 * (c & 1))) & 0xFFFFu;
-        const uint32_t hb = ((c < 4 ? h.x : h.y) >> (8 * (c & 3))) & 0xFFu;
-        kk[8 * q + c] = (hb << 16) | lo16;
-      }
+  for (int q = 0; q < RX2_PER / 8; ++q) {
+    const uint32_t g = (uint32_t)q * RX2_THREADS + tid;      // group of eight elements
+    uint4 x = make_uint4(RX_PAD, RX_PAD, RX_PAD, RX_PAD);
+    uint2 h = make_uint2(RX_PAD, RX_PAD);
+    if (8u * g < nt) {
+      x = slo[g];
+      if (v.hi8) h = shi[g]; else h = make_uint2(0u, 0u);
     }
-  } else {
+    const uint32_t w[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
-    for (int i = 0; i < RX2_PER; ++i) {
-      const uint32_t idx = (uint32_t)i * RX2_THREADS + tid;
-      kk[i] = (idx < nt) ? ((uint32_t)slo[idx] | (v.hi8 ? (uint32_t)shi[idx] << 16 : 0u)) : 0u;
+    for (int c = 0; c < 8; ++c) {
+      const uint32_t lo16 = (c & 1) ? (w[c >> 1] >> 16) : (w[c >> 1] & 0xFFFFu);
+      const uint32_t hw = c < 4 ? h.x : h.y;
+      const uint32_t hb = ((c & 3) == 3) ? (hw >> 24) : ((hw >> (8 * (c & 3))) & 0xFFu);
+      kk[8 * q + c] = (hb << 16) | lo16;
     }
   }
-#pragma unroll
-  for (int i = 0; i < RX2_PER; ++i)
-    if (idx_of(i) < nt) atomicAdd(&hist[(kk[i] >> v.idx) & m2], 1u);
-  __syncthreads();
-  uint32_t my_base = 0;
-  {
-    const uint32_t c = hist[tid];
-    if (c) my_base = atomicAdd(&v.cnt2[((uint64_t)bin1 << v.b2) + tid], c);
-  }
-  rx_scan<512>(hist, loff, wtot);
+  const uint32_t dummy = 512u + (uint32_t)lane;
 #pragma unroll
   for (int i = 0; i < RX2_PER; ++i) {
-    if (idx_of(i) < nt) {
-      const uint32_t b = (kk[i] >> v.idx) & m2;
-      sorted[loff[b] + atomicAdd(&fill[b], 1u)] = kk[i];
-    }
+    const uint32_t b = (kk[i] < klim) ? ((kk[i] >> idxb) & m2) : dummy;
+    rk[i] = atomicAdd(&hist[b], 1u);
   }
-  gbase[tid] = my_base;
-  __syncthreads();
-  for (uint32_t p = tid; p < nt; p += RX2_THREADS) {
-    const uint32_t key = sorted[p];
-    const uint32_t b = (key >> v.idx) & m2;
-    const uint32_t dst = gbase[b] + (p - loff[b]);
-    const uint64_t leaf = ((uint64_t)bin1 << v.b2) + b;
-    if (v.exact) {
-      if (dst < v.lcap[leaf]) v.key2[v.lbase[leaf] + dst] = (uint16_t)(key & ((1u << v.idx) - 1u));
-      else { t.stats[ST_SPILLED] = 1; table_add1(t, (uint64_t)rx_unmix(v, (bin1 << (2 * v.k - v.b1)) | key), 1u); }   // cannot happen
-    } else if (dst < v.cap2) {
-      v.key2[leaf * v.cap2 + dst] = (uint16_t)(key & ((1u << v.idx) - 1u));
-    } else {
-      v.stats[ST_L2OVF] = 1;       // the cursor keeps counting: the host redoes RX2 with exact sizes
-    }
+  lds_barrier();
+  const uint32_t c = hist[tid];                          // (non-zero only for tid <= m2)
+  const uint32_t cp = (c + (RX_GROUP - 1)) & ~(uint32_t)(RX_GROUP - 1);
+  hp[tid] = cp;
+  uint32_t my_base = 0;
+  const uint64_t leaf = ((uint64_t)bin1 << v.b2) + (uint32_t)tid;
+  if (cp) my_base = atomicAdd(&v.cnt2[leaf], cp);
+  block_scan<512, true>(hp, loff, wtot);
+  const uint32_t imask = (1u << idxb) - 1u;
+#pragma unroll
+  for (int i = 0; i < RX2_PER; ++i) {
+    const uint32_t b = (kk[i] < klim) ? ((kk[i] >> idxb) & m2) : dummy;
+    s16[min(loff[b] + rk[i], (uint32_t)TRASH + 63u)] = (uint16_t)(kk[i] & imask);
+  }
+  lds_barrier();
+  if (v.dbg & CFRK_ABL_RX2_NO_OUT) return;
+  if (cp) {
+    const uint64_t cap = v.exact ? (uint64_t)v.lcap[leaf] : v.cap2;
+    const uint64_t at = (v.exact ? v.lbase[leaf] : leaf * v.cap2) + my_base;
+    const uint64_t room = cap > (uint64_t)my_base ? cap - my_base : 0;
+    if ((uint64_t)cp > room) v.stats[ST_L2OVF] = 1;       // the cursor keeps counting: the host redoes RX2 with exact sizes
+    const uint32_t nv = (uint32_t)min((uint64_t)cp, room) / RX_GROUP;
+    const uint32_t src = loff[tid] / RX_GROUP;
+    uint4 *const d = reinterpret_cast<uint4 *>(v.key2 + at);
+    for (uint32_t j = 0; j < nv; ++j) d[j] = s4[src + j];
   }
 }
 
@@ -296,87 +299,180 @@ __global__ __launch_bounds__(1024) void rx_layout_kernel(const uint32_t *__restr
 }
 
 // ------------------------------------------------------------------------------------------ RX3
-__global__ __launch_bounds__(RX3_THREADS) void rx3_kernel(RxView v) {
-  __shared__ uint32_t cnt[1 << RX_IDX_MAX];
+// 2^13 LDS counters per leaf (2^idx of them, replicated 2^rlog times when a leaf has fewer), one ds_add per
+// key; a leaf's stream is whole vectors of eight elements (pads go to a spare counter of their lane).
+// PERSISTENT workgroups: a workgroup walks leaves b, b + grid, ...; the next leaf's size is asked for before
+// the current leaf is counted and its first keys before the current leaf is scanned.
+// ONE CURSOR ATOMIC PER ~10 LEAVES: 131 072 returning atomics on the single result cursor were 0.73 of this
+// kernel's 1.7 ms (same-address atomics serialise at the memory side, ~5.5 ns each;
+// profiles/r04/c2_radix_ablations.txt).  A workgroup therefore collects the (key, count) entries of its leaves in
+// an LDS buffer and takes one range from the cursor when the buffer fills up (C2: ~76 entries per leaf); the
+// flush also writes the list in whole coalesced lines instead of one 8 + 4 byte pair per thread.
+constexpr int RX3_INFL = 6;            // 16-byte loads in flight per thread (12 288 elements per round of the workgroup)
+constexpr int RX3_OB = 704;            // buffered result entries (5.5 KB: four workgroups still fit a CU's LDS)
+__global__ __launch_bounds__(RX3_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void rx3_kernel(RxView v, uint32_t nleaf) {
+  constexpr int NC = 1 << RX_IDX_MAX;
+  __shared__ uint4 cnt4[(NC + 64) / 4];          // + one spare counter per lane for the pads
+  __shared__ uint32_t ob_key[RX3_OB], ob_cnt[RX3_OB];
   __shared__ unsigned long long wg_base;
+  __shared__ uint32_t wsum[RX3_THREADS / 64];
+  uint32_t *const cnt = reinterpret_cast<uint32_t *>(cnt4);
   const int tid = threadIdx.x, lane = tid & 63;
-  const uint32_t leaf = blockIdx.x;
-  const uint64_t n = min((uint64_t)v.cnt2[leaf], v.exact ? (uint64_t)v.lcap[leaf] : v.cap2);
-  if (n == 0) return;
-  const uint32_t nidx = 1u << v.idx, imask = nidx - 1u;
+  const uint32_t nidx = 1u << v.idx;
   // few counters per leaf (small k): every thread group gets its own replica, or all 256 threads
-  // would serialise on a handful of LDS words
+  // would serialise on a handful of LDS words.  nidx << rlog = 2^13 for every k this path serves (idx >= 5).
   const int rlog = min(RX_IDX_MAX - v.idx, 8);
-  const uint32_t rmask = (1u << rlog) - 1u;
-  for (uint32_t s = tid; s < (nidx << rlog); s += RX3_THREADS) cnt[s] = 0;
-  __syncthreads();
-  const uint16_t *src = v.exact ? v.key2 + v.lbase[leaf] : v.key2 + (uint64_t)leaf * v.cap2;
-  {
-    // 16-byte loads (eight 16-bit keys), four of them in flight per thread: the stream is read as
-    // uint4 from the 16-byte boundary below its first key, elements outside [0, n) are skipped
-    const uint32_t head = (uint32_t)((reinterpret_cast<uintptr_t>(src) >> 1) & 7u);
-    const uint4 *src4 = reinterpret_cast<const uint4 *>(src - head);
-    const uint64_t n4 = (head + n + 7) >> 3;                 // uint4 elements that hold keys
-    const uint64_t lo = head, hi = head + n;                 // valid element range in the aligned view
-    constexpr int INFL = 4;
-    for (uint64_t q0 = 0; q0 < n4; q0 += (uint64_t)INFL * RX3_THREADS) {
-      uint4 x[INFL];
+  const uint32_t rmask = (1u << rlog) - 1u, rep = (uint32_t)tid & rmask;
+  const uint32_t spare = (uint32_t)NC + (uint32_t)lane;
+  constexpr int NQ = NC / 4 / RX3_THREADS;       // uint4 groups of counters per thread (8)
+  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+  uint32_t leaf = blockIdx.x;
+  if (leaf >= nleaf) return;
 #pragma unroll
-      for (int u = 0; u < INFL; ++u) {
-        const uint64_t q = q0 + (uint64_t)u * RX3_THREADS + tid;
-        x[u] = make_uint4(0u, 0u, 0u, 0u);
-        if (q < n4) x[u] = src4[q];
-      }
+  for (int j = 0; j < NQ; ++j) cnt4[j * RX3_THREADS + tid] = zero4;
+  if (tid < 16) cnt4[NC / 4 + tid] = zero4;
+
+  auto leaf_n = [&](uint32_t l) { return (uint32_t)min((uint64_t)v.cnt2[l], v.exact ? (uint64_t)v.lcap[l] : v.cap2); };
+  auto leaf_p = [&](uint32_t l) {                 // (a leaf's stream starts on a multiple of eight elements)
+    return reinterpret_cast<const uint4 *>(v.exact ? v.key2 + v.lbase[l] : v.key2 + (uint64_t)l * v.cap2);
+  };
+  uint4 x[RX3_INFL];
+  auto load_round = [&](const uint4 *p, uint32_t n4, uint32_t q0) {
 #pragma unroll
-      for (int u = 0; u < INFL; ++u) {
-        const uint64_t e = 8 * (q0 + (uint64_t)u * RX3_THREADS + tid);
-        const uint32_t w[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
+    for (int u = 0; u < RX3_INFL; ++u) {
+      const uint32_t q = q0 + (uint32_t)u * RX3_THREADS + tid;
+      x[u] = make_uint4(RX_PAD, RX_PAD, RX_PAD, RX_PAD);
+      if (q < n4) x[u] = p[q];
+    }
+  };
+  auto count_round = [&]() {
+#pragma unroll
+    for (int u = 0; u < RX3_INFL; ++u) {
+      const uint32_t w[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
+      if (rlog == 0) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-          const uint32_t key = (w[c >> 1] >> (16 * (c & 1))) & 0xFFFFu;
-          if (e + c >= lo && e + c < hi) atomicAdd(&cnt[((key & imask) << rlog) | ((uint32_t)tid & rmask)], 1u);
+          const uint32_t key = (c & 1) ? (w[c >> 1] >> 16) : (w[c >> 1] & 0xFFFFu);
+          atomicAdd(&cnt[min(key, spare)], 1u);                       // (keys are < 2^13, a pad is 0xFFFF)
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const uint32_t key = (c & 1) ? (w[c >> 1] >> 16) : (w[c >> 1] & 0xFFFFu);
+          atomicAdd(&cnt[key < nidx ? ((key << rlog) | rep) : spare], 1u);
         }
       }
     }
-  }
-  __syncthreads();
-  if (rlog) {                       // fold the replicas into replica 0
-    for (uint32_t s = tid; s < nidx; s += RX3_THREADS) {
-      uint32_t c = 0;
-      for (uint32_t r = 0; r <= rmask; ++r) c += cnt[(s << rlog) | r];
-      cnt[s << rlog] = c;
-    }
+  };
+  // flush the buffered entries: one range of the result list, written in order
+  uint32_t fill = 0;                               // (the same in every thread)
+  auto flush = [&]() {
+    if (tid == 0) wg_base = (v.dbg & CFRK_ABL_RX3_NO_CURSOR) ? (unsigned long long)blockIdx.x * 16384ull
+                                                              : atomicAdd((unsigned long long *)&v.stats[ST_CURSOR], (unsigned long long)fill);
     __syncthreads();
-  }
-  // compaction: every thread counts the non-zero counters among its own (counter q * 256 + tid: the
-  // reads are conflict-free), one block scan gives it a range of the workgroup's reservation, and it
-  // writes its entries there -- no ballot and no LDS atomic per 256 counters (the two passes of 32
-  // such steps were half of this kernel's instructions at k = 15)
-  __shared__ uint32_t wsum[RX3_THREADS / 64];
-  uint32_t mine = 0;
-  for (uint32_t s = tid; s < nidx; s += RX3_THREADS) mine += (cnt[s << rlog] != 0u) ? 1u : 0u;
-  uint32_t incl = mine;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t y = __shfl_up(incl, d);
-    if (lane >= d) incl += y;
-  }
-  if (lane == 63) wsum[tid >> 6] = incl;
-  __syncthreads();
-  uint32_t base = 0, total = 0;
-  for (int w = 0; w < RX3_THREADS / 64; ++w) { const uint32_t x = wsum[w]; base += (w < (tid >> 6)) ? x : 0u; total += x; }
-  if (tid == 0) wg_base = atomicAdd((unsigned long long *)&v.stats[ST_CURSOR], (unsigned long long)total);
-  __syncthreads();
-  unsigned long long dst = wg_base + base + incl - mine;
-  for (uint32_t s = tid; s < nidx; s += RX3_THREADS) {
-    const uint32_t c = cnt[s << rlog];
-    if (c) {
-      const uint32_t mixed = (leaf << v.idx) | s;
-      if (dst < v.out_cap) { v.out_keys[dst] = (uint64_t)rx_unmix(v, mixed); v.out_cnt[dst] = c; }
+    const unsigned long long b = wg_base;
+    for (uint32_t i = tid; i < fill; i += RX3_THREADS) {
+      if (b + i < v.out_cap) { v.out_keys[b + i] = (uint64_t)rx_unmix(v, ob_key[i]); v.out_cnt[b + i] = ob_cnt[i]; }
       else v.stats[ST_OVERFLOW] = 1;
-      ++dst;
     }
+    lds_barrier();                                 // (the buffer and wg_base are free again)
+    fill = 0;
+  };
+
+  uint32_t n = leaf_n(leaf);
+  const uint4 *cur = leaf_p(leaf);
+  load_round(cur, n / RX_GROUP, 0);
+  lds_barrier();                                  // the counters are clear
+  for (;;) {
+    const uint32_t next = leaf + gridDim.x;
+    const bool more = next < nleaf;
+    uint32_t n_next = 0;
+    if (more) n_next = leaf_n(next);              // (in flight while this leaf is counted)
+    const uint32_t n4 = n / RX_GROUP;
+    if (!(v.dbg & CFRK_ABL_RX3_NO_COUNT)) count_round();
+    for (uint32_t q0 = (uint32_t)RX3_INFL * RX3_THREADS; q0 < n4; q0 += (uint32_t)RX3_INFL * RX3_THREADS) {
+      load_round(cur, n4, q0);
+      count_round();
+    }
+    lds_barrier();
+    const uint4 *nxp = leaf_p(more ? next : leaf);
+    if (more) load_round(nxp, n_next / RX_GROUP, 0);   // (in flight while this leaf is scanned and its entries collected)
+    if (n) {                                      // (wave-uniform: one leaf per workgroup)
+      if (rlog) {                                 // fold the replicas into replica 0
+        for (uint32_t s = tid; s < nidx; s += RX3_THREADS) {
+          uint32_t c = 0;
+          for (uint32_t r = 0; r <= rmask; ++r) c += cnt[(s << rlog) | r];
+          cnt[s << rlog] = c;
+        }
+        lds_barrier();
+      }
+      // compaction: a thread counts the non-zero counters among its own, one block scan gives it a range of
+      // the leaf's entries.  rlog == 0 (k >= 12: idx = 13): its counters are eight groups of four consecutive
+      // ones; otherwise counter s sits at s << rlog.
+      uint32_t mine = 0;
+      if (rlog == 0) {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+          const uint4 c4 = cnt4[j * RX3_THREADS + tid];
+          mine += (c4.x != 0u) + (c4.y != 0u) + (c4.z != 0u) + (c4.w != 0u);
+        }
+      } else {
+        for (uint32_t s = tid; s < nidx; s += RX3_THREADS) mine += (cnt[s << rlog] != 0u) ? 1u : 0u;
+      }
+      const uint32_t incl = dev_wave_scan_incl(mine);
+      if (lane == 63) wsum[tid >> 6] = incl;
+      lds_barrier();
+      uint32_t base = 0, total = 0;
+#pragma unroll
+      for (int w = 0; w < RX3_THREADS / 64; ++w) { const uint32_t xw = wsum[w]; base += (w < (tid >> 6)) ? xw : 0u; total += xw; }
+      // where this leaf's entries go: behind the buffered ones, or -- a leaf with more entries than the
+      // buffer holds -- straight to a range of the list of its own
+      const bool direct = total > (uint32_t)RX3_OB;
+      if (fill && (direct || fill + total > (uint32_t)RX3_OB)) flush();
+      unsigned long long dbase = 0;
+      if (direct) {
+        if (tid == 0) wg_base = atomicAdd((unsigned long long *)&v.stats[ST_CURSOR], (unsigned long long)total);
+        __syncthreads();
+        dbase = wg_base;
+      }
+      uint32_t d = (direct ? 0u : fill) + base + incl - mine;
+      const uint32_t leaf_hi = leaf << v.idx;
+      auto emit = [&](uint32_t s, uint32_t c) {
+        if (direct) {
+          if (dbase + d < v.out_cap) { v.out_keys[dbase + d] = (uint64_t)rx_unmix(v, leaf_hi | s); v.out_cnt[dbase + d] = c; }
+          else v.stats[ST_OVERFLOW] = 1;
+        } else { ob_key[d] = leaf_hi | s; ob_cnt[d] = c; }
+        ++d;
+      };
+      if (rlog == 0) {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+          if (mine) {
+            const uint4 c4 = cnt4[j * RX3_THREADS + tid];
+            const uint32_t s0 = 4u * (uint32_t)(j * RX3_THREADS + tid);
+            if (c4.x) emit(s0, c4.x);
+            if (c4.y) emit(s0 + 1u, c4.y);
+            if (c4.z) emit(s0 + 2u, c4.z);
+            if (c4.w) emit(s0 + 3u, c4.w);
+          }
+          cnt4[j * RX3_THREADS + tid] = zero4;     // (this thread is the only reader of these four)
+        }
+      } else {
+        for (uint32_t s = tid; s < nidx; s += RX3_THREADS) {
+          const uint32_t c = cnt[s << rlog];
+          if (c) emit(s, c);
+        }
+        lds_barrier();
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) cnt4[j * RX3_THREADS + tid] = zero4;
+      }
+      if (!direct) fill += total;
+      lds_barrier();                              // the counters are clear again (and wsum / wg_base are free)
+    }
+    if (!more) break;
+    leaf = next; n = n_next; cur = nxp;
   }
+  if (fill) flush();
 }
 
 // ------------------------------------------------------------------------------- k <= 7: direct
@@ -493,11 +589,16 @@ int cfrk_radix_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   v.b2 = 2 * k - v.b1 - v.idx;
   v.kmask = (uint32_t)((1ull << (2 * k)) - 1ull);
   v.mul = 0x9E3779B1u;
+  v.dbg = ctx->dbg_flags;
   v.inv = inv_odd32(v.mul);
   const uint64_t nb1 = 1ull << v.b1, nleaf = 1ull << (v.b1 + v.b2);
-  const uint64_t cap1 = ((uint64_t)((double)nN / (double)(nb1 * RX_NREG) * 1.3) + 4096 + 15) & ~15ull;   // (RX2 loads 8 keys at a time)
-  const uint64_t cap2 = (uint64_t)((double)nN / (double)nleaf * 1.5) + 1024;
-  v.hi8 = (2 * k - v.b1 > 16) ? 1u : 0u;
+  // (segments are rounded up to eight elements: a tile of RX1 adds ~3.5 pads to each of its 256 segments of ~29 keys,
+  //  a tile of RX2 to each of its <= 512 segments; regions start on multiples of 16 / 8 elements)
+  const double pad1 = 1.0 + 3.5 * 256.0 / (double)RX1_KEYS, pad2 = pad1 * (1.0 + 3.5 * (double)(1u << v.b2) / (double)RX2_KEYS);
+  const uint64_t cap1 = ((uint64_t)((double)nN / (double)(nb1 * RX_NREG) * 1.3 * pad1) + 4096 + 15) & ~15ull;
+  const uint64_t cap2 = ((uint64_t)((double)nN / (double)nleaf * 1.5 * pad2) + 1024 + 7) & ~7ull;
+  // the 8-bit plane also exists when the level's keys fill the 16-bit plane exactly (k = 12): a pad must not look like a key
+  v.hi8 = (2 * k - v.b1 >= 16) ? 1u : 0u;
   const size_t l1_elems = (size_t)nb1 * RX_NREG * cap1;
   const size_t need = l1_elems * 3 + (size_t)nleaf * cap2 * 2 + (size_t)ctx->g_cap * 12;
   const size_t have = ctx->pool[BUF_MSP_L1].cap + ctx->pool[BUF_MSP_L2].cap + ctx->pool[BUF_MSP_OUTK].cap + ctx->pool[BUF_MSP_OUTC].cap;
@@ -582,7 +683,8 @@ int cfrk_radix_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
     settled = true;
   }
   if (!settled) return cfrk_fail(ctx, CFRK_ERR_STATE, "the key regions did not settle after an exact layout");
-  hipLaunchKernelGGL(rx3_kernel, dim3((unsigned)nleaf), dim3(RX3_THREADS), 0, ctx->stream, v);
+  // persistent: four workgroups (32 KB of counters each) per CU walk the leaves
+  hipLaunchKernelGGL(rx3_kernel, dim3((unsigned)std::min<uint64_t>(nleaf, (uint64_t)std::max(1, ctx->num_cus) * 4)), dim3(RX3_THREADS), 0, ctx->stream, v, (uint32_t)nleaf);
   HIP_TRY(ctx, hipGetLastError());
   // the result list lives where msp.hip keeps its own: digest / export / fold are shared
   ms->view.out_keys = v.out_keys; ms->view.out_cnt = v.out_cnt; ms->view.out_cap = v.out_cap;
