@@ -6,7 +6,11 @@
   --leaf: the counted-list exchange of round 1 for comparison (count, export by leaf, LDS merge).
 Prints per phase the slowest rank's time, the bytes a rank puts on the wire, and checks that owner 0's
 sum of counts is its share of the job.   usage: scale_emul.py [world [reads [k]]] [--leaf] [--L=n] [--glen=n] [--weak]
---weak: `reads` is what EVERY rank holds (the job has world x reads reads: BASELINE configs[4] is 8 x 125 M x 250 bp)."""
+--weak: `reads` is what EVERY rank holds (the job has world x reads reads: BASELINE configs[4] is 8 x 125 M x 250 bp).
+--link-gbs=G: WIRE MODEL (no multi-GPU box exists to measure one): every rank sends 1/(world-1) of its bytes to each peer over
+that peer's own xGMI link (point-to-point topology: up to 7 links per GPU), G GB/s per link and direction (default 120 =
+0.8 x the 153 GB/s the links are specified at), plus --wire-lat-us (default 30: two collectives' launch + one host read of
+the sizes).  `step_ms_model` = critical path + modelled wire, nothing overlapped (what the code does today)."""
 import json
 import os
 import sys
@@ -100,4 +104,11 @@ res = {
     "critical_path_ms": max(t[1] for t in t_count) + max(t_export) + t_owner[0],
     "wire_bytes_per_rank_max": max(wire), "owner0_distinct": dg[0], "owner0_sum": dg[1],
 }
+link = float(opt.get("link-gbs", 120.0))
+lat = float(opt.get("wire-lat-us", 30.0))
+if world > 1:
+    wire_ms = max(wire) / (world - 1) / (link * 1e9) * 1e3 + lat * 1e-3
+    res["wire_model"] = {"link_GBps": link, "links_used": world - 1, "latency_us": lat, "wire_ms": wire_ms,
+                         "assumption": "point-to-point xGMI, one link per peer, all links in parallel; NOT measured"}
+    res["step_ms_model"] = res["critical_path_ms"] + wire_ms
 print(json.dumps(res), flush=True)
