@@ -32,7 +32,7 @@ namespace {
 constexpr int RX_NXG = 8;                 // workgroup-id groups (XCD affinity, speed only)
 constexpr int RX_NREG = 32;               // sub-regions (cursors) per level-1 bin, RX_NREG / RX_NXG per XCD:
                                           // the returning atomics on one cursor serialise (see msp_dev.h: NXG)
-constexpr int RX1_THREADS = 256, RX1_KEYS = RX1_THREADS * 32;
+constexpr int RX1_THREADS = 512, RX1_PER = 16, RX1_KEYS = RX1_THREADS * RX1_PER;
 constexpr int RX2_THREADS = 512, RX2_PER = 16, RX2_KEYS = RX2_THREADS * RX2_PER;
 constexpr int RX3_THREADS = 256;
 constexpr int RX_IDX_MAX = 13;
@@ -76,10 +76,27 @@ constexpr uint32_t RX_PAD = 0xFFFFFFFFu;
 constexpr int RX_GROUP = 8;
 
 // ------------------------------------------------------------------------------------------ RX1
-// Instruction count is what bounds the rest of this kernel (the vector pipe issued 76 % of the time), so: ONE
-// returning LDS atomic per key (its rank inside the bin; the rank waits in a register for the scan -- no second
-// "fill" atomic), window starts that are no k-mer go to a dummy bin of their lane and to spare slots instead of
-// around the atomics in branches, LDS-only barriers and DPP scans (msp_dev.h), 32-bit arithmetic throughout.
+// 512 threads x 16 window starts (round 4; it was 256 x 32): the tile and its LDS are the same, but a lane holds
+// 16 keys + 8 packed ranks instead of 32 + 32, so a SIMD holds eight waves instead of four -- the kernel's compute
+// phases (vector issue, LDS atomics) and its write phase belong to different workgroups of a CU and overlap only as
+// far as there are waves to overlap them.  ONE returning LDS atomic per key (its rank inside the bin; the rank
+// waits in a register for the scan -- no second "fill" atomic), window starts that are no k-mer go to a dummy bin
+// of their lane and to spare slots instead of around the atomics in branches, LDS-only barriers and DPP scans
+// (msp_dev.h), 32-bit arithmetic throughout.
+__device__ __forceinline__ void rx_load_chunk16(const int8_t *__restrict__ data, int64_t off, int64_t nN, uint32_t &b, uint32_t &bad) {
+  if (off + 16 <= nN) {
+    dev_pack16(*reinterpret_cast<const uint4 *>(data + off), b, bad);
+  } else {                                       // the buffer's last bytes
+    b = 0; bad = 0;
+    for (int j = 0; j < 16; ++j) {
+      const int c = (off + j < nN) ? (int)data[off + j] : -1;
+      const bool inv = (c < 0 || c > 3);
+      b |= (inv ? 0u : (uint32_t)c) << (30 - 2 * j);
+      if (inv) bad |= 1u << (15 - j);
+    }
+  }
+}
+
 template <bool CANON>
 __global__ __launch_bounds__(RX1_THREADS) void rx1_kernel(const int8_t *__restrict__ data, int64_t nN,
                                                           RxView v, TableView t) {
@@ -88,95 +105,101 @@ __global__ __launch_bounds__(RX1_THREADS) void rx1_kernel(const int8_t *__restri
   static_assert((SLOTS + 64) % 8 == 0, "whole vectors");
   __shared__ uint4 slo4[(SLOTS + 64) / 8];                     // 16-bit plane
   __shared__ uint2 shi2[(SLOTS + 64) / 8];                     // 8-bit plane
-  __shared__ uint32_t hist[320], hp[256], loff[320];           // (bins 256 .. 319: one dummy bin per lane)
+  __shared__ uint32_t hist[320], hp[256], loff[320], gb[256];  // (bins 256 .. 319: one dummy bin per lane)
   __shared__ uint32_t wtot[4];
   (void)t;
   uint16_t *const slo = reinterpret_cast<uint16_t *>(slo4);
   uint8_t *const shi = reinterpret_cast<uint8_t *>(shi2);
   const int tid = threadIdx.x, lane = tid & 63;
   const int k = v.k;
-  hist[tid] = 0;
-  if (tid < 64) { hist[256 + tid] = 0; loff[256 + tid] = (uint32_t)TRASH; }
+  if (tid < 320) hist[tid] = 0;
+  if (tid < 64) loff[256 + tid] = (uint32_t)TRASH;
   for (int s = tid; s < (SLOTS + 64) / 8; s += RX1_THREADS) {  // pads everywhere; the keys overwrite their slots
     slo4[s] = make_uint4(RX_PAD, RX_PAD, RX_PAD, RX_PAD);
     shi2[s] = make_uint2(RX_PAD, RX_PAD);
   }
   lds_barrier();
 
-  const int64_t off = ((int64_t)blockIdx.x * RX1_THREADS + tid) * 32;
-  uint32_t b0, b1w, bad;
-  dev_load_chunk32(data, off, nN, b0, b1w, bad);
-  uint32_t n0 = dev_lane_next(b0), n1 = dev_lane_next(b1w), nbad = dev_lane_next(bad);
-  if (lane == 63) dev_load_chunk32(data, off + 32, nN, n0, n1, nbad);
-  (void)n1;
+  const int64_t off = ((int64_t)blockIdx.x * RX1_THREADS + tid) * RX1_PER;
+  uint32_t b0, bad0;
+  rx_load_chunk16(data, off, nN, b0, bad0);
+  uint32_t n0 = dev_lane_next(b0), nbad = dev_lane_next(bad0);
+  if (lane == 63) rx_load_chunk16(data, off + 16, nN, n0, nbad);
   const int sh1 = 2 * k - v.b1;
   // The k-mer at position i is the top 2k bits of the 32-bit window of the base string that starts
   // there (one v_alignbit with a static shift), its reverse complement the low 2k bits of a window
   // of the reverse-complemented string that ENDS where the k-mer starts (msp_dev.h: msp_minimizers),
-  // its validity the top k bits of a window of the invalid-base mask: 32-bit work throughout.
-  const uint32_t D[3] = {b0, b1w, n0};
-  uint32_t R[4];
+  // its validity the top k bits of the invalid-base mask shifted to the position: 32-bit work throughout.
+  const uint32_t D[2] = {b0, n0};
+  uint32_t R[3];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < 2; ++i) {
     uint32_t x = __brev(D[i]);
     x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
-    R[3 - i] = ~x;
+    R[2 - i] = ~x;
   }
   R[0] = 0;
+  const uint32_t M = (bad0 << 16) | (nbad & 0xFFFFu);          // bit (31 - j): base j of the 32 is invalid
   const int fsh = 32 - 2 * k;
   const uint32_t vlim = 1u << (32 - k);            // a window whose top k mask bits are clear is below this
   const uint32_t mul = v.mul, kmask = v.kmask;
 
-  uint32_t keys[32], rk[32];
+  uint32_t keys[RX1_PER], rk2[RX1_PER / 2];                   // (two ranks per register)
   const uint32_t inval = (256u + (uint32_t)lane) << sh1;      // "key" of this lane's dummy bin (sh1 <= 22: fits)
 #pragma unroll
-  for (int i = 0; i < 32; ++i) {
-    const int o = 2 * i, q = o >> 5, r = o & 31;
-    const uint32_t X = r ? __builtin_amdgcn_alignbit(D[q], D[q + 1], 32 - r) : D[q];
+  for (int i = 0; i < RX1_PER; ++i) {
+    const uint32_t X = i ? __builtin_amdgcn_alignbit(D[0], D[1], 32 - 2 * i) : D[0];
     uint32_t key = X >> fsh;
     if (CANON) {
-      const int o2 = 96 - 2 * i, q2 = o2 >> 5, r2 = o2 & 31;
+      const int o2 = 64 - 2 * i, q2 = o2 >> 5, r2 = o2 & 31;
       const uint32_t Y = r2 ? __builtin_amdgcn_alignbit(R[q2], R[q2 + 1], 32 - r2) : R[q2];
       key = min(key, Y & kmask);
     }
-    const uint32_t Wm = i ? __builtin_amdgcn_alignbit(bad, nbad, 32 - i) : bad;
+    const uint32_t Wm = M << i;
     key = (key * mul) & kmask;
     key = (Wm < vlim) ? key : inval;
     keys[i] = key;
-    rk[i] = atomicAdd(&hist[key >> sh1], 1u);
+    const uint32_t r_ = atomicAdd(&hist[key >> sh1], 1u);
+    rk2[i >> 1] = (i & 1) ? (rk2[i >> 1] | (r_ << 16)) : r_;
   }
   lds_barrier();
-  // ---- thread b owns bin b: one reservation (a multiple of eight), padded offsets ----
+  // ---- thread b < 256 owns bin b: one reservation (a multiple of eight), padded offsets ----
   const uint32_t subreg = blockIdx.x & (RX_NREG - 1);
-  const uint32_t reg = rx_reg(v, tid, subreg);
-  const uint32_t c = hist[tid];
-  const uint32_t cp = (c + (RX_GROUP - 1)) & ~(uint32_t)(RX_GROUP - 1);
-  hp[tid] = cp;
-  uint32_t my_base = 0;
-  if (cp) my_base = atomicAdd(&v.cnt1[reg], cp);
+  uint32_t my_base = 0;                                  // (returning atomic: consumed after the sort)
+  if (tid < 256) {
+    const uint32_t c = hist[tid];
+    const uint32_t cp = (c + (RX_GROUP - 1)) & ~(uint32_t)(RX_GROUP - 1);
+    hp[tid] = cp;
+    if (cp) my_base = atomicAdd(&v.cnt1[rx_reg(v, tid, subreg)], cp);
+  }
   block_scan<256, true>(hp, loff, wtot);
   const uint32_t lowmask = (1u << sh1) - 1u;
 #pragma unroll
-  for (int i = 0; i < 32; ++i) {
-    const uint32_t pos = min(loff[keys[i] >> sh1] + rk[i], (uint32_t)TRASH + 63u);
+  for (int i = 0; i < RX1_PER; ++i) {
+    const uint32_t r_ = (i & 1) ? (rk2[i >> 1] >> 16) : (rk2[i >> 1] & 0xFFFFu);
+    const uint32_t pos = min(loff[keys[i] >> sh1] + r_, (uint32_t)TRASH + 63u);
     slo[pos] = (uint16_t)(keys[i] & lowmask);          // (below 16 bits per key the bin's bits would read as a pad)
     if (v.hi8) shi[pos] = (uint8_t)((keys[i] & lowmask) >> 16);
   }
+  if (tid < 256) gb[tid] = my_base;
   lds_barrier();
   if (v.dbg & CFRK_ABL_RX1_NO_OUT) return;
-  // ---- copy out: thread b writes its bin's groups, 16 + 8 bytes at a time ----
+  // ---- copy out: threads b and b + 256 write bin b's even / odd groups, 16 + 8 bytes at a time ----
   {
+    const uint32_t b = (uint32_t)tid & 255u, half = (uint32_t)tid >> 8;
+    const uint32_t reg = rx_reg(v, b, subreg);
+    const uint32_t cp = hp[b], my_base = gb[b];
     const uint64_t cap = v.exact1 ? (uint64_t)v.rcap[reg] : v.cap1;
     uint64_t at = (v.exact1 ? v.rbase[reg] : (uint64_t)reg * v.cap1) + my_base;
-    if (v.dbg & CFRK_ABL_RX1_LINEAR) at = (uint64_t)(blockIdx.x & 255u) * 16384u + loff[tid];   // (timing: the tile stays in its XCD's L2)
+    if (v.dbg & CFRK_ABL_RX1_LINEAR) at = (uint64_t)(blockIdx.x & 255u) * 16384u + loff[b];   // (timing: the tile stays in its XCD's L2)
     const uint64_t room = cap > (uint64_t)my_base ? cap - my_base : 0;          // (a multiple of eight)
     // the cursor keeps counting past the region: the host then redoes RX1 with exact sizes
-    if ((uint64_t)cp > room) v.stats[ST_L1OVF] = 1;
+    if (half == 0 && (uint64_t)cp > room) v.stats[ST_L1OVF] = 1;
     const uint32_t nv = (uint32_t)min((uint64_t)cp, room) / RX_GROUP;
-    const uint32_t src = loff[tid] / RX_GROUP;
+    const uint32_t src = loff[b] / RX_GROUP;
     uint4 *const dlo = reinterpret_cast<uint4 *>(v.k1lo + at);
     uint2 *const dhi = reinterpret_cast<uint2 *>(v.k1hi + at);
-    for (uint32_t j = 0; j < nv; ++j) {
+    for (uint32_t j = half; j < nv; j += 2) {
       dlo[j] = slo4[src + j];
       if (v.hi8) dhi[j] = shi2[src + j];
     }
