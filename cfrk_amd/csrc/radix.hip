@@ -67,22 +67,28 @@ __device__ __forceinline__ uint32_t rx_unmix(const RxView &v, uint32_t x) { retu
 // WIDE STORES (round 4).  What the two partition kernels cost was their copy-out, and not the scatter: a
 // wave-wide 2-byte (or 1-byte) store occupies the CU's address path for ~20 clocks whatever it carries, 128 bytes or
 // 1024 (profiles/r04/c2_radix_ablations.txt: RX1 2.17 ms, 1.16 without its copy-out, 1.95 with the 16-bit plane written
-// back to back instead of scattered).  So everything that reaches HBM moves in groups of EIGHT keys: a bin's segment of
-// a tile is rounded up to a multiple of eight with pad elements (all ones: no key of the level looks like that), every
-// cursor therefore advances in multiples of eight and every region starts on one, and a LANE copies its bin's groups
-// as whole 16-byte (16-bit plane, leaf streams) and 8-byte (8-bit plane) vectors.  The readers drop the pads: the
-// second-level kernel by value (a key of the level is below 2^(2k-b1)), the leaf kernel sends them to a spare counter.
+// back to back instead of scattered).  RX2 therefore writes the leaf streams in groups of EIGHT keys: a sub-bin's segment
+// of a tile is rounded up to a multiple of eight with pad elements (all ones: no key of a leaf looks like that), every
+// leaf cursor advances in multiples of eight and every leaf stream starts on one, and a LANE copies its sub-bin's groups
+// as whole 16-byte vectors; the leaf kernel sends the pads to a spare counter.  (RX1 was built the same way and measured
+// slower, see there: level 1 is written key by key.)
 constexpr uint32_t RX_PAD = 0xFFFFFFFFu;
 constexpr int RX_GROUP = 8;
+// RX1 writes key by key (see there): sorted position p of bin b lands at element dabs + p of the level-1 buffer
+// while p < plim (the part of the bin's reservation that fits its region).  One ds_read_b128 per key.
+struct RxDst { uint32_t dlo, dhi, plim, pad; };
+static_assert(sizeof(RxDst) == 16, "one LDS read");
 
 // ------------------------------------------------------------------------------------------ RX1
-// 512 threads x 16 window starts (round 4; it was 256 x 32): the tile and its LDS are the same, but a lane holds
-// 16 keys + 8 packed ranks instead of 32 + 32, so a SIMD holds eight waves instead of four -- the kernel's compute
-// phases (vector issue, LDS atomics) and its write phase belong to different workgroups of a CU and overlap only as
-// far as there are waves to overlap them.  ONE returning LDS atomic per key (its rank inside the bin; the rank
-// waits in a register for the scan -- no second "fill" atomic), window starts that are no k-mer go to a dummy bin
-// of their lane and to spare slots instead of around the atomics in branches, LDS-only barriers and DPP scans
-// (msp_dev.h), 32-bit arithmetic throughout.
+// 512 threads x 16 window starts (a lane holds 16 keys + 8 packed ranks: eight waves per SIMD).  ONE returning LDS
+// atomic per key (its rank inside the bin; the rank waits in a register for the scan -- no second "fill" atomic),
+// window starts that are no k-mer go to a dummy bin of their lane and to spare slots instead of around the atomics
+// in branches, LDS-only barriers and DPP scans (msp_dev.h), 32-bit arithmetic throughout.
+// This kernel is bound by its LDS work (~4 LDS operations per key, the atomics and the sort's scattered writes with
+// 3-5-way bank conflicts): variants that pad every bin's segment to groups of eight and copy them out as 16- and 8-byte
+// vectors (as RX2 does) were measured SLOWER, 2.48 / 2.58 ms against 2.15 -- the second plane's LDS write and the pad
+// fill cost more than the wide stores save (profiles/r04/c2_radix_ablations.txt) -- so level 1 is written key by key
+// and is not padded.
 __device__ __forceinline__ void rx_load_chunk16(const int8_t *__restrict__ data, int64_t off, int64_t nN, uint32_t &b, uint32_t &bad) {
   if (off + 16 <= nN) {
     dev_pack16(*reinterpret_cast<const uint4 *>(data + off), b, bad);
@@ -100,24 +106,15 @@ __device__ __forceinline__ void rx_load_chunk16(const int8_t *__restrict__ data,
 template <bool CANON>
 __global__ __launch_bounds__(RX1_THREADS) void rx1_kernel(const int8_t *__restrict__ data, int64_t nN,
                                                           RxView v, TableView t) {
-  constexpr int SLOTS = RX1_KEYS + 256 * (RX_GROUP - 1) + 8;   // the bin-sorted tile with every bin rounded up to 8
-  constexpr int TRASH = SLOTS;                                 // + 64 spare slots for the dummy bins
-  static_assert((SLOTS + 64) % 8 == 0, "whole vectors");
-  __shared__ uint4 slo4[(SLOTS + 64) / 8];                     // 16-bit plane
-  __shared__ uint2 shi2[(SLOTS + 64) / 8];                     // 8-bit plane
-  __shared__ uint32_t hist[320], hp[256], loff[320], gb[256];  // (bins 256 .. 319: one dummy bin per lane)
+  __shared__ uint32_t sorted[RX1_KEYS + 64];                   // + 64 spare slots for the dummy bins
+  __shared__ uint32_t hist[320], loff[320];                    // (bins 256 .. 319: one dummy bin per lane)
+  __shared__ RxDst dst[256];
   __shared__ uint32_t wtot[4];
   (void)t;
-  uint16_t *const slo = reinterpret_cast<uint16_t *>(slo4);
-  uint8_t *const shi = reinterpret_cast<uint8_t *>(shi2);
   const int tid = threadIdx.x, lane = tid & 63;
   const int k = v.k;
   if (tid < 320) hist[tid] = 0;
-  if (tid < 64) loff[256 + tid] = (uint32_t)TRASH;
-  for (int s = tid; s < (SLOTS + 64) / 8; s += RX1_THREADS) {  // pads everywhere; the keys overwrite their slots
-    slo4[s] = make_uint4(RX_PAD, RX_PAD, RX_PAD, RX_PAD);
-    shi2[s] = make_uint2(RX_PAD, RX_PAD);
-  }
+  if (tid < 64) loff[256 + tid] = (uint32_t)RX1_KEYS;
   lds_barrier();
 
   const int64_t off = ((int64_t)blockIdx.x * RX1_THREADS + tid) * RX1_PER;
@@ -163,45 +160,45 @@ __global__ __launch_bounds__(RX1_THREADS) void rx1_kernel(const int8_t *__restri
     rk2[i >> 1] = (i & 1) ? (rk2[i >> 1] | (r_ << 16)) : r_;
   }
   lds_barrier();
-  // ---- thread b < 256 owns bin b: one reservation (a multiple of eight), padded offsets ----
+  // ---- thread b < 256 owns bin b: one reservation per non-empty bin, bin offsets, destinations ----
   const uint32_t subreg = blockIdx.x & (RX_NREG - 1);
+  const uint32_t c = tid < 256 ? hist[tid] : 0u;
   uint32_t my_base = 0;                                  // (returning atomic: consumed after the sort)
-  if (tid < 256) {
-    const uint32_t c = hist[tid];
-    const uint32_t cp = (c + (RX_GROUP - 1)) & ~(uint32_t)(RX_GROUP - 1);
-    hp[tid] = cp;
-    if (cp) my_base = atomicAdd(&v.cnt1[rx_reg(v, tid, subreg)], cp);
-  }
-  block_scan<256, true>(hp, loff, wtot);
-  const uint32_t lowmask = (1u << sh1) - 1u;
+  if (c) my_base = atomicAdd(&v.cnt1[rx_reg(v, tid, subreg)], c);
+  block_scan<256, true>(hist, loff, wtot);
 #pragma unroll
   for (int i = 0; i < RX1_PER; ++i) {
     const uint32_t r_ = (i & 1) ? (rk2[i >> 1] >> 16) : (rk2[i >> 1] & 0xFFFFu);
-    const uint32_t pos = min(loff[keys[i] >> sh1] + r_, (uint32_t)TRASH + 63u);
-    slo[pos] = (uint16_t)(keys[i] & lowmask);          // (below 16 bits per key the bin's bits would read as a pad)
-    if (v.hi8) shi[pos] = (uint8_t)((keys[i] & lowmask) >> 16);
+    sorted[min(loff[keys[i] >> sh1] + r_, (uint32_t)RX1_KEYS + 63u)] = keys[i];
   }
-  if (tid < 256) gb[tid] = my_base;
+  if (tid < 256) {
+    const uint32_t reg = rx_reg(v, tid, subreg);
+    const uint64_t cap = v.exact1 ? (uint64_t)v.rcap[reg] : v.cap1;
+    const uint64_t at = v.exact1 ? v.rbase[reg] : (uint64_t)reg * v.cap1;
+    const uint32_t lo = loff[tid];
+    uint64_t d = at + my_base - lo;
+    if (v.dbg & CFRK_ABL_RX1_LINEAR) d = (uint64_t)(blockIdx.x & 255u) * 16384u;   // (timing: the tile stays in its XCD's L2)
+    const uint64_t room = cap > (uint64_t)my_base ? cap - my_base : 0;
+    RxDst e;
+    e.dlo = (uint32_t)d; e.dhi = (uint32_t)(d >> 32);
+    e.plim = (uint32_t)min((uint64_t)lo + room, (uint64_t)0xFFFFFFFFu);
+    e.pad = 0;
+    dst[tid] = e;
+    // the cursor keeps counting past the region: the host then redoes RX1 with exact sizes
+    if ((uint64_t)c > room) v.stats[ST_L1OVF] = 1;
+  }
   lds_barrier();
   if (v.dbg & CFRK_ABL_RX1_NO_OUT) return;
-  // ---- copy out: threads b and b + 256 write bin b's even / odd groups, 16 + 8 bytes at a time ----
-  {
-    const uint32_t b = (uint32_t)tid & 255u, half = (uint32_t)tid >> 8;
-    const uint32_t reg = rx_reg(v, b, subreg);
-    const uint32_t cp = hp[b], my_base = gb[b];
-    const uint64_t cap = v.exact1 ? (uint64_t)v.rcap[reg] : v.cap1;
-    uint64_t at = (v.exact1 ? v.rbase[reg] : (uint64_t)reg * v.cap1) + my_base;
-    if (v.dbg & CFRK_ABL_RX1_LINEAR) at = (uint64_t)(blockIdx.x & 255u) * 16384u + loff[b];   // (timing: the tile stays in its XCD's L2)
-    const uint64_t room = cap > (uint64_t)my_base ? cap - my_base : 0;          // (a multiple of eight)
-    // the cursor keeps counting past the region: the host then redoes RX1 with exact sizes
-    if (half == 0 && (uint64_t)cp > room) v.stats[ST_L1OVF] = 1;
-    const uint32_t nv = (uint32_t)min((uint64_t)cp, room) / RX_GROUP;
-    const uint32_t src = loff[b] / RX_GROUP;
-    uint4 *const dlo = reinterpret_cast<uint4 *>(v.k1lo + at);
-    uint2 *const dhi = reinterpret_cast<uint2 *>(v.k1hi + at);
-    for (uint32_t j = half; j < nv; j += 2) {
-      dlo[j] = slo4[src + j];
-      if (v.hi8) dhi[j] = shi2[src + j];
+  // ---- copy out in bin order: consecutive lanes -> consecutive elements of one region ----
+  const uint32_t total = loff[255] + hist[255];
+  const uint32_t lowmask = (1u << sh1) - 1u;
+  for (uint32_t p = tid; p < total; p += RX1_THREADS) {
+    const uint32_t key = sorted[p];
+    const RxDst e = dst[key >> sh1];
+    if (p < e.plim) {
+      const uint64_t at = (((uint64_t)e.dhi << 32) | e.dlo) + p;
+      v.k1lo[at] = (uint16_t)(key & lowmask);          // (below 16 bits per key the bin's bits would read as a pad)
+      if (v.hi8) v.k1hi[at] = (uint8_t)((key & lowmask) >> 16);
     }
   }
 }
@@ -210,6 +207,7 @@ __global__ __launch_bounds__(RX1_THREADS) void rx1_kernel(const int8_t *__restri
 // One tile of RX2_KEYS elements of one level-1 region, split by the next b2 bits (<= 512 sub-bins) into the
 // leaves' 16-bit streams.  Same economy as RX1: one returning LDS atomic per key, pads and the elements beyond
 // the tile's end go to a dummy bin of their lane, thread b writes sub-bin b's groups as 16-byte vectors.
+template <bool VEC>   // VEC: level 1 in its fixed-stride layout (regions start on 16-element boundaries: vector loads)
 __global__ __launch_bounds__(RX2_THREADS) void rx2_kernel(int tiles_per_sub, RxView v, TableView t) {
   constexpr int SLOTS = RX2_KEYS + 512 * (RX_GROUP - 1) + 8;
   constexpr int TRASH = SLOTS;
@@ -232,7 +230,7 @@ __global__ __launch_bounds__(RX2_THREADS) void rx2_kernel(int tiles_per_sub, RxV
   const uint32_t sub = (seq % per_bin) / (uint32_t)tiles_per_sub;
   const uint32_t tile = (seq % per_bin) % (uint32_t)tiles_per_sub;
   const uint32_t reg = rx_reg(v, bin1, sub);
-  const uint64_t n = min((uint64_t)v.cnt1[reg], v.exact1 ? (uint64_t)v.rcap[reg] : v.cap1);   // (a multiple of eight)
+  const uint64_t n = min((uint64_t)v.cnt1[reg], v.exact1 ? (uint64_t)v.rcap[reg] : v.cap1);
   const uint64_t r0 = (uint64_t)tile * RX2_KEYS;
   if (r0 >= n) return;
   const uint32_t nt = (uint32_t)min((uint64_t)RX2_KEYS, n - r0);
@@ -241,35 +239,54 @@ __global__ __launch_bounds__(RX2_THREADS) void rx2_kernel(int tiles_per_sub, RxV
   for (int s = tid; s < (SLOTS + 64) / 8; s += RX2_THREADS) s4[s] = make_uint4(RX_PAD, RX_PAD, RX_PAD, RX_PAD);
   lds_barrier();
   const uint64_t rb = (v.exact1 ? v.rbase[reg] : (uint64_t)reg * v.cap1) + r0;
-  const uint4 *slo = reinterpret_cast<const uint4 *>(v.k1lo + rb);       // (regions start on a multiple of eight)
-  const uint2 *shi = reinterpret_cast<const uint2 *>(v.k1hi + rb);
   const uint32_t idxb = (uint32_t)v.idx, m2 = (1u << v.b2) - 1u;
   const uint32_t klim = 1u << (2 * v.k - v.b1);              // a key of this level is below it, a pad is not
-  uint32_t kk[RX2_PER], rk[RX2_PER];             // the 2k - b1 bits below the bin; rank inside the sub-bin
+  uint32_t kk[RX2_PER], rk2[RX2_PER / 2];        // the 2k - b1 bits below the bin; ranks inside the sub-bins, two per register
   static_assert(RX2_PER % 8 == 0, "keys are loaded eight at a time");
+  // 16-byte loads of the 16-bit plane (eight keys) and 8-byte loads of the 8-bit plane (a region starts on a
+  // 16-element boundary unless the level was laid out again: cap1 is a multiple of 16); elements beyond the
+  // region's keys become pads.  Which key a thread holds does not matter to a counting sort.
+  if (VEC) {
+    const uint4 *slo = reinterpret_cast<const uint4 *>(v.k1lo + rb);
+    const uint2 *shi = reinterpret_cast<const uint2 *>(v.k1hi + rb);
+    const bool full = nt == (uint32_t)RX2_KEYS;
 #pragma unroll
-  for (int q = 0; q < RX2_PER / 8; ++q) {
-    const uint32_t g = (uint32_t)q * RX2_THREADS + tid;      // group of eight elements
-    uint4 x = make_uint4(RX_PAD, RX_PAD, RX_PAD, RX_PAD);
-    uint2 h = make_uint2(RX_PAD, RX_PAD);
-    if (8u * g < nt) {
-      x = slo[g];
-      if (v.hi8) h = shi[g]; else h = make_uint2(0u, 0u);
+    for (int q = 0; q < RX2_PER / 8; ++q) {
+      const uint32_t g = (uint32_t)q * RX2_THREADS + tid;      // group of eight elements
+      uint4 x = make_uint4(RX_PAD, RX_PAD, RX_PAD, RX_PAD);
+      uint2 h = make_uint2(RX_PAD, RX_PAD);
+      if (8u * g < nt) {
+        x = slo[g];
+        if (v.hi8) h = shi[g]; else h = make_uint2(0u, 0u);
+      }
+      const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const uint32_t lo16 = (c & 1) ? (w[c >> 1] >> 16) : (w[c >> 1] & 0xFFFFu);
+        const uint32_t hw = c < 4 ? h.x : h.y;
+        const uint32_t hb = ((c & 3) == 3) ? (hw >> 24) : ((hw >> (8 * (c & 3))) & 0xFFu);
+        kk[8 * q + c] = (hb << 16) | lo16;
+      }
+      if (!full) {                                             // (the region's last tile: wave-uniform)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) if (8u * g + (uint32_t)c >= nt) kk[8 * q + c] = RX_PAD;
+      }
     }
-    const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+  } else {
+    const uint16_t *slo = v.k1lo + rb;
+    const uint8_t *shi = v.k1hi + rb;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const uint32_t lo16 = (c & 1) ? (w[c >> 1] >> 16) : (w[c >> 1] & 0xFFFFu);
-      const uint32_t hw = c < 4 ? h.x : h.y;
-      const uint32_t hb = ((c & 3) == 3) ? (hw >> 24) : ((hw >> (8 * (c & 3))) & 0xFFu);
-      kk[8 * q + c] = (hb << 16) | lo16;
+    for (int i = 0; i < RX2_PER; ++i) {
+      const uint32_t idx = (uint32_t)i * RX2_THREADS + tid;
+      kk[i] = (idx < nt) ? ((uint32_t)slo[idx] | (v.hi8 ? (uint32_t)shi[idx] << 16 : 0u)) : RX_PAD;
     }
   }
   const uint32_t dummy = 512u + (uint32_t)lane;
 #pragma unroll
   for (int i = 0; i < RX2_PER; ++i) {
     const uint32_t b = (kk[i] < klim) ? ((kk[i] >> idxb) & m2) : dummy;
-    rk[i] = atomicAdd(&hist[b], 1u);
+    const uint32_t r_ = atomicAdd(&hist[b], 1u);
+    rk2[i >> 1] = (i & 1) ? (rk2[i >> 1] | (r_ << 16)) : r_;
   }
   lds_barrier();
   const uint32_t c = hist[tid];                          // (non-zero only for tid <= m2)
@@ -283,7 +300,8 @@ __global__ __launch_bounds__(RX2_THREADS) void rx2_kernel(int tiles_per_sub, RxV
 #pragma unroll
   for (int i = 0; i < RX2_PER; ++i) {
     const uint32_t b = (kk[i] < klim) ? ((kk[i] >> idxb) & m2) : dummy;
-    s16[min(loff[b] + rk[i], (uint32_t)TRASH + 63u)] = (uint16_t)(kk[i] & imask);
+    const uint32_t r_ = (i & 1) ? (rk2[i >> 1] >> 16) : (rk2[i >> 1] & 0xFFFFu);
+    s16[min(loff[b] + r_, (uint32_t)TRASH + 63u)] = (uint16_t)(kk[i] & imask);
   }
   lds_barrier();
   if (v.dbg & CFRK_ABL_RX2_NO_OUT) return;
@@ -615,10 +633,10 @@ int cfrk_radix_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   v.dbg = ctx->dbg_flags;
   v.inv = inv_odd32(v.mul);
   const uint64_t nb1 = 1ull << v.b1, nleaf = 1ull << (v.b1 + v.b2);
-  // (segments are rounded up to eight elements: a tile of RX1 adds ~3.5 pads to each of its 256 segments of ~29 keys,
-  //  a tile of RX2 to each of its <= 512 segments; regions start on multiples of 16 / 8 elements)
-  const double pad1 = 1.0 + 3.5 * 256.0 / (double)RX1_KEYS, pad2 = pad1 * (1.0 + 3.5 * (double)(1u << v.b2) / (double)RX2_KEYS);
-  const uint64_t cap1 = ((uint64_t)((double)nN / (double)(nb1 * RX_NREG) * 1.3 * pad1) + 4096 + 15) & ~15ull;
+  // (a tile of RX2 rounds each of its <= 512 segments up to eight elements, ~3.5 pads each; level-1 regions start on
+  //  multiples of 16 elements, leaf streams on multiples of 8)
+  const double pad2 = 1.0 + 3.5 * (double)(1u << v.b2) / (double)RX2_KEYS;
+  const uint64_t cap1 = ((uint64_t)((double)nN / (double)(nb1 * RX_NREG) * 1.3) + 4096 + 15) & ~15ull;
   const uint64_t cap2 = ((uint64_t)((double)nN / (double)nleaf * 1.5 * pad2) + 1024 + 7) & ~7ull;
   // the 8-bit plane also exists when the level's keys fill the 16-bit plane exactly (k = 12): a pad must not look like a key
   v.hi8 = (2 * k - v.b1 >= 16) ? 1u : 0u;
@@ -670,7 +688,8 @@ int cfrk_radix_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
     const int64_t g2 = bins_per_group * RX_NXG * RX_NREG * tiles_per_sub;
     if (g2 > 0x7FFFFFFF) return cfrk_fail(ctx, CFRK_ERR_ARG, "batch too large for one add");
     HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_L2OVF, 0, sizeof(uint64_t), ctx->stream));
-    hipLaunchKernelGGL(rx2_kernel, dim3((unsigned)g2), dim3(RX2_THREADS), 0, ctx->stream, (int)tiles_per_sub, v, t);
+    if (v.exact1) hipLaunchKernelGGL((rx2_kernel<false>), dim3((unsigned)g2), dim3(RX2_THREADS), 0, ctx->stream, (int)tiles_per_sub, v, t);
+    else hipLaunchKernelGGL((rx2_kernel<true>), dim3((unsigned)g2), dim3(RX2_THREADS), 0, ctx->stream, (int)tiles_per_sub, v, t);
     HIP_TRY(ctx, hipGetLastError());
     uint64_t st[ST_NWORDS];
     HIP_TRY(ctx, hipMemcpyAsync(st, ctx->g_stats, sizeof st, hipMemcpyDeviceToHost, ctx->stream));
