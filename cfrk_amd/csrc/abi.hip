@@ -167,8 +167,10 @@ int cfrk_memcpy_d2h(cfrk_ctx *ctx, void *dst, const void *src, size_t bytes) {
 int cfrk_memcpy_peer(cfrk_ctx *dst_ctx, void *dst, cfrk_ctx *src_ctx, const void *src, size_t bytes) {
   if (!dst_ctx || !src_ctx || (bytes && (!dst || !src))) return CFRK_ERR_ARG;
   if (bytes == 0) return CFRK_OK;
-  HIP_TRY(src_ctx, hipSetDevice(src_ctx->device));
-  HIP_TRY(src_ctx, hipStreamSynchronize(src_ctx->stream));
+  // every failure is reported on dst_ctx: several owners (threads, each with its own dst_ctx) may copy from ONE
+  // source context at the same time, and a context's error text has a single writer -- its own thread
+  HIP_TRY(dst_ctx, hipSetDevice(src_ctx->device));
+  HIP_TRY(dst_ctx, hipStreamSynchronize(src_ctx->stream));      // (draining a stream from several threads is safe)
   HIP_TRY(dst_ctx, hipSetDevice(dst_ctx->device));
   if (dst_ctx->device != src_ctx->device) {
     int can = 0;

@@ -93,8 +93,9 @@ int  cfrk_memcpy_d2h(cfrk_ctx *ctx, void *dst_host, const void *src_device, size
  * peer-to-peer (hipMemcpyPeerAsync; peer access is enabled on first use where the topology allows it),
  * enqueued on dst_ctx's stream.  src_ctx's stream is drained first, so whatever src_ctx was asked to
  * write is complete in the copy; the call returns once the copy is enqueued (dst_ctx's later work is
- * ordered behind it).  This is the exchange step of a one-process multi-GPU host (the `cfrk` CLI);
- * one process per GPU uses RCCL instead (cfrk_amd/sharded.py). */
+ * ordered behind it).  src_ctx is only read: several threads may copy from one source context at the same time, each
+ * into its own dst_ctx, and every failure is reported on dst_ctx (cfrk_last_error(dst_ctx)).  This is the exchange
+ * step of a one-process multi-GPU host (the `cfrk` CLI); one process per GPU uses RCCL instead (cfrk_amd/sharded.py). */
 int  cfrk_memcpy_peer(cfrk_ctx *dst_ctx, void *dst_device, cfrk_ctx *src_ctx, const void *src_device, size_t bytes);
 
 /* ---- per-read dense counting: the drop-in for kmer_main ------------------------------- */
