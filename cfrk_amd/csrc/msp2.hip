@@ -833,14 +833,22 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, uint32_t mod
       c += n;
     };
     if (!SHARED) {
-      Rec2 nxt = zrec;
-      if ((uint64_t)tid < ns[3]) nxt = leaf_rec[tid];
-      for (uint64_t r = tid; r < ((ns[3] + 63) & ~63ull); r += Q3_THREADS) {
-        const bool valid = r < ns[3];
-        const Rec2 rec = nxt;
-        nxt = zrec;
-        if (r + Q3_THREADS < ns[3]) nxt = leaf_rec[r + Q3_THREADS];
-        home(rec, valid);
+      // four loads in flight per lane: ONE workgroup runs on a CU, so what its 1024 threads have in flight is all
+      // the CU has in flight -- with one prefetched record per thread (32 KB per CU) the scan ran at what a 2 us
+      // round trip allows, ~4 TB/s for the chip (round 4)
+      const uint64_t nr = (ns[3] + 63) & ~63ull;
+      for (uint64_t r = tid; r < nr; r += 4 * Q3_THREADS) {
+        Rec2 q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          q[u] = zrec;
+          if (r + (uint64_t)u * Q3_THREADS < ns[3]) q[u] = leaf_rec[r + (uint64_t)u * Q3_THREADS];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (r + (uint64_t)u * Q3_THREADS >= nr) break;      // (wave-uniform)
+          home(q[u], r + (uint64_t)u * Q3_THREADS < ns[3]);
+        }
       }
     } else {
       // a shared leaf: most records read here are another workgroup's.  Four loads are in flight per
@@ -939,14 +947,22 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, uint32_t mod
   {
     constexpr uint32_t TW_NONE = 0xFFFFFFFFu, TW_TWIN = 0x80000000u;
     uint32_t tw[TL2_PER], trank[TL2_PER];
+    // (all TL2_PER records of a thread are asked for before the first is looked up: one workgroup per CU, so four
+    //  dependent round trips here were four times ~2 us with nothing else to run -- round 4)
+    Rec2 trec[TL2_PER];
+#pragma unroll
+    for (int i = 0; i < TL2_PER; ++i) {
+      const uint32_t g = (uint32_t)(i * Q3_THREADS + tid);
+      trec[i] = zrec;
+      if (anchors_on && g < tl) trec[i] = *trunc_at(g);
+    }
 #pragma unroll
     for (int i = 0; i < TL2_PER; ++i) {
       const uint32_t g = (uint32_t)(i * Q3_THREADS + tid);
       bool valid = anchors_on && g < tl;
       tw[i] = TW_NONE; trank[i] = 0u;
       if (!anchors_on || !__ballot(valid)) continue;
-      Rec2 rec = zrec;
-      if (valid) rec = *trunc_at(g);
+      Rec2 rec = trec[i];
       valid = valid && mine(rec);
       const uint32_t nm1 = rec.b.w & 31u;
       if (valid) tw[i] = nm1;
