@@ -134,7 +134,13 @@ int cfrk_global_begin(cfrk_ctx *ctx, int k, int flags, uint64_t capacity_hint);
 int cfrk_global_add(cfrk_ctx *ctx, const int8_t *data, const int64_t *start,
                     const int32_t *length, int64_t nN, int64_t nS);
 
-/* Device-resident data (16-byte aligned); asynchronous on the context stream. */
+/* Device-resident data (16-byte aligned).  The kernels run on the context stream and the call does not wait for the
+ * last of them (cfrk_global_finish / digest / export do), but it is NOT free of host synchronisation: the partitioned
+ * paths (k <= 64 without CFRK_FORCE_HASH) read a few words back per add -- the region cursors after the second-level
+ * kernel (did anything overflow?) and, for a batch large enough to be counted in chunks, the record count of the first
+ * chunk, from which the leaf streams are sized -- each a small D2H copy + hipStreamSynchronize in the middle of the call.
+ * A batch whose first chunk is no measure of the rest (sorted or clustered reads, an N-rich or short-read prefix) costs
+ * one more partition pass over the input: its leaf streams are then laid out exactly, in a buffer that grows to fit. */
 int cfrk_global_add_device(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN);
 
 /* Add pre-counted (key, count) pairs, e.g. another GPU's export received over RCCL.
