@@ -54,3 +54,22 @@ def test_product_never_imports_oracle():
                 if "oracle_lib" in text or "liboracle" in text or "cfrk_oracle" in text:
                     bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_python_mirror_constants_equal_the_header(built):
+    """every CFRK_* flag / debug bit / parameter index that cfrk_amd/lib.py mirrors has the value include/cfrk_abi.h
+    defines (the header is the contract; the round-3 review found it drifting from the code), and the library reads
+    no environment variables"""
+    import re
+    from cfrk_amd import lib
+    text = open(os.path.join(ROOT, "include", "cfrk_abi.h")).read()
+    defs = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"#define\s+(CFRK_[A-Z0-9_]+)\s+(-?(?:0x[0-9a-fA-F]+|\d+))\b", text)}
+    mirrored = [n for n in dir(lib) if n.startswith("CFRK_")]
+    assert len(mirrored) >= 12
+    for n in mirrored:
+        assert n in defs, f"{n} is not defined in the header"
+        assert getattr(lib, n) == defs[n], n
+    for dp, _, files in os.walk(os.path.join(ROOT, "cfrk_amd", "csrc")):
+        for f in files:
+            if f.endswith((".hip", ".h")):
+                assert "getenv" not in open(os.path.join(dp, f), errors="ignore").read(), f
