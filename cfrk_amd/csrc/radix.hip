@@ -214,6 +214,8 @@ __global__ __launch_bounds__(RX2_THREADS) void rx2_kernel(int tiles_per_sub, RxV
   static_assert((SLOTS + 64) % 8 == 0, "whole vectors");
   __shared__ uint4 s4[(SLOTS + 64) / 8];
   __shared__ uint32_t hist[576], hp[512], loff[576];
+  __shared__ unsigned long long dabs[512];
+  __shared__ uint16_t vb[(SLOTS + 64) / 8];
   __shared__ uint32_t wtot[8];
   (void)t;
   uint16_t *const s16 = reinterpret_cast<uint16_t *>(s4);
@@ -303,17 +305,29 @@ __global__ __launch_bounds__(RX2_THREADS) void rx2_kernel(int tiles_per_sub, RxV
     const uint32_t r_ = (i & 1) ? (rk2[i >> 1] >> 16) : (rk2[i >> 1] & 0xFFFFu);
     s16[min(loff[b] + r_, (uint32_t)TRASH + 63u)] = (uint16_t)(kk[i] & imask);
   }
+  // copy out: consecutive lanes take consecutive 16-byte groups of the padded tile (a wave-wide store then touches
+  // ~27 streams instead of 64: what a store costs grows with the lines it touches); thread b first publishes where
+  // sub-bin b's groups go and marks them
+  {
+    uint32_t nv = 0;
+    uint64_t at = 0;
+    if (cp) {
+      const uint64_t cap = v.exact ? (uint64_t)v.lcap[leaf] : v.cap2;
+      at = (v.exact ? v.lbase[leaf] : leaf * v.cap2) + my_base;
+      const uint64_t room = cap > (uint64_t)my_base ? cap - my_base : 0;
+      if ((uint64_t)cp > room) v.stats[ST_L2OVF] = 1;     // the cursor keeps counting: the host redoes RX2 with exact sizes
+      nv = (uint32_t)min((uint64_t)cp, room) / RX_GROUP;
+    }
+    const uint32_t src = loff[tid] / RX_GROUP;
+    dabs[tid] = at - (uint64_t)loff[tid];                // element of group g of the tile: dabs + 8 g
+    for (uint32_t j = 0; j < cp / RX_GROUP; ++j) vb[src + j] = (j < nv) ? (uint16_t)tid : (uint16_t)0xFFFFu;
+  }
   lds_barrier();
   if (v.dbg & CFRK_ABL_RX2_NO_OUT) return;
-  if (cp) {
-    const uint64_t cap = v.exact ? (uint64_t)v.lcap[leaf] : v.cap2;
-    const uint64_t at = (v.exact ? v.lbase[leaf] : leaf * v.cap2) + my_base;
-    const uint64_t room = cap > (uint64_t)my_base ? cap - my_base : 0;
-    if ((uint64_t)cp > room) v.stats[ST_L2OVF] = 1;       // the cursor keeps counting: the host redoes RX2 with exact sizes
-    const uint32_t nv = (uint32_t)min((uint64_t)cp, room) / RX_GROUP;
-    const uint32_t src = loff[tid] / RX_GROUP;
-    uint4 *const d = reinterpret_cast<uint4 *>(v.key2 + at);
-    for (uint32_t j = 0; j < nv; ++j) d[j] = s4[src + j];
+  const uint32_t totalv = (loff[511] + hp[511]) / RX_GROUP;
+  for (uint32_t g = tid; g < totalv; g += RX2_THREADS) {
+    const uint32_t b = vb[g];
+    if (b != 0xFFFFu) reinterpret_cast<uint4 *>(v.key2 + dabs[b])[g] = s4[g];
   }
 }
 
