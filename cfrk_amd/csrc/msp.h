@@ -6,7 +6,8 @@ struct ResultSrc;
 struct TableView;
 
 // Timing ablations (cfrk_debug_set_flags, internal bits): the kernel skips one of its phases, so the
-// counts are WRONG -- only for measuring what a phase costs (tools/ablate.sh).
+// counts are WRONG -- only for measuring what a phase costs (tools/ablate.sh).  The P3 flags act on the leaf
+// kernels of both msp.hip and msp2.hip.
 #define CFRK_ABL_P3_NO_TRUNC 0x100u   // leaf kernel: truncated runs are not expanded
 #define CFRK_ABL_P3_NO_CEXP  0x200u   // leaf kernel: distinct complete runs are not expanded
 #define CFRK_ABL_P3_NO_RTAB  0x400u   // leaf kernel: complete runs are not read / deduplicated

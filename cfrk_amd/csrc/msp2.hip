@@ -837,7 +837,7 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, uint32_t mod
       // the CU has in flight -- with one prefetched record per thread (32 KB per CU) the scan ran at what a 2 us
       // round trip allows, ~4 TB/s for the chip (round 4)
       const uint64_t nr = (ns[3] + 63) & ~63ull;
-      for (uint64_t r = tid; r < nr; r += 4 * Q3_THREADS) {
+      for (uint64_t r = tid; r < nr && !(v.dbg & CFRK_ABL_P3_NO_RTAB); r += 4 * Q3_THREADS) {
         Rec2 q[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -868,7 +868,7 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, uint32_t mod
         Cr.a = make_uint4(set[0], set[1], set[2], set[3]); Cr.b = make_uint4(set[4], set[5], set[6], set[7]);
         cc += n;
       };
-      for (uint64_t r = tid; r < ((ns[3] + 63) & ~63ull); r += 4 * Q3_THREADS) {
+      for (uint64_t r = tid; r < ((ns[3] + 63) & ~63ull) && !(v.dbg & CFRK_ABL_P3_NO_RTAB); r += 4 * Q3_THREADS) {
         Rec2 q[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -942,7 +942,7 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, uint32_t mod
     const Rec2 *src = v.exact ? v.rec2 + v.lbase[NCLS * leaf + cl] : leaf_rec + v.cap2c + (uint64_t)cl * v.cap2t;
     return src + i;
   };
-  const bool anchors_on = !big && !(v.dbg & CFRK_DEBUG_NO_ANCHORS);
+  const bool anchors_on = !big && !(v.dbg & (CFRK_DEBUG_NO_ANCHORS | CFRK_ABL_P3_NO_TRUNC));
   bool use_anchors = false;
   {
     constexpr uint32_t TW_NONE = 0xFFFFFFFFu, TW_TWIN = 0x80000000u;
@@ -1049,7 +1049,7 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, uint32_t mod
       int parts = 1;
       while (parts < 8 && nocc_ * (uint32_t)(parts + 1) <= (uint32_t)Q3_THREADS) ++parts;
       const uint32_t precip = (65536u + (uint32_t)parts - 1u) / (uint32_t)parts;     // i / parts for i < 8192
-      const uint32_t nitems = nocc_ * (uint32_t)parts;
+      const uint32_t nitems = (v.dbg & CFRK_ABL_P3_NO_CEXP) ? 0u : nocc_ * (uint32_t)parts;
       for (uint32_t i = tid; i < ((nitems + 63u) & ~63u); i += Q3_THREADS) {
         const bool valid = i < nitems;
         const uint32_t ri = (i * precip) >> 16;
@@ -1081,7 +1081,7 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, uint32_t mod
       }
     }
     if (!SHARED) {
-      for (int cl = 2; cl >= 0; --cl) {
+      for (int cl = 2; cl >= 0 && !(v.dbg & CFRK_ABL_P3_NO_TRUNC); --cl) {
         const Rec2 *src = v.exact ? v.rec2 + v.lbase[NCLS * leaf + cl] : leaf_rec + v.cap2c + (uint64_t)cl * v.cap2t;
         Rec2 nxt = zrec;
         const uint64_t r_first = (uint64_t)cov[cl] + tid;        // (the anchored ones are done)
@@ -1115,7 +1115,7 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, uint32_t mod
         Sr.a = make_uint4(set[0], set[1], set[2], set[3]); Sr.b = make_uint4(set[4], set[5], 0u, set[6]);
         sc += n;
       };
-      for (int cl = big ? 3 : 2; cl >= 0; --cl) {
+      for (int cl = big ? 3 : 2; cl >= 0 && !(cl < 3 && (v.dbg & CFRK_ABL_P3_NO_TRUNC)); --cl) {
         if (cl == 3 && weighted) {
           // (distinct runs with multiplicities and no room to merge them: rare enough to expand them where they lie)
           for (uint64_t r = tid; r < ((ns[3] + 63) & ~63ull); r += Q3_THREADS) {
