@@ -366,7 +366,7 @@ __global__ __launch_bounds__(1024) void rx_layout_kernel(const uint32_t *__restr
 constexpr int RX3_INFL = 6;            // 16-byte loads in flight per thread (12 288 elements per round of the workgroup)
 constexpr int RX3_OB = 704;            // buffered result entries (5.5 KB: four workgroups still fit a CU's LDS)
 __global__ __launch_bounds__(RX3_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void rx3_kernel(RxView v, uint32_t nleaf) {
-  constexpr int NC = 1 << RX_IDX_MAX;
+  constexpr int NC = 1 << RX_IDX_MAX;            // 32-bit counter words (2^13)
   __shared__ uint4 cnt4[(NC + 64) / 4];          // + one spare counter per lane for the pads
   __shared__ uint32_t ob_key[RX3_OB], ob_cnt[RX3_OB];
   __shared__ unsigned long long wg_base;
@@ -374,12 +374,18 @@ __global__ __launch_bounds__(RX3_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
   uint32_t *const cnt = reinterpret_cast<uint32_t *>(cnt4);
   const int tid = threadIdx.x, lane = tid & 63;
   const uint32_t nidx = 1u << v.idx;
-  // few counters per leaf (small k): every thread group gets its own replica, or all 256 threads
-  // would serialise on a handful of LDS words.  nidx << rlog = 2^13 for every k this path serves (idx >= 5).
-  const int rlog = min(RX_IDX_MAX - v.idx, 8);
+  // idx = 14 (k >= 13): a leaf has 2^14 keys and the 2^13 words hold them as PACKED 16-bit counters -- exact as long as
+  // the leaf holds fewer than 2^16 elements (no half can carry into its neighbour), which the leaf's size tells before
+  // anything is counted; a larger leaf is counted in two passes over its stream, one per half of its key range, with
+  // 32-bit counters.  Half as many leaves as with idx = 13: half the per-leaf work here, half the sub-bins (twice as
+  // long segments, half the pads) in RX2.
+  // idx = 13: one 32-bit counter per key.  idx < 13 (small k): 2^idx counters replicated 2^rlog times -- or all 256
+  // threads would serialise on a handful of LDS words (nidx << rlog = 2^13 for every k this path serves: idx >= 5).
+  const bool wide = v.idx > RX_IDX_MAX;
+  const int rlog = wide ? 0 : min(RX_IDX_MAX - v.idx, 8);
   const uint32_t rmask = (1u << rlog) - 1u, rep = (uint32_t)tid & rmask;
   const uint32_t spare = (uint32_t)NC + (uint32_t)lane;
-  constexpr int NQ = NC / 4 / RX3_THREADS;       // uint4 groups of counters per thread (8)
+  constexpr int NQ = NC / 4 / RX3_THREADS;       // uint4 groups of counter words per thread (8)
   const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
   uint32_t leaf = blockIdx.x;
   if (leaf >= nleaf) return;
@@ -400,22 +406,19 @@ __global__ __launch_bounds__(RX3_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
       if (q < n4) x[u] = p[q];
     }
   };
-  auto count_round = [&]() {
+  // mode 0: one 32-bit counter per key (idx = 13); 1: replicated (idx < 13); 2: packed 16-bit (idx = 14, small leaf);
+  // 3: idx = 14, the keys of half `hsel` only, 32-bit counters
+  auto count_round = [&](int mode, uint32_t hsel) {
 #pragma unroll
     for (int u = 0; u < RX3_INFL; ++u) {
       const uint32_t w[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
-      if (rlog == 0) {
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          const uint32_t key = (c & 1) ? (w[c >> 1] >> 16) : (w[c >> 1] & 0xFFFFu);
-          atomicAdd(&cnt[min(key, spare)], 1u);                       // (keys are < 2^13, a pad is 0xFFFF; skipping the pads' atomics by a branch measured the same)
-        }
-      } else {
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          const uint32_t key = (c & 1) ? (w[c >> 1] >> 16) : (w[c >> 1] & 0xFFFFu);
-          atomicAdd(&cnt[key < nidx ? ((key << rlog) | rep) : spare], 1u);
-        }
+      for (int c = 0; c < 8; ++c) {
+        const uint32_t key = (c & 1) ? (w[c >> 1] >> 16) : (w[c >> 1] & 0xFFFFu);       // (a pad is 0xFFFF)
+        if (mode == 0) atomicAdd(&cnt[min(key, spare)], 1u);
+        else if (mode == 1) atomicAdd(&cnt[key < nidx ? ((key << rlog) | rep) : spare], 1u);
+        else if (mode == 2) atomicAdd(&cnt[min(key >> 1, spare)], (key & 1u) ? 0x10000u : 1u);
+        else atomicAdd(&cnt[(key >> RX_IDX_MAX) == hsel ? (key & (uint32_t)(NC - 1)) : spare], 1u);
       }
     }
   };
@@ -444,15 +447,19 @@ __global__ __launch_bounds__(RX3_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
     uint32_t n_next = 0;
     if (more) n_next = leaf_n(next);              // (in flight while this leaf is counted)
     const uint32_t n4 = n / RX_GROUP;
-    if (!(v.dbg & CFRK_ABL_RX3_NO_COUNT)) count_round();
-    for (uint32_t q0 = (uint32_t)RX3_INFL * RX3_THREADS; q0 < n4; q0 += (uint32_t)RX3_INFL * RX3_THREADS) {
-      load_round(cur, n4, q0);
-      count_round();
-    }
-    lds_barrier();
+    const int mode = !wide ? (rlog ? 1 : 0) : (n < 65536u ? 2 : 3);
+    const uint32_t npass = mode == 3 ? 2u : 1u;
     const uint4 *nxp = leaf_p(more ? next : leaf);
-    if (more) load_round(nxp, n_next / RX_GROUP, 0);   // (in flight while this leaf is scanned and its entries collected)
-    if (n) {                                      // (wave-uniform: one leaf per workgroup)
+    for (uint32_t pass = 0; pass < npass; ++pass) {
+      if (pass) { load_round(cur, n4, 0); }       // (the second half of a large leaf: its stream once more)
+      if (!(v.dbg & CFRK_ABL_RX3_NO_COUNT)) count_round(mode, pass);
+      for (uint32_t q0 = (uint32_t)RX3_INFL * RX3_THREADS; q0 < n4; q0 += (uint32_t)RX3_INFL * RX3_THREADS) {
+        load_round(cur, n4, q0);
+        count_round(mode, pass);
+      }
+      lds_barrier();
+      if (more && pass + 1u == npass) load_round(nxp, n_next / RX_GROUP, 0);   // (in flight while this leaf is scanned and its entries collected)
+      if (!n) continue;                           // (wave-uniform: one leaf per workgroup)
       if (rlog) {                                 // fold the replicas into replica 0
         for (uint32_t s = tid; s < nidx; s += RX3_THREADS) {
           uint32_t c = 0;
@@ -462,17 +469,19 @@ __global__ __launch_bounds__(RX3_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
         lds_barrier();
       }
       // compaction: a thread counts the non-zero counters among its own, one block scan gives it a range of
-      // the leaf's entries.  rlog == 0 (k >= 12: idx = 13): its counters are eight groups of four consecutive
-      // ones; otherwise counter s sits at s << rlog.
+      // the leaf's entries.  Modes 0, 2, 3: its counters are eight groups of four consecutive words (two counters
+      // per word in mode 2); mode 1: counter s sits at word s << rlog.
       uint32_t mine = 0;
-      if (rlog == 0) {
+      if (mode == 1) {
+        for (uint32_t s = tid; s < nidx; s += RX3_THREADS) mine += (cnt[s << rlog] != 0u) ? 1u : 0u;
+      } else {
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
           const uint4 c4 = cnt4[j * RX3_THREADS + tid];
-          mine += (c4.x != 0u) + (c4.y != 0u) + (c4.z != 0u) + (c4.w != 0u);
+          if (mode == 2) mine += ((c4.x & 0xFFFFu) != 0u) + ((c4.x >> 16) != 0u) + ((c4.y & 0xFFFFu) != 0u) + ((c4.y >> 16) != 0u) +
+                                 ((c4.z & 0xFFFFu) != 0u) + ((c4.z >> 16) != 0u) + ((c4.w & 0xFFFFu) != 0u) + ((c4.w >> 16) != 0u);
+          else mine += (c4.x != 0u) + (c4.y != 0u) + (c4.z != 0u) + (c4.w != 0u);
         }
-      } else {
-        for (uint32_t s = tid; s < nidx; s += RX3_THREADS) mine += (cnt[s << rlog] != 0u) ? 1u : 0u;
       }
       const uint32_t incl = dev_wave_scan_incl(mine);
       if (lane == 63) wsum[tid >> 6] = incl;
@@ -480,8 +489,8 @@ __global__ __launch_bounds__(RX3_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
       uint32_t base = 0, total = 0;
 #pragma unroll
       for (int w = 0; w < RX3_THREADS / 64; ++w) { const uint32_t xw = wsum[w]; base += (w < (tid >> 6)) ? xw : 0u; total += xw; }
-      // where this leaf's entries go: behind the buffered ones, or -- a leaf with more entries than the
-      // buffer holds -- straight to a range of the list of its own
+      // where this leaf's entries go: behind the buffered ones, or -- more entries than the buffer
+      // holds -- straight to a range of the list of their own
       const bool direct = total > (uint32_t)RX3_OB;
       if (fill && (direct || fill + total > (uint32_t)RX3_OB)) flush();
       unsigned long long dbase = 0;
@@ -491,7 +500,7 @@ __global__ __launch_bounds__(RX3_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
         dbase = wg_base;
       }
       uint32_t d = (direct ? 0u : fill) + base + incl - mine;
-      const uint32_t leaf_hi = leaf << v.idx;
+      const uint32_t leaf_hi = (leaf << v.idx) | (mode == 3 ? pass << RX_IDX_MAX : 0u);
       auto emit = [&](uint32_t s, uint32_t c) {
         if (direct) {
           if (dbase + d < v.out_cap) { v.out_keys[dbase + d] = (uint64_t)rx_unmix(v, leaf_hi | s); v.out_cnt[dbase + d] = c; }
@@ -499,20 +508,7 @@ __global__ __launch_bounds__(RX3_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
         } else { ob_key[d] = leaf_hi | s; ob_cnt[d] = c; }
         ++d;
       };
-      if (rlog == 0) {
-#pragma unroll
-        for (int j = 0; j < NQ; ++j) {
-          if (mine) {
-            const uint4 c4 = cnt4[j * RX3_THREADS + tid];
-            const uint32_t s0 = 4u * (uint32_t)(j * RX3_THREADS + tid);
-            if (c4.x) emit(s0, c4.x);
-            if (c4.y) emit(s0 + 1u, c4.y);
-            if (c4.z) emit(s0 + 2u, c4.z);
-            if (c4.w) emit(s0 + 3u, c4.w);
-          }
-          cnt4[j * RX3_THREADS + tid] = zero4;     // (this thread is the only reader of these four)
-        }
-      } else {
+      if (mode == 1) {
         for (uint32_t s = tid; s < nidx; s += RX3_THREADS) {
           const uint32_t c = cnt[s << rlog];
           if (c) emit(s, c);
@@ -520,6 +516,23 @@ __global__ __launch_bounds__(RX3_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
         lds_barrier();
 #pragma unroll
         for (int j = 0; j < NQ; ++j) cnt4[j * RX3_THREADS + tid] = zero4;
+      } else {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+          if (mine) {
+            const uint4 c4 = cnt4[j * RX3_THREADS + tid];
+            const uint32_t w0 = 4u * (uint32_t)(j * RX3_THREADS + tid);
+            const uint32_t cw[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              if (mode == 2) {
+                if (cw[q] & 0xFFFFu) emit(2u * (w0 + (uint32_t)q), cw[q] & 0xFFFFu);
+                if (cw[q] >> 16) emit(2u * (w0 + (uint32_t)q) + 1u, cw[q] >> 16);
+              } else if (cw[q]) emit(w0 + (uint32_t)q, cw[q]);
+            }
+          }
+          cnt4[j * RX3_THREADS + tid] = zero4;     // (this thread is the only reader of these four)
+        }
       }
       if (!direct) fill += total;
       lds_barrier();                              // the counters are clear again (and wsum / wg_base are free)
@@ -640,7 +653,8 @@ int cfrk_radix_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   }
   // at least 2048 leaves (one workgroup each in RX3), at most 2^13 counters per leaf
   v.b1 = 8;
-  v.idx = std::max(0, std::min(RX_IDX_MAX, 2 * k - 11));
+  // (k >= 13: 2^14 keys per leaf, counted as packed 16-bit counters -- rx3_kernel)
+  v.idx = (2 * k - 11 > RX_IDX_MAX) ? RX_IDX_MAX + 1 : std::max(0, 2 * k - 11);
   v.b2 = 2 * k - v.b1 - v.idx;
   v.kmask = (uint32_t)((1ull << (2 * k)) - 1ull);
   v.mul = 0x9E3779B1u;
