@@ -47,6 +47,10 @@ def parse():
     p.add_argument("--no-canonical", action="store_true")
     p.add_argument("--cpu-reads", type=int, default=10_000_000,
                    help="reads of the same generator timed on the host cores (0: skip)")
+    p.add_argument("--e2e-reads", type=int, default=10_000_000,
+                   help="N = 1 only, outside the timed region: reads of a FASTA FILE written with the same generator and "
+                        "counted by the `cfrk` CLI (parse + H2D + count + export + write) -> the `end_to_end` object; "
+                        "0 or --cpu-reads 0: skip")
     p.add_argument("--cpu-threads", type=int, default=0)
     p.add_argument("--cpu-runs", type=int, default=3, help="runs of the cpu_baseline sample (the median is reported)")
     p.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -322,8 +326,8 @@ def main():
         def step():
             runs = world > 1 and exch == "runs"
             eng.g = cfrk_amd.GlobalCounter(ctx, k, flags | (cfrk_amd.CFRK_RUNS_ONLY if runs else 0), hint)
-            if os.environ.get("CFRK_DEBUG_FLAGS"):       # timing ablations (tools/ablate.sh): wrong counts
-                eng.g.set_debug_flags(int(os.environ["CFRK_DEBUG_FLAGS"], 0))
+            if os.environ.get("CFRK_DEBUG_FLAGS"):       # test switches; bits >= 0x100 are the timing ablations, which only
+                eng.g.set_debug_flags(int(os.environ["CFRK_DEBUG_FLAGS"], 0))   # an ablation build accepts (tools/ablate.sh)
             for kv in filter(None, os.environ.get("CFRK_BENCH_PARAMS", "").split(",")):   # sizing experiments
                 eng.g.set_debug_param(int(kv.split(":")[0]), float(kv.split(":")[1]))
             budget = runs and args.debug_runs_budget and int(args.debug_runs_budget.split(":")[0]) == rank
@@ -333,11 +337,13 @@ def main():
             try:
                 eng.g.add_device(d_data.data_ptr(), nN)
             except cfrk_amd.CfrkError as e:
-                # a CFRK_RUNS_ONLY job must fit device memory in one pass (CFRK_ERR_NOMEM / CFRK_ERR_STATE):
-                # this rank votes "no runs" in the size exchange and every rank takes the leaf exchange together
-                if not (runs and e.code in (-2, -4)):
+                # a CFRK_RUNS_ONLY job must fit device memory in one pass (CFRK_ERR_RUNS_REFUSED -- and only that
+                # code: a genuine call-sequence error is not turned into a vote): this rank votes "no runs" in the
+                # size exchange and every rank takes the leaf exchange together
+                if not (runs and e.code == cfrk_amd.CFRK_ERR_RUNS_REFUSED):
                     raise
                 eng.runs_refused = True
+                used["runs_refused"] = str(e)
             finally:
                 if budget:
                     eng.g.set_mem_budget(0)
@@ -486,13 +492,19 @@ def main():
                 return g.digest()
             out["cpu_baseline"], parity = cpu_baseline(args, args.glen or args.reads, gpu_digest_of_prefix)
             out["prefix_parity"] = parity
+            if args.e2e_reads > 0:
+                # the product end to end on a FILE (SURVEY 8d "what is timed"; /root/reference/src/main.cu:259-268):
+                # reported beside the headline, never as `value`
+                from tools import bench_e2e
+                out["end_to_end"] = bench_e2e.measure(min(args.e2e_reads, args.reads), L, k, 0, ctx=ctx, quick=True)   # (genome = reads: configs[1]'s shape)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    if not ok and not os.environ.get("CFRK_DEBUG_FLAGS"):
+    # (only a timing ablation -- bits >= 0x100, accepted by an ablation build of the library alone -- may miscount)
+    if not ok and not (int(os.environ.get("CFRK_DEBUG_FLAGS", "0"), 0) & ~0xFF):
         raise SystemExit(f"sum(count) != {total}")
     if parity is False:
         raise SystemExit("prefix_parity false: the HIP path and the oracle disagree on the cpu_baseline sample")

@@ -55,6 +55,8 @@ const char *cfrk_strerror(int code) {
     case CFRK_ERR_ALIGN: return "device pointer not 16-byte aligned";
     case CFRK_ERR_NO_DEVICE: return "no usable gfx950 device";
     case CFRK_ERR_SMALL_BUF: return "output buffer too small";
+    case CFRK_ERR_COUNT_OVERFLOW: return "a key's count reached 2^32 - 2 and was saturated";
+    case CFRK_ERR_RUNS_REFUSED: return "the CFRK_RUNS_ONLY add does not fit device memory in one pass";
     default: return "unknown error";
   }
 }
@@ -301,11 +303,13 @@ int cfrk_global_add_device(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   int rc;
   rc = CFRK_ERR_NOMEM;
   ctx->last_passes = 0;
-  if (cfrk_msp_usable(ctx)) rc = cfrk_msp_count(ctx, d_data, nN);
-  else if (cfrk_radix_usable(ctx)) rc = cfrk_radix_count(ctx, d_data, nN);
+  if (cfrk_radix_prefers(ctx, nN)) {
+    rc = cfrk_radix_count(ctx, d_data, nN);
+    if (rc == CFRK_ERR_NOMEM && cfrk_msp_usable(ctx)) { (void)hipGetLastError(); rc = cfrk_msp_count(ctx, d_data, nN); }   // (k = 16)
+  } else if (cfrk_msp_usable(ctx)) rc = cfrk_msp_count(ctx, d_data, nN);
   else if (cfrk_msp2_usable(ctx)) rc = cfrk_msp2_count(ctx, d_data, nN);
   if (rc == CFRK_ERR_NOMEM && (cfrk_msp_usable(ctx) || cfrk_radix_usable(ctx) || cfrk_msp2_usable(ctx)) &&
-      !(ctx->msp && ctx->msp->pending)) {
+      !(ctx->msp && ctx->msp->pending)) {     // (CFRK_INTERNAL_FLOOD: no second attempt, straight to the general path)
     // The pool only grows: buffers sized by earlier jobs of this context (another k, a larger batch) may be
     // what stands in the way.  Nothing of the partitioned paths is live between adds unless a result list is
     // pending: give their buffers back and plan the batch once more before giving the fast path up.
@@ -320,13 +324,20 @@ int cfrk_global_add_device(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
       if (b.p) { freed += b.cap; (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
     }
     if (freed) {
-      if (cfrk_msp_usable(ctx)) rc = cfrk_msp_count(ctx, d_data, nN);
-      else if (cfrk_radix_usable(ctx)) rc = cfrk_radix_count(ctx, d_data, nN);
-      else rc = cfrk_msp2_count(ctx, d_data, nN);
+      if (cfrk_radix_prefers(ctx, nN)) rc = cfrk_radix_count(ctx, d_data, nN);
+      if (rc == CFRK_ERR_NOMEM && cfrk_msp_usable(ctx)) { (void)hipGetLastError(); rc = cfrk_msp_count(ctx, d_data, nN); }
+      else if (rc == CFRK_ERR_NOMEM && cfrk_msp2_usable(ctx)) rc = cfrk_msp2_count(ctx, d_data, nN);
     }
   }
-  if (rc == CFRK_ERR_NOMEM && (ctx->g_flags & CFRK_RUNS_ONLY))
-    return cfrk_fail(ctx, CFRK_ERR_NOMEM, "the shard's record buffers do not fit device memory");
+  if ((rc == CFRK_ERR_NOMEM || rc == CFRK_INTERNAL_FLOOD) && (ctx->g_flags & CFRK_RUNS_ONLY))
+    return cfrk_fail(ctx, CFRK_ERR_RUNS_REFUSED, rc == CFRK_ERR_NOMEM ? "the shard's record buffers do not fit device memory"
+                                                                        : "2^32 records in one leaf stream: count without CFRK_RUNS_ONLY");
+  if (rc == CFRK_INTERNAL_FLOOD) {
+    // a single-key flood wrapped a 32-bit stream cursor before anything of this add was counted: the general path
+    // (one saturating HBM atomic per occurrence) counts it instead
+    HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_CWRAP, 0, sizeof(uint64_t), ctx->stream));
+    rc = CFRK_ERR_NOMEM;
+  }
   if (rc == CFRK_ERR_NOMEM) {
     // no partitioned path for this k, or its record buffers (about 7 bytes per input byte) do
     // not fit next to the caller's data: count with the general HBM-table path instead
@@ -451,11 +462,11 @@ int cfrk_global_merge_device(cfrk_ctx *ctx, const uint64_t *d_lo, const uint64_t
 }
 
 int cfrk_global_finish(cfrk_ctx *ctx, uint64_t *n_distinct) {
-  uint64_t d[4];
+  uint64_t d[4] = {0, 0, 0, 0};
   int rc = cfrk_global_digest(ctx, d);
-  if (rc) return rc;
-  if (n_distinct) *n_distinct = d[0];
-  return CFRK_OK;
+  if (rc && rc != CFRK_ERR_COUNT_OVERFLOW) return rc;
+  if (n_distinct) *n_distinct = d[0];     // (a saturated result is complete: every key is there, some counts are CFRK_COUNT_MAX)
+  return rc;
 }
 
 int cfrk_global_digest(cfrk_ctx *ctx, uint64_t out[4]) {
@@ -470,6 +481,7 @@ int cfrk_global_digest(cfrk_ctx *ctx, uint64_t out[4]) {
   if ((rc = cfrk_result_scan(ctx, use_list ? &src : nullptr, st))) return rc;
   if (st[ST_OVERFLOW]) return cfrk_fail(ctx, CFRK_ERR_TABLE_FULL, "table of %llu slots overflowed", (unsigned long long)ctx->g_cap);
   out[0] = st[ST_DIG0]; out[1] = st[ST_DIG1]; out[2] = st[ST_DIG2]; out[3] = st[ST_DIG3];
+  if (st[ST_SAT]) return cfrk_fail(ctx, CFRK_ERR_COUNT_OVERFLOW, "a key occurred 2^32 - 2 times or more: its count is held at 0xFFFFFFFE");
   return CFRK_OK;
 }
 
@@ -491,7 +503,8 @@ int cfrk_global_export(cfrk_ctx *ctx, uint64_t *keys_lo, uint64_t *keys_hi, uint
   if (!ctx || !n_out) return CFRK_ERR_ARG;
   uint64_t n = 0;
   int rc = cfrk_global_finish(ctx, &n);
-  if (rc) return rc;
+  const bool saturated = rc == CFRK_ERR_COUNT_OVERFLOW;   // the result is exported all the same, the code returned at the end
+  if (rc && !saturated) return rc;
   *n_out = n;
   if (n > cap) return cfrk_fail(ctx, CFRK_ERR_SMALL_BUF, "%llu entries, room for %llu", (unsigned long long)n, (unsigned long long)cap);
   if (n == 0) return CFRK_OK;
@@ -515,6 +528,7 @@ int cfrk_global_export(cfrk_ctx *ctx, uint64_t *keys_lo, uint64_t *keys_hi, uint
   }
   HIP_TRY(ctx, hipMemcpyAsync(counts, s_cnt, n * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (saturated) return cfrk_fail(ctx, CFRK_ERR_COUNT_OVERFLOW, "a key occurred 2^32 - 2 times or more: its count is held at 0xFFFFFFFE");
   return CFRK_OK;
 }
 

@@ -10,6 +10,9 @@
 #include "../../include/cfrk_abi.h"
 
 #define CFRK_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
+// internal (never leaves the library): a partitioned path found 2^32 records in one stream (ST_CWRAP) -- a single-key
+// flood; cfrk_global_add_device counts the add through the HBM table instead
+#define CFRK_INTERNAL_FLOOD (-100)
 #define CFRK_MAX_PROBE (1u << 22)
 
 enum {  // pool slots
@@ -29,7 +32,10 @@ enum {  // device stats words (uint64 each)
   ST_MULTISEG /* a leaf was counted in several key-subset passes: its list entries are not contiguous */,
   ST_L1OVF /* level-1 regions were too small by a lot: the first level is redone with exact sizes */,
   ST_OVFN1 /* records parked because their level-1 region was full (a few) */,
-  ST_NWORDS = 16
+  ST_SAT /* a count reached CFRK_COUNT_MAX and was held there (finish / digest / export: CFRK_ERR_COUNT_OVERFLOW) */,
+  ST_CWRAP /* a 32-bit region / stream cursor of a partitioned path wrapped (>= 2^32 records in one region: a
+              single-key flood): the add is counted again through the HBM table */,
+  ST_NWORDS = 18
 };
 
 struct cfrk_buf { void *p; size_t cap; };

@@ -134,12 +134,14 @@ __global__ __launch_bounds__(256) void result_scan_kernel(ResultSrc r) {
     uint64_t lo, hi; uint32_t c;
     if (!src_read(r, i, lo, hi, c)) continue;
     const uint64_t kh = two ? lo + dev_splitmix64(hi) : lo;
+    if (c >= CFRK_COUNT_MAX) r.stats[ST_SAT] = 1;      // (a saturated count, here or on the rank this entry came from)
     d += 1; s += c;
     w += (uint64_t)c * dev_splitmix64(kh);
     x ^= dev_splitmix64(kh ^ (uint64_t)c);
   }
   if (tid == 0 && !two) {
-    const uint64_t ones = r.stats[ST_ONES];
+    const uint64_t ones = sat_ones(r.stats[ST_ONES]);
+    if (ones >= CFRK_COUNT_MAX) r.stats[ST_SAT] = 1;
     if (ones) {
       d += 1; s += ones;
       w += ones * dev_splitmix64(CFRK_EMPTY_KEY);
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(256) void result_export_scatter_kernel(ResultSrc r,
     if (ones) {
       const unsigned long long dst = atomicAdd(&part_cursor[owner_of(CFRK_EMPTY_KEY, 0, false, parts)], 1ull);
       out_lo[dst] = CFRK_EMPTY_KEY;
-      out_cnt[dst] = (uint32_t)ones;
+      out_cnt[dst] = sat_ones(ones);
     }
   }
 }

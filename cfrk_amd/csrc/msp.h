@@ -5,22 +5,34 @@
 struct ResultSrc;
 struct TableView;
 
-// Timing ablations (cfrk_debug_set_flags, internal bits): the kernel skips one of its phases, so the
-// counts are WRONG -- only for measuring what a phase costs (tools/ablate.sh).  The P3 flags act on the leaf
-// kernels of both msp.hip and msp2.hip.
-#define CFRK_ABL_P3_NO_TRUNC 0x100u   // leaf kernel: truncated runs are not expanded
-#define CFRK_ABL_P3_NO_CEXP  0x200u   // leaf kernel: distinct complete runs are not expanded
-#define CFRK_ABL_P3_NO_RTAB  0x400u   // leaf kernel: complete runs are not read / deduplicated
-#define CFRK_ABL_P3_NO_OUT   0x800u   // leaf kernel: no compaction to the result list
-#define CFRK_ABL_P1_NO_EMIT  0x1000u  // partition kernel: front end only, no records built
-#define CFRK_ABL_P2_NO_ATOMIC 0x2000u // second-level kernel: no cursor atomics (every tile's segments land at the stream starts)
-#define CFRK_ABL_RX3_NO_CURSOR 0x10000u // radix leaf kernel: no atomic on the result cursor (every leaf writes to leaf * 64)
-#define CFRK_ABL_RX3_NO_COUNT  0x20000u // radix leaf kernel: keys are loaded but not counted
-#define CFRK_ABL_RX2_NO_OUT    0x40000u // radix second-level kernel: the sorted tile is not written out
-#define CFRK_ABL_RX1_NO_OUT    0x80000u // radix first-level kernel: the sorted tile is not written out
-#define CFRK_ABL_RX1_LINEAR    0x100000u // radix first-level kernel: the sorted tile goes out back to back (no scatter into regions)
-#define CFRK_ABL_RX1_NO_HI     0x200000u // radix first-level kernel: the 8-bit plane is not written
-#define CFRK_ABL_P2_LINEAR_OUT 0x4000u // second-level kernel: sorted tiles written back to back (what the scatter into 512 streams per bin costs)
+// Timing ablations: the kernel skips one of its phases, so the counts are WRONG -- only for measuring what a
+// phase costs.  They exist only in a library built with -DCFRK_ABLATIONS (`make -C cfrk_amd/csrc abl` ->
+// tools/_bin/libcfrk_hip_abl.so, which tools/ablate.sh swaps in); in the product build every bit is 0, the
+// branches fold away, and cfrk_debug_set_flags refuses the bits with CFRK_ERR_ARG.  The P3 flags act on the
+// leaf kernels of both msp.hip and msp2.hip.
+#ifdef CFRK_ABLATIONS
+#define CFRK_ABL_BIT(x) (x)
+#else
+#define CFRK_ABL_BIT(x) 0u
+#endif
+#define CFRK_ABL_P3_NO_TRUNC   CFRK_ABL_BIT(0x100u)     // leaf kernel: truncated runs are not expanded
+#define CFRK_ABL_P3_NO_CEXP    CFRK_ABL_BIT(0x200u)     // leaf kernel: distinct complete runs are not expanded
+#define CFRK_ABL_P3_NO_RTAB    CFRK_ABL_BIT(0x400u)     // leaf kernel: complete runs are not read / deduplicated
+#define CFRK_ABL_P3_NO_OUT     CFRK_ABL_BIT(0x800u)     // leaf kernel: no compaction to the result list
+#define CFRK_ABL_P1_NO_EMIT    CFRK_ABL_BIT(0x1000u)    // partition kernel: front end only, no records built
+#define CFRK_ABL_P2_NO_ATOMIC  CFRK_ABL_BIT(0x2000u)    // second-level kernel: no cursor atomics (every tile's segments land at the stream starts)
+#define CFRK_ABL_P2_LINEAR_OUT CFRK_ABL_BIT(0x4000u)    // second-level kernel: sorted tiles written back to back (what the scatter into 512 streams per bin costs)
+#define CFRK_ABL_RX3_NO_CURSOR CFRK_ABL_BIT(0x10000u)   // radix leaf kernel: no atomic on the result cursor (workgroup b writes from entry b * 16384)
+#define CFRK_ABL_RX3_NO_COUNT  CFRK_ABL_BIT(0x20000u)   // radix leaf kernel: keys are loaded but not counted
+#define CFRK_ABL_RX2_NO_OUT    CFRK_ABL_BIT(0x40000u)   // radix second-level kernel: the sorted tile is not written out
+#define CFRK_ABL_RX1_NO_OUT    CFRK_ABL_BIT(0x80000u)   // radix first-level kernel: the sorted tile is not written out
+#define CFRK_ABL_RX1_LINEAR    CFRK_ABL_BIT(0x100000u)  // radix first-level kernel: the sorted tile goes out back to back (no scatter into regions)
+// every bit cfrk_debug_set_flags accepts: the documented test switches of include/cfrk_abi.h, plus the ablations of an ablation build
+#ifdef CFRK_ABLATIONS
+#define CFRK_DEBUG_KNOWN_BITS (0x7Fu | 0x7F00u | 0x1F0000u)
+#else
+#define CFRK_DEBUG_KNOWN_BITS 0x7Fu
+#endif
 
 bool cfrk_msp_usable(const cfrk_ctx *ctx);                 // fast path applies to this begin()?
 int  cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN);
@@ -98,5 +110,6 @@ int  cfrk_msp2_merge_runs(cfrk_ctx *ctx, const void *d_packed, const uint64_t *r
 
 // radix.hip: k <= 15
 bool cfrk_radix_usable(const cfrk_ctx *ctx);
+bool cfrk_radix_prefers(const cfrk_ctx *ctx, int64_t nN);   // ... or k = 16 and a batch small enough for its leaves (radix.hip)
 int  cfrk_radix_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN);
 

@@ -59,7 +59,7 @@ constexpr int TS_LOG = 12, TS = 1 << TS_LOG;   // LDS table slots per leaf
 // count every k-mer of a record straight into the global HBM table
 // (the table view by value: a reference makes every thread of the calling kernel store the view
 // to scratch memory at kernel entry -- 48 bytes per thread that reach HBM)
-__device__ __noinline__ void spill_record(uint4 rec, int k, bool canon, TableView t) {
+__device__ __noinline__ void spill_record(uint4 rec, int k, bool canon, TableView t, uint32_t weight = 1u) {
   t.stats[ST_SPILLED] = 1;
   dev_count_event(&t.stats[ST_AUX0]);
   const int nk = (int)(rec.w & 63u) + 1;
@@ -72,7 +72,7 @@ __device__ __noinline__ void spill_record(uint4 rec, int k, bool canon, TableVie
       const uint64_t rc = dev_revcomp64(key, k);
       key = rc < key ? rc : key;
     }
-    table_add1(t, key, 1u);
+    table_add1(t, key, weight);
   }
 }
 
@@ -572,6 +572,9 @@ __device__ __forceinline__ void p2_item(uint4 *pool, uint32_t b1, uint32_t grp, 
       uint64_t at = (leaf >> v.sel_bits) * (v.cap2c + v.cap2t) + (cls ? 0 : v.cap2c);
       if (exact2) { cap = v.lcap[b1 * NSUB + sb]; at = v.lbase[b1 * NSUB + sb]; }
       const uint64_t dst = dabs[sb] + p - at;              // = the stream's reserved base + rank inside the segment
+      // a stream position beyond 2^31: a single-key flood is on its way to wrapping the 32-bit cursor -- the host counts
+      // the add through the HBM table instead (checked HERE, on the full-stream path only: a flood fills its stream first)
+      if (dst >= 0x80000000ull) v.stats[ST_CWRAP] = 1;
       if (dst < cap) v.rec2[at + dst] = rec;
       else if (exact2) spill_record(rec, k, canon != 0, t);      // cannot happen: cap is the exact count
       else {
@@ -662,7 +665,10 @@ constexpr int KT_TRIPS_SPLIT = 16;          // (buckets of two slots)
 // lane had none): written to keep lane masks out of loop-carried values and control-flow merges
 // (each costs the compiler three scalar instructions) -- the only branch is the rare claim, its
 // outcome lands in a VGPR, and lanes with nothing to count add 0.
+// SAT: the count saturates at CFRK_COUNT_MAX (table.h: sat_add) -- the merge of lists whose counts nothing bounds;
+// the leaf kernel's own counts cannot overflow (HUGE_LEAF)
 constexpr uint32_t KT_DONE = 0x80000000u;
+template <bool SAT = false>
 __device__ __forceinline__ void kt_try(unsigned long long *keys, uint32_t *cnts, uint64_t key, uint32_t &b,
                                        uint32_t add) {
   const bool p = (int32_t)b >= 0;
@@ -678,17 +684,23 @@ __device__ __forceinline__ void kt_try(unsigned long long *keys, uint32_t *cnts,
     won = (old == CFRK_EMPTY_KEY || old == key) ? 1u : 0u;      // lost to another key: same bucket again
   }
   const bool ok = hit || won != 0u;
-  atomicAdd(&cnts[s], (p && ok) ? add : 0u);
+  if (SAT) {
+    if (p && ok) {
+      const uint32_t old = atomicAdd(&cnts[s], add);
+      if (old > CFRK_COUNT_MAX - add) atomicExch(&cnts[s], CFRK_COUNT_MAX);
+    }
+  } else atomicAdd(&cnts[s], (p && ok) ? add : 0u);
   const bool full = !(hit || e0 || e1);
   const uint32_t nb = full ? ((bb + 1) & (NBUCKET - 1)) : bb;
   b = (p && !ok) ? nb : (b | KT_DONE);
 }
 
-// count one key per lane (valid lanes) `add` times; every lane of the wave must call
+// count one key per lane (valid lanes) `add` times, saturating; every lane of the wave must call
 __device__ __forceinline__ void kt_count(unsigned long long *keys, uint32_t *cnts, uint64_t key, uint32_t add,
                                          bool valid, const TableView &t) {
   uint32_t b = lds_bucket(key) | (valid ? 0u : KT_DONE);
-  for (int it = 0; it < KT_TRIPS && __ballot((int32_t)b >= 0); ++it) kt_try(keys, cnts, key, b, add);
+  add = min(add, CFRK_COUNT_MAX);
+  for (int it = 0; it < KT_TRIPS && __ballot((int32_t)b >= 0); ++it) kt_try<true>(keys, cnts, key, b, add);
   if ((int32_t)b >= 0) spill_kmer(t, key, add);
 }
 
@@ -968,6 +980,42 @@ __device__ __noinline__ uint32_t p3_big_dedupe(uint4 *pool, uint4 *stream, uint6
   return p3_compact(pool, stream, wsum);
 }
 
+// HUGE LEAF: 2^25 records or more in one leaf (half a gigabyte: a single-key flood -- a homopolymer, one amplicon
+// sequenced 10^8 times).  The record table keeps a run's multiplicity in 26 bits and the LDS k-mer counts are 32-bit:
+// below this size neither can overflow (2^25 records x 32 k-mers < 2^31); at or above it the leaf is not counted in
+// LDS at all but k-mer by k-mer in the HBM table, whose adds SATURATE (table.h: sat_add).  Slow and exact.
+// (A sender of the runs exchange does not deduplicate a leaf of 2^19 complete runs or more, so that the multiplicities
+// an owner adds up for one run stay below 64 ranks x 2^19 + 2^25 = 2^26.)
+constexpr uint64_t HUGE_LEAF = 1ull << 25;
+constexpr uint64_t HUGE_LEAF_SENDER = 1ull << 19;
+// (a kernel of its own, launched behind the leaf kernel: every thread looks at ONE leaf's sizes and normally finds
+//  nothing -- a few microseconds; inside the leaf kernel the same loop cost the canonical instantiation four more
+//  spilled dwords)
+__global__ __launch_bounds__(256) void msp_huge_leaves_kernel(int k, int canon, int weighted, uint32_t nl /* leaves of this pass / owner */, MspView v, TableView t) {
+  __shared__ uint32_t nhuge, huge[256];
+  if (threadIdx.x == 0) nhuge = 0;
+  __syncthreads();
+  const uint32_t i0 = blockIdx.x * 256u + threadIdx.x;
+  if (i0 < nl) {
+    const uint32_t leaf = (i0 << v.sel_bits) | v.sel_val;
+    const uint64_t nt = min((uint64_t)v.cnt2[NCLS * leaf + 0], v.exact ? (uint64_t)v.lcap[NCLS * leaf + 0] : v.cap2t);
+    const uint64_t n1 = min((uint64_t)v.cnt2[NCLS * leaf + 1], v.exact ? (uint64_t)v.lcap[NCLS * leaf + 1] : v.cap2c);
+    if (nt + n1 >= HUGE_LEAF) huge[atomicAdd(&nhuge, 1u)] = i0;
+  }
+  __syncthreads();
+  for (uint32_t q = 0; q < nhuge; ++q) {
+    const uint32_t i = huge[q], leaf = (i << v.sel_bits) | v.sel_val;
+    const uint64_t nt = min((uint64_t)v.cnt2[NCLS * leaf + 0], v.exact ? (uint64_t)v.lcap[NCLS * leaf + 0] : v.cap2t);
+    const uint64_t n1 = min((uint64_t)v.cnt2[NCLS * leaf + 1], v.exact ? (uint64_t)v.lcap[NCLS * leaf + 1] : v.cap2c);
+    const uint4 *c1 = v.exact ? v.rec2 + v.lbase[NCLS * leaf + 1] : v.rec2 + (uint64_t)i * (v.cap2c + v.cap2t);
+    const uint4 *c0 = v.exact ? v.rec2 + v.lbase[NCLS * leaf + 0] : c1 + v.cap2c;
+    for (uint64_t j = threadIdx.x; j < n1 + nt; j += 256) {
+      const uint4 rec = (j < n1) ? c1[j] : c0[j - n1];
+      spill_record(rec, k, canon != 0, t, (weighted && j < n1) ? (rec.w >> 6) : 1u);
+    }
+  }
+}
+
 // mode: P3_WEIGHTED = the complete stream holds DISTINCT runs, header word = multiplicity << 6 | n-1
 // (what msp_dedupe_export_kernel leaves behind; from several ranks): an owner counting the runs it received.
 // SHARED: 2^sub_bits workgroups per leaf, each taking the records whose sub-value -- the extra
@@ -982,8 +1030,24 @@ __device__ __noinline__ uint32_t p3_big_dedupe(uint4 *pool, uint4 *stream, uint6
 // branch in place: without it the canonical kernel spills six dwords instead of two and P3 takes 7.10
 // instead of 6.80 ms on C3.
 constexpr uint32_t P3_EXPORT = 1u, P3_WEIGHTED = 2u;
-template <bool CANON, bool SHARED>
-__global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void msp_p3_kernel(int k, uint32_t mode, MspView v, TableView t) {
+// LISTS (round 5, the owner side of the PIPELINED runs exchange): the leaf's runs are not two streams in rec2 but the
+// N lists its ranks sent, read IN PLACE from the receive buffer -- rank r's segment of this group starts with a header
+// (row 0: {rows used, leaves, first local leaf, magic}, then one uint4 {row offset, distinct, truncated, noted} per local
+// leaf), and a leaf's rows are [distinct complete runs, header = multiplicity << 6 | n-1][truncated runs][notes, eight per
+// row].  A note is turned back into the run it stands for (the first n k-mers of its twin) where it is read.  No layout
+// kernels, no scatter pass, no host synchronisation before the leaf kernel.  An instantiation of its own
+// (msp_p3_lists_kernel): the one-GPU kernel's code and registers are what they were.
+template <bool LISTS> struct P3ListsT {};
+template <> struct P3ListsT<true> {
+  const uint4 *packed;       // the receive buffer of this group: rank r's segment at row rr.rstart[r], rr.rows[r] rows
+  RunsRecv rr;
+  int parts;
+  uint32_t ll0, lcount;      // the group's local leaves [ll0, ll0 + lcount): workgroup b counts local leaf ll0 + b
+};
+constexpr uint32_t RUNS2_MAGIC = 0x32535543u;   // "CUS2"
+
+template <bool CANON, bool SHARED, bool LISTS>
+__device__ __forceinline__ void p3_body(int k, uint32_t mode, const MspView &v, const TableView &t, const P3ListsT<LISTS> &lx) {
   // k-mer table (keys, counts) and record table in one allocation: p3_big_dedupe uses all of it
   __shared__ uint4 pool[BT];
   static_assert(BT * 16 == TS * 12 + RT * 16, "the pool is exactly the k-mer table plus the record table");
@@ -1019,10 +1083,55 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
   const uint32_t vq = blockIdx.x >> 3, rsel = vq & smask;
   const uint32_t leaf = ((SHARED ? (((vq >> sub_bits) << 3) | (blockIdx.x & 7u)) : blockIdx.x) << v.sel_bits) | v.sel_val;
   auto mine = [&](uint32_t w) { return !SHARED || ((w >> 24) & smask) == rsel; };
-  const uint64_t nt = min((uint64_t)v.cnt2[NCLS * leaf + 0], v.exact ? (uint64_t)v.lcap[NCLS * leaf + 0] : v.cap2t);  // truncated runs
-  const uint64_t n1 = min((uint64_t)v.cnt2[NCLS * leaf + 1], v.exact ? (uint64_t)v.lcap[NCLS * leaf + 1] : v.cap2c);  // complete runs
-  const uint4 *leaf_rec = v.exact ? v.rec2 + v.lbase[NCLS * leaf + 1] : v.rec2 + (uint64_t)(leaf >> v.sel_bits) * (v.cap2c + v.cap2t);
-  if (nt + n1 == 0) return;
+  // LISTS: rank r's lists of this leaf -- l_base[r] = its first row, complete runs [l_cpre[r], l_cpre[r+1]) of the leaf's
+  // complete "stream", truncated runs + notes [l_tpre[r], l_tpre[r+1]) of its truncated one (l_nu[r] records, then the notes)
+  __shared__ uint32_t l_cpre[LISTS ? 65 : 1], l_tpre[LISTS ? 65 : 1], l_nu[LISTS ? 64 : 1];
+  __shared__ const uint4 *l_base[LISTS ? 64 : 1];
+  uint64_t nt_ = 0, n1_ = 0;
+  if constexpr (LISTS) {
+    if (tid < 64) {
+      const int r = tid;
+      uint32_t nd = 0, nu = 0, na = 0;
+      const uint4 *base = nullptr;
+      if (r < lx.parts) {
+        const uint4 *hdr = lx.packed + lx.rr.rstart[r];
+        const uint64_t rows = lx.rr.rows[r], hrows = 1ull + lx.lcount;
+        bool ok = rows >= hrows;
+        if (ok) { const uint4 h0 = hdr[0]; ok = h0.y == lx.lcount && h0.z == lx.ll0 && h0.w == RUNS2_MAGIC; }
+        if (ok) {
+          const uint4 e = hdr[1u + blockIdx.x];
+          const uint64_t tot = (uint64_t)e.y + e.z + (e.w + (uint32_t)NOTES_PER_ROW - 1u) / (uint32_t)NOTES_PER_ROW;
+          // (a segment that does not add up, or notes without a run they could point at, is not followed)
+          if ((uint64_t)e.x + tot <= rows - hrows && (e.w == 0u || e.y != 0u)) { nd = e.y; nu = e.z; na = e.w; base = hdr + hrows + e.x; }
+          else if (tot) ok = false;
+        }
+        if (!ok) v.stats[ST_OVERFLOW] = 1;                 // (reported by finish / digest: the result would be incomplete)
+      }
+      const uint32_t ci = dev_wave_scan_incl(nd), ti = dev_wave_scan_incl(nu + na);
+      l_cpre[r] = ci - nd; l_tpre[r] = ti - (nu + na); l_nu[r] = nu; l_base[r] = base;
+      if (r == 63) { l_cpre[64] = ci; l_tpre[64] = ti; }
+    }
+    __syncthreads();
+    n1_ = l_cpre[64]; nt_ = l_tpre[64];
+  } else {
+    nt_ = min((uint64_t)v.cnt2[NCLS * leaf + 0], v.exact ? (uint64_t)v.lcap[NCLS * leaf + 0] : v.cap2t);  // truncated runs
+    n1_ = min((uint64_t)v.cnt2[NCLS * leaf + 1], v.exact ? (uint64_t)v.lcap[NCLS * leaf + 1] : v.cap2c);  // complete runs
+  }
+  const uint64_t nt = nt_, n1 = n1_;
+  const uint4 *leaf_rec = LISTS ? nullptr : (v.exact ? v.rec2 + v.lbase[NCLS * leaf + 1] : v.rec2 + (uint64_t)(leaf >> v.sel_bits) * (v.cap2c + v.cap2t));
+  // record i of the leaf's complete runs / of its truncated runs, wherever they lie
+  auto l_find = [&](const uint32_t *pre, uint32_t i) {        // rank r with pre[r] <= i < pre[r + 1] (LISTS)
+    uint32_t lo = 0, hi = 64;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pre[mid] <= i) lo = mid; else hi = mid; }
+    return lo;
+  };
+  auto ld_c = [&](uint64_t i) -> uint4 {
+    if constexpr (LISTS) { const uint32_t r = l_find(l_cpre, (uint32_t)i); return l_base[r][(uint32_t)i - l_cpre[r]]; }
+    else return leaf_rec[i];
+  };
+  if constexpr (!LISTS) {
+    if (nt + n1 - 1ull >= HUGE_LEAF - 1ull) return;     // nothing to count -- or a HUGE leaf: msp_huge_leaves_kernel counts it
+  }
   // Short windows (k < 28) mean more distinct runs per leaf than the record table holds (~600 at
   // k = 21, heavy leaves several times that): the complete runs are then deduplicated in a table
   // over the whole pool right away and listed in the stream (see p3_big_dedupe / p3_compact).
@@ -1030,7 +1139,7 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
   // fewer than BT_MIN_RUNS complete runs cannot hold many copies of more than ~10^3 distinct ones
   // (low coverage of a large genome: the stream path is the better fallback there).
   // (a shared leaf never rewrites its stream: the other workgroups are reading it)
-  const bool big_first = !SHARED && k < 28 && n1 >= (uint64_t)BT_MIN_RUNS;
+  const bool big_first = !SHARED && !LISTS && k < 28 && n1 >= (uint64_t)BT_MIN_RUNS;   // (lists are read in place: nothing to rewrite)
   uint4 *const tab = big_first ? pool : rtab;
   const int tab_log = big_first ? BT_LOG : RT_LOG;
   const uint32_t tab_mask = (1u << tab_log) - 1u;
@@ -1061,8 +1170,34 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
   const uint64_t kmask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1ull);
   const int rcsh = 2 * k - 2;
   // truncated runs that go through the length-sorted list: as many as fit
-  const uint4 *trunc = v.exact ? v.rec2 + v.lbase[NCLS * leaf + 0] : leaf_rec + v.cap2c;
+  const uint4 *trunc = LISTS ? nullptr : (v.exact ? v.rec2 + v.lbase[NCLS * leaf + 0] : leaf_rec + v.cap2c);
   const uint32_t tl = (uint32_t)min(nt, (uint64_t)TL_CAP);
+  auto ld_t = [&](uint64_t i) -> uint4 {
+    if constexpr (LISTS) {
+      const uint32_t r = l_find(l_tpre, (uint32_t)i), j = (uint32_t)i - l_tpre[r];
+      const uint4 *b = l_base[r];
+      const uint32_t nd_r = l_cpre[r + 1] - l_cpre[r], nu_r = l_nu[r];
+      if (j < nu_r) return b[nd_r + j];
+      // a note: the first n k-mers of its twin, closed on the left only (msp_runs_scatter_kernel did this in a pass of its own)
+      const uint32_t note = reinterpret_cast<const uint16_t *>(b + nd_r + nu_r)[j - nu_r];
+      const uint4 twin = b[min(note >> 5, nd_r - 1u)];                    // a position outside the list is not followed
+      const uint32_t nm1 = min(note & 31u, twin.w & 31u);
+      const int rb = 2 * ((int)nm1 + k) - 32;                           // bits of the run beyond the first word: 0 .. 64
+      const uint32_t my = (rb >= 32) ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> rb);
+      const uint32_t mz = (rb <= 32) ? 0u : ((rb >= 64) ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> (rb - 32)));
+      return make_uint4(twin.x, twin.y & my, twin.z & mz, 64u | nm1);
+    } else return trunc[i];
+  };
+  if constexpr (LISTS) {
+    if (nt + n1 == 0) return;
+    if (nt + n1 >= HUGE_LEAF) {                        // (see HUGE_LEAF: counted in the HBM table, whose adds saturate)
+      for (uint64_t i = tid; i < n1 + nt; i += P3_THREADS) {
+        const uint4 rec = (i < n1) ? ld_c(i) : ld_t(i - n1);
+        spill_record(rec, k, CANON, t, (i < n1) ? (rec.w >> 6) : 1u);
+      }
+      return;
+    }
+  }
 
   // ---- phase 1a: complete runs, one record-table update per record.  Most records find their
   //      twin in the home slot: that case is one LDS read + one LDS add with every lane busy.
@@ -1129,8 +1264,8 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         const uint64_t r1 = r + P3_THREADS;
         const bool v0 = r < n1a, v1 = r1 < n1a;
         uint4 rec0 = zero4, rec1 = zero4;
-        if (v0) rec0 = src[r];
-        if (v1) rec1 = src[r1];
+        if (v0) rec0 = LISTS ? ld_c(r) : src[r];
+        if (v1) rec1 = LISTS ? ld_c(r1) : src[r1];
         home(rec0, v0);
         home(rec1, v1);
       }
@@ -1207,7 +1342,7 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     return;
   }
   if (big_first || rt_fail != 0u) {              // (rt_fail read after the barrier above: uniform)
-    if (!SHARED && !big_first && (n1 >= (uint64_t)BT_MIN_RUNS || (v.dbg & CFRK_DEBUG_FORCE_RT_OVERFLOW))) nd = p3_big_dedupe(pool, const_cast<uint4 *>(leaf_rec), n1, wsum, &rt_fail, (mode & P3_WEIGHTED) != 0u);
+    if (!SHARED && !LISTS && !big_first && (n1 >= (uint64_t)BT_MIN_RUNS || (v.dbg & CFRK_DEBUG_FORCE_RT_OVERFLOW))) nd = p3_big_dedupe(pool, const_cast<uint4 *>(leaf_rec), n1, wsum, &rt_fail, (mode & P3_WEIGHTED) != 0u);
     else if (!big_first) __syncthreads();        // (as below)
     else if (rt_fail == 0u) nd = p3_compact(pool, const_cast<uint4 *>(leaf_rec), wsum);
     else __syncthreads();                        // (the pool is cleared below: everybody has read rt_fail and the table)
@@ -1241,7 +1376,7 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     for (int i = 0; i < TL_PER; ++i) trec[i] = make_uint4(0u, 0u, 0u, 0u);
     if (tl) {                                        // (uniform; lanes past the end load the last record again: no
 #pragma unroll                                       //  per-lane branch, so the four loads are in flight together)
-      for (int i = 0; i < TL_PER; ++i) trec[i] = trunc[min((uint32_t)(i * P3_THREADS + tid), tl - 1u)];
+      for (int i = 0; i < TL_PER; ++i) trec[i] = ld_t(min((uint32_t)(i * P3_THREADS + tid), tl - 1u));
     }
 #pragma unroll
     for (int i = 0; i < TL_PER; ++i) {
@@ -1288,7 +1423,7 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
       for (int i = 0; i < TL_PER; ++i) {
         if (tw[i] == TW_NONE) continue;
         const uint32_t g = (uint32_t)(i * P3_THREADS + tid);
-        tw[i] = trunc[g].w & 31u;                    // (a twin that was found is not used)
+        tw[i] = ld_t(g).w & 31u;                     // (a twin that was found is not used)
         trank[i] = atomicAdd(&thist[tw[i]], 1u);
       }
     }
@@ -1401,7 +1536,7 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         for (uint64_t i = tid; i < ((n1 + 63) & ~63ull); i += P3_THREADS) {
           const bool valid = i < n1;
           uint4 rec = make_uint4(0u, 0u, 0u, 0u);
-          if (valid) rec = leaf_rec[i];
+          if (valid) rec = ld_c(i);
           count_record_v2<CANON>(keys, cnts, rec, (!SHARED && (mode & P3_WEIGHTED)) ? (rec.w >> 6) : 1u, valid && mine(rec.w), k, kmask, rcsh, t, ss, ovf);
         }
       }
@@ -1410,14 +1545,14 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
       for (uint32_t i = tid; i < ((ntr + 63u) & ~63u) && !(v.dbg & CFRK_ABL_P3_NO_TRUNC); i += P3_THREADS) {
         const bool valid = i < ntr;
         uint4 rec = make_uint4(0u, 0u, 0u, 0u);
-        if (valid) rec = trunc[use_anchors ? flist[i] : tlist[i]];
+        if (valid) rec = ld_t(use_anchors ? flist[i] : tlist[i]);
         count_record_v2<CANON>(keys, cnts, rec, 1u, valid, k, kmask, rcsh, t, ss, ovf);
       }
       // truncated runs beyond the sorted list (very large leaves): in stream order
       for (uint64_t i = (uint64_t)tl + tid; i < ((nt + 63) & ~63ull) && tl < nt; i += P3_THREADS) {
         const bool valid = i < nt;
         uint4 rec = make_uint4(0u, 0u, 0u, 0u);
-        if (valid) rec = trunc[i];
+        if (valid) rec = ld_t(i);
         count_record_v2<CANON>(keys, cnts, rec, 1u, valid && mine(rec.w), k, kmask, rcsh, t, ss, ovf);
       }
     }
@@ -1448,11 +1583,13 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
       // (a shared leaf: one index entry per sub-value, (leaf << sub_bits) | sub-value)
       uint32_t sg = leaf;
       if (SHARED) sg = (leaf << sub_bits) | rsel;
-      if (nseg == 0) v.leaf_off[sg] = wg_base;
-      else if (wg_total) v.stats[ST_MULTISEG] = 1;
+      if (!LISTS) {                                  // (an owner's result is not kept in leaf form)
+        if (nseg == 0) v.leaf_off[sg] = wg_base;
+        else if (wg_total) v.stats[ST_MULTISEG] = 1;
+      }
       if (wg_total) nseg = nseg + 1;
       leaf_total += wg_total;
-      v.leaf_n[sg] = leaf_total;
+      if (!LISTS) v.leaf_n[sg] = leaf_total;
     }
     __syncthreads();
     wg_emit_slots<NIT, P3_THREADS>(wbase, wg_base, occupied, [&](int s, unsigned long long dst) {
@@ -1461,6 +1598,16 @@ __global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     });
     __syncthreads();
   }
+}
+
+template <bool CANON, bool SHARED>
+__global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void msp_p3_kernel(int k, uint32_t mode, MspView v, TableView t) {
+  p3_body<CANON, SHARED, false>(k, mode, v, t, P3ListsT<false>{});
+}
+// the owner of the pipelined runs exchange: workgroup b counts local leaf lx.ll0 + b from the lists its ranks sent
+template <bool CANON>
+__global__ __launch_bounds__(P3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void msp_p3_lists_kernel(int k, MspView v, TableView t, P3ListsT<true> lx) {
+  p3_body<CANON, false, true>(k, P3_WEIGHTED, v, t, lx);
 }
 
 // ---------------------------------------------------------------------------- multi-GPU by leaf
@@ -1558,10 +1705,12 @@ __global__ __launch_bounds__(DX_THREADS) void msp_dedupe_export_kernel(int k, in
   if (n1 == 0) return;
   uint4 *const stream = v.exact ? v.rec2 + v.lbase[NCLS * leaf + 1] : v.rec2 + (uint64_t)(leaf >> v.sel_bits) * (v.cap2c + v.cap2t);
   for (int s = tid; s < RT; s += DX_THREADS) rtab[s] = make_uint4(0u, 0u, 0u, RT_EMPTY);
-  if (tid == 0) { rt_fail = (v.dbg & CFRK_DEBUG_FORCE_RT_OVERFLOW) ? 1u : 0u; noted = 0u; }
+  // (a leaf of 2^19 complete runs or more leaves undeduplicated: see HUGE_LEAF)
+  const bool too_many = n1 >= HUGE_LEAF_SENDER;
+  if (tid == 0) { rt_fail = ((v.dbg & CFRK_DEBUG_FORCE_RT_OVERFLOW) || too_many) ? 1u : 0u; noted = 0u; }
   __syncthreads();
   const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
-  {
+  if (!too_many) {
     uint32_t *rmeta = reinterpret_cast<uint32_t *>(rtab);
     uint4 L = zero4;                 // leftover records, lanes [0, c) (see the leaf kernel's phase 1a)
     uint32_t Lh = 0;
@@ -1680,6 +1829,222 @@ __global__ __launch_bounds__(DX_THREADS) void msp_dedupe_export_kernel(int k, in
   if (tid == 0) { v.leaf_n[leaf] = nd; v.leaf_off[leaf] = noted; }
 }
 
+// ------------------------------------------------------------------- multi-GPU by runs, PIPELINED (round 5)
+// The sender's half of the pipelined exchange: deduplication AND packing in one kernel, one group of leaves at a
+// time, straight into the send buffer -- no rewrite of the streams, no sizes / plan / gather kernels, no host
+// round trip (the gather alone was 0.21 ms of a 5.1 ms critical path at N = 8).
+// The leaves of an owner are cut into `ngroups` ranges of local indices; group g of owner p has its segment at
+// rows [(g * parts + p) * seg_cap, ...) of the send buffer: header (row 0 = {rows used, leaves, first local leaf,
+// magic}, written by msp_runs_group_finish_kernel; then one uint4 {row offset, distinct, truncated, noted} per local
+// leaf) followed by the leaves' rows in the order their workgroups CLAIM them (one atomic on the segment's cursor
+// per leaf; the header says where each leaf went).  Only the used rows of a segment travel.
+// A leaf's rows: [distinct complete runs, header word = multiplicity << 6 | n-1][truncated runs that found no twin]
+// [notes: 16 bits each, position of the twin in the leaf's list << 5 | n-1, eight per row, padded with 0xFFFF].
+// One workgroup per leaf, everything a thread needs of the complete stream in flight at once (DS_INFL loads: a
+// shard's leaf is ~2700 records); the truncated runs are looked up once, their verdict (note or record) waits in LDS
+// for the leaf's row count, then they are written from a second read that hits the L2.
+constexpr int DS_THREADS = 256, DS_INFL = 12, DS_TCAP = 4096;
+struct RunsSend {
+  uint4 *packed;             // this GROUP's segments: owner p's at packed + p * seg_cap
+  uint64_t seg_cap;          // rows per segment (header included)
+  uint32_t *cursor;          // [parts] rows claimed behind the header (zeroed before the kernel)
+  uint32_t leaf0, nleaf;     // the group's leaves [leaf0, leaf0 + nleaf): all owners' local leaves [ll0, ll0 + lcount)
+  uint32_t ll0, lcount;
+  int parts;
+};
+__global__ __launch_bounds__(DS_THREADS) void msp_dedupe_send_kernel(int k, int canon, MspView v, RunsSend sg) {
+  __shared__ uint4 rtab[RT];
+  __shared__ uint16_t sidx[RT];                    // record-table slot -> position in the leaf's list
+  __shared__ uint16_t tres[DS_TCAP];               // truncated run g: its note, or 0xFFFF = travels as a record
+  __shared__ uint32_t wsum[DS_THREADS / 64];
+  __shared__ uint32_t rt_fail, noted, cu, cn, row0;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t leaf = sg.leaf0 + blockIdx.x;
+  const uint32_t own = leaf % (uint32_t)sg.parts, ll = leaf / (uint32_t)sg.parts;
+  uint4 *const seg = sg.packed + (uint64_t)own * sg.seg_cap;
+  const uint32_t hrows = 1u + sg.lcount;
+  uint4 *const entry = seg + 1u + (ll - sg.ll0);
+  const uint64_t n1 = min((uint64_t)v.cnt2[NCLS * leaf + 1], v.exact ? (uint64_t)v.lcap[NCLS * leaf + 1] : v.cap2c);
+  const uint64_t nt64 = min((uint64_t)v.cnt2[NCLS * leaf + 0], v.exact ? (uint64_t)v.lcap[NCLS * leaf + 0] : v.cap2t);
+  if (n1 + nt64 == 0) { if (tid == 0) *entry = make_uint4(0u, 0u, 0u, 0u); return; }
+  const uint4 *const c1 = v.exact ? v.rec2 + v.lbase[NCLS * leaf + 1] : v.rec2 + (uint64_t)(leaf >> v.sel_bits) * (v.cap2c + v.cap2t);
+  const uint4 *const c0 = v.exact ? v.rec2 + v.lbase[NCLS * leaf + 0] : c1 + v.cap2c;
+  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+  // (a leaf of 2^19 complete runs or more leaves undeduplicated: see HUGE_LEAF; a row count beyond 32 bits cannot be claimed)
+  const bool too_many = n1 >= HUGE_LEAF_SENDER;
+  const bool unclaimable = n1 + nt64 >= 0xFFFFFFFFull;
+  // the first round of the complete stream is asked for before anything else is done
+  uint4 recs[DS_INFL];
+#pragma unroll
+  for (int u = 0; u < DS_INFL; ++u) {
+    const uint64_t r = (uint64_t)u * DS_THREADS + tid;
+    recs[u] = zero4;
+    if (r < n1 && !too_many) recs[u] = c1[r];
+  }
+  for (int s2 = tid; s2 < RT; s2 += DS_THREADS) rtab[s2] = make_uint4(0u, 0u, 0u, RT_EMPTY);
+  if (tid == 0) { rt_fail = ((v.dbg & CFRK_DEBUG_FORCE_RT_OVERFLOW) || too_many) ? 1u : 0u; noted = 0u; cu = 0u; cn = 0u; }
+  __syncthreads();
+  if (!too_many) {
+    uint32_t *rmeta = reinterpret_cast<uint32_t *>(rtab);
+    uint4 L = zero4;                 // leftover records, lanes [0, c) (see the leaf kernel's phase 1a)
+    uint32_t Lh = 0;
+    int c = 0;                       // wave-uniform
+    auto drain = [&](int cnt) {
+      uint32_t h = Lh | ((lane < cnt) ? 0u : RT_DONE);
+      rtab_insert_loop(rtab, L, h, RT - 1, RT_TRIPS);
+      if ((int32_t)h >= 0) rt_fail = 1u;
+    };
+    for (uint64_t r0 = 0; r0 < n1; r0 += (uint64_t)DS_INFL * DS_THREADS) {
+      if (r0) {
+#pragma unroll
+        for (int u = 0; u < DS_INFL; ++u) {
+          const uint64_t r = r0 + (uint64_t)u * DS_THREADS + tid;
+          recs[u] = zero4;
+          if (r < n1) recs[u] = c1[r];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < DS_INFL; ++u) {
+        const uint64_t r = r0 + (uint64_t)u * DS_THREADS + tid;
+        if (r0 + (uint64_t)u * DS_THREADS >= n1) break;          // (wave-uniform)
+        const bool valid = r < n1;
+        const uint4 rec = recs[u];
+        const uint32_t h = rtab_slot_k(rec, k, RT_LOG);
+        const uint4 e = rtab[h];
+        const bool match = valid && rtab_diff(e, rec) == 0u;
+        if (match) atomicAdd(&rmeta[4 * h + 3], 1u << 6);
+        const bool left = valid && !match;
+        const unsigned long long mask = __ballot(left);
+        if (mask == 0ull) continue;
+        const int n = __popcll(mask);
+        if (c + n > 64) { drain(c); c = 0; }
+        uint32_t set[5] = {L.x, L.y, L.z, L.w, Lh};
+        const uint32_t mine_[5] = {rec.x, rec.y, rec.z, rec.w, h};
+        wave_append<5>(set, mine_, left, mask, c, n);
+        L = make_uint4(set[0], set[1], set[2], set[3]); Lh = set[4];
+        c += n;
+      }
+    }
+    if (c) drain(c);
+  }
+  __syncthreads();
+  const bool plain = rt_fail != 0u;                 // no deduplication: every complete run leaves with multiplicity 1, no notes
+  const uint32_t nt = (uint32_t)min(nt64, (uint64_t)0xFFFFFFFFull);
+  uint32_t nd, at0 = 0;
+  constexpr int PER = RT / DS_THREADS;
+  if (plain) {
+    nd = (uint32_t)min(n1, (uint64_t)0xFFFFFFFFull);
+  } else {
+    // occupied slots -> positions in the leaf's list (four slots per thread)
+    const uint32_t *meta = reinterpret_cast<const uint32_t *>(rtab);
+    uint32_t mine = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) mine += (meta[4 * (PER * tid + i) + 3] != RT_EMPTY) ? 1u : 0u;
+    const uint32_t incl = dev_wave_scan_incl(mine);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+    for (int w = 0; w < DS_THREADS / 64; ++w) { const uint32_t x = wsum[w]; base += (w < wave) ? x : 0u; total += x; }
+    at0 = base + incl - mine;
+    uint32_t at = at0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      sidx[PER * tid + i] = (uint16_t)at;
+      if (meta[4 * (PER * tid + i) + 3] != RT_EMPTY) ++at;
+    }
+    nd = total;
+    __syncthreads();
+    // truncated runs: which of the first DS_TCAP are a prefix of a distinct complete run of this rank (a suffix, read on
+    // the other strand; canonical counting only)?  The verdict waits in LDS (the lookup of the leaf kernel's anchoring)
+    const uint32_t tlook = (v.dbg & CFRK_DEBUG_NO_ANCHORS) ? 0u : min(nt, (uint32_t)DS_TCAP);
+    for (uint32_t g0 = 0; g0 < tlook; g0 += DS_THREADS) {
+      const uint32_t g = g0 + tid;
+      const bool valid = g < tlook;
+      uint4 rec = zero4;
+      if (valid) rec = c0[g];
+      const uint32_t nm1 = rec.w & 31u;
+      const bool lc = (rec.w & 64u) != 0u, rc_ = (rec.w & 128u) != 0u;
+      const bool suf = canon && valid && !lc && rc_;
+      if (suf) rec = revcomp_record(rec, (int)nm1 + k);
+      const bool anchored = suf || (valid && lc && !rc_);
+      uint32_t h = anchored ? rtab_slot_k(rec, k, RT_LOG) : RT_DONE;
+      uint32_t found = 0xFFFFFFFFu;
+      for (int it = 0; it < 32 && __ballot((int32_t)h >= 0); ++it) {
+        const bool p = (int32_t)h >= 0;
+        const uint32_t hh = h & (uint32_t)(RT - 1);
+        const uint4 e2 = rtab[hh];
+        const bool empty = e2.w == RT_EMPTY;
+        const bool hit = p && !empty && (e2.w & 31u) >= nm1 && rec_prefix_equal(e2, rec, (int)nm1 + k);
+        found = hit ? hh : found;
+        h = (p && !hit && !empty) ? ((hh + 1u) & (uint32_t)(RT - 1)) : (h | RT_DONE);
+      }
+      const bool hit = found != 0xFFFFFFFFu;
+      if (valid) tres[g] = hit ? (uint16_t)(((uint32_t)sidx[found] << 5) | nm1) : (uint16_t)0xFFFFu;
+      const unsigned long long hb = __ballot(hit);
+      if (lane == 0 && hb) atomicAdd(&noted, (uint32_t)__popcll(hb));
+    }
+    __syncthreads();
+  }
+  const uint32_t na = plain ? 0u : noted, nu = nt - na;
+  const uint64_t rows = (uint64_t)nd + nu + (na + NOTES_PER_ROW - 1) / NOTES_PER_ROW;
+  if (tid == 0) {
+    // one claim per leaf; a segment that runs out of room (or a flood that cannot be claimed at all) shows in its
+    // cursor -- used rows > seg_cap -- and the host takes the classic exchange instead
+    const uint32_t claim = unclaimable ? 0xFFFFFFFFu : (uint32_t)rows;
+    const uint32_t pos = atomicAdd(&sg.cursor[own], claim);
+    const bool fits = !unclaimable && (uint64_t)pos + rows <= sg.seg_cap - hrows && pos + claim >= pos;
+    if (!fits) atomicMax(&sg.cursor[own], 0xFFFFFFF0u);              // (stays "too many" whatever is added later)
+    *entry = fits ? make_uint4(pos, nd, nu, na) : make_uint4(0u, 0u, 0u, 0u);
+    row0 = fits ? pos : 0xFFFFFFFFu;
+  }
+  __syncthreads();
+  if (row0 == 0xFFFFFFFFu) return;
+  uint4 *const dst = seg + hrows + row0;
+  if (plain) {
+    for (uint64_t i = tid; i < n1; i += DS_THREADS) { uint4 r = c1[i]; r.w = (1u << 6) | (r.w & 63u); dst[i] = r; }
+    for (uint32_t i = tid; i < nt; i += DS_THREADS) dst[nd + i] = c0[i];
+    return;
+  }
+  {
+    uint32_t at = at0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const uint4 e = rtab[PER * tid + i];
+      if (e.w != RT_EMPTY) dst[at++] = e;
+    }
+  }
+  uint16_t *const notes = reinterpret_cast<uint16_t *>(dst + nd + nu);
+  for (uint32_t i = tid; i < ((nt + 63u) & ~63u); i += DS_THREADS) {
+    const bool valid = i < nt;
+    const uint32_t note = (valid && i < (uint32_t)DS_TCAP && !(v.dbg & CFRK_DEBUG_NO_ANCHORS)) ? (uint32_t)tres[i] : 0xFFFFu;
+    const bool isn = valid && note != 0xFFFFu;
+    const unsigned long long mn = __ballot(isn), mu = __ballot(valid && !isn);
+    uint32_t bn = 0, bu = 0;
+    if (lane == 0) {
+      if (mn) bn = atomicAdd(&cn, (uint32_t)__popcll(mn));
+      if (mu) bu = atomicAdd(&cu, (uint32_t)__popcll(mu));
+    }
+    bn = __shfl(bn, 0); bu = __shfl(bu, 0);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (isn) { const uint32_t at = bn + (uint32_t)__popcll(mn & below); if (at < na) notes[at] = (uint16_t)note; }
+    else if (valid) { const uint32_t at = bu + (uint32_t)__popcll(mu & below); if (at < nu) dst[nd + at] = c0[i]; }
+  }
+  const uint32_t pad = (NOTES_PER_ROW - na % NOTES_PER_ROW) % NOTES_PER_ROW;
+  if ((uint32_t)tid < pad) notes[na + tid] = 0xFFFFu;
+}
+
+// ... and the group's epilogue: row 0 of every segment's header, the rows every segment uses, the job's flags
+__global__ __launch_bounds__(64) void msp_runs_group_finish_kernel(RunsSend sg, const uint64_t *__restrict__ stats, uint64_t *__restrict__ used /* [parts + 1] */) {
+  const int p = threadIdx.x;
+  if (p < sg.parts) {
+    const uint64_t u = 1ull + sg.lcount + (uint64_t)sg.cursor[p];
+    used[p] = u;
+    sg.packed[(uint64_t)p * sg.seg_cap] = make_uint4((uint32_t)min(u, (uint64_t)0xFFFFFFFFull), sg.lcount, sg.ll0, RUNS2_MAGIC);
+  }
+  if (p == 0) used[sg.parts] = (stats[ST_SPILLED] || stats[ST_ONES] || stats[ST_L1OVF] || stats[ST_L2OVF] || stats[ST_OVFN] ||
+                                stats[ST_OVFN1] || stats[ST_CWRAP] || stats[ST_OVERFLOW]) ? 1ull : 0ull;
+}
+
 // ---------------------------------------------------------------------------- multi-GPU by runs
 // Strong scaling: with the reads split over N ranks every rank still meets almost every locus, so
 // counting on every rank and exchanging (key, count) lists (above) makes each rank expand every
@@ -1782,13 +2147,15 @@ __global__ __launch_bounds__(256) void msp_runs_scatter_kernel(const uint4 *__re
 
 // exact layout of a level from the demand the first attempt counted: base = exclusive prefix sum
 // of the n cursors, cap = the cursors themselves (single workgroup, 1024 threads)
+// (slack: room beyond the counted demand per region -- the chunked path runs P1 again, and which records its
+//  first level PARKED last time depended on the order of atomics: a stream's demand may differ by a few)
 __global__ __launch_bounds__(1024) void msp_layout_kernel(const uint32_t *__restrict__ cnt, uint32_t n,
-                                                          uint64_t *__restrict__ base, uint32_t *__restrict__ cap) {
+                                                          uint64_t *__restrict__ base, uint32_t *__restrict__ cap, uint32_t slack = 0u) {
   __shared__ unsigned long long part[1024];
   const uint32_t per = (n + 1023u) / 1024u;
   const uint32_t tid = threadIdx.x;
   unsigned long long s = 0;
-  for (uint32_t i = 0; i < per; ++i) { const uint32_t l = tid * per + i; if (l < n) s += cnt[l]; }
+  for (uint32_t i = 0; i < per; ++i) { const uint32_t l = tid * per + i; if (l < n) s += (unsigned long long)cnt[l] + slack; }
   part[tid] = s;
   __syncthreads();
   if (tid == 0) {
@@ -1799,7 +2166,7 @@ __global__ __launch_bounds__(1024) void msp_layout_kernel(const uint32_t *__rest
   unsigned long long run = part[tid];
   for (uint32_t i = 0; i < per; ++i) {
     const uint32_t l = tid * per + i;
-    if (l < n) { const uint32_t c = cnt[l]; base[l] = run; cap[l] = c; run += c; }
+    if (l < n) { const uint32_t c = cnt[l] + slack; base[l] = run; cap[l] = c; run += c; }
   }
 }
 
@@ -2035,13 +2402,13 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
   // stream's capacity): streams back to back, each with exactly the room it needs; the buffer grows
   // when the batch holds more records than it was sized for (a chunked batch's streams were sized from
   // its first chunk)
-  auto layout_l2 = [&]() -> int {
+  auto layout_l2 = [&](uint32_t slack) -> int {
     int rc2;
     void *q;
     if ((rc2 = cfrk_pool_get(ctx, BUF_MSP_LAYOUT, (size_t)NCLS * NLEAF * (sizeof(uint64_t) + sizeof(uint32_t)), &q))) return rc2;
     uint64_t *lbase = (uint64_t *)q;
     uint32_t *lcap = (uint32_t *)(lbase + NCLS * NLEAF);
-    hipLaunchKernelGGL(msp_layout_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)v.cnt2, (uint32_t)(NCLS * NLEAF), lbase, lcap);
+    hipLaunchKernelGGL(msp_layout_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)v.cnt2, (uint32_t)(NCLS * NLEAF), lbase, lcap, slack);
     HIP_TRY(ctx, hipGetLastError());
     if ((rc2 = cfrk_pool_get(ctx, BUF_SCRATCH, 64 * sizeof(uint64_t), &q))) return rc2;
     hipLaunchKernelGGL(msp_sum_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)v.cnt2, (uint32_t)(NCLS * NLEAF), (uint64_t *)q);
@@ -2049,6 +2416,7 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
     uint64_t all = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&all, q, sizeof all, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    all += (uint64_t)slack * NCLS * NLEAF;
     if ((size_t)all * sizeof(uint4) > ctx->pool[BUF_MSP_L2].cap) {
       if ((rc2 = cfrk_pool_get(ctx, BUF_MSP_L2, (size_t)all * sizeof(uint4), &q))) return rc2;
       v.rec2 = (uint4 *)q;
@@ -2126,7 +2494,10 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
     uint64_t st[ST_NWORDS];
     HIP_TRY(ctx, hipMemcpyAsync(st, ctx->g_stats, sizeof st, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (piped && st[ST_L1OVF]) {
+    if (st[ST_CWRAP]) return CFRK_INTERNAL_FLOOD;      // (nothing of this pass has been counted yet)
+    // (level-1 records PARKED in a chunked attempt whose leaf streams overflowed: which records are parked depends on
+    //  the order of atomics, so the exact stream sizes counted now need not hold when P1 runs again -- same remedy)
+    if (piped && (st[ST_L1OVF] || (st[ST_L2OVF] && st[ST_OVFN1]))) {
       // a level-1 region overflowed by more than the parking buffer takes: the level-1 cursors of a chunk
       // do not add up to the batch's demand (the buffer is reused), so the batch starts over on the
       // one-chunk path, which lays the overflowing level out exactly -- with the leaf streams the
@@ -2146,7 +2517,8 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
       // clustered, a short-read or N-rich prefix, concatenated libraries).  Their cursors counted on
       // over ALL chunks, so the batch's exact demand is known: lay the streams out back to back and
       // run the chunks again (one more P1 + P2 over the input; the level-1 buffer stays one chunk).
-      if ((rc = layout_l2())) return rc;
+      // (nothing was parked on level 1 -- see above -- so P1 makes the same records again; eight to spare per stream)
+      if ((rc = layout_l2(8u))) return rc;
       continue;
     }
     if (st[ST_L1OVF]) {
@@ -2181,7 +2553,7 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
     }
     parked1 = st[ST_OVFN1];
     if (st[ST_L2OVF]) {
-      if ((rc = layout_l2())) return rc;
+      if ((rc = layout_l2(0u))) return rc;
       run_p1 = false;
       continue;
     }
@@ -2210,6 +2582,10 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
   else if (canon) hipLaunchKernelGGL((msp_p3_kernel<true, false>), dim3((unsigned)NLEAF >> sel_bits), dim3(P3_THREADS), 0, ctx->stream, k, 0u, v, t);
   else hipLaunchKernelGGL((msp_p3_kernel<false, false>), dim3((unsigned)NLEAF >> sel_bits), dim3(P3_THREADS), 0, ctx->stream, k, 0u, v, t);
   HIP_TRY(ctx, hipGetLastError());
+  if (!runs_only) {
+    hipLaunchKernelGGL(msp_huge_leaves_kernel, dim3((((unsigned)NLEAF >> sel_bits) + 255u) / 256u), dim3(256), 0, ctx->stream, k, canon, 0, (uint32_t)NLEAF >> sel_bits, v, t);
+    HIP_TRY(ctx, hipGetLastError());
+  }
   ms->pending = !runs_only;
   ms->runs_ready = runs_only;
   ms->leaf_form = !runs_only;
@@ -2263,7 +2639,7 @@ int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   ctx->last_passes = passes;
   if (ctx->g_flags & CFRK_RUNS_ONLY) {
     if (ms->runs_ready) return cfrk_fail(ctx, CFRK_ERR_STATE, "a CFRK_RUNS_ONLY job takes one add");
-    if (passes != 1) return cfrk_fail(ctx, CFRK_ERR_STATE, "a CFRK_RUNS_ONLY job must fit device memory in one pass");
+    if (passes != 1) return cfrk_fail(ctx, CFRK_ERR_RUNS_REFUSED, "a CFRK_RUNS_ONLY job must fit device memory in one pass");
   }
   if (ms->pending && (rc = cfrk_msp_flush_to_table(ctx))) return rc;
   if (passes == 1) {
@@ -2293,7 +2669,7 @@ int cfrk_msp_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
     if ((rc = msp_count_tiles(ctx, ms, d_data, nN, 0, ntiles, 1.0, sel_bits, (uint32_t)pass, pass == 0))) {
       // a refusal after the first pass must not reach the caller's fallback (it would count
       // the finished passes twice)
-      if (pass > 0 && rc == CFRK_ERR_NOMEM) return cfrk_fail(ctx, CFRK_ERR_STATE, "out of device memory in pass %d of a multi-pass add", pass);
+      if (pass > 0 && (rc == CFRK_ERR_NOMEM || rc == CFRK_INTERNAL_FLOOD)) return cfrk_fail(ctx, CFRK_ERR_STATE, "out of device memory in pass %d of a multi-pass add", pass);
       return rc;
     }
   }
@@ -2368,6 +2744,8 @@ extern "C" int cfrk_debug_set_param(cfrk_ctx *ctx, int which, double value) {
 }
 extern "C" int cfrk_debug_set_flags(cfrk_ctx *ctx, uint32_t flags) {
   if (!ctx) return CFRK_ERR_ARG;
+  // (the timing ablations of msp.h exist in an ablation build only: in the product they are refused, not ignored)
+  if (flags & ~CFRK_DEBUG_KNOWN_BITS) return cfrk_fail(ctx, CFRK_ERR_ARG, "cfrk_debug_set_flags: unknown bits 0x%x", flags & ~CFRK_DEBUG_KNOWN_BITS);
   ctx->dbg_flags = flags;
   return CFRK_OK;
 }
@@ -2633,6 +3011,8 @@ extern "C" int cfrk_global_merge_runs_device(cfrk_ctx *ctx, const void *d_packed
   HIP_TRY(ctx, hipGetLastError());
   if (canon) hipLaunchKernelGGL((msp_p3_kernel<true, false>), dim3(lpp), dim3(P3_THREADS), 0, ctx->stream, k, P3_WEIGHTED, v, t);
   else hipLaunchKernelGGL((msp_p3_kernel<false, false>), dim3(lpp), dim3(P3_THREADS), 0, ctx->stream, k, P3_WEIGHTED, v, t);
+  HIP_TRY(ctx, hipGetLastError());
+  hipLaunchKernelGGL(msp_huge_leaves_kernel, dim3(((unsigned)lpp + 255u) / 256u), dim3(256), 0, ctx->stream, k, canon, 1, (uint32_t)lpp, v, t);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   ctx->ev_valid = true;

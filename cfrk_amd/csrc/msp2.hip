@@ -123,7 +123,7 @@ struct Roll2 {
 };
 
 // (record and table view by value: references pin the caller's copies to scratch memory)
-__device__ __noinline__ void spill_record2(uint4 ra, uint4 rb, int k, bool canon, TableView t) {
+__device__ __noinline__ void spill_record2(uint4 ra, uint4 rb, int k, bool canon, TableView t, uint32_t weight = 1u) {
   const Rec2 rec = {ra, rb};
   t.stats[ST_SPILLED] = 1;
   dev_count_event(&t.stats[ST_AUX0]);
@@ -132,7 +132,7 @@ __device__ __noinline__ void spill_record2(uint4 ra, uint4 rb, int k, bool canon
   r.init(rec, k);
   for (int j = 0; j < nk; ++j) {
     const u128 key = (canon && r.rc < r.fwd) ? r.rc : r.fwd;
-    table_add2(t, (uint64_t)key, (uint64_t)(key >> 64), 1u);
+    table_add2(t, (uint64_t)key, (uint64_t)(key >> 64), weight);
     r.next();
   }
 }
@@ -505,6 +505,7 @@ __global__ __launch_bounds__(Q2_THREADS) void msp2_p2_kernel(int groups_per_bin,
       uint64_t at = (leaf >> v.sel_bits) * (v.cap2c + 3 * v.cap2t) + ((cls == 3u) ? 0 : v.cap2c + cls * v.cap2t);
       if (v.exact) { cap = v.lcap[b1 * NSUB + sb]; at = v.lbase[b1 * NSUB + sb]; }
       if (dst < cap) v.rec2[at + dst] = rec;
+      else if (dst >= 0x80000000u) v.stats[ST_CWRAP] = 1;                 // a flood on its way to wrapping the 32-bit cursor (msp.hip)
       else if (v.exact) spill_record2(rec.a, rec.b, k, canon != 0, t);    // cannot happen: cap is the exact count
       else if (*(volatile uint64_t *)&v.stats[ST_L2OVF] == 0) {
         // too small by a little: park the record; by a lot: the host redoes Q2 with exact sizes
@@ -529,6 +530,10 @@ __device__ __forceinline__ uint32_t t2_slot(uint64_t lo, uint64_t hi) {
 constexpr uint32_t T2_DONE = 0x80000000u;
 constexpr int T2_TRIPS = 96;
 constexpr int T2_TRIPS_SPLIT = 24;
+// SAT: the count saturates at CFRK_COUNT_MAX (the merge of lists whose counts nothing bounds; the count word is the
+// slot state, so a wrapped value must never show: compare-and-swap).  The leaf kernel's own counts cannot overflow
+// (msp.hip: HUGE_LEAF).
+template <bool SAT = false>
 __device__ __forceinline__ void t2_step(ulonglong2 *keys, uint32_t *cnts, uint64_t lo, uint64_t hi,
                                         uint32_t add, uint32_t &h) {
   const bool p = (int32_t)h >= 0;
@@ -548,7 +553,17 @@ __device__ __forceinline__ void t2_step(ulonglong2 *keys, uint32_t *cnts, uint64
       won = 1u;
     }
   }
-  if (p && match) atomicAdd(&cnts[hh], add);
+  if (SAT) {
+    if (p && match) {
+      uint32_t cur = cst;
+      for (;;) {
+        const uint32_t want = (cur > CFRK_COUNT_MAX - add) ? CFRK_COUNT_MAX : cur + add;
+        const uint32_t old = atomicCAS(&cnts[hh], cur, want);
+        if (old == cur) break;
+        cur = old;
+      }
+    }
+  } else if (p && match) atomicAdd(&cnts[hh], add);
   // an empty slot lost to another lane, or a locked one, is read again
   const bool stay = match || empty || locked;
   const uint32_t nh = stay ? hh : ((hh + 1) & (T2 - 1));
@@ -722,6 +737,7 @@ __device__ __forceinline__ void r2_insert_loop(Rec2 *rtab, const Rec2 &rec, uint
 // mode & Q3_WEIGHTED: the complete streams hold DISTINCT runs with multiplicities (header = count << 6 |
 // n-1, what msp2_dedupe_export_kernel leaves behind): an owner counting the runs its ranks sent
 constexpr uint32_t Q3_WEIGHTED = 1u;
+constexpr uint64_t Q3_HUGE_LEAF = 1ull << 25, Q3_HUGE_LEAF_SENDER = 1ull << 19;   // (msp.hip: HUGE_LEAF)
 template <bool CANON, bool SHARED>
 __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, uint32_t mode, View2 v, TableView t) {
   __shared__ ulonglong2 keys[T2];
@@ -774,7 +790,7 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, uint32_t mod
                  v.exact ? (uint64_t)v.lcap[NCLS * leaf + cl] : (cl == 3 ? v.cap2c : v.cap2t));
     total += ns[cl];
   }
-  if (total == 0) return;
+  if (total - 1ull >= Q3_HUGE_LEAF - 1ull) return;    // nothing to count -- or a HUGE leaf: msp2_huge_leaves_kernel counts it
   for (int s = tid; s < T2; s += Q3_THREADS) cnts[s] = 0;
   {
     Rec2 z;
@@ -1184,6 +1200,36 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, uint32_t mod
   }
 }
 
+// HUGE leaves (msp.hip: HUGE_LEAF -- 2^25 records or more, a single-key flood): not counted in LDS, where a run's
+// 26-bit multiplicity or a 32-bit count could overflow, but k-mer by k-mer in the HBM table, whose adds saturate.
+// Launched behind the leaf kernel; 256 workgroups look at the leaves' sizes and normally find nothing.
+__global__ __launch_bounds__(256) void msp2_huge_leaves_kernel(int k, int canon, int weighted, uint32_t nl, View2 v, TableView t) {
+  __shared__ uint32_t nhuge, huge[256];
+  if (threadIdx.x == 0) nhuge = 0;
+  __syncthreads();
+  auto size_of = [&](uint32_t leaf, int cl) {
+    return min((uint64_t)v.cnt2[NCLS * leaf + cl], v.exact ? (uint64_t)v.lcap[NCLS * leaf + cl] : (cl == 3 ? v.cap2c : v.cap2t));
+  };
+  const uint32_t i0 = blockIdx.x * 256u + threadIdx.x;          // every thread looks at one leaf's sizes
+  if (i0 < nl) {
+    const uint32_t leaf = (i0 << v.sel_bits) | v.sel_val;
+    if (size_of(leaf, 0) + size_of(leaf, 1) + size_of(leaf, 2) + size_of(leaf, 3) >= Q3_HUGE_LEAF) huge[atomicAdd(&nhuge, 1u)] = i0;
+  }
+  __syncthreads();
+  for (uint32_t q = 0; q < nhuge; ++q) {
+    const uint32_t i = huge[q], leaf = (i << v.sel_bits) | v.sel_val;
+    const Rec2 *l0 = v.rec2 + (uint64_t)i * (v.cap2c + 3 * v.cap2t);
+    for (int cl = 0; cl < NCLS; ++cl) {
+      const Rec2 *src = v.exact ? v.rec2 + v.lbase[NCLS * leaf + cl] : (cl == 3 ? l0 : l0 + v.cap2c + (uint64_t)cl * v.cap2t);
+      const uint64_t n = size_of(leaf, cl);
+      for (uint64_t j = threadIdx.x; j < n; j += 256) {
+        const Rec2 r = src[j];
+        spill_record2(r.a, r.b, k, canon != 0, t, (weighted && cl == 3) ? (r.b.w >> 6) : 1u);
+      }
+    }
+  }
+}
+
 // exact layout of the second level from the demand the first attempt counted (see msp.hip)
 // bytes that are not a base (read terminators, N): one 64-bit sum (a batch that does not fit is looked
 // at before it is planned again: every such byte ends up to k k-mers)
@@ -1291,9 +1337,9 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_merge_kernel(const uint64_t *
     for (uint32_t i = tid; i < ((n + 63u) & ~63u); i += Q3_THREADS) {
       const bool valid = i < n;
       const uint64_t lo = valid ? in_lo[off + i] : 0ull, hi = valid ? in_hi[off + i] : 0ull;
-      const uint32_t c = valid ? in_cnt[off + i] : 0u;
+      const uint32_t c = valid ? min(in_cnt[off + i], CFRK_COUNT_MAX) : 0u;
       uint32_t h = t2_slot(lo, hi) | ((valid && c != 0u) ? 0u : T2_DONE);
-      for (int it = 0; it < T2_TRIPS && __ballot((int32_t)h >= 0); ++it) t2_step(keys, cnts, lo, hi, c, h);
+      for (int it = 0; it < T2_TRIPS && __ballot((int32_t)h >= 0); ++it) t2_step<true>(keys, cnts, lo, hi, c, h);
       if ((int32_t)h >= 0) {
         t.stats[ST_SPILLED] = 1;
         dev_count_event(&t.stats[ST_AUX1]);
@@ -1363,9 +1409,11 @@ __global__ __launch_bounds__(DX2_THREADS) void msp2_dedupe_export_kernel(int k, 
     z.b.w = R2_EMPTY;
     for (int s = tid; s < RX; s += DX2_THREADS) rtab[s] = z;
   }
-  if (tid == 0) { rt_fail = (v.dbg & CFRK_DEBUG_FORCE_RT_OVERFLOW) ? 1u : 0u; noted = 0u; }
+  // (a leaf of 2^19 complete runs or more leaves undeduplicated: msp.hip, HUGE_LEAF)
+  const bool too_many = (uint64_t)n1 >= Q3_HUGE_LEAF_SENDER;
+  if (tid == 0) { rt_fail = ((v.dbg & CFRK_DEBUG_FORCE_RT_OVERFLOW) || too_many) ? 1u : 0u; noted = 0u; }
   __syncthreads();
-  for (uint32_t r0 = 0; r0 < n1; r0 += (uint32_t)DX2_INFL * DX2_THREADS) {
+  for (uint32_t r0 = 0; r0 < n1 && !too_many; r0 += (uint32_t)DX2_INFL * DX2_THREADS) {
     Rec2 recs[DX2_INFL];
 #pragma unroll
     for (int u = 0; u < DX2_INFL; ++u) {
@@ -1752,6 +1800,7 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
       uint64_t stc[ST_NWORDS];
       HIP_TRY(ctx, hipMemcpyAsync(stc, ctx->g_stats, sizeof stc, hipMemcpyDeviceToHost, ctx->stream));
       HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      if (stc[ST_CWRAP]) return CFRK_INTERNAL_FLOOD;                     // (msp.hip: nothing of this pass has been counted yet)
       if (stc[ST_L1OVF] || stc[ST_L2OVF]) return CFRK_ERR_SMALL_BUF;   // (no error text: the caller starts over, the old way)
       parked1 = stc[ST_OVFN1]; parked2 = stc[ST_OVFN];
       settled = true;
@@ -1768,6 +1817,7 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
     uint64_t st[ST_NWORDS];
     HIP_TRY(ctx, hipMemcpyAsync(st, ctx->g_stats, sizeof st, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (st[ST_CWRAP]) return CFRK_INTERNAL_FLOOD;
     if (st[ST_L1OVF]) {
       // exact level-1 layout; Q2 ran on an incomplete level 1 and is redone as well
       if ((rc = cfrk_pool_get(ctx, BUF_MSP_LAYOUT1, nreg * (sizeof(uint64_t) + sizeof(uint32_t)), &p))) return rc;
@@ -1863,6 +1913,8 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
       if (canon) hipLaunchKernelGGL((msp2_p3_kernel<true, false>), g3, b3, 0, ctx->stream, k, 0u, v, t);
       else hipLaunchKernelGGL((msp2_p3_kernel<false, false>), g3, b3, 0, ctx->stream, k, 0u, v, t);
     }
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(msp2_huge_leaves_kernel, dim3((((unsigned)NLEAF >> sel_bits) + 255u) / 256u), dim3(256), 0, ctx->stream, k, canon, 0, (uint32_t)NLEAF >> sel_bits, v, t);
   }
   HIP_TRY(ctx, hipGetLastError());
   ms->view.out_keys = v.out_lo; ms->view.out_hi = v.out_hi; ms->view.out_cnt = v.out_cnt;
@@ -2015,6 +2067,8 @@ int cfrk_msp2_merge_runs(cfrk_ctx *ctx, const void *d_packed, const uint64_t *re
       if (canon) hipLaunchKernelGGL((msp2_p3_kernel<true, false>), g3, b3, 0, ctx->stream, k, Q3_WEIGHTED, v, t);
       else hipLaunchKernelGGL((msp2_p3_kernel<false, false>), g3, b3, 0, ctx->stream, k, Q3_WEIGHTED, v, t);
     }
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(msp2_huge_leaves_kernel, dim3(((unsigned)lpp + 255u) / 256u), dim3(256), 0, ctx->stream, k, canon, 1, (uint32_t)lpp, v, t);
   }
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
@@ -2091,7 +2145,7 @@ int cfrk_msp2_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   if (groups == 0) return cfrk_fail(ctx, CFRK_ERR_NOMEM, "partitioned path does not fit device memory");
   const int passes = groups;
   ctx->last_passes = passes;
-  if (runs_only && passes != 1) return cfrk_fail(ctx, CFRK_ERR_STATE, "a CFRK_RUNS_ONLY job must fit device memory in one pass");
+  if (runs_only && passes != 1) return cfrk_fail(ctx, CFRK_ERR_RUNS_REFUSED, "a CFRK_RUNS_ONLY job must fit device memory in one pass");
   if (ms->pending && (rc = cfrk_msp_flush_to_table(ctx))) return rc;
   if (passes == 1 && lean) return msp2_count_tiles(ctx, ms, d_data, nN, 0, ntiles, 1.0, 0, 0, true, true);
   if (passes == 1) {
@@ -2115,7 +2169,7 @@ int cfrk_msp2_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
     if ((rc = msp2_count_tiles(ctx, ms, d_data, nN, 0, ntiles, 1.0, sel_bits, (uint32_t)pass, pass == 0, lean))) {
       // a refusal after the first pass must not reach the caller's fallback (it would count
       // the finished passes twice)
-      if (pass > 0 && rc == CFRK_ERR_NOMEM) return cfrk_fail(ctx, CFRK_ERR_STATE, "out of device memory in pass %d of a multi-pass add", pass);
+      if (pass > 0 && (rc == CFRK_ERR_NOMEM || rc == CFRK_INTERNAL_FLOOD)) return cfrk_fail(ctx, CFRK_ERR_STATE, "out of device memory in pass %d of a multi-pass add", pass);
       return rc;
     }
   }

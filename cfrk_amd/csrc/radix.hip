@@ -1,22 +1,29 @@
-// radix.hip -- global k-mer counting for k <= 15 on gfx950: keys fit 30 bits, so instead of
+// radix.hip -- global k-mer counting for k <= 16 on gfx950: keys fit 32 bits, so instead of
 // hashing the key is radix-partitioned and counted by DIRECT ADDRESS in LDS.
 //
 //   keys are first scrambled by one odd multiply mod 4^k (a bijection) -- canonical k-mers are skewed low and
 //   real genomes are not uniform, the product's top bits are;
 //   RX1  extract (canonical) k-mers (2 x dwordx4 per lane, 2-bit packing in registers), counting
-//        sort a tile of 8192 keys by the top b1 bits in LDS (one returning LDS atomic per key), one HBM
+//        sort a tile of 8192 keys by the top b1 = 8 bits in LDS (one returning LDS atomic per key), one HBM
 //        atomic per bin per tile;
-//   RX2  split every region by the next b2 bits the same way;
-//   RX3  persistent workgroups walk the leaves: an LDS array of 2^idx counters, ds_add_u32 by the low idx
-//        bits, then the non-zero counters are un-scrambled and appended to the result list through an LDS
-//        buffer (one cursor atomic per ~10 leaves).
-//   8 <= k <= 15: b1 = 8, idx = min(13, 2k - 11), b2 = 2k - 8 - idx (3..9): >= 2048 leaves.
+//   RX2  split every region by the next b2 bits the same way (leaf streams written in padded groups of eight);
+//   RX3  persistent workgroups walk the leaves: an LDS array of counters addressed by the low idx bits, then the
+//        non-zero counters are un-scrambled and appended to the result list through an LDS buffer (one cursor
+//        atomic per ~10 leaves).
+//   Leaf shape, chosen on the HOST from k and the batch size (cfrk_radix_count):
+//     8 <= k <= 12: idx = 2k - 11 (5..13) counters of 32 bits, replicated when there are fewer than 2^13;
+//     13 <= k <= 15: idx = 14 -- 2^14 keys per leaf as PACKED 16-bit counters in 2^13 words -- while a leaf is
+//        expected to stay well under 2^16 elements (exact below that: no half can carry; a leaf that turns out
+//        larger is counted in two passes over its stream with 32-bit counters), else idx = 13, 32-bit counters;
+//     k = 16 (round 5): idx = 15, packed 16-bit counters in 2^14 words (64 KB of LDS, 512 threads), b2 = 9 --
+//        for batches whose leaves stay under 2^16 elements (~4e9 bases); larger ones take msp.hip;
+//     b2 = 2k - 8 - idx (3..9): >= 2048 leaves.
 //   k <= 7 (at most 16384 keys): no partition at all, every workgroup counts into a replicated
 //   LDS table and adds it to a dense HBM array once.
 //
 // HBM never sees the bits a key's region already implies: level 1 stores the 2k-8 bits below the
-// bin as a 16-bit plane plus (2k-8 >= 16) an 8-bit plane -- 3 bytes per k-mer at k = 15 instead of
-// 4 --, the leaves store the low idx <= 13 bits as 16-bit words; everything moves in groups of eight
+// bin as a 16-bit plane plus (2k-8 >= 16) an 8-bit plane -- 3 bytes per k-mer at k = 15 and 16 instead of
+// 4 --, the leaves store the low idx <= 15 bits as 16-bit words; everything moves in groups of eight
 // elements (16- and 8-byte vectors; segments are padded, see RX_PAD); every occurrence is one LDS atomic.
 // Same semantics and the same result-list form as msp.hip (which covers 16 <= k <= 32); a level that
 // overflows its regions is laid out again with exact sizes.
@@ -34,8 +41,7 @@ constexpr int RX_NREG = 32;               // sub-regions (cursors) per level-1 b
                                           // the returning atomics on one cursor serialise (see msp_dev.h: NXG)
 constexpr int RX1_THREADS = 512, RX1_PER = 16, RX1_KEYS = RX1_THREADS * RX1_PER;
 constexpr int RX2_THREADS = 512, RX2_PER = 16, RX2_KEYS = RX2_THREADS * RX2_PER;   // (32 per thread: 11 % pads instead of 22 %, but 114 VGPRs and two workgroups per CU: RX2 2.33 ms against 2.1)
-constexpr int RX3_THREADS = 256;
-constexpr int RX_IDX_MAX = 13;
+constexpr int RX_IDX_MAX = 13;            // 2^13 32-bit counter words per leaf workgroup (k <= 15); k = 16: 2^14
 
 struct RxView {
   // level 1: the 2k - b1 bits of a key below its bin, low 16 in k1lo, the rest (if any: hi8) in k1hi
@@ -103,7 +109,10 @@ __device__ __forceinline__ void rx_load_chunk16(const int8_t *__restrict__ data,
   }
 }
 
-template <bool CANON>
+// K16: k = 16 -- a key fills its 32-bit register, so a window start that is no k-mer cannot be told by a "key" whose
+// bin is 256 + lane; its bin is worked out from the validity mask again where it is needed (three instructions
+// per key more; an instantiation of its own so that k <= 15 does not pay)
+template <bool CANON, bool K16>
 __global__ __launch_bounds__(RX1_THREADS) void rx1_kernel(const int8_t *__restrict__ data, int64_t nN,
                                                           RxView v, TableView t) {
   __shared__ uint32_t sorted[RX1_KEYS + 64];                   // + 64 spare slots for the dummy bins
@@ -142,21 +151,23 @@ __global__ __launch_bounds__(RX1_THREADS) void rx1_kernel(const int8_t *__restri
   const uint32_t mul = v.mul, kmask = v.kmask;
 
   uint32_t keys[RX1_PER], rk2[RX1_PER / 2];                   // (two ranks per register)
-  const uint32_t inval = (256u + (uint32_t)lane) << sh1;      // "key" of this lane's dummy bin (sh1 <= 22: fits)
+  const uint32_t dummy = 256u + (uint32_t)lane;               // this lane's dummy bin
+  const uint32_t inval = K16 ? 0u : (dummy << sh1);           // ... and its "key" (sh1 <= 22: fits)
+  auto bin_of = [&](int i) { return (!K16 || (M << i) < vlim) ? (keys[i] >> sh1) : dummy; };
 #pragma unroll
   for (int i = 0; i < RX1_PER; ++i) {
     const uint32_t X = i ? __builtin_amdgcn_alignbit(D[0], D[1], 32 - 2 * i) : D[0];
-    uint32_t key = X >> fsh;
+    uint32_t key = K16 ? X : (X >> fsh);
     if (CANON) {
       const int o2 = 64 - 2 * i, q2 = o2 >> 5, r2 = o2 & 31;
       const uint32_t Y = r2 ? __builtin_amdgcn_alignbit(R[q2], R[q2 + 1], 32 - r2) : R[q2];
-      key = min(key, Y & kmask);
+      key = min(key, K16 ? Y : (Y & kmask));
     }
     const uint32_t Wm = M << i;
-    key = (key * mul) & kmask;
-    key = (Wm < vlim) ? key : inval;
+    key = K16 ? key * mul : ((key * mul) & kmask);
+    if (!K16) key = (Wm < vlim) ? key : inval;
     keys[i] = key;
-    const uint32_t r_ = atomicAdd(&hist[key >> sh1], 1u);
+    const uint32_t r_ = atomicAdd(&hist[bin_of(i)], 1u);
     rk2[i >> 1] = (i & 1) ? (rk2[i >> 1] | (r_ << 16)) : r_;
   }
   lds_barrier();
@@ -169,7 +180,7 @@ __global__ __launch_bounds__(RX1_THREADS) void rx1_kernel(const int8_t *__restri
 #pragma unroll
   for (int i = 0; i < RX1_PER; ++i) {
     const uint32_t r_ = (i & 1) ? (rk2[i >> 1] >> 16) : (rk2[i >> 1] & 0xFFFFu);
-    sorted[min(loff[keys[i] >> sh1] + r_, (uint32_t)RX1_KEYS + 63u)] = keys[i];
+    sorted[min(loff[bin_of(i)] + r_, (uint32_t)RX1_KEYS + 63u)] = keys[i];
   }
   if (tid < 256) {
     const uint32_t reg = rx_reg(v, tid, subreg);
@@ -315,7 +326,10 @@ __global__ __launch_bounds__(RX2_THREADS) void rx2_kernel(int tiles_per_sub, RxV
       const uint64_t cap = v.exact ? (uint64_t)v.lcap[leaf] : v.cap2;
       at = (v.exact ? v.lbase[leaf] : leaf * v.cap2) + my_base;
       const uint64_t room = cap > (uint64_t)my_base ? cap - my_base : 0;
-      if ((uint64_t)cp > room) v.stats[ST_L2OVF] = 1;     // the cursor keeps counting: the host redoes RX2 with exact sizes
+      if ((uint64_t)cp > room) {
+        v.stats[ST_L2OVF] = 1;                              // the cursor keeps counting: the host redoes RX2 with exact sizes
+        if (my_base >= 0x80000000u) v.stats[ST_CWRAP] = 1;  // ... unless a single-key flood is about to wrap it: counted through the HBM table
+      }
       nv = (uint32_t)min((uint64_t)cp, room) / RX_GROUP;
     }
     const uint32_t src = loff[tid] / RX_GROUP;
@@ -365,8 +379,11 @@ __global__ __launch_bounds__(1024) void rx_layout_kernel(const uint32_t *__restr
 // flush also writes the list in whole coalesced lines instead of one 8 + 4 byte pair per thread.
 constexpr int RX3_INFL = 6;            // 16-byte loads in flight per thread (12 288 elements per round of the workgroup)
 constexpr int RX3_OB = 704;            // buffered result entries (5.5 KB: four workgroups still fit a CU's LDS)
+// NCLOG = log2 of the 32-bit counter words: 13 with 256 threads (32 KB: four workgroups per CU) for k <= 15, 14 with
+// 512 threads (64 KB: two per CU, the same sixteen waves) for k = 16, whose leaves hold 2^15 keys as packed counters
+template <int NCLOG, int RX3_THREADS>
 __global__ __launch_bounds__(RX3_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void rx3_kernel(RxView v, uint32_t nleaf) {
-  constexpr int NC = 1 << RX_IDX_MAX;            // 32-bit counter words (2^13)
+  constexpr int NC = 1 << NCLOG;                 // 32-bit counter words
   __shared__ uint4 cnt4[(NC + 64) / 4];          // + one spare counter per lane for the pads
   __shared__ uint32_t ob_key[RX3_OB], ob_cnt[RX3_OB];
   __shared__ unsigned long long wg_base;
@@ -381,8 +398,8 @@ __global__ __launch_bounds__(RX3_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
   // long segments, half the pads) in RX2.
   // idx = 13: one 32-bit counter per key.  idx < 13 (small k): 2^idx counters replicated 2^rlog times -- or all 256
   // threads would serialise on a handful of LDS words (nidx << rlog = 2^13 for every k this path serves: idx >= 5).
-  const bool wide = v.idx > RX_IDX_MAX;
-  const int rlog = wide ? 0 : min(RX_IDX_MAX - v.idx, 8);
+  const bool wide = v.idx > NCLOG;
+  const int rlog = wide ? 0 : min(NCLOG - v.idx, 8);
   const uint32_t rmask = (1u << rlog) - 1u, rep = (uint32_t)tid & rmask;
   const uint32_t spare = (uint32_t)NC + (uint32_t)lane;
   constexpr int NQ = NC / 4 / RX3_THREADS;       // uint4 groups of counter words per thread (8)
@@ -418,7 +435,7 @@ __global__ __launch_bounds__(RX3_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
         if (mode == 0) atomicAdd(&cnt[min(key, spare)], 1u);
         else if (mode == 1) atomicAdd(&cnt[key < nidx ? ((key << rlog) | rep) : spare], 1u);
         else if (mode == 2) atomicAdd(&cnt[min(key >> 1, spare)], (key & 1u) ? 0x10000u : 1u);
-        else atomicAdd(&cnt[(key >> RX_IDX_MAX) == hsel ? (key & (uint32_t)(NC - 1)) : spare], 1u);
+        else atomicAdd(&cnt[(key >> NCLOG) == hsel ? (key & (uint32_t)(NC - 1)) : spare], 1u);
       }
     }
   };
@@ -500,7 +517,7 @@ __global__ __launch_bounds__(RX3_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
         dbase = wg_base;
       }
       uint32_t d = (direct ? 0u : fill) + base + incl - mine;
-      const uint32_t leaf_hi = (leaf << v.idx) | (mode == 3 ? pass << RX_IDX_MAX : 0u);
+      const uint32_t leaf_hi = (leaf << v.idx) | (mode == 3 ? pass << NCLOG : 0u);
       auto emit = [&](uint32_t s, uint32_t c) {
         if (direct) {
           if (dbase + d < v.out_cap) { v.out_keys[dbase + d] = (uint64_t)rx_unmix(v, leaf_hi | s); v.out_cnt[dbase + d] = c; }
@@ -616,6 +633,18 @@ bool cfrk_radix_usable(const cfrk_ctx *ctx) {
   return !ctx->g_two && ctx->g_k >= 1 && ctx->g_k <= 15 && !(ctx->g_flags & CFRK_FORCE_HASH);
 }
 
+// k = 16: msp.hip's window is four k-mers there (2.2 x the step of k = 31 on the same reads, profiles/r05/ksweep_*);
+// the radix path takes the batch while its 2^17 leaves of 2^15 keys stay well under 2^16 elements each (packed 16-bit
+// counters), i.e. up to ~4e9 bases per add.  Not for CFRK_RUNS_ONLY jobs (the runs exchange is msp.hip's).
+constexpr int RX16_IDX = 15, RX16_B2 = 9;
+static double rx_pad2(int b2) { return 1.0 + 3.5 * (double)(1u << b2) / (double)RX2_KEYS; }
+bool cfrk_radix_prefers(const cfrk_ctx *ctx, int64_t nN) {
+  if (cfrk_radix_usable(ctx)) return true;
+  if (ctx->g_two || ctx->g_k != 16 || (ctx->g_flags & (CFRK_FORCE_HASH | CFRK_RUNS_ONLY)) || (ctx->dbg_flags & CFRK_DEBUG_NO_RADIX16)) return false;
+  const double per_leaf = (double)nN / (double)(1u << (8 + RX16_B2)) * rx_pad2(RX16_B2);
+  return per_leaf * 1.5 <= 49152.0;
+}
+
 int cfrk_radix_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   cfrk_msp *ms = cfrk_msp_get(ctx);
   if (!ms) return cfrk_fail(ctx, CFRK_ERR_NOMEM, "host allocation failed");
@@ -651,10 +680,18 @@ int cfrk_radix_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
     ms->list_n_valid = false;
     return CFRK_OK;
   }
-  // at least 2048 leaves (one workgroup each in RX3), at most 2^13 counters per leaf
+  // at least 2048 leaves (one workgroup each in RX3), at most 2^13 counter words per leaf (k = 16: 2^14)
   v.b1 = 8;
-  // (k >= 13: 2^14 keys per leaf, counted as packed 16-bit counters -- rx3_kernel)
-  v.idx = (2 * k - 11 > RX_IDX_MAX) ? RX_IDX_MAX + 1 : std::max(0, 2 * k - 11);
+  if (k == 16) v.idx = RX16_IDX;
+  else if (2 * k - 11 > RX_IDX_MAX) {
+    // k >= 13: 2^14 keys per leaf as packed 16-bit counters (half the leaves, half RX2's fan-out) pay while a leaf
+    // stays under 2^16 elements; a leaf above that is counted in two passes over its stream, so a batch whose MEAN
+    // leaf comes near it (k = 13 from ~2e8 bases, k = 14 from ~8e8, k = 15 from ~3e9) keeps 2^13 keys per leaf and
+    // 32-bit counters instead (measured at configs[1]'s size: profiles/r05/ksweep_*)
+    const int b2w = 2 * k - v.b1 - (RX_IDX_MAX + 1);
+    const double per_leaf = (double)nN / (double)(1ull << (v.b1 + b2w)) * rx_pad2(b2w);
+    v.idx = (per_leaf * 1.5 <= 49152.0) ? RX_IDX_MAX + 1 : RX_IDX_MAX;
+  } else v.idx = std::max(0, 2 * k - 11);
   v.b2 = 2 * k - v.b1 - v.idx;
   v.kmask = (uint32_t)((1ull << (2 * k)) - 1ull);
   v.mul = 0x9E3779B1u;
@@ -663,7 +700,7 @@ int cfrk_radix_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   const uint64_t nb1 = 1ull << v.b1, nleaf = 1ull << (v.b1 + v.b2);
   // (a tile of RX2 rounds each of its <= 512 segments up to eight elements, ~3.5 pads each; level-1 regions start on
   //  multiples of 16 elements, leaf streams on multiples of 8)
-  const double pad2 = 1.0 + 3.5 * (double)(1u << v.b2) / (double)RX2_KEYS;
+  const double pad2 = rx_pad2(v.b2);
   const uint64_t cap1 = ((uint64_t)((double)nN / (double)(nb1 * RX_NREG) * 1.3) + 4096 + 15) & ~15ull;
   const uint64_t cap2 = ((uint64_t)((double)nN / (double)nleaf * 1.5 * pad2) + 1024 + 7) & ~7ull;
   // the 8-bit plane also exists when the level's keys fill the 16-bit plane exactly (k = 12): a pad must not look like a key
@@ -709,8 +746,12 @@ int cfrk_radix_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   for (int attempt = 0; attempt < 4 && !settled; ++attempt) {
     if (run_rx1) {
       HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_L1OVF, 0, sizeof(uint64_t), ctx->stream));
-      if (canon) hipLaunchKernelGGL((rx1_kernel<true>), dim3((unsigned)tiles), dim3(RX1_THREADS), 0, ctx->stream, d_data, nN, v, t);
-      else hipLaunchKernelGGL((rx1_kernel<false>), dim3((unsigned)tiles), dim3(RX1_THREADS), 0, ctx->stream, d_data, nN, v, t);
+      const dim3 g1((unsigned)tiles), b1d(RX1_THREADS);
+      if (k == 16) {
+        if (canon) hipLaunchKernelGGL((rx1_kernel<true, true>), g1, b1d, 0, ctx->stream, d_data, nN, v, t);
+        else hipLaunchKernelGGL((rx1_kernel<false, true>), g1, b1d, 0, ctx->stream, d_data, nN, v, t);
+      } else if (canon) hipLaunchKernelGGL((rx1_kernel<true, false>), g1, b1d, 0, ctx->stream, d_data, nN, v, t);
+      else hipLaunchKernelGGL((rx1_kernel<false, false>), g1, b1d, 0, ctx->stream, d_data, nN, v, t);
       HIP_TRY(ctx, hipGetLastError());
     }
     const int64_t g2 = bins_per_group * RX_NXG * RX_NREG * tiles_per_sub;
@@ -722,6 +763,7 @@ int cfrk_radix_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
     uint64_t st[ST_NWORDS];
     HIP_TRY(ctx, hipMemcpyAsync(st, ctx->g_stats, sizeof st, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (st[ST_CWRAP]) return CFRK_INTERNAL_FLOOD;      // (nothing of this add has been counted yet)
     if (st[ST_L1OVF]) {
       if ((rc = cfrk_pool_get(ctx, BUF_MSP_LAYOUT1, nreg * (sizeof(uint64_t) + sizeof(uint32_t)), &p))) return rc;
       uint64_t *rbase = (uint64_t *)p;
@@ -754,7 +796,8 @@ int cfrk_radix_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   }
   if (!settled) return cfrk_fail(ctx, CFRK_ERR_STATE, "the key regions did not settle after an exact layout");
   // persistent: four workgroups (32 KB of counters each) per CU walk the leaves
-  hipLaunchKernelGGL(rx3_kernel, dim3((unsigned)std::min<uint64_t>(nleaf, (uint64_t)std::max(1, ctx->num_cus) * 4)), dim3(RX3_THREADS), 0, ctx->stream, v, (uint32_t)nleaf);
+  if (k == 16) hipLaunchKernelGGL((rx3_kernel<14, 512>), dim3((unsigned)std::min<uint64_t>(nleaf, (uint64_t)std::max(1, ctx->num_cus) * 2)), dim3(512), 0, ctx->stream, v, (uint32_t)nleaf);
+  else hipLaunchKernelGGL((rx3_kernel<RX_IDX_MAX, 256>), dim3((unsigned)std::min<uint64_t>(nleaf, (uint64_t)std::max(1, ctx->num_cus) * 4)), dim3(256), 0, ctx->stream, v, (uint32_t)nleaf);
   HIP_TRY(ctx, hipGetLastError());
   // the result list lives where msp.hip keeps its own: digest / export / fold are shared
   ms->view.out_keys = v.out_keys; ms->view.out_cnt = v.out_cnt; ms->view.out_cap = v.out_cap;

@@ -18,6 +18,33 @@ struct TableView {
   int shift;  // 64 - log2(cap)
 };
 
+// Counts are 32-bit and SATURATE at CFRK_COUNT_MAX = 2^32 - 2 (the reference's rows are `int`,
+// /root/reference/src/tipos.h:28, and simply wrap).  sat_add: a returning add; the one add in 2^32 that carries
+// the word past the maximum (old > MAX - add) puts it back to MAX and raises ST_SAT.  Between its wrapped add and its
+// exchange other adds may land on the small wrapped value: they are overwritten by the exchange, and any add after
+// the LAST exchange finds old = MAX and exchanges again -- the word ends at MAX whatever the order.  (One-word table
+// only: its count word is not the slot state, so the transient wrapped value harms nobody.)
+__device__ __forceinline__ void sat_add(uint32_t *cnt, uint32_t add, uint64_t *stats) {
+  const uint32_t old = atomicAdd(cnt, add);
+  if (old > CFRK_COUNT_MAX - add) {
+    atomicExch(cnt, CFRK_COUNT_MAX);
+    stats[ST_SAT] = 1;
+  }
+}
+// ... where the count word is also the slot state (two-word table: 0 = empty, 0xFFFFFFFF = locked) a wrapped value
+// must never be visible: compare-and-swap from the value just read
+__device__ __forceinline__ void sat_add_cas(uint32_t *cnt, uint32_t cur, uint32_t add, uint64_t *stats) {
+  for (;;) {
+    const bool over = cur > CFRK_COUNT_MAX - add;
+    const uint32_t want = over ? CFRK_COUNT_MAX : cur + add;
+    const uint32_t old = atomicCAS(cnt, cur, want);
+    if (old == cur) { if (over) stats[ST_SAT] = 1; return; }
+    cur = old;                                       // (never 0 or LOCKED again: the slot holds this key)
+  }
+}
+// the k = 32 all-T forward key lives in a 64-bit side word (ST_ONES): clamped where it is read
+__device__ __forceinline__ uint32_t sat_ones(uint64_t ones) { return ones > (uint64_t)CFRK_COUNT_MAX ? CFRK_COUNT_MAX : (uint32_t)ones; }
+
 __device__ __forceinline__ void table_add1(const TableView &t, uint64_t key, uint32_t add) {
   if (key == CFRK_EMPTY_KEY) {
     atomicAdd((unsigned long long *)&t.stats[ST_ONES], (unsigned long long)add);
@@ -32,7 +59,7 @@ __device__ __forceinline__ void table_add1(const TableView &t, uint64_t key, uin
       if (cur == CFRK_EMPTY_KEY) cur = key;
     }
     if (cur == key) {
-      atomicAdd(&t.cnt[h], add);
+      sat_add(&t.cnt[h], add, t.stats);
       return;
     }
     h = (h + 1) & t.mask;
@@ -43,6 +70,7 @@ __device__ __forceinline__ void table_add1(const TableView &t, uint64_t key, uin
 __device__ __forceinline__ void table_add2(const TableView &t, uint64_t lo, uint64_t hi, uint32_t add) {
   uint64_t h = dev_mix64(lo ^ dev_mix64(hi)) >> t.shift;
   uint32_t probe = 0, spins = 0;
+  if (add > CFRK_COUNT_MAX) add = CFRK_COUNT_MAX;    // (a published count is never the LOCKED pattern)
   while (probe < CFRK_MAX_PROBE && spins < (1u << 24)) {
     uint32_t c = ld_agent(&t.cnt[h]);
     if (c == 0) {
@@ -58,10 +86,16 @@ __device__ __forceinline__ void table_add2(const TableView &t, uint64_t lo, uint
       continue;  // somebody else took the slot: look at it again
     }
     if (c == LOCKED) { ++spins; continue; }
+    // the count word vouches for the key words: they are read after it (pairs with the claimer's release)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     const uint64_t klo = ld_agent(&t.lo[h]);
     const uint64_t khi = ld_agent(&t.hi[h]);
     if (klo == lo && khi == hi) {
-      atomicAdd(&t.cnt[h], add);
+      // in the lower half of the range the plain add is safe (2^31 adds of one cannot land on one word between this
+      // lane's read of c and its add: same-address atomics take ~5 ns each); above it, or with a weight of its own
+      // (merges), compare-and-swap
+      if (add == 1u && c < 0x80000000u) atomicAdd(&t.cnt[h], 1u);
+      else sat_add_cas(&t.cnt[h], c, add, t.stats);
       return;
     }
     h = (h + 1) & t.mask;

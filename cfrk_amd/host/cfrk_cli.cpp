@@ -26,6 +26,10 @@
 //                    (16 <= k <= 64) the reads are range-partitioned over the N devices, every device
 //                    partitions and deduplicates its shard, and the owner of a leaf counts it (the
 //                    runs exchange of cfrk_abi.h, staged through host memory here)
+//   --timing         one line on stderr, `cfrk-timing {json}`: seconds spent parsing the FASTA, in the counting calls
+//                    (H2D copy + kernels), in the export (device sort + D2H) and in formatting + writing the output --
+//                    the wall-clock breakdown the reference has as commented-out printf()s (src/main.cu:259-268,303-305)
+//   --parse-threads N  host threads of the FASTA parser (default min(hardware threads, 16))
 //   --batch N        the Swift/T workflow's loop (swift/cfrk.swf:15-20) in one process: for i < N
 //                    count <dataset_prefix>_<i>.fasta into <out_prefix>_<i>.cfrk
 // Chunk pipeline: every device runs two contexts (two HIP streams), each on a host thread of its
@@ -39,6 +43,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <string>
@@ -53,9 +58,18 @@ namespace {
 struct Options {
   int k = 0, threads = 12;
   long chunk_size = 8192;
-  bool all_chunks = false, native = false, global = false, canonical = false, same_device = false, binary = false;
+  bool all_chunks = false, native = false, global = false, canonical = false, same_device = false, binary = false, timing = false;
   int device = 0, gpus = 1;
 };
+
+// --timing: wall-clock seconds by phase (one file; with --batch the last file's)
+struct Timing {
+  double parse = 0, add_call = 0, finish_wait = 0, export_ = 0, format = 0, write = 0, per_read = 0, total = 0;
+  float count_kernels_ms = 0;
+  int64_t fasta_bytes = 0, nN = 0, nS = 0;
+  uint64_t entries = 0, out_bytes = 0;
+} g_timing;
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 struct Worker {            // one context (= one HIP stream + buffer pool) on one device
   cfrk_ctx *ctx = nullptr;
@@ -162,14 +176,18 @@ int run_per_read(const Options &o, const cfrk_batch &batch, std::vector<Worker> 
 void write_global(const Options &o, const uint64_t *lo, const uint64_t *hi, const uint32_t *cnt, uint64_t n, FILE *out) {
   const uint64_t *hi2 = (o.k > 32) ? hi : nullptr;
   std::string buf;
+  const double t0 = now_s();
   if (o.binary) {
     buf.resize(cfrk_host_write_binary(o.k, o.canonical ? CFRK_BIN_CANONICAL : 0, lo, hi2, cnt, n, nullptr, 0));
     cfrk_host_write_binary(o.k, o.canonical ? CFRK_BIN_CANONICAL : 0, lo, hi2, cnt, n, &buf[0], buf.size());
   } else {
-    buf.resize(cfrk_host_format_sparse2(lo, hi2, cnt, n, nullptr, 0));
-    cfrk_host_format_sparse2(lo, hi2, cnt, n, &buf[0], buf.size());
+    buf.resize(cfrk_host_format_sparse_mt(lo, hi2, cnt, n, nullptr, 0, o.threads));
+    cfrk_host_format_sparse_mt(lo, hi2, cnt, n, &buf[0], buf.size(), o.threads);
   }
+  const double t1 = now_s();
   fwrite(buf.data(), 1, buf.size(), out);
+  fflush(out);
+  g_timing.format = t1 - t0; g_timing.write = now_s() - t1; g_timing.entries = n; g_timing.out_bytes = buf.size();
 }
 
 int run_global(const Options &o, const cfrk_batch &batch, Worker &w, FILE *out) {
@@ -181,12 +199,21 @@ int run_global(const Options &o, const cfrk_batch &batch, Worker &w, FILE *out) 
   if (hint < (1ull << 20)) hint = 1ull << 20;
   if (hint > (1ull << 31)) hint = 1ull << 31;
   if ((rc = cfrk_global_begin(ctx, o.k, o.canonical ? CFRK_CANONICAL : 0, hint))) return die(ctx, rc, "cfrk_global_begin");
+  const double t0 = now_s();
   if ((rc = cfrk_global_add(ctx, batch.data, batch.start, batch.length, batch.nN, batch.nS))) return die(ctx, rc, "cfrk_global_add");
+  const double t1 = now_s();
   uint64_t n = 0;
-  if ((rc = cfrk_global_finish(ctx, &n))) return die(ctx, rc, "cfrk_global_finish");
+  rc = cfrk_global_finish(ctx, &n);
+  // (counts are 32-bit and saturate: the result is complete, the user is told)
+  if (rc == CFRK_ERR_COUNT_OVERFLOW) fprintf(stderr, "cfrk: warning: %s\n", cfrk_last_error(ctx));
+  else if (rc) return die(ctx, rc, "cfrk_global_finish");
+  const double t2 = now_s();
+  cfrk_global_last_add_ms(ctx, &g_timing.count_kernels_ms);
   std::vector<uint64_t> keys(n), hi(n);
   std::vector<uint32_t> cnt(n);
-  if ((rc = cfrk_global_export(ctx, keys.data(), hi.data(), cnt.data(), n, &n))) return die(ctx, rc, "cfrk_global_export");
+  rc = cfrk_global_export(ctx, keys.data(), hi.data(), cnt.data(), n, &n);
+  if (rc && rc != CFRK_ERR_COUNT_OVERFLOW) return die(ctx, rc, "cfrk_global_export");
+  g_timing.add_call = t1 - t0; g_timing.finish_wait = t2 - t1; g_timing.export_ = now_s() - t2;
   write_global(o, keys.data(), hi.data(), cnt.data(), n, out);
   return 0;
 }
@@ -221,7 +248,7 @@ int run_global_multi(const Options &o, const cfrk_batch &batch, std::vector<std:
         if ((rc = cfrk_global_begin(ctx, o.k, flags | CFRK_RUNS_ONLY, hint))) { status[(size_t)sh] = die(ctx, rc, "cfrk_global_begin"); return; }
         if (b1 <= b0) return;
         if ((rc = cfrk_global_add(ctx, batch.data + b0, nullptr, nullptr, b1 - b0, 0))) {
-          if (rc == CFRK_ERR_NOMEM || rc == CFRK_ERR_STATE) { refused[(size_t)sh] = 1; return; }
+          if (rc == CFRK_ERR_RUNS_REFUSED) { refused[(size_t)sh] = 1; return; }     // (the shard needs several passes)
           status[(size_t)sh] = die(ctx, rc, "cfrk_global_add");
           return;
         }
@@ -284,9 +311,12 @@ int run_global_multi(const Options &o, const cfrk_batch &batch, std::vector<std:
           if (rc) { status[(size_t)ow] = die(ctx, rc, "cfrk_global_merge_runs_device"); return; }
         }
         uint64_t n = 0;
-        if ((rc = cfrk_global_finish(ctx, &n))) { status[(size_t)ow] = die(ctx, rc, "cfrk_global_finish"); return; }
+        rc = cfrk_global_finish(ctx, &n);
+        if (rc == CFRK_ERR_COUNT_OVERFLOW) fprintf(stderr, "cfrk: warning: %s\n", cfrk_last_error(ctx));
+        else if (rc) { status[(size_t)ow] = die(ctx, rc, "cfrk_global_finish"); return; }
         keys[(size_t)ow].resize(n); cnts[(size_t)ow].resize(n); his[(size_t)ow].resize(n);
-        if ((rc = cfrk_global_export(ctx, keys[(size_t)ow].data(), his[(size_t)ow].data(), cnts[(size_t)ow].data(), n, &n))) status[(size_t)ow] = die(ctx, rc, "cfrk_global_export");
+        rc = cfrk_global_export(ctx, keys[(size_t)ow].data(), his[(size_t)ow].data(), cnts[(size_t)ow].data(), n, &n);
+        if (rc && rc != CFRK_ERR_COUNT_OVERFLOW) status[(size_t)ow] = die(ctx, rc, "cfrk_global_export");
       });
     for (auto &t : th) t.join();
     free_packed();
@@ -319,14 +349,29 @@ int run_global_multi(const Options &o, const cfrk_batch &batch, std::vector<std:
 int run_file(const Options &o, const char *in, const char *outp, std::vector<Worker> &workers,
              std::vector<std::vector<Worker>> *per_dev = nullptr) {
   cfrk_batch batch;
+  const double t0 = now_s();
   int rc = cfrk_host_read_fasta(in, (o.native || o.global) ? 0 : CFRK_INGEST_COMPAT, &batch);
   if (rc) { fprintf(stderr, "cfrk: cannot read %s (error %d)\n", in, rc); return 1; }
+  const double t1 = now_s();
+  g_timing = Timing();
+  g_timing.parse = t1 - t0; g_timing.nN = batch.nN; g_timing.nS = batch.nS;
+  { FILE *f = fopen(in, "rb"); if (f) { fseek(f, 0, SEEK_END); g_timing.fasta_bytes = (int64_t)ftell(f); fclose(f); } }
   FILE *out = fopen(outp, "wb");                      // PrintFreq opens with "w" even when empty
   if (!out) { fprintf(stderr, "cfrk: cannot write %s\n", outp); cfrk_host_free_batch(&batch); return 1; }
   if (o.global && per_dev && per_dev->size() > 1 && o.k >= 16 && o.k <= 64 && batch.nS >= (int64_t)per_dev->size()) rc = run_global_multi(o, batch, *per_dev, out);
-  else rc = o.global ? run_global(o, batch, workers[0], out) : run_per_read(o, batch, workers, out);
+  else if (o.global) rc = run_global(o, batch, workers[0], out);
+  else { const double p0 = now_s(); rc = run_per_read(o, batch, workers, out); g_timing.per_read = now_s() - p0; }
+  if (!o.global) { fflush(out); g_timing.out_bytes = (uint64_t)ftell(out); }
   fclose(out);
   cfrk_host_free_batch(&batch);
+  g_timing.total = now_s() - t0;
+  if (o.timing)
+    fprintf(stderr, "cfrk-timing {\"fasta_bytes\": %lld, \"reads\": %lld, \"code_bytes\": %lld, \"parse_s\": %.4f, \"add_call_s\": %.4f, "
+            "\"finish_wait_s\": %.4f, \"count_kernels_ms\": %.3f, \"export_s\": %.4f, \"format_s\": %.4f, \"write_s\": %.4f, "
+            "\"per_read_pipeline_s\": %.4f, \"entries\": %llu, \"out_bytes\": %llu, \"wall_s\": %.4f}\n",
+            (long long)g_timing.fasta_bytes, (long long)g_timing.nS, (long long)g_timing.nN, g_timing.parse, g_timing.add_call,
+            g_timing.finish_wait, (double)g_timing.count_kernels_ms, g_timing.export_, g_timing.format, g_timing.write,
+            g_timing.per_read, (unsigned long long)g_timing.entries, (unsigned long long)g_timing.out_bytes, g_timing.total);
   return rc;
 }
 
@@ -342,6 +387,8 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[i], "--global")) o.global = true;
     else if (!strcmp(argv[i], "--canonical")) o.canonical = true;
     else if (!strcmp(argv[i], "--binary")) o.binary = true;
+    else if (!strcmp(argv[i], "--timing")) o.timing = true;
+    else if (!strcmp(argv[i], "--parse-threads") && i + 1 < argc) cfrk_host_set_parse_threads(atoi(argv[++i]));
     else if (!strcmp(argv[i], "--same-device")) o.same_device = true;   // rehearsal: every "device" is --device
     else if (!strcmp(argv[i], "--device") && i + 1 < argc) o.device = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) o.gpus = atoi(argv[++i]);

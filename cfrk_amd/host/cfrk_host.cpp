@@ -35,9 +35,15 @@ inline char *put_i32(char *p, int32_t v) {          // "%d"
 }
 inline size_t len_u64(uint64_t v) { size_t n = 1; while (v >= 10) { v /= 10; ++n; } return n; }
 
+// threads the parser may use (cfrk_host_set_parse_threads; 0 = min(hardware threads, 16): beyond that the two
+// passes are bound by memory bandwidth and by the serial merge of the per-thread line lists, profiles/r05/end_to_end.txt)
+int g_parse_threads = 0;
+
 }  // namespace
 
 extern "C" {
+
+void cfrk_host_set_parse_threads(int n) { g_parse_threads = n > 0 ? n : 0; }
 
 void cfrk_host_free_batch(cfrk_batch *b) {
   if (!b) return;
@@ -56,7 +62,8 @@ int cfrk_host_parse_fasta(const char *buf, size_t len, int flags, cfrk_batch *ou
   std::vector<Rec> recs;
   std::vector<std::pair<size_t, size_t>> lines;     // (begin, end incl. newline) of sequence lines
   unsigned nthr = std::thread::hardware_concurrency();
-  if (nthr > 16) nthr = 16;
+  if (g_parse_threads > 0) { if (nthr == 0 || nthr > (unsigned)g_parse_threads) nthr = (unsigned)g_parse_threads; }
+  else if (nthr > 16) nthr = 16;
   if (nthr < 2 || len < ((size_t)8 << 20)) nthr = 1;
   {
     struct Part { std::vector<size_t> rec_first; std::vector<std::pair<size_t, size_t>> lines; };
@@ -305,6 +312,33 @@ size_t cfrk_host_format_sparse2(const uint64_t *keys_lo, const uint64_t *keys_hi
     p = put_u64(p, counts[i]); *p++ = '\n';
   }
   return (size_t)(p - buf);
+}
+
+size_t cfrk_host_format_sparse_mt(const uint64_t *keys_lo, const uint64_t *keys_hi, const uint32_t *counts,
+                                  uint64_t n, char *buf, size_t cap, int threads) {
+  int T = threads < 1 ? 1 : threads;
+  if ((uint64_t)T > n / 65536 + 1) T = (int)(n / 65536 + 1);      // (a thread per 64 K entries at least)
+  if (T == 1) return cfrk_host_format_sparse2(keys_lo, keys_hi, counts, n, buf, cap);
+  // entry ranges per thread: sizes first (the text of a range starts where the previous one ends)
+  auto e_of = [&](int t) { return n * (uint64_t)t / (uint64_t)T; };
+  auto part = [&](int t, char *dst) {
+    const uint64_t e0 = e_of(t), e1 = e_of(t + 1);
+    return cfrk_host_format_sparse2(keys_lo + e0, keys_hi ? keys_hi + e0 : nullptr, counts + e0, e1 - e0, dst, dst ? (size_t)-1 : 0);
+  };
+  std::vector<size_t> sz((size_t)T), off((size_t)T);
+  {
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) th.emplace_back([&, t] { sz[(size_t)t] = part(t, nullptr); });
+    for (auto &x : th) x.join();
+  }
+  size_t total = 0;
+  for (int t = 0; t < T; ++t) { off[(size_t)t] = total; total += sz[(size_t)t]; }
+  if (!buf) return total;
+  if (cap < total) return 0;
+  std::vector<std::thread> th;
+  for (int t = 0; t < T; ++t) th.emplace_back([&, t] { part(t, buf + off[(size_t)t]); });
+  for (auto &x : th) x.join();
+  return total;
 }
 
 static void put_le(char *p, uint64_t x, int bytes) { for (int i = 0; i < bytes; ++i) p[i] = (char)(x >> (8 * i)); }

@@ -37,6 +37,8 @@ typedef struct cfrk_batch {      /* struct read (src/tipos.h:23-30) with owned s
 int  cfrk_host_read_fasta(const char *path, int flags, cfrk_batch *out);
 int  cfrk_host_parse_fasta(const char *buf, size_t len, int flags, cfrk_batch *out);
 void cfrk_host_free_batch(cfrk_batch *b);
+/* threads the parser may use for large inputs (0 = the default, min(hardware threads, 16)) */
+void cfrk_host_set_parse_threads(int n);
 
 /* Chunk [first, first+count) of a batch with chunk-relative start[] (SelectChunk,
  * src/main.cu:160-206): views into the batch, nothing is copied; start_out needs count slots. */
@@ -56,6 +58,9 @@ size_t cfrk_host_format_sparse(const uint64_t *keys, const uint32_t *counts, uin
                                size_t cap);
 size_t cfrk_host_format_sparse2(const uint64_t *keys_lo, const uint64_t *keys_hi, const uint32_t *counts,
                                 uint64_t n, char *buf, size_t cap);
+/* the same text, formatted by `threads` host threads (entry ranges); keys_hi may be NULL (k <= 32) */
+size_t cfrk_host_format_sparse_mt(const uint64_t *keys_lo, const uint64_t *keys_hi, const uint32_t *counts,
+                                  uint64_t n, char *buf, size_t cap, int threads);
 
 /* Binary global form, little endian, everything in one file:
  *   header, 32 bytes:  char magic[8] = "CFRKGLB1"; uint32 k; uint32 flags (bit 0: canonical counting,

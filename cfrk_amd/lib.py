@@ -21,6 +21,10 @@ CFRK_DEBUG_NO_ANCHORS = 0x4
 CFRK_DEBUG_RECORD_SUBSETS = 0x8
 CFRK_DEBUG_NO_PIPELINE = 0x10
 CFRK_DEBUG_SMALL_PIPELINE = 0x20
+CFRK_DEBUG_NO_RADIX16 = 0x40
+CFRK_ERR_COUNT_OVERFLOW = -10        # finish / digest / export: some count was held at CFRK_COUNT_MAX
+CFRK_ERR_RUNS_REFUSED = -11          # a CFRK_RUNS_ONLY add that needs more than one pass
+CFRK_COUNT_MAX = 0xFFFFFFFE
 CFRK_PARAM_MSP_CHUNKS, CFRK_PARAM_L2_SLACK_COMPLETE, CFRK_PARAM_L2_SLACK_TRUNCATED, CFRK_PARAM_MSP2_SUBVALUE_BITS = 0, 1, 2, 3   # cfrk_debug_set_param
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -222,14 +226,20 @@ class GlobalCounter:
                                                         C.c_void_p(d_cnt), n),
                        "cfrk_global_merge_device")
 
-    def finish(self):
+    def finish(self, allow_saturated=False):
         n = C.c_uint64()
-        self.ctx.check(self._L.cfrk_global_finish(self.ctx._h, C.byref(n)), "cfrk_global_finish")
+        rc = self._L.cfrk_global_finish(self.ctx._h, C.byref(n))
+        if not (allow_saturated and rc == CFRK_ERR_COUNT_OVERFLOW):
+            self.ctx.check(rc, "cfrk_global_finish")
         return n.value
 
-    def digest(self):
+    def digest(self, allow_saturated=False):
+        """allow_saturated: a result with counts held at CFRK_COUNT_MAX (CFRK_ERR_COUNT_OVERFLOW) is returned
+        instead of raised -- the digest is that of the saturated result"""
         out = (C.c_uint64 * 4)()
-        self.ctx.check(self._L.cfrk_global_digest(self.ctx._h, out), "cfrk_global_digest")
+        rc = self._L.cfrk_global_digest(self.ctx._h, out)
+        if not (allow_saturated and rc == CFRK_ERR_COUNT_OVERFLOW):
+            self.ctx.check(rc, "cfrk_global_digest")
         return tuple(int(x) for x in out)
 
     def leaves_per_part(self, parts):
@@ -295,15 +305,16 @@ class GlobalCounter:
         self.ctx.check(self._L.cfrk_global_last_add_ms(self.ctx._h, C.byref(ms)), "cfrk_global_last_add_ms")
         return ms.value
 
-    def export(self):
+    def export(self, allow_saturated=False):
         """-> (keys_lo, keys_hi, counts) sorted by (hi, lo)"""
-        n = self.finish()
+        n = self.finish(allow_saturated)
         lo = np.empty(n, np.uint64)
         hi = np.empty(n, np.uint64)
         cnt = np.empty(n, np.uint32)
         got = C.c_uint64()
-        self.ctx.check(self._L.cfrk_global_export(self.ctx._h, _ptr(lo), _ptr(hi), _ptr(cnt), n,
-                                                  C.byref(got)), "cfrk_global_export")
+        rc = self._L.cfrk_global_export(self.ctx._h, _ptr(lo), _ptr(hi), _ptr(cnt), n, C.byref(got))
+        if not (allow_saturated and rc == CFRK_ERR_COUNT_OVERFLOW):
+            self.ctx.check(rc, "cfrk_global_export")
         assert got.value == n
         return lo, hi, cnt
 

@@ -50,6 +50,11 @@ extern "C" {
 #define CFRK_ERR_ALIGN      -7   /* device data pointer not 16-byte aligned                      */
 #define CFRK_ERR_NO_DEVICE  -8   /* no usable gfx950 device                                      */
 #define CFRK_ERR_SMALL_BUF  -9   /* output buffer smaller than the result                        */
+#define CFRK_ERR_COUNT_OVERFLOW -10 /* a key occurred 2^32 - 2 times or more: counts are 32-bit and SATURATE at
+                                    2^32 - 2 (0xFFFFFFFE) instead of wrapping; finish / digest / export report it */
+#define CFRK_ERR_RUNS_REFUSED -11 /* a CFRK_RUNS_ONLY add that does not fit device memory in one pass: nothing was
+                                    counted, the job is still empty; count without the flag (leaf / key exchange)   */
+#define CFRK_COUNT_MAX 0xFFFFFFFE   /* (an unsigned int: a hexadecimal constant that does not fit int) */
 
 /* flags */
 #define CFRK_COMPAT     0x1  /* per-read dense only: reproduce ComputeFreqNew exactly (no -1 guard ->
@@ -249,6 +254,13 @@ int cfrk_debug_last_add_passes(cfrk_ctx *ctx, int *out_passes);
  * chunked path reachable with small inputs (tests). */
 #define CFRK_DEBUG_NO_PIPELINE 0x10
 #define CFRK_DEBUG_SMALL_PIPELINE 0x20
+/* Bit 6: k = 16 never takes the radix path (normally it does for adds of up to ~4e9 bases: the minimizer window of
+ * the partitioned path is only four k-mers at k = 16); makes the partitioned path at k = 16 reachable with small
+ * inputs (tests). */
+#define CFRK_DEBUG_NO_RADIX16 0x40
+/* Any other bit is refused with CFRK_ERR_ARG.  (The timing ablations that skip a kernel phase and so produce WRONG
+ * counts -- cfrk_amd/csrc/msp.h: CFRK_ABL_* -- are compiled into a separate ablation build only, `make -C
+ * cfrk_amd/csrc abl`; the product library does not contain them.) */
 int cfrk_debug_set_flags(cfrk_ctx *ctx, uint32_t flags);
 
 /* Sizing knobs of the partitioned paths for experiments and tests (value 0 = the library's own choice;

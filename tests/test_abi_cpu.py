@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(built):
 
 def test_strerror_covers_all_codes(built):
     L = built.load_library()
-    for code in range(0, -10, -1):
+    for code in range(0, -12, -1):
         assert L.cfrk_strerror(code) not in (None, b"", b"unknown error")
 
 

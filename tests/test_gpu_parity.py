@@ -173,6 +173,31 @@ def test_global_vs_oracle(ctx, k, canonical, force_hash):
     _cmp_global(ctx, data, k, canonical, start=start, length=length, force_hash=force_hash)
 
 
+@pytest.mark.parametrize("canonical", [False, True])
+def test_k16_on_the_partitioned_path_when_the_radix_path_is_switched_off(ctx, canonical):
+    """k = 16 takes radix.hip for batches up to ~4e9 bases (round 5) and msp.hip (windows of four k-mers) beyond:
+    CFRK_DEBUG_NO_RADIX16 keeps the small-input coverage of the latter"""
+    import cfrk_amd
+    rng = np.random.default_rng(216)
+    reads = _random_reads(rng, 3000, 1, 300)
+    reads.append(np.full(200, 0, np.int8))
+    data, start, length = refsem.flatten(reads)
+    flags = cfrk_amd.CFRK_CANONICAL if canonical else 0
+    g = cfrk_amd.GlobalCounter(ctx, 16, flags, 1 << 20)
+    g.set_debug_flags(cfrk_amd.CFRK_DEBUG_NO_RADIX16)
+    try:
+        g.add(data, start, length)
+        lo, hi, cnt = g.export()
+        assert g.msp_info()["l2_records"] > 0                 # (the partitioned path's records: it really ran)
+    finally:
+        g.set_debug_flags(0)
+    wlo, whi, wcnt = orc.global_count(data, 16, orc.ORC_CANONICAL if canonical else 0)
+    assert len(lo) == len(wlo) and (lo == wlo).all() and (cnt.astype(np.uint64) == wcnt).all()
+    g2 = cfrk_amd.GlobalCounter(ctx, 16, flags, 1 << 20)
+    g2.add(data, start, length)
+    assert g2.msp_info()["l2_records"] == 0 and g2.digest() == orc.digest(wlo, whi, wcnt)   # (radix.hip: no records)
+
+
 def test_global_ragged_tail_sizes(ctx):
     """buffer lengths around the 32-byte chunk / 2 KiB tile edges of the packed front end"""
     rng = np.random.default_rng(5)
@@ -506,15 +531,18 @@ def test_two_word_single_amplicon_overflows_its_level1_regions_and_is_laid_out_a
     assert info["spilled_records"] == 0 and info["spilled_kmers"] == 0
 
 
-@pytest.mark.parametrize("k", [9, 15])
+@pytest.mark.parametrize("k", [9, 13, 14, 15, 16])
 def test_radix_single_amplicon_overflows_its_level1_regions_and_is_laid_out_again(ctx, k):
-    """the same for 8 <= k <= 15 (radix.hip): a million copies of one read put every key into ~140 of
+    """the same for 8 <= k <= 16 (radix.hip): 800 000 copies of one read put every key into ~140 of
     the first level's regions' bins, more than their fixed stride holds; the level is laid out again
-    with exact sizes instead of counting the excess through the HBM table"""
+    with exact sizes instead of counting the excess through the HBM table.  For k >= 13 the batch is small
+    enough for the host to choose leaves of packed 16-bit counters (idx = 14; 15 at k = 16), and every leaf
+    that holds a key then has 800 000 elements or more -- above 2^16: the leaf kernel's two-pass mode with
+    32-bit counters (mode 3; ADVICE r4 asked for k = 13 / 14 cases that reach it)"""
     import cfrk_amd
     rng = np.random.default_rng(6)
     read = np.append(rng.integers(0, 4, 150).astype(np.int8), np.int8(-1))
-    R = 1_000_000
+    R = 800_000
     data = np.tile(read, R)
     want = orc.global_count(data, k, orc.ORC_CANONICAL, threads=8)
     assert int(want[2].min()) >= R
