@@ -65,6 +65,9 @@ def parse():
                    help="force the generic hash-owner exchange + HBM-table merge")
     p.add_argument("--debug-runs-budget", default="", metavar="RANK:BYTES",
                    help="(tests) cap rank RANK's record buffers at BYTES during its CFRK_RUNS_ONLY add")
+    p.add_argument("--pipeline-groups", type=int, default=2,
+                   help="N > 1, runs exchange, k <= 32: groups of leaves of the PIPELINED form (dedupe of group g+1 and the "
+                        "owner's counting of group g-1 run beside the wire of group g); 0: the one-shot exchange")
     p.add_argument("--exchange", default="auto", choices=["auto", "runs", "leaf", "owner"],
                    help="N > 1: what the ranks exchange.  runs (auto for 16 <= k <= 64): deduplicated "
                         "runs, counted by the leaf's owner; leaf: counted per-leaf lists; owner: counted keys")
@@ -257,6 +260,7 @@ def main():
                 self.bufs = None
                 self.lbufs = None
                 self.runs_refused = False
+                self.deferred = False
 
             def export_leaves(self, parts):
                 lpp = self.g.leaves_per_part(parts)
@@ -285,7 +289,7 @@ def main():
                     #  never more than the shard's super-k-mers; a too small buffer is doubled below)
                     rows = int(min(14 * Rl, 2.5 * Rl + 0.3 * glen)) * (2 if k > 32 else 1) + (1 << 17)   # (k > 32: two rows per record)
                     self.rbuf = torch.empty((max(1 << 20, rows), 2), dtype=torch.int64, device=dev)
-                for _ in range(3):
+                for _ in range(4):
                     try:
                         pr = self.g.export_runs_device(self.rbuf.data_ptr(), self.rbuf.shape[0], parts)
                         return self.rbuf, pr
@@ -295,8 +299,50 @@ def main():
                             continue
                         if e.code != -4:
                             raise
+                        if self.deferred:         # a CFRK_RUNS_DEFER add that overflowed a region: add again, the settling way
+                            self.deferred = False
+                            self.g = cfrk_amd.GlobalCounter(ctx, k, flags | cfrk_amd.CFRK_RUNS_ONLY, hint)
+                            try:
+                                self.g.add_device(d_data.data_ptr(), nN)
+                            except cfrk_amd.CfrkError as e2:
+                                if e2.code != cfrk_amd.CFRK_ERR_RUNS_REFUSED:
+                                    raise
+                                return None
+                            continue
                         return None
                 return None
+
+            # -- pipelined runs exchange (sharded.exchange_by_runs_pipelined) --
+            def export_runs_pipelined_begin(self, parts, groups):
+                if self.runs_refused or k > 32:
+                    return None
+                lpp = self.g.leaves_per_part(parts)
+                if getattr(self, "pbuf", None) is None or self.pbuf.shape[:2] != (groups, parts):
+                    # rows of a rank as for the one-shot form, spread over groups x parts segments, a quarter to spare
+                    # (a segment that runs out is reported by the wait: the step takes the one-shot form and the next
+                    #  step gets twice the room)
+                    rows = int(min(14 * Rl, 2.5 * Rl + 0.3 * glen)) + (1 << 17)
+                    cap = int(rows / (groups * parts) * 1.25 * getattr(self, "pgrow", 1)) + (lpp + groups - 1) // groups + 4096
+                    self.pbuf = torch.empty((groups, parts, cap, 2), dtype=torch.int64, device=dev)
+                try:
+                    self.g.export_runs_async(self.pbuf.data_ptr(), self.pbuf.shape[2], parts, groups)
+                except cfrk_amd.CfrkError as e:
+                    if e.code != -4:
+                        raise
+                    return None
+                return self.pbuf
+
+            def export_runs_pipelined_wait(self, grp):
+                try:
+                    return self.g.export_runs_wait(grp)
+                except cfrk_amd.CfrkError as e:
+                    if e.code == -9:             # a segment ran out of room: more next time
+                        self.pgrow = 2 * getattr(self, "pgrow", 1)
+                        self.pbuf = None
+                    elif e.code != -4:
+                        raise
+                    used["pipelined_refused"] = str(e)
+                    return None
 
             def export_parts(self, parts):
                 if self.bufs is None:
@@ -325,7 +371,10 @@ def main():
 
         def step():
             runs = world > 1 and exch == "runs"
-            eng.g = cfrk_amd.GlobalCounter(ctx, k, flags | (cfrk_amd.CFRK_RUNS_ONLY if runs else 0), hint)
+            piped = runs and k <= 32 and args.pipeline_groups > 0
+            eng.deferred = piped
+            eng.g = cfrk_amd.GlobalCounter(ctx, k, flags | (cfrk_amd.CFRK_RUNS_ONLY if runs else 0)
+                                           | (cfrk_amd.CFRK_RUNS_DEFER if piped else 0), hint)
             if os.environ.get("CFRK_DEBUG_FLAGS"):       # test switches; bits >= 0x100 are the timing ablations, which only
                 eng.g.set_debug_flags(int(os.environ["CFRK_DEBUG_FLAGS"], 0))   # an ablation build accepts (tools/ablate.sh)
             for kv in filter(None, os.environ.get("CFRK_BENCH_PARAMS", "").split(",")):   # sizing experiments
@@ -352,6 +401,23 @@ def main():
                 return eng.g
             og = cfrk_amd.GlobalCounter(owner_ctx, k, flags, hint // world + 1024)
             ta = time.perf_counter()
+            if piped:
+                # groups of leaves: dedupe(g+1) || wire(g) || owner(g-1); nothing but the comm side ever waits
+                kept, wb = sharded.exchange_by_runs_pipelined(
+                    eng, lambda recv, rows, grp, ngrp: og.merge_runs_group_device(recv.data_ptr(), rows, grp, ngrp),
+                    world, dev, wire, args.pipeline_groups)
+                if kept is not None:
+                    tb = time.perf_counter()
+                    owner_ctx.sync()
+                    phase_s[0] += tb - ta
+                    phase_s[1] += time.perf_counter() - tb
+                    used["exchange"] = f"runs, pipelined in {args.pipeline_groups} groups"
+                    used["wire_bytes"] = wb
+                    used["owner_ms"] = og.last_add_ms()
+                    return og
+                # some rank could not deliver group `wb`: everybody takes the one-shot form, on a fresh owner job
+                used["pipelined_fell_back_at_group"] = wb
+                og = cfrk_amd.GlobalCounter(owner_ctx, k, flags, hint // world + 1024)
             if runs:
                 got = sharded.exchange_by_runs(eng, world, dev, wire)
                 if got is not None:   # the owner expands and counts the runs of its leaves

@@ -124,6 +124,8 @@ void cfrk_ctx_destroy(cfrk_ctx *ctx) {
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->g_stats) (void)hipFree(ctx->g_stats);
   if (ctx->h_stats) (void)hipHostFree(ctx->h_stats);
+  if (ctx->h_runs) (void)hipHostFree(ctx->h_runs);
+  for (int g = 0; g < CFRK_RUNS_MAX_GROUPS; ++g) if (ctx->runs_ev[g]) (void)hipEventDestroy(ctx->runs_ev[g]);
   if (ctx->stage_ev[0]) (void)hipEventDestroy(ctx->stage_ev[0]);
   if (ctx->stage_ev[1]) (void)hipEventDestroy(ctx->stage_ev[1]);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -249,6 +251,7 @@ int cfrk_global_begin(cfrk_ctx *ctx, int k, int flags, uint64_t capacity_hint) {
   if (k < 1 || k > 64) return cfrk_fail(ctx, CFRK_ERR_ARG, "k=%d outside 1..64", k);
   if ((flags & CFRK_RUNS_ONLY) && (k < 16 || k > 64 || (flags & CFRK_FORCE_HASH)))
     return cfrk_fail(ctx, CFRK_ERR_ARG, "CFRK_RUNS_ONLY needs a partitioned path (16 <= k <= 64)");
+  if ((flags & CFRK_RUNS_DEFER) && !(flags & CFRK_RUNS_ONLY)) return cfrk_fail(ctx, CFRK_ERR_ARG, "CFRK_RUNS_DEFER goes with CFRK_RUNS_ONLY");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   // Was the HBM table left untouched by the previous job (the partitioned path only writes it

@@ -14,6 +14,7 @@
 // flood; cfrk_global_add_device counts the add through the HBM table instead
 #define CFRK_INTERNAL_FLOOD (-100)
 #define CFRK_MAX_PROBE (1u << 22)
+#define CFRK_RUNS_MAX_GROUPS 16
 
 enum {  // pool slots
   BUF_DATA = 0, BUF_START, BUF_LENGTH, BUF_FREQ, BUF_SPILL, BUF_EXPORT_LO, BUF_EXPORT_HI,
@@ -22,6 +23,7 @@ enum {  // pool slots
   BUF_MSP_LAYOUT,                             // exact second-level layout (stream bases and sizes)
   BUF_MSP_OVF,                                // records that did not fit their leaf stream (a few)
   BUF_MSP_OVF1, BUF_MSP_LAYOUT1,              // the same for the level-1 regions
+  BUF_RUNS_AUX,                               // pipelined runs exchange: segment cursors, used rows per group
   BUF_NSLOTS
 };
 
@@ -63,6 +65,11 @@ struct cfrk_ctx {
   hipEvent_t ev0, ev1;
   bool ev_valid;
   hipEvent_t stage_ev[2];   // H2D staging (cfrk_global_add)
+  // pipelined runs exchange (cfrk_global_export_runs_async / _wait): one event per group, the groups' used rows in pinned memory
+  hipEvent_t runs_ev[CFRK_RUNS_MAX_GROUPS];
+  uint64_t *h_runs;         // pinned, CFRK_RUNS_MAX_GROUPS x (64 + 1) words
+  int runs_groups, runs_parts;
+  uint64_t runs_seg_cap;
   // minimizer-partitioned fast path (msp.hip)
   struct cfrk_msp *msp;
   int last_passes;       // passes the most recent add took on a partitioned path (1 unless memory was short)

@@ -75,7 +75,10 @@ struct MspView {
 
 struct cfrk_msp {
   bool leaf_form;      // the list is grouped by minimizer leaf (msp.hip); false for radix.hip
-  bool runs_ready;     // CFRK_RUNS_ONLY job: the leaf streams hold deduplicated runs ready for cfrk_global_export_runs_device
+  bool runs_ready;     // CFRK_RUNS_ONLY job: the leaf streams hold the shard's runs, ready for cfrk_global_export_runs_*
+  bool runs_deduped;   // ... deduplicated in place already (msp_dedupe_export_kernel); false after a CFRK_RUNS_DEFER add
+  bool runs_unchecked; // ... and nobody has looked at the add's overflow flags yet (CFRK_RUNS_DEFER: no host sync after P2)
+  int  lists_group;    // owner of the pipelined exchange: groups merged so far (cfrk_global_merge_runs_group_device)
   bool pending;        // a leaf-output list exists that has not been folded into the table
   bool table_dirty;    // the table holds counts of its own since begin()
   // expected records = positions x density x dens_scale: 1 unless a batch did not fit and its invalid

@@ -2239,7 +2239,8 @@ bool cfrk_msp_usable(const cfrk_ctx *ctx) {
 
 void cfrk_msp_reset(cfrk_ctx *ctx) {
   if (ctx->msp) ctx->msp->view.seg_bits = 0;
-  if (ctx->msp) { ctx->msp->pending = false; ctx->msp->table_dirty = false; ctx->msp->list_n_valid = false; ctx->msp->runs_ready = false; }
+  if (ctx->msp) { ctx->msp->pending = false; ctx->msp->table_dirty = false; ctx->msp->list_n_valid = false; ctx->msp->runs_ready = false;
+                  ctx->msp->runs_deduped = false; ctx->msp->runs_unchecked = false; ctx->msp->lists_group = 0; }
 }
 
 void cfrk_msp_note_table_write(cfrk_ctx *ctx) {
@@ -2426,6 +2427,7 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
     return CFRK_OK;
   };
   const unsigned p2_grid = 2u * (unsigned)std::max(8, ctx->num_cus / 8 * 8);   // P2: persistent, two workgroups per CU, a multiple of 8
+  const bool defer = (ctx->g_flags & CFRK_RUNS_ONLY) && (ctx->g_flags & CFRK_RUNS_DEFER);
   bool run_p1 = true, settled = false, piped = pipelined;
   uint64_t parked1 = 0, parked2 = 0;
   for (int attempt = 0; attempt < 5; ++attempt) {
@@ -2491,6 +2493,9 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
     hipLaunchKernelGGL(msp_p2_kernel, dim3(p2_grid), dim3(P2_THREADS), 0, ctx->stream, k, canon, v, t);
     HIP_TRY(ctx, hipGetLastError());
     }
+    // CFRK_RUNS_DEFER: the add ends here, unsynchronised -- whether a region overflowed is looked at by the export
+    // (the group epilogue of the pipelined one folds the flags into what the host waits for anyway)
+    if (defer) { settled = true; break; }
     uint64_t st[ST_NWORDS];
     HIP_TRY(ctx, hipMemcpyAsync(st, ctx->g_stats, sizeof st, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -2573,7 +2578,7 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
     HIP_TRY(ctx, hipGetLastError());
   }
   const bool runs_only = (ctx->g_flags & CFRK_RUNS_ONLY) != 0;
-  if (runs_only) hipLaunchKernelGGL(msp_dedupe_export_kernel, dim3(NLEAF), dim3(DX_THREADS), 0, ctx->stream, k, canon, v);
+  if (runs_only) { if (!defer) hipLaunchKernelGGL(msp_dedupe_export_kernel, dim3(NLEAF), dim3(DX_THREADS), 0, ctx->stream, k, canon, v); }
   else if (sub) {
     const dim3 g3(((unsigned)NLEAF >> sel_bits) << v.sub_bits);
     if (canon) hipLaunchKernelGGL((msp_p3_kernel<true, true>), g3, dim3(P3_THREADS), 0, ctx->stream, k, 0u, v, t);
@@ -2588,6 +2593,8 @@ static int msp_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, in
   }
   ms->pending = !runs_only;
   ms->runs_ready = runs_only;
+  ms->runs_deduped = runs_only && !defer;
+  ms->runs_unchecked = defer;
   ms->leaf_form = !runs_only;
   ms->list_n_valid = false;
   return CFRK_OK;
@@ -2912,6 +2919,20 @@ extern "C" int cfrk_global_export_runs_device(cfrk_ctx *ctx, void *d_packed, uin
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (ctx->g_two) return cfrk_msp2_export_runs(ctx, d_packed, cap_rows, parts, part_rows);
   const MspView &v = ms->view;
+  if (ms->runs_unchecked) {
+    // a CFRK_RUNS_DEFER add: did its regions hold?  (an add without the flag lays an overflowing level out again)
+    uint64_t st0[ST_NWORDS];
+    int rc0 = cfrk_msp_sync_stats(ctx, st0);
+    if (rc0) return rc0;
+    if (st0[ST_L1OVF] || st0[ST_L2OVF] || st0[ST_OVFN] || st0[ST_OVFN1] || st0[ST_CWRAP])
+      return cfrk_fail(ctx, CFRK_ERR_STATE, "the CFRK_RUNS_DEFER add overflowed a record region: add again without the flag");
+    ms->runs_unchecked = false;
+  }
+  if (!ms->runs_deduped) {
+    hipLaunchKernelGGL(msp_dedupe_export_kernel, dim3(NLEAF), dim3(DX_THREADS), 0, ctx->stream, ctx->g_k, (ctx->g_flags & CFRK_CANONICAL) ? 1 : 0, v);
+    HIP_TRY(ctx, hipGetLastError());
+    ms->runs_deduped = true;
+  }
   const int lpp = (NLEAF + parts - 1) / parts;           // leaves per part (owner p: leaves p, p+parts, ...)
   const int hrows = runs_header_rows(lpp);
   int rc;
@@ -3021,5 +3042,136 @@ extern "C" int cfrk_global_merge_runs_device(cfrk_ctx *ctx, const void *d_packed
   ms->pending = true;
   ms->leaf_form = false;
   ms->list_n_valid = false;
+  return CFRK_OK;
+}
+
+// ------------------------------------------------------------------ multi-GPU exchange by runs, pipelined
+static inline uint32_t runs_ll0(int lpp, int g, int ngroups) { return (uint32_t)(((int64_t)lpp * g) / ngroups); }
+
+extern "C" int cfrk_global_export_runs_async(cfrk_ctx *ctx, void *d_packed, uint64_t seg_cap_rows, int parts, int ngroups) {
+  if (!ctx || parts < 1 || parts > 64 || ngroups < 1 || ngroups > CFRK_RUNS_MAX_GROUPS) return CFRK_ERR_ARG;
+  cfrk_msp *ms = ctx->msp;
+  if (!ctx->g_active || !ms || !ms->runs_ready)
+    return cfrk_fail(ctx, CFRK_ERR_STATE, "no runs to export (begin with CFRK_RUNS_ONLY, then one add)");
+  if (ctx->g_two) return cfrk_fail(ctx, CFRK_ERR_STATE, "the pipelined runs export serves one-word keys (16 <= k <= 32): cfrk_global_export_runs_device");
+  if (ms->runs_deduped) return cfrk_fail(ctx, CFRK_ERR_STATE, "the leaf streams were deduplicated in place already (add with CFRK_RUNS_DEFER for the pipelined export)");
+  if (!d_packed) return cfrk_fail(ctx, CFRK_ERR_ARG, "NULL buffer");
+  const int lpp = (NLEAF + parts - 1) / parts;
+  if (ngroups > lpp) return cfrk_fail(ctx, CFRK_ERR_ARG, "more groups than leaves per owner");
+  if (seg_cap_rows < (uint64_t)(lpp + ngroups - 1) / ngroups + 2 || seg_cap_rows > 0xFFFFFFF0ull)
+    return cfrk_fail(ctx, CFRK_ERR_ARG, "segment capacity out of range (at least a group's header: leaves per owner / groups + 2 rows)");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (!ctx->h_runs) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_runs, (size_t)CFRK_RUNS_MAX_GROUPS * 65 * sizeof(uint64_t), hipHostMallocDefault));
+  for (int g = 0; g < ngroups; ++g)
+    if (!ctx->runs_ev[g]) HIP_TRY(ctx, hipEventCreate(&ctx->runs_ev[g]));          // (with timing: cfrk_global_runs_group_ms)
+  int rc;
+  void *p;
+  const size_t ncur = (size_t)ngroups * parts;
+  if ((rc = cfrk_pool_get(ctx, BUF_RUNS_AUX, ((ncur * sizeof(uint32_t) + 15) & ~(size_t)15) + (size_t)ngroups * 65 * sizeof(uint64_t), &p))) return rc;
+  uint32_t *d_cur = (uint32_t *)p;
+  uint64_t *d_used = (uint64_t *)((char *)p + ((ncur * sizeof(uint32_t) + 15) & ~(size_t)15));
+  HIP_TRY(ctx, hipMemsetAsync(d_cur, 0, ncur * sizeof(uint32_t), ctx->stream));
+  const MspView &v = ms->view;
+  const int k = ctx->g_k, canon = (ctx->g_flags & CFRK_CANONICAL) ? 1 : 0;
+  for (int g = 0; g < ngroups; ++g) {
+    RunsSend sg;
+    sg.packed = (uint4 *)d_packed + (uint64_t)g * parts * seg_cap_rows;
+    sg.seg_cap = seg_cap_rows;
+    sg.cursor = d_cur + (size_t)g * parts;
+    sg.ll0 = runs_ll0(lpp, g, ngroups);
+    sg.lcount = runs_ll0(lpp, g + 1, ngroups) - sg.ll0;
+    sg.leaf0 = sg.ll0 * (uint32_t)parts;
+    sg.nleaf = std::min<uint32_t>((sg.ll0 + sg.lcount) * (uint32_t)parts, (uint32_t)NLEAF) - sg.leaf0;
+    sg.parts = parts;
+    if (sg.nleaf < sg.lcount * (uint32_t)parts) {
+      // (parts does not divide 65536: the last local leaf of the last owners stands for no leaf -- its header entry is zero)
+      for (uint32_t q = sg.nleaf; q < sg.lcount * (uint32_t)parts; ++q) {
+        const uint32_t leaf = sg.leaf0 + q, own = leaf % (uint32_t)parts, ll = leaf / (uint32_t)parts;
+        HIP_TRY(ctx, hipMemsetAsync(sg.packed + (uint64_t)own * seg_cap_rows + 1u + (ll - sg.ll0), 0, sizeof(uint4), ctx->stream));
+      }
+    }
+    if (sg.nleaf) {
+      hipLaunchKernelGGL(msp_dedupe_send_kernel, dim3(sg.nleaf), dim3(DS_THREADS), 0, ctx->stream, k, canon, v, sg);
+      HIP_TRY(ctx, hipGetLastError());
+    }
+    hipLaunchKernelGGL(msp_runs_group_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, sg, (const uint64_t *)ctx->g_stats, d_used + (size_t)g * 65);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_runs + (size_t)g * 65, d_used + (size_t)g * 65, (size_t)(parts + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->runs_ev[g], ctx->stream));
+  }
+  ctx->runs_groups = ngroups; ctx->runs_parts = parts; ctx->runs_seg_cap = seg_cap_rows;
+  return CFRK_OK;
+}
+
+extern "C" int cfrk_global_export_runs_wait(cfrk_ctx *ctx, int group, uint64_t *part_rows) {
+  if (!ctx || !part_rows) return CFRK_ERR_ARG;
+  if (group < 0 || group >= ctx->runs_groups || !ctx->h_runs) return cfrk_fail(ctx, CFRK_ERR_STATE, "no such group in flight (cfrk_global_export_runs_async first)");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipEventSynchronize(ctx->runs_ev[group]));
+  const uint64_t *u = ctx->h_runs + (size_t)group * 65;
+  const int parts = ctx->runs_parts;
+  if (u[parts]) return cfrk_fail(ctx, CFRK_ERR_STATE, "the add overflowed a record region or spilled: the shard's runs are not all in the leaf streams");
+  if (ctx->msp) ctx->msp->runs_unchecked = false;      // (the flags were clean when this group finished: the add held)
+  for (int q = 0; q < parts; ++q)
+    if (u[q] > ctx->runs_seg_cap) return cfrk_fail(ctx, CFRK_ERR_SMALL_BUF, "segment (group %d, owner %d) needs more than %llu rows", group, q, (unsigned long long)ctx->runs_seg_cap);
+  for (int q = 0; q < parts; ++q) part_rows[q] = u[q];
+  return CFRK_OK;
+}
+
+extern "C" int cfrk_global_merge_runs_group_device(cfrk_ctx *ctx, const void *d_recv, const uint64_t *recv_rows, int parts, int group, int ngroups) {
+  if (!ctx || parts < 1 || parts > 64 || !recv_rows || !d_recv || ngroups < 1 || ngroups > CFRK_RUNS_MAX_GROUPS || group < 0 || group >= ngroups) return CFRK_ERR_ARG;
+  if (!ctx->g_active) return cfrk_fail(ctx, CFRK_ERR_STATE, "merge_runs_group needs an active job");
+  if (!cfrk_msp_usable(ctx) || (ctx->g_flags & CFRK_RUNS_ONLY)) return cfrk_fail(ctx, CFRK_ERR_ARG, "merge_runs_group needs a counting job with 16 <= k <= 32");
+  cfrk_msp *ms = cfrk_msp_get(ctx);
+  if (!ms) return cfrk_fail(ctx, CFRK_ERR_NOMEM, "host allocation failed");
+  if (group != ms->lists_group) return cfrk_fail(ctx, CFRK_ERR_STATE, "groups are merged in order: expected group %d", ms->lists_group);
+  if (group == 0 && (ms->pending || ms->table_dirty)) return cfrk_fail(ctx, CFRK_ERR_STATE, "merge_runs_group needs an empty job (call cfrk_global_begin first)");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int lpp = (NLEAF + parts - 1) / parts;
+  if (ngroups > lpp) return cfrk_fail(ctx, CFRK_ERR_ARG, "more groups than leaves per owner");
+  int rc;
+  void *p;
+  MspView &v = ms->view;
+  if (group == 0) {
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    memset(&v, 0, sizeof v);
+    if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTK, (size_t)ctx->g_cap * 8, &p))) return rc;
+    v.out_keys = (uint64_t *)p;
+    if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTC, (size_t)ctx->g_cap * 4, &p))) return rc;
+    v.out_cnt = (uint32_t *)p; v.out_cap = ctx->g_cap;
+    v.stats = ctx->g_stats; v.dbg = ctx->dbg_flags;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_CURSOR, 0, sizeof(uint64_t), ctx->stream));
+  }
+  P3ListsT<true> lx;
+  memset(&lx, 0, sizeof lx);
+  lx.packed = (const uint4 *)d_recv;
+  uint64_t at = 0;
+  for (int r = 0; r < parts; ++r) { lx.rr.rstart[r] = at; lx.rr.rows[r] = recv_rows[r]; at += recv_rows[r]; }
+  lx.parts = parts;
+  lx.ll0 = runs_ll0(lpp, group, ngroups);
+  lx.lcount = runs_ll0(lpp, group + 1, ngroups) - lx.ll0;
+  TableView t = cfrk_table_view(ctx);
+  if (lx.lcount) {
+    if (ctx->g_flags & CFRK_CANONICAL) hipLaunchKernelGGL((msp_p3_lists_kernel<true>), dim3(lx.lcount), dim3(P3_THREADS), 0, ctx->stream, ctx->g_k, v, t, lx);
+    else hipLaunchKernelGGL((msp_p3_lists_kernel<false>), dim3(lx.lcount), dim3(P3_THREADS), 0, ctx->stream, ctx->g_k, v, t, lx);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  ctx->ev_valid = true;
+  ctx->h_stats_valid = false;                          // the leaf kernel may have spilled into the table
+  ms->lists_group = group + 1;
+  ms->pending = true;
+  ms->leaf_form = false;
+  ms->list_n_valid = false;
+  return CFRK_OK;
+}
+
+// Device time (ms) from the start of the job's add (its first kernel) to the end of group `group` of the pipelined export
+// (HIP events on the context stream): the rehearsal tool's clock (tools/scale_emul.py).  Synchronises on that group.
+extern "C" int cfrk_global_runs_group_ms(cfrk_ctx *ctx, int group, float *ms) {
+  if (!ctx || !ms) return CFRK_ERR_ARG;
+  if (group < 0 || group >= ctx->runs_groups || !ctx->ev_valid) return cfrk_fail(ctx, CFRK_ERR_STATE, "no such group in flight");
+  HIP_TRY(ctx, hipEventSynchronize(ctx->runs_ev[group]));
+  HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->runs_ev[group]));
   return CFRK_OK;
 }

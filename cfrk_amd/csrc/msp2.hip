@@ -1899,6 +1899,7 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
     memcpy(ms->view2, &v, sizeof v);
     ms->pending = false;
     ms->runs_ready = true;
+    ms->runs_deduped = true; ms->runs_unchecked = false;   // (CFRK_RUNS_DEFER is a one-word-key form: ignored here)
     ms->leaf_form = false;
     ms->list_n_valid = false;
     return CFRK_OK;

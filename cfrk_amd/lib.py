@@ -15,6 +15,7 @@ CFRK_CANONICAL = 0x2
 CFRK_FORCE_HASH = 0x4
 CFRK_RUNS_ONLY = 0x8
 CFRK_FLOAT_INDEX = 0x10
+CFRK_RUNS_DEFER = 0x20
 CFRK_DEBUG_FORCE_RT_OVERFLOW = 0x1   # cfrk_debug_set_flags
 CFRK_DEBUG_SMALL_WAVE_CAP = 0x2
 CFRK_DEBUG_NO_ANCHORS = 0x4
@@ -91,6 +92,10 @@ def load_library():
         "cfrk_global_merge_leaves_device": ([vp, vp, vp, vp, C.POINTER(u64), vp, C.c_int], C.c_int),
         "cfrk_global_export_runs_device": ([vp, vp, u64, C.c_int, C.POINTER(u64)], C.c_int),
         "cfrk_global_merge_runs_device": ([vp, vp, C.POINTER(u64), C.c_int], C.c_int),
+        "cfrk_global_export_runs_async": ([vp, vp, u64, C.c_int, C.c_int], C.c_int),
+        "cfrk_global_export_runs_wait": ([vp, C.c_int, C.POINTER(u64)], C.c_int),
+        "cfrk_global_merge_runs_group_device": ([vp, vp, C.POINTER(u64), C.c_int, C.c_int, C.c_int], C.c_int),
+        "cfrk_global_runs_group_ms": ([vp, C.c_int, C.POINTER(C.c_float)], C.c_int),
         "cfrk_debug_msp_info": ([vp, C.POINTER(u64)], C.c_int),
         "cfrk_debug_set_mem_budget": ([vp, u64], C.c_int),
         "cfrk_debug_device_bytes": ([vp, C.POINTER(u64)], C.c_int),
@@ -100,7 +105,9 @@ def load_library():
         "cfrk_synth_reads_device": ([vp, i64, i64, i32, i64, u64, u64, u64, i32, vp, vp, vp], C.c_int),
     }
     for name, (args, res) in sig.items():
-        f = getattr(L, name)
+        f = getattr(L, name, None)
+        if f is None:       # an OLDER build swapped in by tools/ab.sh: the entry point raises when it is called
+            continue        # (tests/test_abi_cpu.py checks that the product exports every symbol the header declares)
         f.argtypes = args
         f.restype = res
     _lib = L
@@ -278,6 +285,31 @@ class GlobalCounter:
         rr = (C.c_uint64 * parts)(*[int(x) for x in recv_rows])
         self.ctx.check(self._L.cfrk_global_merge_runs_device(self.ctx._h, C.c_void_p(d_packed), rr, parts),
                        "cfrk_global_merge_runs_device")
+
+    # -- pipelined runs exchange (CFRK_RUNS_ONLY | CFRK_RUNS_DEFER jobs; one-word keys) ----------------------
+    def export_runs_async(self, d_packed, seg_cap_rows, parts, ngroups):
+        """enqueue deduplication + packing of every group of leaves into the send buffer; returns at once"""
+        self.ctx.check(self._L.cfrk_global_export_runs_async(self.ctx._h, C.c_void_p(d_packed), seg_cap_rows, parts, ngroups),
+                       "cfrk_global_export_runs_async")
+        self._runs_parts = parts
+
+    def export_runs_wait(self, group):
+        """wait for group `group` only -> rows per owner segment; CfrkError -9 (segment too small) / -4 (overflow, spill)"""
+        pr = (C.c_uint64 * self._runs_parts)()
+        self.ctx.check(self._L.cfrk_global_export_runs_wait(self.ctx._h, group, pr), "cfrk_global_export_runs_wait")
+        return [int(x) for x in pr]
+
+    def merge_runs_group_device(self, d_recv, recv_rows, group, ngroups):
+        """owner: count group `group` from the received segments, read in place; enqueued, no host synchronisation"""
+        parts = len(recv_rows)
+        rr = (C.c_uint64 * parts)(*[int(x) for x in recv_rows])
+        self.ctx.check(self._L.cfrk_global_merge_runs_group_device(self.ctx._h, C.c_void_p(d_recv), rr, parts, group, ngroups),
+                       "cfrk_global_merge_runs_group_device")
+
+    def runs_group_ms(self, group):
+        ms = C.c_float()
+        self.ctx.check(self._L.cfrk_global_runs_group_ms(self.ctx._h, group, C.byref(ms)), "cfrk_global_runs_group_ms")
+        return ms.value
 
     def msp_info(self):
         out = (C.c_uint64 * 9)()

@@ -67,6 +67,11 @@ extern "C" {
 #define CFRK_RUNS_ONLY  0x8  /* global only, 16 <= k <= 64: the job partitions and deduplicates ONE add
                                 (which must fit device memory in one pass) and stops there; its result
                                 leaves through cfrk_global_export_runs_device (multi-GPU exchange)   */
+#define CFRK_RUNS_DEFER 0x20  /* with CFRK_RUNS_ONLY, one-word keys (16 <= k <= 32): the add only PARTITIONS -- no
+                                deduplication kernel and no host synchronisation at its end (its overflow flags are looked
+                                at by the export).  The shard then leaves through the PIPELINED export,
+                                cfrk_global_export_runs_async / _wait (deduplication and packing in one kernel per group of
+                                leaves), or through cfrk_global_export_runs_device, which deduplicates first.             */
 #define CFRK_FLOAT_INDEX 0x10 /* per-read dense only, matters for k = 13..15: the window index is accumulated
                                 through float exactly as ComputeIndex does (index += nuc * powf(4, k-1-i),
                                 src/kmer_kernel.cu:38), rounding errors, the all-T window's carry into the
@@ -204,6 +209,37 @@ int cfrk_global_merge_leaves_device(cfrk_ctx *ctx, const uint64_t *d_keys, const
 int cfrk_global_export_runs_device(cfrk_ctx *ctx, void *d_packed, uint64_t cap_rows, int parts,
                                    uint64_t *part_rows);
 int cfrk_global_merge_runs_device(cfrk_ctx *ctx, const void *d_packed, const uint64_t *recv_rows, int parts);
+
+/* PIPELINED form of the exchange by runs (round 5; one-word keys).  The owners' leaves are cut into `ngroups` ranges of
+ * local leaf indices (group g = local leaves [lpp * g / ngroups, lpp * (g + 1) / ngroups), lpp = cfrk_global_leaves_per_part);
+ * a rank deduplicates and packs group after group straight into the send buffer and hands every finished group to the
+ * wire while the next one is in the works, the owner counts every received group while the next one is on the wire:
+ *     rank:  begin(CFRK_RUNS_ONLY | CFRK_RUNS_DEFER), add_device (returns with the kernels enqueued),
+ *            export_runs_async (enqueues everything, returns at once),
+ *            for g: export_runs_wait(g) -> rows per owner -> all-to-all of group g (segment (g, p) to owner p)
+ *     owner: begin (same k and strand flag), for g: merge_runs_group_device(g) (enqueued, no host synchronisation)
+ * Send buffer: segment (g, p) = rows [(g * parts + p) * seg_cap_rows, ...), 16-byte rows; only its first part_rows[p]
+ * rows travel.  Segment = header (row 0: {rows used, local leaves of the group, first local leaf, magic}; then per local
+ * leaf a uint4 {row offset behind the header, distinct, truncated, noted}) + the leaves' rows in the order they were
+ * claimed: [distinct complete runs with multiplicities][truncated runs][16-bit notes, eight per row].
+ * export_runs_wait: waits for group g only (one event); CFRK_ERR_SMALL_BUF when a segment of the group ran out of room
+ * (seg_cap_rows too small), CFRK_ERR_STATE when the add overflowed a region or spilled (the shard's runs are not all in
+ * the leaf streams): in both cases nothing of the group may be sent -- add again without CFRK_RUNS_DEFER and take
+ * cfrk_global_export_runs_device, or count the shard and exchange counts.  The leaf streams stay as the add left them,
+ * so cfrk_global_export_runs_device may follow on the same job.
+ * merge_runs_group_device: d_recv = the `parts` received segments of group g in rank order (recv_rows[r] rows from rank
+ * r).  Groups must be merged in order, 0 .. ngroups-1, on a context fresh from cfrk_global_begin; the call returns with
+ * the leaf kernel enqueued (it reads the lists in place: d_recv must stay untouched until the context is synchronised).
+ * A segment whose header does not add up is not followed and makes finish / digest fail with CFRK_ERR_TABLE_FULL.
+ * parts <= 64, ngroups <= 16.  Replaces the pthread fan-out of src/main.cu:277-295 (which has no merge step). */
+int cfrk_global_export_runs_async(cfrk_ctx *ctx, void *d_packed, uint64_t seg_cap_rows, int parts, int ngroups);
+int cfrk_global_export_runs_wait(cfrk_ctx *ctx, int group, uint64_t *part_rows);
+int cfrk_global_merge_runs_group_device(cfrk_ctx *ctx, const void *d_recv, const uint64_t *recv_rows, int parts,
+                                        int group, int ngroups);
+/* Device time (ms, HIP events) from the start of the job's add to the end of group `group` of the pipelined export;
+ * synchronises on that group.  (cfrk_global_last_add_ms after cfrk_global_merge_runs_group_device: the owner's kernels
+ * from group 0 up to the last group merged.) */
+int cfrk_global_runs_group_ms(cfrk_ctx *ctx, int group, float *ms);
 
 /* Order-independent digest: out[0]=distinct, out[1]=sum count,
  * out[2]=sum count*splitmix64(kh) mod 2^64, out[3]=xor splitmix64(kh ^ count);

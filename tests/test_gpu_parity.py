@@ -465,7 +465,25 @@ def test_bench_under_torchrun_as_the_driver_launches_it():
     assert len(lines) == 1, r.stdout[-2000:]
     two = json.loads(lines[0])
     assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["sum_count_ok"]
-    assert two["digest"] == one["digest"] and two["exchange"]["exchange"] == "runs"
+    assert two["digest"] == one["digest"] and two["exchange"]["exchange"].startswith("runs")
+
+
+def test_bench_two_ranks_take_the_pipelined_runs_exchange_and_the_one_shot_form_on_request():
+    """strong scaling at k = 31: the default is the PIPELINED exchange (two groups of leaves, CFRK_RUNS_DEFER add,
+    owner reads the lists in place); `--pipeline-groups 0` keeps the one-shot form; four groups work as well -- all
+    give the 1-GPU digest (rehearsal: both ranks on cuda:0, collectives over gloo)"""
+    common = ["--steps", "2", "--warmup", "1", "--reads", "2000000", "--cpu-reads", "0"]
+    one = _bench_line(["--gpus", "1"] + common)
+    rehearsal = ["--gpus", "2", "--same-gpu", "--dist-backend", "gloo", "--scaling", "strong"]
+    two = _bench_line(rehearsal + common)
+    assert two["sum_count_ok"] and two["digest"] == one["digest"]
+    assert two["exchange"]["exchange"] == "runs, pipelined in 2 groups" and two["exchange"]["wire_bytes"] > 0
+    classic = _bench_line(rehearsal + ["--pipeline-groups", "0"] + common)
+    assert classic["digest"] == one["digest"] and classic["exchange"]["exchange"] == "runs"
+    four = _bench_line(rehearsal + ["--pipeline-groups", "4"] + common)
+    assert four["digest"] == one["digest"] and four["exchange"]["exchange"] == "runs, pipelined in 4 groups"
+    # the wire carries the same runs either way (the pipelined segments have a few header rows more)
+    assert abs(four["exchange"]["wire_bytes"] - classic["exchange"]["wire_bytes"]) < 0.05 * classic["exchange"]["wire_bytes"]
 
 
 def test_bench_two_ranks_exchange_runs_of_two_word_keys():
@@ -475,7 +493,7 @@ def test_bench_two_ranks_exchange_runs_of_two_word_keys():
     one = _bench_line(["--gpus", "1"] + common)
     two = _bench_line(["--gpus", "2", "--same-gpu", "--dist-backend", "gloo", "--scaling", "strong"] + common)
     assert one["sum_count_ok"] and two["sum_count_ok"] and two["digest"] == one["digest"]
-    assert two["exchange"]["exchange"] == "runs" and two["exchange"]["wire_bytes"] > 0
+    assert two["exchange"]["exchange"].startswith("runs") and two["exchange"]["wire_bytes"] > 0
 
 
 def test_bench_two_ranks_over_rccl_on_two_gpus():
@@ -1743,3 +1761,162 @@ def test_two_word_leaves_with_more_keys_than_their_table_are_split_by_record(ctx
             g.set_debug_flags(0)
             g.set_debug_param(cfrk_amd.lib.CFRK_PARAM_MSP2_SUBVALUE_BITS, 0)
         assert (lo == want[0]).all() and (hi == want[1]).all() and (cnt.astype(np.uint64) == want[2]).all()
+
+
+# ------------------------------------------------------------------ pipelined runs exchange (round 5)
+
+def _pipelined_exchange(ctx, data, R, L, k, flags, world, ngroups, hint, seg_cap=1 << 18, dbg=0):
+    """`world` emulated ranks on one GPU through the PIPELINED runs exchange: CFRK_RUNS_DEFER add, export_runs_async,
+    per group export_runs_wait + "all-to-all" (host copies) + merge_runs_group_device on every owner.
+    -> {key: count} over all owners, or None when a rank's export refused (overflow / spill / small segment)"""
+    import cfrk_amd
+    per_rank = []                                     # [rank][group] -> (rows per owner, host copy of the group's segments)
+    for r in range(world):
+        r0, r1 = R * r // world, R * (r + 1) // world
+        shard = np.ascontiguousarray(data[r0 * (L + 1):r1 * (L + 1)])
+        g = cfrk_amd.GlobalCounter(ctx, k, flags | cfrk_amd.CFRK_RUNS_ONLY | cfrk_amd.CFRK_RUNS_DEFER, hint)
+        g.set_debug_flags(dbg)
+        try:
+            g.add(shard)
+            d = ctx.alloc(ngroups * world * seg_cap * 16)
+            g.export_runs_async(d, seg_cap, world, ngroups)
+            groups = []
+            for gi in range(ngroups):
+                try:
+                    rows = g.export_runs_wait(gi)
+                except cfrk_amd.CfrkError as e:
+                    assert e.code in (-4, -9), e
+                    ctx.sync()
+                    ctx.free(d)
+                    return None
+                host = np.empty((world * seg_cap, 2), np.uint64)
+                ctx.d2h(host, d + gi * world * seg_cap * 16)
+                groups.append((rows, host))
+            ctx.sync()
+            ctx.free(d)
+        finally:
+            g.set_debug_flags(0)
+        per_rank.append(groups)
+    merged = {}
+    for owner in range(world):
+        og = cfrk_amd.GlobalCounter(ctx, k, flags, hint)
+        og.set_debug_flags(dbg & cfrk_amd.lib.CFRK_DEBUG_NO_ANCHORS)
+        bufs = []
+        for gi in range(ngroups):
+            segs, recv = [], []
+            for r in range(world):
+                rows, host = per_rank[r][gi]
+                segs.append(host[owner * seg_cap:owner * seg_cap + rows[owner]])
+                recv.append(rows[owner])
+            buf = np.concatenate(segs)
+            d = ctx.alloc(len(buf) * 16)
+            ctx.h2d(d, buf)
+            og.merge_runs_group_device(d, recv, gi, ngroups)      # enqueued: the buffer stays until the export below
+            bufs.append(d)
+        lo, hi, cnt = og.export()
+        og.set_debug_flags(0)
+        for d in bufs:
+            ctx.free(d)
+        for key, c in zip(lo, cnt):
+            assert int(key) not in merged            # owners hold disjoint key sets
+            merged[int(key)] = int(c)
+    return merged
+
+
+@pytest.mark.parametrize("k,canonical,world,ngroups,G,dbg", [
+    (31, True, 2, 2, 300_000, 0), (31, True, 8, 2, 300_000, 0), (31, True, 8, 1, 300_000, 0), (21, True, 4, 3, 300_000, 0),
+    (28, False, 3, 2, 300_000, 0), (16, True, 2, 4, 5_000_000, 0), (32, True, 5, 2, 300_000, 0),
+    (31, True, 4, 2, 300_000, "rt_overflow"), (31, True, 4, 2, 300_000, "no_anchors"), (25, True, 3, 2, 300_000, "chunked"),
+    (31, False, 4, 16, 300_000, 0)])
+def test_pipelined_runs_exchange_emulated_ranks_equal_the_oracle(ctx, k, canonical, world, ngroups, G, dbg):
+    """the pipelined form of the strong-scaling exchange (cfrk_global_export_runs_async / _wait,
+    cfrk_global_merge_runs_group_device): the sender deduplicates and packs one group of leaves after the
+    other straight into the send buffer (no gather pass, notes decided in LDS), the owner's leaf kernel reads the N lists
+    of a leaf in place (no layout / scatter kernels, notes expanded where they are read) -- the union of the owners'
+    results equals the oracle's count of ALL reads, key by key.  (Genome 300 000, 12 x coverage: the leaf streams of a
+    deferred add keep their fixed stride -- it cannot lay them out again; that refusal is the next test's.)
+    Variants: a world that does not divide 65 536, one to
+    sixteen groups, leaves whose record table is forced to overflow (runs leave undeduplicated), no anchoring, a chunked
+    add, forward-strand counting."""
+    import cfrk_amd
+    R, L = 24_000, 150
+    data, _, _ = orc.synth_reads(0, R, L, G)
+    data = data.copy()
+    data[::1013] = -1
+    data.reshape(R, L + 1)[:, L] = -1
+    flags = cfrk_amd.CFRK_CANONICAL if canonical else 0
+    bits = {0: 0, "rt_overflow": cfrk_amd.CFRK_DEBUG_FORCE_RT_OVERFLOW, "no_anchors": cfrk_amd.lib.CFRK_DEBUG_NO_ANCHORS,
+            "chunked": cfrk_amd.CFRK_DEBUG_SMALL_PIPELINE}[dbg]
+    merged = _pipelined_exchange(ctx, data, R, L, k, flags, world, ngroups, 2 * G, dbg=bits)
+    assert merged is not None
+    wlo, whi, wcnt = orc.global_count(data, k, orc.ORC_CANONICAL if canonical else 0, threads=4)
+    assert len(merged) == len(wlo)
+    assert all(merged[int(a)] == int(b) for a, b in zip(wlo, wcnt))
+
+
+def test_pipelined_runs_exchange_refuses_what_it_cannot_carry_and_the_classic_export_follows(ctx):
+    """(1) a segment capacity that is too small: export_runs_wait returns CFRK_ERR_SMALL_BUF for the group, nothing is
+    written beyond a segment, and the CLASSIC export still works on the same job (the leaf streams were not touched);
+    (2) a shard whose leaf streams overflow their fixed stride (deep coverage of a 1200-base genome): the deferred add
+    cannot lay them out again -- export_runs_wait returns CFRK_ERR_STATE, and so does the classic export: the rank adds
+    again without CFRK_RUNS_DEFER; (3) call-sequence errors."""
+    import cfrk_amd
+    R, L, k = 24_000, 150, 31
+    data, _, _ = orc.synth_reads(0, R, L, 300_000)
+    data = data.copy()
+    flags = cfrk_amd.CFRK_CANONICAL
+    g = cfrk_amd.GlobalCounter(ctx, k, flags | cfrk_amd.CFRK_RUNS_ONLY | cfrk_amd.CFRK_RUNS_DEFER, 600_000)
+    g.add(data)
+    lpp = g.leaves_per_part(2)
+    cap = lpp // 2 + 2 + 64                                   # the header and 64 rows: far too small
+    d = ctx.alloc(2 * 2 * cap * 16 + 4096)
+    guard = np.full(256, 0xABABABABABABABAB, np.uint64)
+    ctx.h2d(d + 2 * 2 * cap * 16, guard)
+    g.export_runs_async(d, cap, 2, 2)
+    with pytest.raises(cfrk_amd.CfrkError) as e:
+        g.export_runs_wait(0)
+    assert e.value.code == -9
+    ctx.sync()
+    back = np.empty(256, np.uint64)
+    ctx.d2h(back, d + 2 * 2 * cap * 16)
+    assert (back == guard).all()
+    ctx.free(d)
+    big = ctx.alloc((1 << 20) * 16)
+    rows = g.export_runs_device(big, 1 << 20, 2)              # the classic export deduplicates first, then packs
+    assert sum(rows) > 0
+    with pytest.raises(cfrk_amd.CfrkError) as e:              # ... after which the streams are no longer what the pipelined form reads
+        g.export_runs_async(big, 1 << 18, 2, 2)
+    assert e.value.code == -4
+    ctx.free(big)
+    # (2)
+    tiny, _, _ = orc.synth_reads(0, R, L, 1_200)
+    g = cfrk_amd.GlobalCounter(ctx, k, flags | cfrk_amd.CFRK_RUNS_ONLY | cfrk_amd.CFRK_RUNS_DEFER, 60_000)
+    g.add(tiny)
+    d = ctx.alloc(2 * 2 * (1 << 18) * 16)
+    g.export_runs_async(d, 1 << 18, 2, 2)
+    with pytest.raises(cfrk_amd.CfrkError) as e:
+        g.export_runs_wait(0)
+    assert e.value.code == -4
+    ctx.sync()
+    with pytest.raises(cfrk_amd.CfrkError) as e:
+        g.export_runs_device(d, 1 << 19, 2)
+    assert e.value.code == -4
+    g = cfrk_amd.GlobalCounter(ctx, k, flags | cfrk_amd.CFRK_RUNS_ONLY, 60_000)     # without the flag the add settles
+    g.add(tiny)
+    assert sum(g.export_runs_device(d, 1 << 19, 2)) > 0
+    # (3)
+    with pytest.raises(cfrk_amd.CfrkError) as e:
+        cfrk_amd.GlobalCounter(ctx, k, cfrk_amd.CFRK_RUNS_DEFER, 1000)              # the flag goes with CFRK_RUNS_ONLY
+    assert e.value.code == -1
+    og = cfrk_amd.GlobalCounter(ctx, k, flags, 60_000)
+    with pytest.raises(cfrk_amd.CfrkError) as e:
+        og.merge_runs_group_device(d, [10, 10], 1, 2)         # groups are merged in order
+    assert e.value.code == -4
+    # a segment whose header is garbage is not followed, and the job says so
+    junk = np.full((4096, 2), 0x1234567812345678, np.uint64)
+    ctx.h2d(d, junk)
+    og.merge_runs_group_device(d, [2048, 2048], 0, 16)
+    with pytest.raises(cfrk_amd.CfrkError) as e:
+        og.finish()
+    assert e.value.code == -6
+    ctx.free(d)
