@@ -1843,6 +1843,10 @@ __global__ __launch_bounds__(DX_THREADS) void msp_dedupe_export_kernel(int k, in
 // One workgroup per leaf, everything a thread needs of the complete stream in flight at once (DS_INFL loads: a
 // shard's leaf is ~2700 records); the truncated runs are looked up once, their verdict (note or record) waits in LDS
 // for the leaf's row count, then they are written from a second read that hits the L2.
+// SPLIT RECORD TABLE.  With 16-byte entries {bases x 3, meta} the count word of every slot sits in LDS bank 3 mod 4: a
+// wave's 64 ds_add on it land on 8 of the 32 banks and serialise 8 ways -- 62 % of this kernel's LDS-active cycles were
+// bank conflicts, the LDS was busy for 76 % of its time (profiles/r05/dedupe_send_pmc_before_split_table.txt).  Here the
+// bases (12 bytes per slot) and the meta words (4 bytes per slot) are two arrays: the adds spread over all banks.
 constexpr int DS_THREADS = 256, DS_INFL = 12, DS_TCAP = 4096;
 struct RunsSend {
   uint4 *packed;             // this GROUP's segments: owner p's at packed + p * seg_cap
@@ -1852,8 +1856,34 @@ struct RunsSend {
   uint32_t ll0, lcount;
   int parts;
 };
+// insert-or-count one record per lane in the split table (rtab_insert_loop's logic); lanes still without RT_DONE found no place
+__device__ __forceinline__ void ds_insert_loop(uint32_t *rb, uint32_t *rm, uint4 rec, uint32_t &h) {
+  const uint32_t nm1 = rec.w & 63u;
+  for (int it = 0; it < RT_TRIPS && __ballot((int32_t)h >= 0); ++it) {
+    const bool p = (int32_t)h >= 0;
+    const uint32_t hh = h & (uint32_t)(RT - 1);
+    const uint32_t m = rm[hh];
+    const uint32_t e0 = rb[3 * hh], e1 = rb[3 * hh + 1], e2 = rb[3 * hh + 2];
+    const bool match = ((e0 ^ rec.x) | (e1 ^ rec.y) | (e2 ^ rec.z) | ((m ^ rec.w) & 63u)) == 0u;
+    const bool empty = m == RT_EMPTY;
+    uint32_t won = 0u;
+    if (p && empty) {
+      if (atomicCAS(&rm[hh], RT_EMPTY, RT_LOCK) == RT_EMPTY) {
+        rb[3 * hh] = rec.x; rb[3 * hh + 1] = rec.y; rb[3 * hh + 2] = rec.z;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        atomicExch(&rm[hh], (1u << 6) | nm1);
+        won = 1u;
+      }
+    }
+    atomicAdd(&rm[hh], (p && match) ? (1u << 6) : 0u);
+    const bool stay = match || empty || m == RT_LOCK;
+    const uint32_t nh = stay ? hh : ((hh + 1) & (uint32_t)(RT - 1));
+    h = (p && !match && won == 0u) ? nh : (h | RT_DONE);
+  }
+}
 __global__ __launch_bounds__(DS_THREADS) void msp_dedupe_send_kernel(int k, int canon, MspView v, RunsSend sg) {
-  __shared__ uint4 rtab[RT];
+  __shared__ uint32_t rb[3 * RT];                  // record table: the bases of slot s at rb[3 s .. 3 s + 2] ...
+  __shared__ uint32_t rm[RT];                      // ... its meta word (count << 6 | n-1; RT_EMPTY, RT_LOCK) at rm[s]
   __shared__ uint16_t sidx[RT];                    // record-table slot -> position in the leaf's list
   __shared__ uint16_t tres[DS_TCAP];               // truncated run g: its note, or 0xFFFF = travels as a record
   __shared__ uint32_t wsum[DS_THREADS / 64];
@@ -1881,17 +1911,16 @@ __global__ __launch_bounds__(DS_THREADS) void msp_dedupe_send_kernel(int k, int 
     recs[u] = zero4;
     if (r < n1 && !too_many) recs[u] = c1[r];
   }
-  for (int s2 = tid; s2 < RT; s2 += DS_THREADS) rtab[s2] = make_uint4(0u, 0u, 0u, RT_EMPTY);
+  for (int s2 = tid; s2 < RT; s2 += DS_THREADS) rm[s2] = RT_EMPTY;
   if (tid == 0) { rt_fail = ((v.dbg & CFRK_DEBUG_FORCE_RT_OVERFLOW) || too_many) ? 1u : 0u; noted = 0u; cu = 0u; cn = 0u; }
   __syncthreads();
   if (!too_many) {
-    uint32_t *rmeta = reinterpret_cast<uint32_t *>(rtab);
     uint4 L = zero4;                 // leftover records, lanes [0, c) (see the leaf kernel's phase 1a)
     uint32_t Lh = 0;
     int c = 0;                       // wave-uniform
     auto drain = [&](int cnt) {
       uint32_t h = Lh | ((lane < cnt) ? 0u : RT_DONE);
-      rtab_insert_loop(rtab, L, h, RT - 1, RT_TRIPS);
+      ds_insert_loop(rb, rm, L, h);
       if ((int32_t)h >= 0) rt_fail = 1u;
     };
     for (uint64_t r0 = 0; r0 < n1; r0 += (uint64_t)DS_INFL * DS_THREADS) {
@@ -1910,9 +1939,11 @@ __global__ __launch_bounds__(DS_THREADS) void msp_dedupe_send_kernel(int k, int 
         const bool valid = r < n1;
         const uint4 rec = recs[u];
         const uint32_t h = rtab_slot_k(rec, k, RT_LOG);
-        const uint4 e = rtab[h];
-        const bool match = valid && rtab_diff(e, rec) == 0u;
-        if (match) atomicAdd(&rmeta[4 * h + 3], 1u << 6);
+        const uint32_t m = rm[h];
+        const uint32_t e0 = rb[3 * h], e1 = rb[3 * h + 1], e2 = rb[3 * h + 2];
+        // (EMPTY and LOCK carry low bits no record has: they never compare equal; stale bases of an empty slot do not matter)
+        const bool match = valid && ((e0 ^ rec.x) | (e1 ^ rec.y) | (e2 ^ rec.z) | ((m ^ rec.w) & 63u)) == 0u;
+        if (match) atomicAdd(&rm[h], 1u << 6);
         const bool left = valid && !match;
         const unsigned long long mask = __ballot(left);
         if (mask == 0ull) continue;
@@ -1936,10 +1967,9 @@ __global__ __launch_bounds__(DS_THREADS) void msp_dedupe_send_kernel(int k, int 
     nd = (uint32_t)min(n1, (uint64_t)0xFFFFFFFFull);
   } else {
     // occupied slots -> positions in the leaf's list (four slots per thread)
-    const uint32_t *meta = reinterpret_cast<const uint32_t *>(rtab);
     uint32_t mine = 0;
 #pragma unroll
-    for (int i = 0; i < PER; ++i) mine += (meta[4 * (PER * tid + i) + 3] != RT_EMPTY) ? 1u : 0u;
+    for (int i = 0; i < PER; ++i) mine += (rm[PER * tid + i] != RT_EMPTY) ? 1u : 0u;
     const uint32_t incl = dev_wave_scan_incl(mine);
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
@@ -1950,7 +1980,7 @@ __global__ __launch_bounds__(DS_THREADS) void msp_dedupe_send_kernel(int k, int 
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       sidx[PER * tid + i] = (uint16_t)at;
-      if (meta[4 * (PER * tid + i) + 3] != RT_EMPTY) ++at;
+      if (rm[PER * tid + i] != RT_EMPTY) ++at;
     }
     nd = total;
     __syncthreads();
@@ -1972,7 +2002,7 @@ __global__ __launch_bounds__(DS_THREADS) void msp_dedupe_send_kernel(int k, int 
       for (int it = 0; it < 32 && __ballot((int32_t)h >= 0); ++it) {
         const bool p = (int32_t)h >= 0;
         const uint32_t hh = h & (uint32_t)(RT - 1);
-        const uint4 e2 = rtab[hh];
+        const uint4 e2 = make_uint4(rb[3 * hh], rb[3 * hh + 1], rb[3 * hh + 2], rm[hh]);
         const bool empty = e2.w == RT_EMPTY;
         const bool hit = p && !empty && (e2.w & 31u) >= nm1 && rec_prefix_equal(e2, rec, (int)nm1 + k);
         found = hit ? hh : found;
@@ -2009,8 +2039,8 @@ __global__ __launch_bounds__(DS_THREADS) void msp_dedupe_send_kernel(int k, int 
     uint32_t at = at0;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-      const uint4 e = rtab[PER * tid + i];
-      if (e.w != RT_EMPTY) dst[at++] = e;
+      const uint32_t sl = PER * tid + i, m = rm[sl];
+      if (m != RT_EMPTY) dst[at++] = make_uint4(rb[3 * sl], rb[3 * sl + 1], rb[3 * sl + 2], m);
     }
   }
   uint16_t *const notes = reinterpret_cast<uint16_t *>(dst + nd + nu);
