@@ -78,7 +78,12 @@ static void encode_bytes(const unsigned char *src, int8_t *dst, size_t n) {
 
 // (huge-page advice for the batch's arrays was tried and dropped: with MADV_HUGEPAGE the first faults of a fresh process
 //  took 0.7 - 1.1 s for a 150 MB array -- compaction at fault time -- against 0.03 s of ordinary first-touch faults)
-static void *big_alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
+static void *big_alloc(size_t bytes) {
+  if (bytes < ((size_t)8 << 20)) return malloc(bytes ? bytes : 1);
+  void *p = nullptr;
+  const size_t rounded = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+  return posix_memalign(&p, (size_t)2 << 20, rounded) == 0 ? p : nullptr;
+}
 
 // threads the parser may use (cfrk_host_set_parse_threads; 0 = min(hardware threads, 16): beyond that the two
 // passes are bound by memory bandwidth and by the serial merge of the per-thread line lists, profiles/r05/end_to_end.txt)
