@@ -828,7 +828,10 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, uint32_t mod
       const uint4 ea = rtab[h].a;
       const bool match = valid && ((((eb.w ^ rec.b.w) & 63u) | (eb.x ^ rec.b.x) | (eb.y ^ rec.b.y) | (ea.x ^ rec.a.x) |
                                     (ea.y ^ rec.a.y) | (ea.z ^ rec.a.z) | (ea.w ^ rec.a.w)) == 0u);
-      if (match) atomicAdd(&words[8 * h + 7], weighted ? (rec.b.w & ~63u) : (1u << 6));
+      // home-slot hits are counted BESIDE the table: the state word of a 32-byte entry sits in LDS bank 7 mod 8 -- a wave's
+      // 64 ds_add on the entries' own words land on 4 of the 32 banks; th[] (the anchoring's group array) is idle during
+      // the scan and takes them on consecutive words, folded into the entries after the scan
+      if (match) atomicAdd(&th[h], weighted ? (rec.b.w >> 6) : 1u);
       const bool left = valid && !match;
       const unsigned long long mask = __ballot(left);
       if (mask == 0ull) return;
@@ -900,6 +903,12 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, uint32_t mod
       if (cc) home(Cr, lane < cc);
     }
     if (c) drain(c);
+  }
+  __syncthreads();
+  {
+    const uint32_t hits = th[tid];                   // (R2 == Q3_THREADS: one slot per thread)
+    if (hits) atomicAdd(&reinterpret_cast<uint32_t *>(rtab)[8 * tid + 7], hits << 6);
+    th[tid] = 0u;
   }
   __syncthreads();
   const bool big = rt_fail != 0u;
