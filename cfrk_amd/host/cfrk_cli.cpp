@@ -29,7 +29,7 @@
 //   --timing         one line on stderr, `cfrk-timing {json}`: seconds spent parsing the FASTA, in the counting calls
 //                    (H2D copy + kernels), in the export (device sort + D2H) and in formatting + writing the output --
 //                    the wall-clock breakdown the reference has as commented-out printf()s (src/main.cu:259-268,303-305)
-//   --parse-threads N  host threads of the FASTA parser (default min(hardware threads, 16))
+//   --parse-threads N  host threads of the FASTA parser (default min(hardware threads, 64))
 //   --batch N        the Swift/T workflow's loop (swift/cfrk.swf:15-20) in one process: for i < N
 //                    count <dataset_prefix>_<i>.fasta into <out_prefix>_<i>.cfrk
 // Chunk pipeline: every device runs two contexts (two HIP streams), each on a host thread of its
@@ -42,6 +42,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -193,17 +194,24 @@ void write_global(const Options &o, const uint64_t *lo, const uint64_t *hi, cons
 int run_global(const Options &o, const cfrk_batch &batch, Worker &w, FILE *out) {
   int rc;
   cfrk_ctx *ctx = w.ctx;
-  // distinct k-mers cannot exceed the number of window starts; the hint sizes the result list
-  // and the spill table (12 B per slot at load 0.5), so it is capped at 2^31 keys
-  uint64_t hint = (uint64_t)(batch.nN > 0 ? batch.nN : 1);
-  if (hint < (1ull << 20)) hint = 1ull << 20;
-  if (hint > (1ull << 31)) hint = 1ull << 31;
-  if ((rc = cfrk_global_begin(ctx, o.k, o.canonical ? CFRK_CANONICAL : 0, hint))) return die(ctx, rc, "cfrk_global_begin");
-  const double t0 = now_s();
-  if ((rc = cfrk_global_add(ctx, batch.data, batch.start, batch.length, batch.nN, batch.nS))) return die(ctx, rc, "cfrk_global_add");
-  const double t1 = now_s();
+  // The capacity hint sizes the result list and the spill table (12 B per slot at load <= 0.5).  Distinct k-mers cannot
+  // exceed the window starts (nN), but a table for nN keys is 25 - 50 GB for a 1.5 GB batch and allocating it took
+  // 5 of the 6 seconds of a k = 31 run (round 5, profiles/r05/end_to_end.txt): the first attempt announces nN / 16 keys
+  // (sequencing depth is rarely below that) and an overflowing result (CFRK_ERR_TABLE_FULL) is counted again with
+  // eight times the room, up to nN (capped at 2^31 keys).
+  const uint64_t hint_max = std::min<uint64_t>(std::max<uint64_t>((uint64_t)(batch.nN > 0 ? batch.nN : 1), 1ull << 20), 1ull << 31);
+  uint64_t hint = std::min<uint64_t>(std::max<uint64_t>(hint_max / 16, 1ull << 20), hint_max);
   uint64_t n = 0;
-  rc = cfrk_global_finish(ctx, &n);
+  double t0 = 0, t1 = 0;
+  for (;;) {
+    if ((rc = cfrk_global_begin(ctx, o.k, o.canonical ? CFRK_CANONICAL : 0, hint))) return die(ctx, rc, "cfrk_global_begin");
+    t0 = now_s();
+    if ((rc = cfrk_global_add(ctx, batch.data, batch.start, batch.length, batch.nN, batch.nS))) return die(ctx, rc, "cfrk_global_add");
+    t1 = now_s();
+    rc = cfrk_global_finish(ctx, &n);
+    if (rc == CFRK_ERR_TABLE_FULL && hint < hint_max) { hint = std::min<uint64_t>(hint * 8, hint_max); continue; }
+    break;
+  }
   // (counts are 32-bit and saturate: the result is complete, the user is told)
   if (rc == CFRK_ERR_COUNT_OVERFLOW) fprintf(stderr, "cfrk: warning: %s\n", cfrk_last_error(ctx));
   else if (rc) return die(ctx, rc, "cfrk_global_finish");
@@ -225,9 +233,9 @@ int run_global(const Options &o, const cfrk_batch &batch, Worker &w, FILE *out) 
 int run_global_multi(const Options &o, const cfrk_batch &batch, std::vector<std::vector<Worker>> &per_dev, FILE *out) {
   const int N = (int)per_dev.size();
   const int flags = o.canonical ? CFRK_CANONICAL : 0;
-  uint64_t hint = (uint64_t)(batch.nN > 0 ? batch.nN : 1);
-  if (hint < (1ull << 20)) hint = 1ull << 20;
-  if (hint > (1ull << 31)) hint = 1ull << 31;
+  // (as in run_global: nN / 16 keys announced first; an owner whose result overflows makes the job count on one device,
+  //  where the hint grows)
+  uint64_t hint = std::min<uint64_t>(std::max<uint64_t>((uint64_t)(batch.nN > 0 ? batch.nN : 1) / 16, 1ull << 20), 1ull << 31);
   // shard s: packed rows stay ON ITS DEVICE (16 bytes per row), rows[s][o] = rows of owner o's segment
   std::vector<void *> d_packed((size_t)N, nullptr);
   std::vector<std::vector<uint64_t>> rows((size_t)N, std::vector<uint64_t>((size_t)N, 0));
@@ -313,6 +321,7 @@ int run_global_multi(const Options &o, const cfrk_batch &batch, std::vector<std:
         uint64_t n = 0;
         rc = cfrk_global_finish(ctx, &n);
         if (rc == CFRK_ERR_COUNT_OVERFLOW) fprintf(stderr, "cfrk: warning: %s\n", cfrk_last_error(ctx));
+        else if (rc == CFRK_ERR_TABLE_FULL) { refused[(size_t)ow] = 1; return; }       // (more distinct k-mers than announced)
         else if (rc) { status[(size_t)ow] = die(ctx, rc, "cfrk_global_finish"); return; }
         keys[(size_t)ow].resize(n); cnts[(size_t)ow].resize(n); his[(size_t)ow].resize(n);
         rc = cfrk_global_export(ctx, keys[(size_t)ow].data(), his[(size_t)ow].data(), cnts[(size_t)ow].data(), n, &n);
@@ -321,6 +330,11 @@ int run_global_multi(const Options &o, const cfrk_batch &batch, std::vector<std:
     for (auto &t : th) t.join();
     free_packed();
     for (int r : status) if (r) return r;
+    for (char r : refused)
+      if (r) {
+        fprintf(stderr, "cfrk: more distinct k-mers than announced; counting on one device\n");
+        return run_global(o, batch, per_dev[0][0], out);
+      }
   }
   // N ascending lists with disjoint keys -> one ascending list
   size_t total = 0;

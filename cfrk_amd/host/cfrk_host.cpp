@@ -85,8 +85,9 @@ static void *big_alloc(size_t bytes) {
   return posix_memalign(&p, (size_t)2 << 20, rounded) == 0 ? p : nullptr;
 }
 
-// threads the parser may use (cfrk_host_set_parse_threads; 0 = min(hardware threads, 16): beyond that the two
-// passes are bound by memory bandwidth and by the serial merge of the per-thread line lists, profiles/r05/end_to_end.txt)
+// threads the parser may use (cfrk_host_set_parse_threads; 0 = min(hardware threads, 64): a 1.63 GB file parses at
+// 4.7 / 5.1 / 7.1 GB/s with 8 / 16 / 64 threads on the GPU box's 256-thread host, profiles/r05/end_to_end.txt -- the
+// 16-thread cap of rounds 1-4 was binding once the file was mapped instead of copied and the encoding vectorised)
 int g_parse_threads = 0;
 
 }  // namespace
@@ -113,7 +114,7 @@ int cfrk_host_parse_fasta(const char *buf, size_t len, int flags, cfrk_batch *ou
   std::vector<std::pair<size_t, size_t>> lines;     // (begin, end incl. newline) of sequence lines
   unsigned nthr = std::thread::hardware_concurrency();
   if (g_parse_threads > 0) { if (nthr == 0 || nthr > (unsigned)g_parse_threads) nthr = (unsigned)g_parse_threads; }
-  else if (nthr > 16) nthr = 16;
+  else if (nthr > 64) nthr = 64;
   if (nthr < 2 || len < ((size_t)8 << 20)) nthr = 1;
   {
     struct Part { std::vector<size_t> rec_first; std::vector<std::pair<size_t, size_t>> lines; };

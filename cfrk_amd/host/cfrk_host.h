@@ -37,7 +37,7 @@ typedef struct cfrk_batch {      /* struct read (src/tipos.h:23-30) with owned s
 int  cfrk_host_read_fasta(const char *path, int flags, cfrk_batch *out);
 int  cfrk_host_parse_fasta(const char *buf, size_t len, int flags, cfrk_batch *out);
 void cfrk_host_free_batch(cfrk_batch *b);
-/* threads the parser may use for large inputs (0 = the default, min(hardware threads, 16)) */
+/* threads the parser may use for large inputs (0 = the default, min(hardware threads, 64)) */
 void cfrk_host_set_parse_threads(int n);
 
 /* Chunk [first, first+count) of a batch with chunk-relative start[] (SelectChunk,

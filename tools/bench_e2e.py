@@ -10,7 +10,7 @@ device-resident reads; this is the whole command on a file.
 Writes a configs[1]-sized FASTA (10 M x 150 bp from the SURVEY 8d generator, 1.6 GB) and runs
   cfrk in.fasta out.cfrk k T --global --canonical --timing                (sparse text)
   ... --binary                                                            (CFRKGLB1)
-  ... --parse-threads 64                                                  (is the parser's 16-thread default binding?)
+  ... --parse-threads 16 / 8                                              (the parser by thread count; default min(hw, 64))
   cfrk in.fasta out4.cfrk 4 T 8192 --timing                               (the reference's own mode: compat, k = 4)
   cfrk first-1M-reads.fasta out4all.cfrk 4 T 8192 --all-chunks --timing   (every chunk written)
 and prints one JSON object: per run the phases `cfrk --timing` reports, as seconds and GB/s.
@@ -101,7 +101,7 @@ def measure(reads=10_000_000, L=150, k=15, glen=0, tmpdir=None, threads=0, ctx=N
         res["global_text"] = run_cfrk([fa, outp, str(k), T, "--global", "--canonical"])
         if not quick:
             res["global_binary"] = run_cfrk([fa, outp, str(k), T, "--global", "--canonical", "--binary"])
-            res["global_text_parse64"] = run_cfrk([fa, outp, str(k), T, "--global", "--canonical", "--parse-threads", "64"])
+            res["global_text_parse16"] = run_cfrk([fa, outp, str(k), T, "--global", "--canonical", "--parse-threads", "16"])
             res["global_text_parse8"] = run_cfrk([fa, outp, str(k), T, "--global", "--canonical", "--parse-threads", "8"])
             res["global_text_k31"] = run_cfrk([fa, outp, "31", T, "--global", "--canonical"])
             res["compat_k4_as_the_reference_writes_it"] = run_cfrk([fa, outp, "4", T, "8192"])
