@@ -159,10 +159,13 @@ int cfrk_global_merge_device(cfrk_ctx *ctx, const uint64_t *d_keys_lo, const uin
                              const uint32_t *d_counts, int64_t n);
 
 /* Wait for all adds; report the number of distinct keys.  CFRK_ERR_TABLE_FULL if the table
- * overflowed. */
+ * overflowed.  CFRK_ERR_COUNT_OVERFLOW if a count saturated: *n_distinct is written all the same
+ * and the job can be digested / exported (the same code comes back from those calls, their outputs
+ * filled, the saturated counts reading CFRK_COUNT_MAX). */
 int cfrk_global_finish(cfrk_ctx *ctx, uint64_t *n_distinct);
 
-/* Sorted ascending by (hi, lo).  keys_hi may be NULL for k <= 32.  cap = entries available. */
+/* Sorted ascending by (hi, lo).  keys_hi may be NULL for k <= 32.  cap = entries available.
+ * CFRK_ERR_COUNT_OVERFLOW: the arrays are complete, at least one count reads CFRK_COUNT_MAX. */
 int cfrk_global_export(cfrk_ctx *ctx, uint64_t *keys_lo, uint64_t *keys_hi, uint32_t *counts,
                        uint64_t cap, uint64_t *n_out);
 
@@ -243,7 +246,8 @@ int cfrk_global_runs_group_ms(cfrk_ctx *ctx, int group, float *ms);
 
 /* Order-independent digest: out[0]=distinct, out[1]=sum count,
  * out[2]=sum count*splitmix64(kh) mod 2^64, out[3]=xor splitmix64(kh ^ count);
- * kh = lo (k<=32) or lo + splitmix64(hi). Synchronises. */
+ * kh = lo (k<=32) or lo + splitmix64(hi). Synchronises.  CFRK_ERR_COUNT_OVERFLOW: out[] is
+ * filled, computed over the saturated counts. */
 int cfrk_global_digest(cfrk_ctx *ctx, uint64_t out[4]);
 
 /* Device time (ms, HIP events on the context stream) of the counting kernels of the most
