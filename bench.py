@@ -314,14 +314,14 @@ def main():
 
             # -- pipelined runs exchange (sharded.exchange_by_runs_pipelined) --
             def export_runs_pipelined_begin(self, parts, groups):
-                if self.runs_refused or k > 32:
+                if self.runs_refused:
                     return None
                 lpp = self.g.leaves_per_part(parts)
                 if getattr(self, "pbuf", None) is None or self.pbuf.shape[:2] != (groups, parts):
                     # rows of a rank as for the one-shot form, spread over groups x parts segments, a quarter to spare
                     # (a segment that runs out is reported by the wait: the step takes the one-shot form and the next
                     #  step gets twice the room)
-                    rows = int(min(14 * Rl, 2.5 * Rl + 0.3 * glen)) + (1 << 17)
+                    rows = int(min(14 * Rl, 2.5 * Rl + 0.3 * glen)) * (2 if k > 32 else 1) + (1 << 17)   # (k > 32: two rows per record)
                     cap = int(rows / (groups * parts) * 1.25 * getattr(self, "pgrow", 1)) + (lpp + groups - 1) // groups + 4096
                     self.pbuf = torch.empty((groups, parts, cap, 2), dtype=torch.int64, device=dev)
                 try:
@@ -371,7 +371,7 @@ def main():
 
         def step():
             runs = world > 1 and exch == "runs"
-            piped = runs and k <= 32 and args.pipeline_groups > 0
+            piped = runs and args.pipeline_groups > 0
             eng.deferred = piped
             eng.g = cfrk_amd.GlobalCounter(ctx, k, flags | (cfrk_amd.CFRK_RUNS_ONLY if runs else 0)
                                            | (cfrk_amd.CFRK_RUNS_DEFER if piped else 0), hint)

@@ -110,6 +110,8 @@ int  cfrk_msp2_merge_lists(cfrk_ctx *ctx, const uint64_t *d_lo, const uint64_t *
 // msp2.hip: the exchange by runs (cfrk_global_export_runs_device / cfrk_global_merge_runs_device) for two-word keys
 int  cfrk_msp2_export_runs(cfrk_ctx *ctx, void *d_packed, uint64_t cap_rows, int parts, uint64_t *part_rows);
 int  cfrk_msp2_merge_runs(cfrk_ctx *ctx, const void *d_packed, const uint64_t *recv_rows, int parts);
+int  cfrk_msp2_export_runs_async(cfrk_ctx *ctx, void *d_packed, uint64_t seg_cap_rows, int parts, int ngroups);
+int  cfrk_msp2_merge_runs_group(cfrk_ctx *ctx, const void *d_recv, const uint64_t *recv_rows, int parts, int group, int ngroups);
 
 // radix.hip: k <= 15
 bool cfrk_radix_usable(const cfrk_ctx *ctx);

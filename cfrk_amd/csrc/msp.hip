@@ -1037,15 +1037,6 @@ constexpr uint32_t P3_EXPORT = 1u, P3_WEIGHTED = 2u;
 // row].  A note is turned back into the run it stands for (the first n k-mers of its twin) where it is read.  No layout
 // kernels, no scatter pass, no host synchronisation before the leaf kernel.  An instantiation of its own
 // (msp_p3_lists_kernel): the one-GPU kernel's code and registers are what they were.
-template <bool LISTS> struct P3ListsT {};
-template <> struct P3ListsT<true> {
-  const uint4 *packed;       // the receive buffer of this group: rank r's segment at row rr.rstart[r], rr.rows[r] rows
-  RunsRecv rr;
-  int parts;
-  uint32_t ll0, lcount;      // the group's local leaves [ll0, ll0 + lcount): workgroup b counts local leaf ll0 + b
-};
-constexpr uint32_t RUNS2_MAGIC = 0x32535543u;   // "CUS2"
-
 template <bool CANON, bool SHARED, bool LISTS>
 __device__ __forceinline__ void p3_body(int k, uint32_t mode, const MspView &v, const TableView &t, const P3ListsT<LISTS> &lx) {
   // k-mer table (keys, counts) and record table in one allocation: p3_big_dedupe uses all of it
@@ -1848,14 +1839,6 @@ __global__ __launch_bounds__(DX_THREADS) void msp_dedupe_export_kernel(int k, in
 // bank conflicts, the LDS was busy for 76 % of its time (profiles/r05/dedupe_send_pmc_before_split_table.txt).  Here the
 // bases (12 bytes per slot) and the meta words (4 bytes per slot) are two arrays: the adds spread over all banks.
 constexpr int DS_THREADS = 256, DS_INFL = 12, DS_TCAP = 4096;
-struct RunsSend {
-  uint4 *packed;             // this GROUP's segments: owner p's at packed + p * seg_cap
-  uint64_t seg_cap;          // rows per segment (header included)
-  uint32_t *cursor;          // [parts] rows claimed behind the header (zeroed before the kernel)
-  uint32_t leaf0, nleaf;     // the group's leaves [leaf0, leaf0 + nleaf): all owners' local leaves [ll0, ll0 + lcount)
-  uint32_t ll0, lcount;
-  int parts;
-};
 // insert-or-count one record per lane in the split table (rtab_insert_loop's logic); lanes still without RT_DONE found no place
 __device__ __forceinline__ void ds_insert_loop(uint32_t *rb, uint32_t *rm, uint4 rec, uint32_t &h) {
   const uint32_t nm1 = rec.w & 63u;
@@ -2061,18 +2044,6 @@ __global__ __launch_bounds__(DS_THREADS) void msp_dedupe_send_kernel(int k, int 
   }
   const uint32_t pad = (NOTES_PER_ROW - na % NOTES_PER_ROW) % NOTES_PER_ROW;
   if ((uint32_t)tid < pad) notes[na + tid] = 0xFFFFu;
-}
-
-// ... and the group's epilogue: row 0 of every segment's header, the rows every segment uses, the job's flags
-__global__ __launch_bounds__(64) void msp_runs_group_finish_kernel(RunsSend sg, const uint64_t *__restrict__ stats, uint64_t *__restrict__ used /* [parts + 1] */) {
-  const int p = threadIdx.x;
-  if (p < sg.parts) {
-    const uint64_t u = 1ull + sg.lcount + (uint64_t)sg.cursor[p];
-    used[p] = u;
-    sg.packed[(uint64_t)p * sg.seg_cap] = make_uint4((uint32_t)min(u, (uint64_t)0xFFFFFFFFull), sg.lcount, sg.ll0, RUNS2_MAGIC);
-  }
-  if (p == 0) used[sg.parts] = (stats[ST_SPILLED] || stats[ST_ONES] || stats[ST_L1OVF] || stats[ST_L2OVF] || stats[ST_OVFN] ||
-                                stats[ST_OVFN1] || stats[ST_CWRAP] || stats[ST_OVERFLOW]) ? 1ull : 0ull;
 }
 
 // ---------------------------------------------------------------------------- multi-GPU by runs
@@ -3076,61 +3047,20 @@ extern "C" int cfrk_global_merge_runs_device(cfrk_ctx *ctx, const void *d_packed
 }
 
 // ------------------------------------------------------------------ multi-GPU exchange by runs, pipelined
-static inline uint32_t runs_ll0(int lpp, int g, int ngroups) { return (uint32_t)(((int64_t)lpp * g) / ngroups); }
 
 extern "C" int cfrk_global_export_runs_async(cfrk_ctx *ctx, void *d_packed, uint64_t seg_cap_rows, int parts, int ngroups) {
   if (!ctx || parts < 1 || parts > 64 || ngroups < 1 || ngroups > CFRK_RUNS_MAX_GROUPS) return CFRK_ERR_ARG;
   cfrk_msp *ms = ctx->msp;
   if (!ctx->g_active || !ms || !ms->runs_ready)
     return cfrk_fail(ctx, CFRK_ERR_STATE, "no runs to export (begin with CFRK_RUNS_ONLY, then one add)");
-  if (ctx->g_two) return cfrk_fail(ctx, CFRK_ERR_STATE, "the pipelined runs export serves one-word keys (16 <= k <= 32): cfrk_global_export_runs_device");
-  if (ms->runs_deduped) return cfrk_fail(ctx, CFRK_ERR_STATE, "the leaf streams were deduplicated in place already (add with CFRK_RUNS_DEFER for the pipelined export)");
+  if (ms->runs_deduped) return cfrk_fail(ctx, CFRK_ERR_STATE, "the leaf streams were deduplicated in place already (add with CFRK_RUNS_DEFER for the pipelined export; leaves shared by sub-value always are)");
   if (!d_packed) return cfrk_fail(ctx, CFRK_ERR_ARG, "NULL buffer");
-  const int lpp = (NLEAF + parts - 1) / parts;
-  if (ngroups > lpp) return cfrk_fail(ctx, CFRK_ERR_ARG, "more groups than leaves per owner");
-  if (seg_cap_rows < (uint64_t)(lpp + ngroups - 1) / ngroups + 2 || seg_cap_rows > 0xFFFFFFF0ull)
-    return cfrk_fail(ctx, CFRK_ERR_ARG, "segment capacity out of range (at least a group's header: leaves per owner / groups + 2 rows)");
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
-  if (!ctx->h_runs) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_runs, (size_t)CFRK_RUNS_MAX_GROUPS * 65 * sizeof(uint64_t), hipHostMallocDefault));
-  for (int g = 0; g < ngroups; ++g)
-    if (!ctx->runs_ev[g]) HIP_TRY(ctx, hipEventCreate(&ctx->runs_ev[g]));          // (with timing: cfrk_global_runs_group_ms)
-  int rc;
-  void *p;
-  const size_t ncur = (size_t)ngroups * parts;
-  if ((rc = cfrk_pool_get(ctx, BUF_RUNS_AUX, ((ncur * sizeof(uint32_t) + 15) & ~(size_t)15) + (size_t)ngroups * 65 * sizeof(uint64_t), &p))) return rc;
-  uint32_t *d_cur = (uint32_t *)p;
-  uint64_t *d_used = (uint64_t *)((char *)p + ((ncur * sizeof(uint32_t) + 15) & ~(size_t)15));
-  HIP_TRY(ctx, hipMemsetAsync(d_cur, 0, ncur * sizeof(uint32_t), ctx->stream));
+  if (ctx->g_two) return cfrk_msp2_export_runs_async(ctx, d_packed, seg_cap_rows, parts, ngroups);
   const MspView &v = ms->view;
   const int k = ctx->g_k, canon = (ctx->g_flags & CFRK_CANONICAL) ? 1 : 0;
-  for (int g = 0; g < ngroups; ++g) {
-    RunsSend sg;
-    sg.packed = (uint4 *)d_packed + (uint64_t)g * parts * seg_cap_rows;
-    sg.seg_cap = seg_cap_rows;
-    sg.cursor = d_cur + (size_t)g * parts;
-    sg.ll0 = runs_ll0(lpp, g, ngroups);
-    sg.lcount = runs_ll0(lpp, g + 1, ngroups) - sg.ll0;
-    sg.leaf0 = sg.ll0 * (uint32_t)parts;
-    sg.nleaf = std::min<uint32_t>((sg.ll0 + sg.lcount) * (uint32_t)parts, (uint32_t)NLEAF) - sg.leaf0;
-    sg.parts = parts;
-    if (sg.nleaf < sg.lcount * (uint32_t)parts) {
-      // (parts does not divide 65536: the last local leaf of the last owners stands for no leaf -- its header entry is zero)
-      for (uint32_t q = sg.nleaf; q < sg.lcount * (uint32_t)parts; ++q) {
-        const uint32_t leaf = sg.leaf0 + q, own = leaf % (uint32_t)parts, ll = leaf / (uint32_t)parts;
-        HIP_TRY(ctx, hipMemsetAsync(sg.packed + (uint64_t)own * seg_cap_rows + 1u + (ll - sg.ll0), 0, sizeof(uint4), ctx->stream));
-      }
-    }
-    if (sg.nleaf) {
-      hipLaunchKernelGGL(msp_dedupe_send_kernel, dim3(sg.nleaf), dim3(DS_THREADS), 0, ctx->stream, k, canon, v, sg);
-      HIP_TRY(ctx, hipGetLastError());
-    }
-    hipLaunchKernelGGL(msp_runs_group_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, sg, (const uint64_t *)ctx->g_stats, d_used + (size_t)g * 65);
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_runs + (size_t)g * 65, d_used + (size_t)g * 65, (size_t)(parts + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipEventRecord(ctx->runs_ev[g], ctx->stream));
-  }
-  ctx->runs_groups = ngroups; ctx->runs_parts = parts; ctx->runs_seg_cap = seg_cap_rows;
-  return CFRK_OK;
+  return runs_export_async_host(ctx, d_packed, seg_cap_rows, parts, ngroups, [&](const RunsSend &sg) {
+    hipLaunchKernelGGL(msp_dedupe_send_kernel, dim3(sg.nleaf), dim3(DS_THREADS), 0, ctx->stream, k, canon, v, sg);
+  });
 }
 
 extern "C" int cfrk_global_export_runs_wait(cfrk_ctx *ctx, int group, uint64_t *part_rows) {
@@ -3151,7 +3081,8 @@ extern "C" int cfrk_global_export_runs_wait(cfrk_ctx *ctx, int group, uint64_t *
 extern "C" int cfrk_global_merge_runs_group_device(cfrk_ctx *ctx, const void *d_recv, const uint64_t *recv_rows, int parts, int group, int ngroups) {
   if (!ctx || parts < 1 || parts > 64 || !recv_rows || !d_recv || ngroups < 1 || ngroups > CFRK_RUNS_MAX_GROUPS || group < 0 || group >= ngroups) return CFRK_ERR_ARG;
   if (!ctx->g_active) return cfrk_fail(ctx, CFRK_ERR_STATE, "merge_runs_group needs an active job");
-  if (!cfrk_msp_usable(ctx) || (ctx->g_flags & CFRK_RUNS_ONLY)) return cfrk_fail(ctx, CFRK_ERR_ARG, "merge_runs_group needs a counting job with 16 <= k <= 32");
+  if (ctx->g_two && !(ctx->g_flags & (CFRK_RUNS_ONLY | CFRK_FORCE_HASH))) return cfrk_msp2_merge_runs_group(ctx, d_recv, recv_rows, parts, group, ngroups);
+  if (!cfrk_msp_usable(ctx) || (ctx->g_flags & CFRK_RUNS_ONLY)) return cfrk_fail(ctx, CFRK_ERR_ARG, "merge_runs_group needs a counting job with 16 <= k <= 64");
   cfrk_msp *ms = cfrk_msp_get(ctx);
   if (!ms) return cfrk_fail(ctx, CFRK_ERR_NOMEM, "host allocation failed");
   if (group != ms->lists_group) return cfrk_fail(ctx, CFRK_ERR_STATE, "groups are merged in order: expected group %d", ms->lists_group);

@@ -738,8 +738,11 @@ __device__ __forceinline__ void r2_insert_loop(Rec2 *rtab, const Rec2 &rec, uint
 // n-1, what msp2_dedupe_export_kernel leaves behind): an owner counting the runs its ranks sent
 constexpr uint32_t Q3_WEIGHTED = 1u;
 constexpr uint64_t Q3_HUGE_LEAF = 1ull << 25, Q3_HUGE_LEAF_SENDER = 1ull << 19;   // (msp.hip: HUGE_LEAF)
-template <bool CANON, bool SHARED>
-__global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, uint32_t mode, View2 v, TableView t) {
+// LISTS (round 5, the owner of the PIPELINED runs exchange, msp.hip: p3_body): the leaf's runs are the N lists its ranks
+// sent, read in place from the receive buffer -- two rows per record, a note expanded where it is read; never SHARED.
+template <bool CANON, bool SHARED, bool LISTS>
+__device__ __forceinline__ void q3_body(int k, uint32_t mode, const View2 &v, const TableView &t, const P3ListsT<LISTS> &lx) {
+  static_assert(!(SHARED && LISTS), "an owner's lists are counted by one workgroup per leaf");
   __shared__ ulonglong2 keys[T2];
   __shared__ uint32_t cnts[T2];
   __shared__ Rec2 rtab[R2];
@@ -761,7 +764,7 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, uint32_t mod
   __shared__ int sp;
   __shared__ uint32_t leaf_total, nseg;
   const int tid = threadIdx.x, lane = tid & 63;
-  const bool weighted = (mode & Q3_WEIGHTED) != 0u;
+  const bool weighted = LISTS || (mode & Q3_WEIGHTED) != 0u;
   // sub_bits > 0: 2^sub_bits workgroups share a leaf, each taking the records whose extra
   // minimizer-hash bits (b.z, written by msp2_p1_kernel<true>) name it -- every occurrence of a
   // k-mer has the same minimizer, so the workgroups' key sets are disjoint.  The workgroups of a
@@ -784,13 +787,51 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, uint32_t mod
   auto mine = [&](const Rec2 &r) { return !SHARED || ((r.b.z >> hbits) & rmask) == rsel; };
   uint64_t ns[NCLS];
   uint64_t total = 0;
+  // LISTS: rank r's lists of this leaf -- l_base[r] = its first row, complete runs [l_cpre[r], l_cpre[r+1]) of the leaf's
+  // complete "stream" (class 3), truncated runs + notes [l_tpre[r], l_tpre[r+1]) of its truncated one (class 0; l_nu[r]
+  // records, then the notes)
+  __shared__ uint32_t l_cpre[LISTS ? 65 : 1], l_tpre[LISTS ? 65 : 1], l_nu[LISTS ? 64 : 1];
+  __shared__ const uint4 *l_base[LISTS ? 64 : 1];
+  if constexpr (LISTS) {
+    if (tid < 64) {
+      const int r = tid;
+      uint32_t nd = 0, nu = 0, na = 0;
+      const uint4 *base = nullptr;
+      if (r < lx.parts) {
+        const uint4 *hdr = lx.packed + lx.rr.rstart[r];
+        const uint64_t rows = lx.rr.rows[r], hrows = 1ull + lx.lcount;
+        bool ok = rows >= hrows;
+        if (ok) { const uint4 h0 = hdr[0]; ok = h0.y == lx.lcount && h0.z == lx.ll0 && h0.w == RUNS2_MAGIC; }
+        if (ok) {
+          const uint4 e = hdr[1u + blockIdx.x];
+          const uint64_t tot = 2ull * ((uint64_t)e.y + e.z) + (e.w + (uint32_t)NOTES_PER_ROW - 1u) / (uint32_t)NOTES_PER_ROW;
+          // (a segment that does not add up, or notes without a run they could point at, is not followed)
+          if ((uint64_t)e.x + tot <= rows - hrows && (e.w == 0u || e.y != 0u)) { nd = e.y; nu = e.z; na = e.w; base = hdr + hrows + e.x; }
+          else if (tot) ok = false;
+        }
+        if (!ok) v.stats[ST_OVERFLOW] = 1;                 // (reported by finish / digest: the result would be incomplete)
+      }
+      const uint32_t ci = dev_wave_scan_incl(nd), ti = dev_wave_scan_incl(nu + na);
+      l_cpre[r] = ci - nd; l_tpre[r] = ti - (nu + na); l_nu[r] = nu; l_base[r] = base;
+      if (r == 63) { l_cpre[64] = ci; l_tpre[64] = ti; }
+    }
+    __syncthreads();
+    ns[0] = l_tpre[64]; ns[1] = 0; ns[2] = 0; ns[3] = l_cpre[64];
+    total = ns[0] + ns[3];
+  } else {
 #pragma unroll
-  for (int cl = 0; cl < NCLS; ++cl) {
-    ns[cl] = min((uint64_t)v.cnt2[NCLS * leaf + cl],
-                 v.exact ? (uint64_t)v.lcap[NCLS * leaf + cl] : (cl == 3 ? v.cap2c : v.cap2t));
-    total += ns[cl];
+    for (int cl = 0; cl < NCLS; ++cl) {
+      ns[cl] = min((uint64_t)v.cnt2[NCLS * leaf + cl],
+                   v.exact ? (uint64_t)v.lcap[NCLS * leaf + cl] : (cl == 3 ? v.cap2c : v.cap2t));
+      total += ns[cl];
+    }
+    if (total - 1ull >= Q3_HUGE_LEAF - 1ull) return;    // nothing to count -- or a HUGE leaf: msp2_huge_leaves_kernel counts it
   }
-  if (total - 1ull >= Q3_HUGE_LEAF - 1ull) return;    // nothing to count -- or a HUGE leaf: msp2_huge_leaves_kernel counts it
+  auto l_find = [&](const uint32_t *pre, uint32_t i) {        // rank r with pre[r] <= i < pre[r + 1] (LISTS)
+    uint32_t lo = 0, hi = 64;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pre[mid] <= i) lo = mid; else hi = mid; }
+    return lo;
+  };
   for (int s = tid; s < T2; s += Q3_THREADS) cnts[s] = 0;
   {
     Rec2 z;
@@ -802,8 +843,49 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, uint32_t mod
   for (int s = tid; s < R2 + 1; s += Q3_THREADS) th[s] = 0;
   __syncthreads();
 
-  const Rec2 *leaf_rec = v.exact ? v.rec2 + v.lbase[NCLS * leaf + 3] : v.rec2 + (uint64_t)(leaf >> v.sel_bits) * (v.cap2c + 3 * v.cap2t);
+  const Rec2 *leaf_rec = LISTS ? nullptr : (v.exact ? v.rec2 + v.lbase[NCLS * leaf + 3] : v.rec2 + (uint64_t)(leaf >> v.sel_bits) * (v.cap2c + 3 * v.cap2t));
   const Rec2 zrec = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
+  // complete run i of the leaf / record i of its truncated class cl, wherever they lie
+  auto ld_c = [&](uint64_t i) -> Rec2 {
+    if constexpr (LISTS) {
+      const uint32_t r = l_find(l_cpre, (uint32_t)i), j = (uint32_t)i - l_cpre[r];
+      const uint4 *b = l_base[r];
+      return Rec2{b[2 * j], b[2 * j + 1]};
+    } else return leaf_rec[i];
+  };
+  auto ld_t = [&](int cl, uint64_t i) -> Rec2 {
+    if constexpr (LISTS) {
+      const uint32_t r = l_find(l_tpre, (uint32_t)i), j = (uint32_t)i - l_tpre[r];
+      const uint4 *b = l_base[r];
+      const uint32_t nd_r = l_cpre[r + 1] - l_cpre[r], nu_r = l_nu[r];
+      const uint4 *st = b + 2ull * nd_r;
+      if (j < nu_r) return Rec2{st[2 * j], st[2 * j + 1]};
+      // a note: the first n k-mers of its twin, closed on the left only (msp2_runs_scatter_kernel does this in a pass of its own)
+      const uint32_t note = reinterpret_cast<const uint16_t *>(st + 2ull * nu_r)[j - nu_r];
+      const uint32_t ti = min(note >> 5, nd_r - 1u);                      // a position outside the list is not followed
+      const uint4 ta = b[2 * ti], tb = b[2 * ti + 1];
+      const uint32_t nm1 = min(note & 31u, tb.w & 31u);
+      const int len = (int)nm1 + k;                                       // bases of the run: 33 .. 93
+      auto mk = [&](int w) {                                              // mask of word w: bits 32 w .. 32 w + 31 of the string
+        const int bb = 2 * len - 32 * w;
+        return (bb >= 32) ? 0xFFFFFFFFu : ((bb <= 0) ? 0u : ~(0xFFFFFFFFu >> bb));
+      };
+      return Rec2{make_uint4(ta.x, ta.y, ta.z & mk(2), ta.w & mk(3)), make_uint4(tb.x & mk(4), tb.y & mk(5), tb.z, 64u | nm1)};
+    } else {
+      const Rec2 *src = v.exact ? v.rec2 + v.lbase[NCLS * leaf + cl] : leaf_rec + v.cap2c + (uint64_t)cl * v.cap2t;
+      return src[i];
+    }
+  };
+  if constexpr (LISTS) {
+    if (total == 0) return;
+    if (total >= Q3_HUGE_LEAF) {                       // (see Q3_HUGE_LEAF: counted in the HBM table, whose adds saturate)
+      for (uint64_t i = tid; i < total; i += Q3_THREADS) {
+        const Rec2 rec = (i < ns[3]) ? ld_c(i) : ld_t(0, i - ns[3]);
+        spill_record2(rec.a, rec.b, k, CANON, t, (i < ns[3]) ? (rec.b.w >> 6) : 1u);
+      }
+      return;
+    }
+  }
   // ---- phase 1: complete runs, one record-table update per record; when the table runs out of
   //      room (more distinct runs than it holds: low coverage of a large genome) the dedupe is
   //      dropped and the whole leaf is counted from its streams
@@ -861,7 +943,7 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, uint32_t mod
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           q[u] = zrec;
-          if (r + (uint64_t)u * Q3_THREADS < ns[3]) q[u] = leaf_rec[r + (uint64_t)u * Q3_THREADS];
+          if (r + (uint64_t)u * Q3_THREADS < ns[3]) q[u] = ld_c(r + (uint64_t)u * Q3_THREADS);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -961,11 +1043,10 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, uint32_t mod
   const uint32_t c0 = (uint32_t)min(ns[0], (uint64_t)TL2_CAP);
   const uint32_t c1 = c0 + (uint32_t)min(ns[1], (uint64_t)(TL2_CAP - c0));
   const uint32_t tl = c1 + (uint32_t)min(ns[2], (uint64_t)(TL2_CAP - c1));
-  auto trunc_at = [&](uint32_t g) -> const Rec2 * {          // record g of the concatenated class streams
+  auto trunc_at = [&](uint32_t g) -> Rec2 {                  // record g of the concatenated class streams
     const int cl = (g < c0) ? 0 : (g < c1) ? 1 : 2;
     const uint32_t i = g - ((cl == 0) ? 0u : (cl == 1) ? c0 : c1);
-    const Rec2 *src = v.exact ? v.rec2 + v.lbase[NCLS * leaf + cl] : leaf_rec + v.cap2c + (uint64_t)cl * v.cap2t;
-    return src + i;
+    return ld_t(cl, i);
   };
   const bool anchors_on = !big && !(v.dbg & (CFRK_DEBUG_NO_ANCHORS | CFRK_ABL_P3_NO_TRUNC));
   bool use_anchors = false;
@@ -979,7 +1060,7 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, uint32_t mod
     for (int i = 0; i < TL2_PER; ++i) {
       const uint32_t g = (uint32_t)(i * Q3_THREADS + tid);
       trec[i] = zrec;
-      if (anchors_on && g < tl) trec[i] = *trunc_at(g);
+      if (anchors_on && g < tl) trec[i] = trunc_at(g);
     }
 #pragma unroll
     for (int i = 0; i < TL2_PER; ++i) {
@@ -1094,28 +1175,27 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, uint32_t mod
       for (uint32_t i = tid; i < ((nfl + 63u) & ~63u) && use_anchors; i += Q3_THREADS) {
         const bool valid = i < nfl;
         Rec2 rec = zrec;
-        if (valid) rec = *trunc_at(flist[i]);
+        if (valid) rec = trunc_at(flist[i]);
         count_record2<CANON>(keys, cnts, rec, 1u, valid, k, t, ss, ovf);
       }
     } else if (!SHARED) {
       for (uint64_t r = tid; r < ((ns[3] + 63) & ~63ull); r += Q3_THREADS) {
         const bool valid = r < ns[3];
         Rec2 rec = zrec;
-        if (valid) rec = leaf_rec[r];
+        if (valid) rec = ld_c(r);
         count_record2<CANON>(keys, cnts, rec, weighted ? (rec.b.w >> 6) : 1u, valid, k, t, ss, ovf);
       }
     }
-    if (!SHARED) {
-      for (int cl = 2; cl >= 0 && !(v.dbg & CFRK_ABL_P3_NO_TRUNC); --cl) {
-        const Rec2 *src = v.exact ? v.rec2 + v.lbase[NCLS * leaf + cl] : leaf_rec + v.cap2c + (uint64_t)cl * v.cap2t;
+    if constexpr (!SHARED) {
+      for (int cl = LISTS ? 0 : 2; cl >= 0 && !(v.dbg & CFRK_ABL_P3_NO_TRUNC); --cl) {
         Rec2 nxt = zrec;
         const uint64_t r_first = (uint64_t)cov[cl] + tid;        // (the anchored ones are done)
-        if (r_first < ns[cl]) nxt = src[r_first];
+        if (r_first < ns[cl]) nxt = ld_t(cl, r_first);
         for (uint64_t r = r_first; r < (uint64_t)cov[cl] + ((ns[cl] - cov[cl] + 63) & ~63ull); r += Q3_THREADS) {
           const bool valid = r < ns[cl];
           const Rec2 rec = nxt;
           nxt = zrec;
-          if (r + Q3_THREADS < ns[cl]) nxt = src[r + Q3_THREADS];
+          if (r + Q3_THREADS < ns[cl]) nxt = ld_t(cl, r + Q3_THREADS);
           count_record2<CANON>(keys, cnts, rec, 1u, valid, k, t, ss, ovf);
         }
       }
@@ -1192,7 +1272,7 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, uint32_t mod
         const uint32_t sg = (leaf << sub_bits) | (rsel << hbits) | sv;
         if (bits == 0u) { v.leaf_off[sg] = wg_base; v.leaf_n[sg] = wg_total; }
         else if (wg_total) v.stats[ST_MULTISEG] = 1;
-      } else {
+      } else if (!LISTS) {                           // (an owner's result is not kept in leaf form)
         if (nseg == 0) v.leaf_off[leaf] = wg_base;
         else if (wg_total) v.stats[ST_MULTISEG] = 1;
         if (wg_total) nseg = nseg + 1;
@@ -1207,6 +1287,16 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, uint32_t mod
     });
     __syncthreads();
   }
+}
+
+template <bool CANON, bool SHARED>
+__global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, uint32_t mode, View2 v, TableView t) {
+  q3_body<CANON, SHARED, false>(k, mode, v, t, P3ListsT<false>{});
+}
+// the owner of the pipelined runs exchange: workgroup b counts local leaf lx.ll0 + b from the lists its ranks sent
+template <bool CANON>
+__global__ __launch_bounds__(Q3_THREADS) void msp2_p3_lists_kernel(int k, View2 v, TableView t, P3ListsT<true> lx) {
+  q3_body<CANON, false, true>(k, Q3_WEIGHTED, v, t, lx);
 }
 
 // HUGE leaves (msp.hip: HUGE_LEAF -- 2^25 records or more, a single-key flood): not counted in LDS, where a run's
@@ -1504,6 +1594,192 @@ __global__ __launch_bounds__(DX2_THREADS) void msp2_dedupe_export_kernel(int k, 
   if (tid == 0) { v.leaf_n[leaf] = nd; v.leaf_off[leaf] = noted; }
 }
 
+// ------------------------------------------------------------------- multi-GPU by runs, PIPELINED (round 5)
+// msp.hip's msp_dedupe_send_kernel for 32-byte records: one workgroup per leaf of a group deduplicates the leaf's
+// complete runs in LDS, looks its read ends up, CLAIMS the leaf's rows in its owner's segment of the send buffer (one
+// atomic) and writes [distinct runs, two rows each][truncated runs without a twin][notes] there -- the leaf streams are
+// not rewritten, nothing is planned or gathered afterwards, the host is not asked.  (Layout: msp_runs.h.)
+constexpr int DS2_THREADS = 256, DS2_INFL = 4, DS2_TCAP = 4096, DS2_LOG = 11;
+__global__ __launch_bounds__(DS2_THREADS) void msp2_dedupe_send_kernel(int k, int canon, View2 v, RunsSend sg) {
+  constexpr int RX = 1 << DS2_LOG;
+  __shared__ Rec2 rtab[RX];
+  __shared__ uint16_t sidx[RX];                    // record-table slot -> position in the leaf's list
+  __shared__ uint16_t tres[DS2_TCAP];              // truncated run g: its note, or 0xFFFF = travels as a record
+  __shared__ uint32_t wsum[DS2_THREADS / 64];
+  __shared__ uint32_t rt_fail, noted, cu, cn, row0;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t leaf = sg.leaf0 + blockIdx.x;
+  const uint32_t own = leaf % (uint32_t)sg.parts, ll = leaf / (uint32_t)sg.parts;
+  uint4 *const seg = sg.packed + (uint64_t)own * sg.seg_cap;
+  const uint32_t hrows = 1u + sg.lcount;
+  uint4 *const entry = seg + 1u + (ll - sg.ll0);
+  const uint32_t n1 = x2_count(v, leaf, 3);
+  const uint32_t t0 = x2_count(v, leaf, 0);
+  const uint64_t t1 = (uint64_t)t0 + x2_count(v, leaf, 1), nt64 = t1 + x2_count(v, leaf, 2);
+  if ((uint64_t)n1 + nt64 == 0) { if (tid == 0) *entry = make_uint4(0u, 0u, 0u, 0u); return; }
+  const Rec2 *const c3 = x2_stream(v, leaf, 3);
+  const Rec2 *const s0 = x2_stream(v, leaf, 0), *const s1 = x2_stream(v, leaf, 1), *const s2 = x2_stream(v, leaf, 2);
+  auto trunc_at = [&](uint64_t g) { return (g < t0) ? s0 + g : (g < t1) ? s1 + (g - t0) : s2 + (g - t1); };
+  const Rec2 zrec = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
+  // (a leaf of 2^19 complete runs or more leaves undeduplicated: msp.hip, HUGE_LEAF; a row count beyond 32 bits cannot be claimed)
+  const bool too_many = (uint64_t)n1 >= Q3_HUGE_LEAF_SENDER;
+  const bool unclaimable = 2ull * ((uint64_t)n1 + nt64) >= 0xFFFFFFF0ull;
+  // the first round of the complete stream is asked for before anything else is done
+  Rec2 recs[DS2_INFL];
+#pragma unroll
+  for (int u = 0; u < DS2_INFL; ++u) {
+    const uint32_t r = (uint32_t)u * DS2_THREADS + tid;
+    recs[u] = zrec;
+    if (r < n1 && !too_many) recs[u] = c3[r];
+  }
+  {
+    Rec2 z = zrec;
+    z.b.w = R2_EMPTY;
+    for (int s_ = tid; s_ < RX; s_ += DS2_THREADS) rtab[s_] = z;
+  }
+  if (tid == 0) { rt_fail = ((v.dbg & CFRK_DEBUG_FORCE_RT_OVERFLOW) || too_many) ? 1u : 0u; noted = 0u; cu = 0u; cn = 0u; }
+  __syncthreads();
+  for (uint32_t r0 = 0; r0 < n1 && !too_many; r0 += (uint32_t)DS2_INFL * DS2_THREADS) {
+    if (r0) {
+#pragma unroll
+      for (int u = 0; u < DS2_INFL; ++u) {
+        const uint32_t r = r0 + (uint32_t)u * DS2_THREADS + tid;
+        recs[u] = zrec;
+        if (r < n1) recs[u] = c3[r];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < DS2_INFL; ++u) {
+      const uint32_t r = r0 + (uint32_t)u * DS2_THREADS + tid;
+      if (r0 + (uint32_t)u * DS2_THREADS >= n1) break;            // (wave-uniform)
+      uint32_t h = r2_slot_k(recs[u], k, DS2_LOG) | ((r < n1) ? 0u : R2_DONE);
+      r2_insert_loop(rtab, recs[u], h, RX - 1);
+      if ((int32_t)h >= 0) rt_fail = 1u;
+    }
+  }
+  __syncthreads();
+  const bool plain = rt_fail != 0u;                 // no deduplication: every complete run leaves with multiplicity 1, no notes
+  const uint32_t nt = (uint32_t)min(nt64, (uint64_t)0xFFFFFFFFull);
+  uint32_t nd, at0 = 0;
+  constexpr int PER = RX / DS2_THREADS;
+  const uint32_t *words = reinterpret_cast<const uint32_t *>(rtab);
+  if (plain) {
+    nd = n1;
+  } else {
+    // occupied slots -> positions in the leaf's list (eight slots per thread)
+    uint32_t mine = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) mine += (words[8 * (PER * tid + i) + 7] != R2_EMPTY) ? 1u : 0u;
+    const uint32_t incl = dev_wave_scan_incl(mine);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+    for (int w = 0; w < DS2_THREADS / 64; ++w) { const uint32_t x = wsum[w]; base += (w < wave) ? x : 0u; total += x; }
+    at0 = base + incl - mine;
+    uint32_t at = at0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      sidx[PER * tid + i] = (uint16_t)at;
+      if (words[8 * (PER * tid + i) + 7] != R2_EMPTY) ++at;
+    }
+    nd = total;
+    __syncthreads();
+    // truncated runs: which of the first DS2_TCAP are a prefix of a distinct complete run of this rank (a suffix, read on
+    // the other strand)?  The verdict waits in LDS (the lookup of the leaf kernel's anchoring)
+    const uint32_t tlook = (v.dbg & CFRK_DEBUG_NO_ANCHORS) ? 0u : min(nt, (uint32_t)DS2_TCAP);
+    const uint32_t pos_max = (v.dbg & CFRK_DEBUG_SMALL_WAVE_CAP) ? 15u : NOTE_POS_MAX;
+    for (uint32_t g0 = 0; g0 < tlook; g0 += DS2_THREADS) {
+      const uint32_t g = g0 + tid;
+      const bool valid = g < tlook;
+      Rec2 rec = zrec;
+      if (valid) rec = *trunc_at(g);
+      const uint32_t nm1 = rec.b.w & 31u;
+      const bool lc = (rec.b.w & 64u) != 0u, rc_ = (rec.b.w & 128u) != 0u;
+      const bool suf = canon && valid && !lc && rc_;
+      if (suf) rec = revcomp_record2(rec, (int)nm1 + k);
+      const bool anchored = suf || (valid && lc && !rc_);
+      uint32_t h = anchored ? r2_slot_k(rec, k, DS2_LOG) : R2_DONE;
+      uint32_t found = 0xFFFFFFFFu;
+      for (int it = 0; it < 32 && __ballot((int32_t)h >= 0); ++it) {
+        const bool p = (int32_t)h >= 0;
+        const uint32_t hh = h & (uint32_t)(RX - 1);
+        const Rec2 e2 = rtab[hh];
+        const bool empty = e2.b.w == R2_EMPTY;
+        const bool hit = p && !empty && (e2.b.w & 31u) >= nm1 && rec2_prefix_equal(e2, rec, (int)nm1 + k);
+        found = hit ? hh : found;
+        h = (p && !hit && !empty) ? ((hh + 1u) & (uint32_t)(RX - 1)) : (h | R2_DONE);
+      }
+      // (a twin beyond position 2047 of a long list cannot be named by a note: the run travels as a record)
+      const bool hit = found != 0xFFFFFFFFu && (uint32_t)sidx[found & (uint32_t)(RX - 1)] <= pos_max;
+      if (valid) tres[g] = hit ? (uint16_t)(((uint32_t)sidx[found] << 5) | nm1) : (uint16_t)0xFFFFu;
+      const unsigned long long hb = __ballot(hit);
+      if (lane == 0 && hb) atomicAdd(&noted, (uint32_t)__popcll(hb));
+    }
+    __syncthreads();
+  }
+  const uint32_t na = plain ? 0u : noted, nu = nt - na;
+  const uint64_t rows = 2ull * ((uint64_t)nd + nu) + (na + NOTES_PER_ROW - 1) / NOTES_PER_ROW;
+  if (tid == 0) {
+    // one claim per leaf; a segment that runs out of room (or a flood that cannot be claimed at all) shows in its
+    // cursor -- used rows > seg_cap -- and the host takes the classic exchange instead
+    const uint32_t claim = unclaimable ? 0xFFFFFFFFu : (uint32_t)rows;
+    const uint32_t pos = atomicAdd(&sg.cursor[own], claim);
+    const bool fits = !unclaimable && (uint64_t)pos + rows <= sg.seg_cap - hrows && pos + claim >= pos;
+    if (!fits) atomicMax(&sg.cursor[own], 0xFFFFFFF0u);              // (stays "too many" whatever is added later)
+    *entry = fits ? make_uint4(pos, nd, nu, na) : make_uint4(0u, 0u, 0u, 0u);
+    row0 = fits ? pos : 0xFFFFFFFFu;
+  }
+  __syncthreads();
+  if (row0 == 0xFFFFFFFFu) return;
+  uint4 *const dst = seg + hrows + row0;
+  if (plain) {
+    // (the halves as two vectors: a Rec2 copied as a whole goes through scratch memory here)
+    for (uint32_t i = tid; i < n1; i += DS2_THREADS) {
+      const uint4 a = c3[i].a;
+      uint4 b = c3[i].b;
+      b.w = (1u << 6) | (b.w & 63u);
+      dst[2 * (uint64_t)i] = a; dst[2 * (uint64_t)i + 1] = b;
+    }
+    uint4 *const dt = dst + 2 * (uint64_t)nd;
+    for (uint32_t i = tid; i < nt; i += DS2_THREADS) {
+      const Rec2 *q = trunc_at(i);
+      const uint4 a = q->a, b = q->b;
+      dt[2 * (uint64_t)i] = a; dt[2 * (uint64_t)i + 1] = b;
+    }
+    return;
+  }
+  {
+    uint32_t at = at0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const Rec2 e = rtab[PER * tid + i];
+      if (e.b.w != R2_EMPTY) { dst[2 * at] = e.a; dst[2 * at + 1] = e.b; ++at; }
+    }
+  }
+  uint4 *const dt = dst + 2 * (uint64_t)nd;
+  uint16_t *const notes = reinterpret_cast<uint16_t *>(dt + 2 * (uint64_t)nu);
+  for (uint32_t i = tid; i < ((nt + 63u) & ~63u); i += DS2_THREADS) {
+    const bool valid = i < nt;
+    const uint32_t note = (valid && i < (uint32_t)DS2_TCAP && !(v.dbg & CFRK_DEBUG_NO_ANCHORS)) ? (uint32_t)tres[i] : 0xFFFFu;
+    const bool isn = valid && note != 0xFFFFu;
+    const unsigned long long mn = __ballot(isn), mu = __ballot(valid && !isn);
+    uint32_t bn = 0, bu = 0;
+    if (lane == 0) {
+      if (mn) bn = atomicAdd(&cn, (uint32_t)__popcll(mn));
+      if (mu) bu = atomicAdd(&cu, (uint32_t)__popcll(mu));
+    }
+    bn = __shfl(bn, 0); bu = __shfl(bu, 0);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (isn) { const uint32_t at = bn + (uint32_t)__popcll(mn & below); if (at < na) notes[at] = (uint16_t)note; }
+    else if (valid) {
+      const uint32_t at = bu + (uint32_t)__popcll(mu & below);
+      if (at < nu) { const Rec2 *q = trunc_at(i); const uint4 a = q->a, b = q->b; dt[2 * (uint64_t)at] = a; dt[2 * (uint64_t)at + 1] = b; }
+    }
+  }
+  const uint32_t pad = (NOTES_PER_ROW - na % NOTES_PER_ROW) % NOTES_PER_ROW;
+  if ((uint32_t)tid < pad) notes[na + tid] = 0xFFFFu;
+}
+
 // sender: what every leaf contributes -- n1 distinct complete runs, nt truncated runs as records, na as
 // notes, rows in all (two per record) -- one thread per leaf
 __global__ __launch_bounds__(256) void msp2_runs_sizes_kernel(View2 v, uint4 *__restrict__ sz, unsigned long long *__restrict__ plan_sync) {
@@ -1665,6 +1941,19 @@ static uint32_t msp2_hbits(const cfrk_ctx *ctx, uint32_t sub_bits, uint64_t per_
 // lean: the leaf streams get no room up front; the second-level kernel first only COUNTS them, they are
 // laid out back to back with exactly that room, and the kernel runs again (a batch that would need
 // more passes over the input otherwise: one more read of the level-1 records is cheaper than a pass)
+// deduplicate every leaf's complete stream where it lies (the one-shot runs export reads the result)
+static int msp2_dedupe_in_place(cfrk_ctx *ctx, const View2 &v) {
+  const int k = ctx->g_k, canon = (ctx->g_flags & CFRK_CANONICAL) ? 1 : 0;
+  const int W2 = msp2_window(k);
+  const double runs_per_leaf = (double)(ctx->g_cap / NLEAF) / 2.0 * 4.0 / (double)(W2 + 1);
+  if (runs_per_leaf > 700.0 || (ctx->dbg_flags & CFRK_DEBUG_RECORD_SUBSETS))
+    hipLaunchKernelGGL((msp2_dedupe_export_kernel<12, 1024>), dim3(NLEAF), dim3(1024), 0, ctx->stream, k, canon, v);
+  else
+    hipLaunchKernelGGL((msp2_dedupe_export_kernel<11, 256>), dim3(NLEAF), dim3(256), 0, ctx->stream, k, canon, v);
+  HIP_TRY(ctx, hipGetLastError());
+  return CFRK_OK;
+}
+
 static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, int64_t nN, int64_t tile0,
                             int64_t ntiles, double slack, int sel_bits = 0, uint32_t sel_val = 0, bool first = true,
                             bool lean = false, bool chunked = false) {
@@ -1745,6 +2034,9 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
   // overflow goes straight to the exact layout
   const bool runs_only = (ctx->g_flags & CFRK_RUNS_ONLY) != 0;
   if (runs_only) v.ovf_cap = v.ovf1_cap = 0;
+  // CFRK_RUNS_DEFER (msp.hip): the add ends behind Q2, unsynchronised; the pipelined export deduplicates group by group.
+  // (Leaves shared by sub-value keep the settling form: their records' extra bits have no place in the owner's list reader.)
+  const bool defer = runs_only && (ctx->g_flags & CFRK_RUNS_DEFER) && !sub && !chunked && !lean;
   v.exact = 0; v.lbase = nullptr; v.lcap = nullptr;
   v.exact1 = 0; v.rbase = nullptr; v.rcap = nullptr;
   const size_t nreg = (size_t)B1 * NXG;
@@ -1823,6 +2115,7 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
     hipLaunchKernelGGL(msp2_p2_kernel, dim3((unsigned)(q2_groups * B1)), dim3(Q2_THREADS), 0, ctx->stream,
                        (int)q2_groups, k, canon, v, t);
     HIP_TRY(ctx, hipGetLastError());
+    if (defer) { settled = true; break; }             // (whether a region overflowed is looked at by the export)
     uint64_t st[ST_NWORDS];
     HIP_TRY(ctx, hipMemcpyAsync(st, ctx->g_stats, sizeof st, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1896,19 +2189,13 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
     HIP_TRY(ctx, hipGetLastError());
   }
   if (runs_only) {
-    // deduplicate the leaves where they lie; the streams stay for cfrk_global_export_runs_device
-    // (the table's size from the expected distinct runs per leaf, as in msp2_hbits)
-    const double runs_per_leaf = (double)(ctx->g_cap / NLEAF) / 2.0 * 4.0 / (double)(W2 + 1);
-    if (runs_per_leaf > 700.0 || (ctx->dbg_flags & CFRK_DEBUG_RECORD_SUBSETS))
-      hipLaunchKernelGGL((msp2_dedupe_export_kernel<12, 1024>), dim3(NLEAF), dim3(1024), 0, ctx->stream, k, canon, v);
-    else
-      hipLaunchKernelGGL((msp2_dedupe_export_kernel<11, 256>), dim3(NLEAF), dim3(256), 0, ctx->stream, k, canon, v);
-    HIP_TRY(ctx, hipGetLastError());
+    // deduplicate the leaves where they lie (unless deferred); the streams stay for the export
     static_assert(sizeof(View2) <= sizeof(ms->view2), "cfrk_msp::view2 holds a View2");
     memcpy(ms->view2, &v, sizeof v);
+    if (!defer && (rc = msp2_dedupe_in_place(ctx, v))) return rc;
     ms->pending = false;
     ms->runs_ready = true;
-    ms->runs_deduped = true; ms->runs_unchecked = false;   // (CFRK_RUNS_DEFER is a one-word-key form: ignored here)
+    ms->runs_deduped = !defer; ms->runs_unchecked = defer;
     ms->leaf_form = false;
     ms->list_n_valid = false;
     return CFRK_OK;
@@ -1960,6 +2247,20 @@ int cfrk_msp2_export_runs(cfrk_ctx *ctx, void *d_packed, uint64_t cap_rows, int 
   cfrk_msp *ms = ctx->msp;
   View2 v;
   memcpy(&v, ms->view2, sizeof v);
+  if (ms->runs_unchecked) {
+    // a CFRK_RUNS_DEFER add: did its regions hold?  (an add without the flag lays an overflowing level out again)
+    uint64_t st0[ST_NWORDS];
+    int rc0 = cfrk_msp_sync_stats(ctx, st0);
+    if (rc0) return rc0;
+    if (st0[ST_L1OVF] || st0[ST_L2OVF] || st0[ST_OVFN] || st0[ST_OVFN1] || st0[ST_CWRAP])
+      return cfrk_fail(ctx, CFRK_ERR_STATE, "the CFRK_RUNS_DEFER add overflowed a record region: add again without the flag");
+    ms->runs_unchecked = false;
+  }
+  if (!ms->runs_deduped) {
+    int rc0 = msp2_dedupe_in_place(ctx, v);
+    if (rc0) return rc0;
+    ms->runs_deduped = true;
+  }
   const int lpp = (NLEAF + parts - 1) / parts;           // leaves per part (owner p: leaves p, p+parts, ...)
   const int hrows = runs_header_rows(lpp);
   int rc;
@@ -2094,6 +2395,70 @@ int cfrk_msp2_merge_runs(cfrk_ctx *ctx, const void *d_packed, const uint64_t *re
   return CFRK_OK;
 }
 
+// ------------------------------------------------------------------ multi-GPU exchange by runs, pipelined (msp.hip)
+int cfrk_msp2_export_runs_async(cfrk_ctx *ctx, void *d_packed, uint64_t seg_cap_rows, int parts, int ngroups) {
+  cfrk_msp *ms = ctx->msp;
+  View2 v;
+  memcpy(&v, ms->view2, sizeof v);
+  const int k = ctx->g_k, canon = (ctx->g_flags & CFRK_CANONICAL) ? 1 : 0;
+  return runs_export_async_host(ctx, d_packed, seg_cap_rows, parts, ngroups, [&](const RunsSend &sg) {
+    hipLaunchKernelGGL(msp2_dedupe_send_kernel, dim3(sg.nleaf), dim3(DS2_THREADS), 0, ctx->stream, k, canon, v, sg);
+  });
+}
+
+int cfrk_msp2_merge_runs_group(cfrk_ctx *ctx, const void *d_recv, const uint64_t *recv_rows, int parts, int group, int ngroups) {
+  cfrk_msp *ms = cfrk_msp_get(ctx);
+  if (!ms) return cfrk_fail(ctx, CFRK_ERR_NOMEM, "host allocation failed");
+  if (group != ms->lists_group) return cfrk_fail(ctx, CFRK_ERR_STATE, "groups are merged in order: expected group %d", ms->lists_group);
+  if (group == 0 && (ms->pending || ms->table_dirty)) return cfrk_fail(ctx, CFRK_ERR_STATE, "merge_runs_group needs an empty job (call cfrk_global_begin first)");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int lpp = (NLEAF + parts - 1) / parts;
+  if (ngroups > lpp) return cfrk_fail(ctx, CFRK_ERR_ARG, "more groups than leaves per owner");
+  int rc;
+  void *p;
+  View2 v;
+  if (group == 0) {
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    memset(&v, 0, sizeof v);
+    if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTK, (size_t)ctx->g_cap * 8, &p))) return rc;
+    v.out_lo = (uint64_t *)p;
+    if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTH, (size_t)ctx->g_cap * 8, &p))) return rc;
+    v.out_hi = (uint64_t *)p;
+    if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTC, (size_t)ctx->g_cap * 4, &p))) return rc;
+    v.out_cnt = (uint32_t *)p; v.out_cap = ctx->g_cap;
+    v.stats = ctx->g_stats; v.dbg = ctx->dbg_flags;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->g_stats + ST_CURSOR, 0, sizeof(uint64_t), ctx->stream));
+    memcpy(ms->view2, &v, sizeof v);
+  } else {
+    memcpy(&v, ms->view2, sizeof v);
+  }
+  P3ListsT<true> lx;
+  memset(&lx, 0, sizeof lx);
+  lx.packed = (const uint4 *)d_recv;
+  uint64_t at = 0;
+  for (int r = 0; r < parts; ++r) { lx.rr.rstart[r] = at; lx.rr.rows[r] = recv_rows[r]; at += recv_rows[r]; }
+  lx.parts = parts;
+  lx.ll0 = runs_ll0(lpp, group, ngroups);
+  lx.lcount = runs_ll0(lpp, group + 1, ngroups) - lx.ll0;
+  TableView t = cfrk_table_view(ctx);
+  if (lx.lcount) {
+    if (ctx->g_flags & CFRK_CANONICAL) hipLaunchKernelGGL((msp2_p3_lists_kernel<true>), dim3(lx.lcount), dim3(Q3_THREADS), 0, ctx->stream, ctx->g_k, v, t, lx);
+    else hipLaunchKernelGGL((msp2_p3_lists_kernel<false>), dim3(lx.lcount), dim3(Q3_THREADS), 0, ctx->stream, ctx->g_k, v, t, lx);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  ctx->ev_valid = true;
+  ctx->h_stats_valid = false;                          // the leaf kernel may have spilled into the table
+  ms->view.out_keys = v.out_lo; ms->view.out_hi = v.out_hi; ms->view.out_cnt = v.out_cnt;
+  ms->view.out_cap = v.out_cap; ms->view.stats = v.stats; ms->view.cnt1 = nullptr;
+  ms->view.leaf_off = nullptr; ms->view.leaf_n = nullptr; ms->view.seg_bits = 0;
+  ms->lists_group = group + 1;
+  ms->pending = true;
+  ms->leaf_form = false;
+  ms->list_n_valid = false;
+  return CFRK_OK;
+}
+
 int cfrk_msp2_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   cfrk_msp *ms = cfrk_msp_get(ctx);
   if (!ms) return cfrk_fail(ctx, CFRK_ERR_NOMEM, "host allocation failed");
@@ -2118,7 +2483,8 @@ int cfrk_msp2_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   {
     int cg = 0;
     const bool big = (double)(nN + 32) * msp2_density(ctx) * 1.35 * 32.0 > 6e9 || (ctx->dbg_flags & CFRK_DEBUG_SMALL_PIPELINE);
-    if (big && !(ctx->dbg_flags & CFRK_DEBUG_NO_PIPELINE) && !ctx->mem_budget &&
+    const bool want_defer = runs_only && (ctx->g_flags & CFRK_RUNS_DEFER);   // (a chunked add sizes its streams from a read-back)
+    if (big && !want_defer && !(ctx->dbg_flags & CFRK_DEBUG_NO_PIPELINE) && !ctx->mem_budget &&
         !(rc = cfrk_msp_plan_groups(ctx, nN + 32, ntiles, (int64_t)Q1_WAVES * Q1_OWN * 32, msp2_need_chunked, (size_t)ctx->g_cap * 20, have, &cg)) &&
         cg == 1) {
       if (ms->pending && (rc = cfrk_msp_flush_to_table(ctx))) return rc;

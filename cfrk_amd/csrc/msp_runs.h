@@ -173,3 +173,89 @@ __global__ __launch_bounds__(1024) void msp_runs_layout_kernel(RunsRecv rr, int 
   if (tid == 0) out[0] = total;
 }
 
+// ------------------------------------------------------------------- the PIPELINED exchange (round 5), both key widths
+// Sender: the leaves of an owner are cut into `ngroups` ranges of local indices; group g of owner p has its segment at
+// rows [(g * parts + p) * seg_cap, ...) of the send buffer: header (row 0 = {rows used, leaves, first local leaf, magic},
+// written by msp_runs_group_finish_kernel; then one uint4 {row offset, distinct, truncated, noted} per local leaf)
+// followed by the leaves' rows in the order their workgroups CLAIM them (one atomic on the segment's cursor per leaf).
+struct RunsSend {
+  uint4 *packed;             // this GROUP's segments: owner p's at packed + p * seg_cap
+  uint64_t seg_cap;          // rows per segment (header included)
+  uint32_t *cursor;          // [parts] rows claimed behind the header (zeroed before the kernel)
+  uint32_t leaf0, nleaf;     // the group's leaves [leaf0, leaf0 + nleaf): all owners' local leaves [ll0, ll0 + lcount)
+  uint32_t ll0, lcount;
+  int parts;
+};
+// Owner: the leaf kernel reads the N lists of a leaf IN PLACE from the receive buffer (msp.hip: p3_body, msp2.hip: q3_body)
+template <bool LISTS> struct P3ListsT {};
+template <> struct P3ListsT<true> {
+  const uint4 *packed;       // the receive buffer of this group: rank r's segment at row rr.rstart[r], rr.rows[r] rows
+  RunsRecv rr;
+  int parts;
+  uint32_t ll0, lcount;      // the group's local leaves [ll0, ll0 + lcount): workgroup b counts local leaf ll0 + b
+};
+constexpr uint32_t RUNS2_MAGIC = 0x32535543u;   // "CUS2"
+
+static inline uint32_t runs_ll0(int lpp, int g, int ngroups) { return (uint32_t)(((int64_t)lpp * g) / ngroups); }
+
+// ... and the group's epilogue: row 0 of every segment's header, the rows every segment uses, the job's flags
+__global__ __launch_bounds__(64) void msp_runs_group_finish_kernel(RunsSend sg, const uint64_t *__restrict__ stats, uint64_t *__restrict__ used /* [parts + 1] */) {
+  const int p = threadIdx.x;
+  if (p < sg.parts) {
+    const uint64_t u = 1ull + sg.lcount + (uint64_t)sg.cursor[p];
+    used[p] = u;
+    sg.packed[(uint64_t)p * sg.seg_cap] = make_uint4((uint32_t)min(u, (uint64_t)0xFFFFFFFFull), sg.lcount, sg.ll0, RUNS2_MAGIC);
+  }
+  if (p == 0) used[sg.parts] = (stats[ST_SPILLED] || stats[ST_ONES] || stats[ST_L1OVF] || stats[ST_L2OVF] || stats[ST_OVFN] ||
+                                stats[ST_OVFN1] || stats[ST_CWRAP] || stats[ST_OVERFLOW]) ? 1ull : 0ull;
+}
+
+
+// host side of cfrk_global_export_runs_async for both key widths: per group, zero headers of the leaves that stand for no
+// leaf, the fused dedupe + pack kernel (launch(sg)), the epilogue, the sizes to pinned memory, the group's event
+template <class Launch>
+static int runs_export_async_host(cfrk_ctx *ctx, void *d_packed, uint64_t seg_cap_rows, int parts, int ngroups, Launch launch) {
+  const int lpp = (NLEAF + parts - 1) / parts;
+  if (ngroups > lpp) return cfrk_fail(ctx, CFRK_ERR_ARG, "more groups than leaves per owner");
+  if (seg_cap_rows < (uint64_t)(lpp + ngroups - 1) / ngroups + 2 || seg_cap_rows > 0xFFFFFFF0ull)
+    return cfrk_fail(ctx, CFRK_ERR_ARG, "segment capacity out of range (at least a group's header: leaves per owner / groups + 2 rows)");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (!ctx->h_runs) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_runs, (size_t)CFRK_RUNS_MAX_GROUPS * 65 * sizeof(uint64_t), hipHostMallocDefault));
+  for (int g = 0; g < ngroups; ++g)
+    if (!ctx->runs_ev[g]) HIP_TRY(ctx, hipEventCreate(&ctx->runs_ev[g]));          // (with timing: cfrk_global_runs_group_ms)
+  int rc;
+  void *p;
+  const size_t ncur = (size_t)ngroups * parts;
+  if ((rc = cfrk_pool_get(ctx, BUF_RUNS_AUX, ((ncur * sizeof(uint32_t) + 15) & ~(size_t)15) + (size_t)ngroups * 65 * sizeof(uint64_t), &p))) return rc;
+  uint32_t *d_cur = (uint32_t *)p;
+  uint64_t *d_used = (uint64_t *)((char *)p + ((ncur * sizeof(uint32_t) + 15) & ~(size_t)15));
+  HIP_TRY(ctx, hipMemsetAsync(d_cur, 0, ncur * sizeof(uint32_t), ctx->stream));
+  for (int g = 0; g < ngroups; ++g) {
+    RunsSend sg;
+    sg.packed = (uint4 *)d_packed + (uint64_t)g * parts * seg_cap_rows;
+    sg.seg_cap = seg_cap_rows;
+    sg.cursor = d_cur + (size_t)g * parts;
+    sg.ll0 = runs_ll0(lpp, g, ngroups);
+    sg.lcount = runs_ll0(lpp, g + 1, ngroups) - sg.ll0;
+    sg.leaf0 = sg.ll0 * (uint32_t)parts;
+    sg.nleaf = std::min<uint32_t>((sg.ll0 + sg.lcount) * (uint32_t)parts, (uint32_t)NLEAF) - sg.leaf0;
+    sg.parts = parts;
+    if (sg.nleaf < sg.lcount * (uint32_t)parts) {
+      // (parts does not divide 65536: the last local leaf of the last owners stands for no leaf -- its header entry is zero)
+      for (uint32_t q = sg.nleaf; q < sg.lcount * (uint32_t)parts; ++q) {
+        const uint32_t leaf = sg.leaf0 + q, own = leaf % (uint32_t)parts, ll = leaf / (uint32_t)parts;
+        HIP_TRY(ctx, hipMemsetAsync(sg.packed + (uint64_t)own * seg_cap_rows + 1u + (ll - sg.ll0), 0, sizeof(uint4), ctx->stream));
+      }
+    }
+    if (sg.nleaf) {
+      launch(sg);
+      HIP_TRY(ctx, hipGetLastError());
+    }
+    hipLaunchKernelGGL(msp_runs_group_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, sg, (const uint64_t *)ctx->g_stats, d_used + (size_t)g * 65);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_runs + (size_t)g * 65, d_used + (size_t)g * 65, (size_t)(parts + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->runs_ev[g], ctx->stream));
+  }
+  ctx->runs_groups = ngroups; ctx->runs_parts = parts; ctx->runs_seg_cap = seg_cap_rows;
+  return CFRK_OK;
+}

@@ -161,7 +161,7 @@ def exchange_by_runs_pipelined(engine, owner_merge, world, device, wire_device=N
     reads the received segments in place.
 
     engine.export_runs_pipelined_begin(parts, groups) -> send buffer (int64 tensor [groups, parts, seg_cap, 2]) or None
-        (this rank cannot: two-word keys, a refused add); enqueues the packing of every group and returns at once.
+        (this rank cannot: a refused add, leaves shared by sub-value); enqueues the packing of every group and returns at once.
     engine.export_runs_pipelined_wait(g) -> rows per owner segment of group g, or None (a segment ran out of room, the
         add overflowed a region).
     owner_merge(recv, recv_rows, g, groups): enqueue the owner's counting of group g from `recv` (rows in rank order).

@@ -1817,9 +1817,10 @@ def _pipelined_exchange(ctx, data, R, L, k, flags, world, ngroups, hint, seg_cap
         og.set_debug_flags(0)
         for d in bufs:
             ctx.free(d)
-        for key, c in zip(lo, cnt):
-            assert int(key) not in merged            # owners hold disjoint key sets
-            merged[int(key)] = int(c)
+        keys = [int(x) for x in lo] if k <= 32 else [(int(h) << 64) | int(l) for l, h in zip(lo, hi)]
+        for key, c in zip(keys, cnt):
+            assert key not in merged                 # owners hold disjoint key sets
+            merged[key] = int(c)
     return merged
 
 
@@ -1827,7 +1828,11 @@ def _pipelined_exchange(ctx, data, R, L, k, flags, world, ngroups, hint, seg_cap
     (31, True, 2, 2, 300_000, 0), (31, True, 8, 2, 300_000, 0), (31, True, 8, 1, 300_000, 0), (21, True, 4, 3, 300_000, 0),
     (28, False, 3, 2, 300_000, 0), (16, True, 2, 4, 5_000_000, 0), (32, True, 5, 2, 300_000, 0),
     (31, True, 4, 2, 300_000, "rt_overflow"), (31, True, 4, 2, 300_000, "no_anchors"), (25, True, 3, 2, 300_000, "chunked"),
-    (31, False, 4, 16, 300_000, 0)])
+    (31, False, 4, 16, 300_000, 0),
+    # two-word keys (msp2.hip: 32-byte records travel as two rows)
+    (63, True, 4, 2, 300_000, 0), (33, False, 3, 2, 300_000, 0), (47, True, 8, 3, 300_000, 0), (64, True, 2, 1, 300_000, 0),
+    (63, True, 4, 2, 300_000, "rt_overflow"), (63, True, 4, 2, 300_000, "no_anchors"), (55, True, 3, 2, 300_000, "note_pos"),
+    (40, True, 5, 16, 300_000, 0)])
 def test_pipelined_runs_exchange_emulated_ranks_equal_the_oracle(ctx, k, canonical, world, ngroups, G, dbg):
     """the pipelined form of the strong-scaling exchange (cfrk_global_export_runs_async / _wait,
     cfrk_global_merge_runs_group_device): the sender deduplicates and packs one group of leaves after the
@@ -1846,12 +1851,15 @@ def test_pipelined_runs_exchange_emulated_ranks_equal_the_oracle(ctx, k, canonic
     data.reshape(R, L + 1)[:, L] = -1
     flags = cfrk_amd.CFRK_CANONICAL if canonical else 0
     bits = {0: 0, "rt_overflow": cfrk_amd.CFRK_DEBUG_FORCE_RT_OVERFLOW, "no_anchors": cfrk_amd.lib.CFRK_DEBUG_NO_ANCHORS,
-            "chunked": cfrk_amd.CFRK_DEBUG_SMALL_PIPELINE}[dbg]
+            "chunked": cfrk_amd.CFRK_DEBUG_SMALL_PIPELINE, "note_pos": cfrk_amd.lib.CFRK_DEBUG_SMALL_WAVE_CAP}[dbg]
     merged = _pipelined_exchange(ctx, data, R, L, k, flags, world, ngroups, 2 * G, dbg=bits)
     assert merged is not None
     wlo, whi, wcnt = orc.global_count(data, k, orc.ORC_CANONICAL if canonical else 0, threads=4)
     assert len(merged) == len(wlo)
-    assert all(merged[int(a)] == int(b) for a, b in zip(wlo, wcnt))
+    if k <= 32:
+        assert all(merged[int(a)] == int(b) for a, b in zip(wlo, wcnt))
+    else:
+        assert all(merged[(int(h) << 64) | int(a)] == int(b) for a, h, b in zip(wlo, whi, wcnt))
 
 
 def test_pipelined_runs_exchange_refuses_what_it_cannot_carry_and_the_classic_export_follows(ctx):

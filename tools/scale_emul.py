@@ -42,8 +42,6 @@ L = int(opt.get("L", 150))
 G_GROUPS = int(opt.get("groups", 2))
 link = float(opt.get("link-gbs", 120.0))
 coll_us = float(opt.get("coll-lat-us", 60.0))
-if k > 32:
-    classic = True                      # (the pipelined form serves one-word keys)
 dev = torch.device("cuda:0")
 stream = torch.cuda.Stream(dev)
 torch.cuda.set_stream(stream)
@@ -76,7 +74,7 @@ def host_sync_latency_us():
 
 if not classic:
     lpp = -(-65536 // world)
-    rows_est = int(min(14 * Rl, 2.5 * Rl + 0.3 * G)) + (1 << 17)
+    rows_est = int(min(14 * Rl, 2.5 * Rl + 0.3 * G)) * (2 if k > 32 else 1) + (1 << 17)   # (k > 32: two rows per record)
     seg_cap = int(rows_est / (G_GROUPS * world) * 1.25) + (lpp + G_GROUPS - 1) // G_GROUPS + 4096
     buf = torch.empty((G_GROUPS, world, seg_cap, 2), dtype=torch.int64, device=dev)
     sync_us = host_sync_latency_us()
