@@ -3,7 +3,8 @@
 minutes for: for random (k, read shape, genome size, strand flag, capacity hint, memory budget)
 the partitioned / radix path must give the digest of the general HBM-table path (whose agreement
 with the oracle the parity tests pin key by key) and sum(count) must equal the number of valid
-k-mers; for 16 <= k <= 64 the runs exchange over 2..5 emulated ranks must give the same digest too.
+k-mers; for 16 <= k <= 64 the runs exchange over 2..5 emulated ranks must give the same digest too, and so must its
+pipelined form (round 5: deferred add, 1..8 groups, 2..8 ranks, both key widths).
 usage (GPU box): tools/fuzz_paths.py [seconds [seed]]      prints one line per case, exits 1 on a mismatch"""
 import os
 import sys
@@ -122,6 +123,65 @@ while time.time() < t_end:
                 ok = ok and ok2
             else:
                 line += " | runs exchange: refused (spill), skipped"
+        if ok and 16 <= k <= 64 and rng.random() < 0.5:
+            # the PIPELINED runs exchange (round 5): deferred add, fused dedupe + pack per group, owners read the lists in place
+            world = int(rng.integers(2, 9))
+            ngroups = int(rng.choice([1, 2, 3, 8]))
+            Rl = [R * r // world for r in range(world + 1)]
+            # rows of a rank: at most its records (about one per four bases and two read ends per read), two rows each for k > 32
+            rows_est = (2 if k > 32 else 1) * ((R // world + 1) * ((L + 1) // 4 + 2)) + (1 << 16)
+            lpp = (65536 + world - 1) // world
+            seg_cap = min(3 * rows_est // (ngroups * world) + lpp + 4096, 0x7FFFFFF)     # (three times an even share)
+            per_rank, refused = [], None
+            for r in range(world):
+                gr = cfrk_amd.GlobalCounter(ctx, k, flags | cfrk_amd.CFRK_RUNS_ONLY | cfrk_amd.CFRK_RUNS_DEFER, hint)
+                nsh = (Rl[r + 1] - Rl[r]) * (L + 1)
+                dsh = ctx.alloc(nsh + 64)
+                ctx.synth_reads_device(Rl[r], Rl[r + 1] - Rl[r], L, G, dsh, uniform=uniform, **seeds)
+                ctx.sync()
+                buf = ctx.alloc(ngroups * world * seg_cap * 16)
+                try:
+                    gr.add_device(dsh, nsh)
+                    gr.export_runs_async(buf, seg_cap, world, ngroups)
+                    groups = []
+                    for gi in range(ngroups):
+                        rows = gr.export_runs_wait(gi)
+                        host = np.empty((world * seg_cap, 2), np.uint64)
+                        ctx.d2h(host, buf + gi * world * seg_cap * 16)
+                        groups.append((rows, [host[o * seg_cap:o * seg_cap + rows[o]].copy() for o in range(world)]))
+                        del host
+                    per_rank.append(groups)
+                except cfrk_amd.CfrkError as e:
+                    if e.code not in (-4, -9, -11):
+                        raise
+                    refused = e.code
+                ctx.sync()
+                ctx.free(buf)
+                ctx.free(dsh)
+                del gr
+                if refused is not None:
+                    break
+            if refused is None:
+                digs = []
+                for owner in range(world):
+                    og = cfrk_amd.GlobalCounter(octx, k, flags, hint // world + 1024)
+                    bufs = []
+                    for gi in range(ngroups):
+                        segs = [per_rank[r][gi][1][owner] for r in range(world)]
+                        allb = np.concatenate(segs)
+                        buf = ctx.alloc(max(len(allb), 1) * 16)
+                        ctx.h2d(buf, allb)
+                        og.merge_runs_group_device(buf, [len(x) for x in segs], gi, ngroups)
+                        bufs.append(buf)
+                    digs.append(og.digest())
+                    del og
+                    for b in bufs:
+                        ctx.free(b)
+                ok3 = merge(digs) == want
+                line += f" | pipelined x{world}/{ngroups}: {'ok' if ok3 else 'MISMATCH ' + str(merge(digs))}"
+                ok = ok and ok3
+            else:
+                line += f" | pipelined x{world}/{ngroups}: refused ({refused}), skipped"
     except cfrk_amd.CfrkError as e:
         ok = False
         line = f"{tag} ERROR {e}"
