@@ -487,13 +487,16 @@ def test_bench_two_ranks_take_the_pipelined_runs_exchange_and_the_one_shot_form_
 
 
 def test_bench_two_ranks_exchange_runs_of_two_word_keys():
-    """the same rehearsal at k = 63: strong scaling takes the runs exchange of msp2.hip (round 3) and
-    gives the 1-GPU digest"""
+    """the same rehearsal at k = 63: strong scaling takes the runs exchange of msp2.hip -- pipelined since round 5,
+    the one-shot form of round 3 on request -- and gives the 1-GPU digest"""
     common = ["--steps", "1", "--warmup", "0", "--reads", "2000000", "--k", "63", "--cpu-reads", "0"]
     one = _bench_line(["--gpus", "1"] + common)
-    two = _bench_line(["--gpus", "2", "--same-gpu", "--dist-backend", "gloo", "--scaling", "strong"] + common)
+    rehearsal = ["--gpus", "2", "--same-gpu", "--dist-backend", "gloo", "--scaling", "strong"]
+    two = _bench_line(rehearsal + common)
     assert one["sum_count_ok"] and two["sum_count_ok"] and two["digest"] == one["digest"]
-    assert two["exchange"]["exchange"].startswith("runs") and two["exchange"]["wire_bytes"] > 0
+    assert two["exchange"]["exchange"] == "runs, pipelined in 2 groups" and two["exchange"]["wire_bytes"] > 0
+    classic = _bench_line(rehearsal + ["--pipeline-groups", "0"] + common)
+    assert classic["digest"] == one["digest"] and classic["exchange"]["exchange"] == "runs"
 
 
 def test_bench_two_ranks_over_rccl_on_two_gpus():
