@@ -1599,7 +1599,12 @@ __global__ __launch_bounds__(DX2_THREADS) void msp2_dedupe_export_kernel(int k, 
 // complete runs in LDS, looks its read ends up, CLAIMS the leaf's rows in its owner's segment of the send buffer (one
 // atomic) and writes [distinct runs, two rows each][truncated runs without a twin][notes] there -- the leaf streams are
 // not rewritten, nothing is planned or gathered afterwards, the host is not asked.  (Layout: msp_runs.h.)
-constexpr int DS2_THREADS = 256, DS2_INFL = 4, DS2_TCAP = 4096, DS2_LOG = 11;
+// DS2_LOG: 1024 slots (32 KB of LDS, four workgroups per CU: a shard's leaf is ~1000 records and half a dozen dependent
+// round trips -- loads, a claim, a second look at the read ends -- and only other workgroups hide them) for leaves of a few
+// hundred distinct runs, 2048 slots (two per CU) beyond.  (A home-slot fast path with the leftovers compacted across the
+// wave, as in the leaf kernel, was measured SLOWER here, 2.47 against 2.10 ms: three records per thread do not pay for it.)
+constexpr int DS2_THREADS = 256, DS2_INFL = 4, DS2_TCAP = 2048;
+template <int DS2_LOG>
 __global__ __launch_bounds__(DS2_THREADS) void msp2_dedupe_send_kernel(int k, int canon, View2 v, RunsSend sg) {
   constexpr int RX = 1 << DS2_LOG;
   __shared__ Rec2 rtab[RX];
@@ -2401,8 +2406,12 @@ int cfrk_msp2_export_runs_async(cfrk_ctx *ctx, void *d_packed, uint64_t seg_cap_
   View2 v;
   memcpy(&v, ms->view2, sizeof v);
   const int k = ctx->g_k, canon = (ctx->g_flags & CFRK_CANONICAL) ? 1 : 0;
+  // (the table's size from the expected distinct runs per leaf, as in msp2_dedupe_in_place)
+  const double runs_per_leaf = (double)(ctx->g_cap / NLEAF) / 2.0 * 4.0 / (double)(msp2_window(k) + 1);
+  const bool small_tab = runs_per_leaf <= 400.0 && !(ctx->dbg_flags & CFRK_DEBUG_RECORD_SUBSETS);
   return runs_export_async_host(ctx, d_packed, seg_cap_rows, parts, ngroups, [&](const RunsSend &sg) {
-    hipLaunchKernelGGL(msp2_dedupe_send_kernel, dim3(sg.nleaf), dim3(DS2_THREADS), 0, ctx->stream, k, canon, v, sg);
+    if (small_tab) hipLaunchKernelGGL((msp2_dedupe_send_kernel<10>), dim3(sg.nleaf), dim3(DS2_THREADS), 0, ctx->stream, k, canon, v, sg);
+    else hipLaunchKernelGGL((msp2_dedupe_send_kernel<11>), dim3(sg.nleaf), dim3(DS2_THREADS), 0, ctx->stream, k, canon, v, sg);
   });
 }
 
