@@ -1604,10 +1604,47 @@ __global__ __launch_bounds__(DX2_THREADS) void msp2_dedupe_export_kernel(int k, 
 // hundred distinct runs, 2048 slots (two per CU) beyond.  (A home-slot fast path with the leftovers compacted across the
 // wave, as in the leaf kernel, was measured SLOWER here, 2.47 against 2.10 ms: three records per thread do not pay for it.)
 constexpr int DS2_THREADS = 256, DS2_INFL = 4, DS2_TCAP = 2048;
+// r2_insert_loop on a SPLIT table (bases 0..63 / bases 64..95 / state words in arrays of their own; the spare word b.z of a
+// deferred add is zero and not kept)
+__device__ __forceinline__ void ds2_insert_loop(uint4 *ra, uint2 *rb, uint32_t *rst, const Rec2 &rec, uint32_t &h, uint32_t mask) {
+  const uint32_t nm1 = rec.b.w & 63u;
+  for (int it = 0; it < R2_TRIPS && __ballot((int32_t)h >= 0); ++it) {
+    const bool p = (int32_t)h >= 0;
+    const uint32_t hh = h & mask;
+    const uint32_t st = rst[hh];
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // the bases only after the state
+    const uint2 eb = rb[hh];
+    const uint4 ea = ra[hh];
+    // EMPTY and LOCK carry low header bits no record has, so they never compare equal
+    const bool match = (((st ^ rec.b.w) & 63u) | (eb.x ^ rec.b.x) | (eb.y ^ rec.b.y) | (ea.x ^ rec.a.x) |
+                        (ea.y ^ rec.a.y) | (ea.z ^ rec.a.z) | (ea.w ^ rec.a.w)) == 0u;
+    const bool empty = st == R2_EMPTY;
+    uint32_t won = 0u;
+    if (p && empty) {
+      if (atomicCAS(&rst[hh], R2_EMPTY, R2_LOCK) == R2_EMPTY) {
+        ra[hh] = rec.a;
+        rb[hh] = make_uint2(rec.b.x, rec.b.y);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        atomicExch(&rst[hh], (1u << 6) | nm1);
+        won = 1u;
+      }
+    }
+    if (p && match) atomicAdd(&rst[hh], 1u << 6);
+    const bool stay = match || empty || st == R2_LOCK;
+    const uint32_t nh = stay ? hh : ((hh + 1) & mask);
+    h = (p && !match && won == 0u) ? nh : (h | R2_DONE);
+  }
+}
 template <int DS2_LOG>
 __global__ __launch_bounds__(DS2_THREADS) void msp2_dedupe_send_kernel(int k, int canon, View2 v, RunsSend sg) {
   constexpr int RX = 1 << DS2_LOG;
-  __shared__ Rec2 rtab[RX];
+  // SPLIT record table (msp.hip: msp_dedupe_send_kernel): with 32-byte entries the state word of every slot sits in LDS
+  // bank 7 mod 8 -- a wave's 64 atomics land on 4 of the 32 banks -- and a wave's 16-byte reads of random entries use half
+  // the banks: 77 % of this kernel's LDS-active cycles were bank conflicts (profiles/r05/pipelined_exchange_kernels_k63_*).
+  // Bases 0..63, bases 64..95 and the state words are three arrays.
+  __shared__ uint4 ra[RX];
+  __shared__ uint2 rb[RX];
+  __shared__ uint32_t rst[RX];
   __shared__ uint16_t sidx[RX];                    // record-table slot -> position in the leaf's list
   __shared__ uint16_t tres[DS2_TCAP];              // truncated run g: its note, or 0xFFFF = travels as a record
   __shared__ uint32_t wsum[DS2_THREADS / 64];
@@ -1637,11 +1674,7 @@ __global__ __launch_bounds__(DS2_THREADS) void msp2_dedupe_send_kernel(int k, in
     recs[u] = zrec;
     if (r < n1 && !too_many) recs[u] = c3[r];
   }
-  {
-    Rec2 z = zrec;
-    z.b.w = R2_EMPTY;
-    for (int s_ = tid; s_ < RX; s_ += DS2_THREADS) rtab[s_] = z;
-  }
+  for (int s_ = tid; s_ < RX; s_ += DS2_THREADS) rst[s_] = R2_EMPTY;
   if (tid == 0) { rt_fail = ((v.dbg & CFRK_DEBUG_FORCE_RT_OVERFLOW) || too_many) ? 1u : 0u; noted = 0u; cu = 0u; cn = 0u; }
   __syncthreads();
   for (uint32_t r0 = 0; r0 < n1 && !too_many; r0 += (uint32_t)DS2_INFL * DS2_THREADS) {
@@ -1658,7 +1691,7 @@ __global__ __launch_bounds__(DS2_THREADS) void msp2_dedupe_send_kernel(int k, in
       const uint32_t r = r0 + (uint32_t)u * DS2_THREADS + tid;
       if (r0 + (uint32_t)u * DS2_THREADS >= n1) break;            // (wave-uniform)
       uint32_t h = r2_slot_k(recs[u], k, DS2_LOG) | ((r < n1) ? 0u : R2_DONE);
-      r2_insert_loop(rtab, recs[u], h, RX - 1);
+      ds2_insert_loop(ra, rb, rst, recs[u], h, RX - 1);
       if ((int32_t)h >= 0) rt_fail = 1u;
     }
   }
@@ -1667,14 +1700,13 @@ __global__ __launch_bounds__(DS2_THREADS) void msp2_dedupe_send_kernel(int k, in
   const uint32_t nt = (uint32_t)min(nt64, (uint64_t)0xFFFFFFFFull);
   uint32_t nd, at0 = 0;
   constexpr int PER = RX / DS2_THREADS;
-  const uint32_t *words = reinterpret_cast<const uint32_t *>(rtab);
   if (plain) {
     nd = n1;
   } else {
     // occupied slots -> positions in the leaf's list (eight slots per thread)
     uint32_t mine = 0;
 #pragma unroll
-    for (int i = 0; i < PER; ++i) mine += (words[8 * (PER * tid + i) + 7] != R2_EMPTY) ? 1u : 0u;
+    for (int i = 0; i < PER; ++i) mine += (rst[PER * tid + i] != R2_EMPTY) ? 1u : 0u;
     const uint32_t incl = dev_wave_scan_incl(mine);
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
@@ -1685,7 +1717,7 @@ __global__ __launch_bounds__(DS2_THREADS) void msp2_dedupe_send_kernel(int k, in
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       sidx[PER * tid + i] = (uint16_t)at;
-      if (words[8 * (PER * tid + i) + 7] != R2_EMPTY) ++at;
+      if (rst[PER * tid + i] != R2_EMPTY) ++at;
     }
     nd = total;
     __syncthreads();
@@ -1708,7 +1740,8 @@ __global__ __launch_bounds__(DS2_THREADS) void msp2_dedupe_send_kernel(int k, in
       for (int it = 0; it < 32 && __ballot((int32_t)h >= 0); ++it) {
         const bool p = (int32_t)h >= 0;
         const uint32_t hh = h & (uint32_t)(RX - 1);
-        const Rec2 e2 = rtab[hh];
+        const uint2 eb2 = rb[hh];
+        const Rec2 e2 = {ra[hh], make_uint4(eb2.x, eb2.y, 0u, rst[hh])};
         const bool empty = e2.b.w == R2_EMPTY;
         const bool hit = p && !empty && (e2.b.w & 31u) >= nm1 && rec2_prefix_equal(e2, rec, (int)nm1 + k);
         found = hit ? hh : found;
@@ -1757,8 +1790,8 @@ __global__ __launch_bounds__(DS2_THREADS) void msp2_dedupe_send_kernel(int k, in
     uint32_t at = at0;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-      const Rec2 e = rtab[PER * tid + i];
-      if (e.b.w != R2_EMPTY) { dst[2 * at] = e.a; dst[2 * at + 1] = e.b; ++at; }
+      const uint32_t sl = PER * tid + i, st = rst[sl];
+      if (st != R2_EMPTY) { const uint2 eb2 = rb[sl]; dst[2 * at] = ra[sl]; dst[2 * at + 1] = make_uint4(eb2.x, eb2.y, 0u, st); ++at; }
     }
   }
   uint4 *const dt = dst + 2 * (uint64_t)nd;

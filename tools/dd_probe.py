@@ -18,7 +18,7 @@ Rl = R // world; nN = Rl * (L + 1)
 d = torch.empty(nN + 64, dtype=torch.int8, device=dev)
 ctx.synth_reads_device(0, Rl, L, R, d.data_ptr()); ctx.sync()
 lpp = -(-65536 // world)
-seg_cap = int((2.5 * Rl + 0.3 * R) / (G * world) * 1.25) + lpp + 4096
+seg_cap = int((2.5 * Rl + 0.3 * R) * (2 if k > 32 else 1) / (G * world) * 1.25) + lpp + 4096     # (k > 32: two rows per record)
 buf = torch.empty((G, world, seg_cap, 2), dtype=torch.int64, device=dev)
 flags = cfrk_amd.CFRK_CANONICAL
 best = None
