@@ -732,6 +732,42 @@ __device__ __forceinline__ void r2_insert_loop(Rec2 *rtab, const Rec2 &rec, uint
   }
 }
 
+// r2_insert_loop on a SPLIT table: bases 0..63 (ra), bases 64..95 (rb), the spare word (rz; nullptr where it is always
+// zero) and the state words (rst) in arrays of their own.  With 32-byte entries the state word of every slot sits in LDS
+// bank 7 mod 8 -- a wave's 64 atomics land on 4 of the 32 banks -- and a wave's 16-byte reads of random entries use half
+// the banks (77 % of the sender kernel's LDS-active cycles were bank conflicts, profiles/r05/pipelined_exchange_kernels_k63_*).
+__device__ __forceinline__ void r2s_insert_loop(uint4 *ra, uint2 *rb, uint32_t *rz, uint32_t *rst, const Rec2 &rec, uint32_t &h,
+                                                uint32_t mask, uint32_t inc = 1u << 6) {
+  const uint32_t nm1 = rec.b.w & 63u;
+  for (int it = 0; it < R2_TRIPS && __ballot((int32_t)h >= 0); ++it) {
+    const bool p = (int32_t)h >= 0;
+    const uint32_t hh = h & mask;
+    const uint32_t st = rst[hh];
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // the bases only after the state
+    const uint2 eb = rb[hh];
+    const uint4 ea = ra[hh];
+    // EMPTY and LOCK carry low header bits no record has, so they never compare equal
+    const bool match = (((st ^ rec.b.w) & 63u) | (eb.x ^ rec.b.x) | (eb.y ^ rec.b.y) | (ea.x ^ rec.a.x) |
+                        (ea.y ^ rec.a.y) | (ea.z ^ rec.a.z) | (ea.w ^ rec.a.w)) == 0u;
+    const bool empty = st == R2_EMPTY;
+    uint32_t won = 0u;
+    if (p && empty) {
+      if (atomicCAS(&rst[hh], R2_EMPTY, R2_LOCK) == R2_EMPTY) {
+        ra[hh] = rec.a;
+        rb[hh] = make_uint2(rec.b.x, rec.b.y);
+        if (rz) rz[hh] = rec.b.z;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        atomicExch(&rst[hh], inc | nm1);
+        won = 1u;
+      }
+    }
+    if (p && match) atomicAdd(&rst[hh], inc);
+    const bool stay = match || empty || st == R2_LOCK;
+    const uint32_t nh = stay ? hh : ((hh + 1) & mask);
+    h = (p && !match && won == 0u) ? nh : (h | R2_DONE);
+  }
+}
+
 // SHARED: 2^sub_bits workgroups per leaf (an instantiation of its own: the ordinary kernel is short
 // of scalar registers as it is)
 // mode & Q3_WEIGHTED: the complete streams hold DISTINCT runs with multiplicities (header = count << 6 |
@@ -745,7 +781,11 @@ __device__ __forceinline__ void q3_body(int k, uint32_t mode, const View2 &v, co
   static_assert(!(SHARED && LISTS), "an owner's lists are counted by one workgroup per leaf");
   __shared__ ulonglong2 keys[T2];
   __shared__ uint32_t cnts[T2];
-  __shared__ Rec2 rtab[R2];
+  // the record table, SPLIT (r2s_insert_loop): slot s = {ra[s], {rb[s].x, rb[s].y, rz[s], rst[s]}}
+  __shared__ uint4 ra[R2];
+  __shared__ uint2 rb[R2];
+  __shared__ uint32_t rz[R2], rst[R2];
+  auto rt_get = [&](uint32_t s_) { const uint2 e = rb[s_]; return Rec2{ra[s_], make_uint4(e.x, e.y, rz[s_], rst[s_])}; };
   __shared__ uint16_t occ_list[R2];
   // truncated runs anchored to their complete twin (msp.hip): per record-table slot the start of
   // the group of lengths noted with it, the lengths, and the runs without a twin
@@ -833,11 +873,7 @@ __device__ __forceinline__ void q3_body(int k, uint32_t mode, const View2 &v, co
     return lo;
   };
   for (int s = tid; s < T2; s += Q3_THREADS) cnts[s] = 0;
-  {
-    Rec2 z;
-    z.a = make_uint4(0u, 0u, 0u, 0u); z.b = make_uint4(0u, 0u, 0u, R2_EMPTY);
-    rtab[tid] = z;
-  }
+  rst[tid] = R2_EMPTY; rz[tid] = 0u;
   if (tid == 0) { wg_total = 0; nocc = 0; rt_fail = 0; kovf = 0; sp = 0; leaf_total = 0; nseg = 0; nfb = 0; nfl = 0; }
   if (tid < NSV * 32 + 1) nhist[tid] = 0;
   for (int s = tid; s < R2 + 1; s += Q3_THREADS) th[s] = 0;
@@ -894,26 +930,24 @@ __device__ __forceinline__ void q3_body(int k, uint32_t mode, const View2 &v, co
   //      set and only a full set runs the probe loop (as in msp.hip).  The next record is asked
   //      for before the current one is inserted: one workgroup per CU, nothing else hides the load.
   {
-    uint32_t *words = reinterpret_cast<uint32_t *>(rtab);
     Rec2 Lr = zrec;                    // leftover records, lanes [0, c)
     uint32_t Lh = 0;
     int c = 0;                         // wave-uniform
     auto drain = [&](int cnt) {
       uint32_t h = Lh | ((lane < cnt) ? 0u : R2_DONE);
-      r2_insert_loop(rtab, Lr, h, R2 - 1, weighted ? (Lr.b.w & ~63u) : (1u << 6));
+      r2s_insert_loop(ra, rb, SHARED ? rz : nullptr, rst, Lr, h, R2 - 1, weighted ? (Lr.b.w & ~63u) : (1u << 6));
       if ((int32_t)h >= 0) rt_fail = 1u;
     };
     auto home = [&](const Rec2 &rec, bool valid) {
       const uint32_t h = r2_slot_k(rec, k);
-      const uint4 eb = rtab[h].b;                              // state word + bases 64..95
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // bases 0..63 only after the state
-      const uint4 ea = rtab[h].a;
-      const bool match = valid && ((((eb.w ^ rec.b.w) & 63u) | (eb.x ^ rec.b.x) | (eb.y ^ rec.b.y) | (ea.x ^ rec.a.x) |
+      const uint32_t st = rst[h];
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // the bases only after the state
+      const uint2 eb = rb[h];
+      const uint4 ea = ra[h];
+      const bool match = valid && ((((st ^ rec.b.w) & 63u) | (eb.x ^ rec.b.x) | (eb.y ^ rec.b.y) | (ea.x ^ rec.a.x) |
                                     (ea.y ^ rec.a.y) | (ea.z ^ rec.a.z) | (ea.w ^ rec.a.w)) == 0u);
-      // home-slot hits are counted BESIDE the table: the state word of a 32-byte entry sits in LDS bank 7 mod 8 -- a wave's
-      // 64 ds_add on the entries' own words land on 4 of the 32 banks; th[] (the anchoring's group array) is idle during
-      // the scan and takes them on consecutive words, folded into the entries after the scan
-      if (match) atomicAdd(&th[h], weighted ? (rec.b.w >> 6) : 1u);
+      // (the state words are an array of their own: a wave's 64 adds spread over all banks)
+      if (match) atomicAdd(&rst[h], weighted ? (rec.b.w & ~63u) : (1u << 6));
       const bool left = valid && !match;
       const unsigned long long mask = __ballot(left);
       if (mask == 0ull) return;
@@ -987,21 +1021,15 @@ __device__ __forceinline__ void q3_body(int k, uint32_t mode, const View2 &v, co
     if (c) drain(c);
   }
   __syncthreads();
-  {
-    const uint32_t hits = th[tid];                   // (R2 == Q3_THREADS: one slot per thread)
-    if (hits) atomicAdd(&reinterpret_cast<uint32_t *>(rtab)[8 * tid + 7], hits << 6);
-    th[tid] = 0u;
-  }
-  __syncthreads();
   const bool big = rt_fail != 0u;
   // ---- phase 2: every distinct complete record once (weight = multiplicity), listed longest
   //      first (a wave expands 64 records in lock-step for as many steps as its longest one),
   //      then the truncated runs by length class, long ones first
   {
-    const uint32_t st = rtab[tid].b.w;
+    const uint32_t st = rst[tid];
     const bool occ = !big && st != R2_EMPTY;
     // list position: by sub-value (shared leaves), then longest first -- entry hidx of the histogram
-    const uint32_t hidx = (SHARED ? (rtab[tid].b.z & hmask) * 32u : 0u) + (31u - (st & 31u));
+    const uint32_t hidx = (SHARED ? (rz[tid] & hmask) * 32u : 0u) + (31u - (st & 31u));
     uint32_t rank = 0;
     if (occ) rank = atomicAdd(&nhist[hidx], 1u);
     __syncthreads();
@@ -1081,7 +1109,7 @@ __device__ __forceinline__ void q3_body(int k, uint32_t mode, const View2 &v, co
       for (int it = 0; it < 32 && __ballot((int32_t)h >= 0); ++it) {
         const bool p = (int32_t)h >= 0;
         const uint32_t hh = h & (uint32_t)(R2 - 1);
-        const Rec2 e2 = rtab[hh];
+        const Rec2 e2 = rt_get(hh);
         const bool empty = e2.b.w == R2_EMPTY;
         // the twin holds at least as many k-mers and starts with the same nm1 + k bases
         const bool hit = p && !empty && (e2.b.w & 31u) >= nm1 && rec2_prefix_equal(e2, rec, (int)nm1 + k);
@@ -1161,7 +1189,7 @@ __device__ __forceinline__ void q3_body(int k, uint32_t mode, const View2 &v, co
         const uint32_t ri = (i * precip) >> 16;
         Rec2 rec = zrec;
         uint32_t slot = 0;
-        if (valid) { slot = occ_list[occ0 + ri]; rec = rtab[slot]; }
+        if (valid) { slot = occ_list[occ0 + ri]; rec = rt_get(slot); }
         if (use_anchors) {
           // ... plus one for every truncated run of this locus that reaches the k-mer
           const uint32_t g0 = th[slot];
@@ -1604,44 +1632,10 @@ __global__ __launch_bounds__(DX2_THREADS) void msp2_dedupe_export_kernel(int k, 
 // hundred distinct runs, 2048 slots (two per CU) beyond.  (A home-slot fast path with the leftovers compacted across the
 // wave, as in the leaf kernel, was measured SLOWER here, 2.47 against 2.10 ms: three records per thread do not pay for it.)
 constexpr int DS2_THREADS = 256, DS2_INFL = 4, DS2_TCAP = 2048;
-// r2_insert_loop on a SPLIT table (bases 0..63 / bases 64..95 / state words in arrays of their own; the spare word b.z of a
-// deferred add is zero and not kept)
-__device__ __forceinline__ void ds2_insert_loop(uint4 *ra, uint2 *rb, uint32_t *rst, const Rec2 &rec, uint32_t &h, uint32_t mask) {
-  const uint32_t nm1 = rec.b.w & 63u;
-  for (int it = 0; it < R2_TRIPS && __ballot((int32_t)h >= 0); ++it) {
-    const bool p = (int32_t)h >= 0;
-    const uint32_t hh = h & mask;
-    const uint32_t st = rst[hh];
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // the bases only after the state
-    const uint2 eb = rb[hh];
-    const uint4 ea = ra[hh];
-    // EMPTY and LOCK carry low header bits no record has, so they never compare equal
-    const bool match = (((st ^ rec.b.w) & 63u) | (eb.x ^ rec.b.x) | (eb.y ^ rec.b.y) | (ea.x ^ rec.a.x) |
-                        (ea.y ^ rec.a.y) | (ea.z ^ rec.a.z) | (ea.w ^ rec.a.w)) == 0u;
-    const bool empty = st == R2_EMPTY;
-    uint32_t won = 0u;
-    if (p && empty) {
-      if (atomicCAS(&rst[hh], R2_EMPTY, R2_LOCK) == R2_EMPTY) {
-        ra[hh] = rec.a;
-        rb[hh] = make_uint2(rec.b.x, rec.b.y);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        atomicExch(&rst[hh], (1u << 6) | nm1);
-        won = 1u;
-      }
-    }
-    if (p && match) atomicAdd(&rst[hh], 1u << 6);
-    const bool stay = match || empty || st == R2_LOCK;
-    const uint32_t nh = stay ? hh : ((hh + 1) & mask);
-    h = (p && !match && won == 0u) ? nh : (h | R2_DONE);
-  }
-}
 template <int DS2_LOG>
 __global__ __launch_bounds__(DS2_THREADS) void msp2_dedupe_send_kernel(int k, int canon, View2 v, RunsSend sg) {
   constexpr int RX = 1 << DS2_LOG;
-  // SPLIT record table (msp.hip: msp_dedupe_send_kernel): with 32-byte entries the state word of every slot sits in LDS
-  // bank 7 mod 8 -- a wave's 64 atomics land on 4 of the 32 banks -- and a wave's 16-byte reads of random entries use half
-  // the banks: 77 % of this kernel's LDS-active cycles were bank conflicts (profiles/r05/pipelined_exchange_kernels_k63_*).
-  // Bases 0..63, bases 64..95 and the state words are three arrays.
+  // SPLIT record table (r2s_insert_loop): bases 0..63, bases 64..95 and the state words are three arrays
   __shared__ uint4 ra[RX];
   __shared__ uint2 rb[RX];
   __shared__ uint32_t rst[RX];
@@ -1691,7 +1685,7 @@ __global__ __launch_bounds__(DS2_THREADS) void msp2_dedupe_send_kernel(int k, in
       const uint32_t r = r0 + (uint32_t)u * DS2_THREADS + tid;
       if (r0 + (uint32_t)u * DS2_THREADS >= n1) break;            // (wave-uniform)
       uint32_t h = r2_slot_k(recs[u], k, DS2_LOG) | ((r < n1) ? 0u : R2_DONE);
-      ds2_insert_loop(ra, rb, rst, recs[u], h, RX - 1);
+      r2s_insert_loop(ra, rb, nullptr, rst, recs[u], h, RX - 1);
       if ((int32_t)h >= 0) rt_fail = 1u;
     }
   }
