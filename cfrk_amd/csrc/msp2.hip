@@ -699,40 +699,10 @@ __device__ __forceinline__ Rec2 revcomp_record2(const Rec2 &rec, int len) {
   return out;
 }
 
-// insert-or-count one record per lane; state = slot h with R2_DONE or-ed in once placed.  On
-// return lanes still without R2_DONE found no place.  (mask: slots - 1; inc: the record's
-// multiplicity << 6 -- 1 << 6 unless the stream holds deduplicated runs, see "multi-GPU by runs")
-__device__ __forceinline__ void r2_insert_loop(Rec2 *rtab, const Rec2 &rec, uint32_t &h, uint32_t mask = R2 - 1, uint32_t inc = 1u << 6) {
-  uint32_t *words = reinterpret_cast<uint32_t *>(rtab);
-  const uint32_t nm1 = rec.b.w & 63u;
-  for (int it = 0; it < R2_TRIPS && __ballot((int32_t)h >= 0); ++it) {
-    const bool p = (int32_t)h >= 0;
-    const uint32_t hh = h & mask;
-    const uint4 eb = rtab[hh].b;                             // state word + bases 64..95
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // bases 0..63 only after the state
-    const uint4 ea = rtab[hh].a;
-    // EMPTY and LOCK carry low header bits no record has, so they never compare equal
-    const bool match = (((eb.w ^ rec.b.w) & 63u) | (eb.x ^ rec.b.x) | (eb.y ^ rec.b.y) | (ea.x ^ rec.a.x) |
-                        (ea.y ^ rec.a.y) | (ea.z ^ rec.a.z) | (ea.w ^ rec.a.w)) == 0u;
-    const bool empty = eb.w == R2_EMPTY;
-    uint32_t won = 0u;
-    if (p && empty) {
-      if (atomicCAS(&words[8 * hh + 7], R2_EMPTY, R2_LOCK) == R2_EMPTY) {
-        rtab[hh].a = rec.a;
-        words[8 * hh + 4] = rec.b.x; words[8 * hh + 5] = rec.b.y; words[8 * hh + 6] = rec.b.z;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        atomicExch(&words[8 * hh + 7], inc | nm1);
-        won = 1u;
-      }
-    }
-    if (p && match) atomicAdd(&words[8 * hh + 7], inc);
-    const bool stay = match || empty || eb.w == R2_LOCK;
-    const uint32_t nh = stay ? hh : ((hh + 1) & mask);
-    h = (p && !match && won == 0u) ? nh : (h | R2_DONE);
-  }
-}
-
-// r2_insert_loop on a SPLIT table: bases 0..63 (ra), bases 64..95 (rb), the spare word (rz; nullptr where it is always
+// insert-or-count one record per lane; state = slot h with R2_DONE or-ed in once placed.  On return lanes still without
+// R2_DONE found no place.  (mask: slots - 1; inc: the record's multiplicity << 6 -- 1 << 6 unless the stream holds
+// deduplicated runs, see "multi-GPU by runs")
+// The record table is SPLIT: bases 0..63 (ra), bases 64..95 (rb), the spare word (rz; nullptr where it is always
 // zero) and the state words (rst) in arrays of their own.  With 32-byte entries the state word of every slot sits in LDS
 // bank 7 mod 8 -- a wave's 64 atomics land on 4 of the 32 banks -- and a wave's 16-byte reads of random entries use half
 // the banks (77 % of the sender kernel's LDS-active cycles were bank conflicts, profiles/r05/pipelined_exchange_kernels_k63_*).
@@ -1521,7 +1491,11 @@ __device__ __forceinline__ uint32_t x2_count(const View2 &v, uint32_t leaf, int 
 template <int RX_LOG, int DX2_THREADS>
 __global__ __launch_bounds__(DX2_THREADS) void msp2_dedupe_export_kernel(int k, int canon, View2 v) {
   constexpr int RX = 1 << RX_LOG;
-  __shared__ Rec2 rtab[RX];
+  // the record table, SPLIT (r2s_insert_loop): slot s = {ra[s], {rb[s].x, rb[s].y, rz[s], rst[s]}}
+  __shared__ uint4 ra[RX];
+  __shared__ uint2 rb[RX];
+  __shared__ uint32_t rz[RX], rst[RX];
+  auto rt_get = [&](uint32_t s_) { const uint2 e = rb[s_]; return Rec2{ra[s_], make_uint4(e.x, e.y, rz[s_], rst[s_])}; };
   __shared__ uint16_t sidx[RX];                    // record-table slot -> position in the leaf's list
   __shared__ uint32_t wsum[DX2_THREADS / 64];
   __shared__ uint32_t rt_fail, noted;
@@ -1531,11 +1505,7 @@ __global__ __launch_bounds__(DX2_THREADS) void msp2_dedupe_export_kernel(int k, 
   if (n1 == 0) return;
   Rec2 *const stream = x2_stream(v, leaf, 3);
   const Rec2 zrec = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
-  {
-    Rec2 z = zrec;
-    z.b.w = R2_EMPTY;
-    for (int s = tid; s < RX; s += DX2_THREADS) rtab[s] = z;
-  }
+  for (int s = tid; s < RX; s += DX2_THREADS) rst[s] = R2_EMPTY;
   // (a leaf of 2^19 complete runs or more leaves undeduplicated: msp.hip, HUGE_LEAF)
   const bool too_many = (uint64_t)n1 >= Q3_HUGE_LEAF_SENDER;
   if (tid == 0) { rt_fail = ((v.dbg & CFRK_DEBUG_FORCE_RT_OVERFLOW) || too_many) ? 1u : 0u; noted = 0u; }
@@ -1552,7 +1522,7 @@ __global__ __launch_bounds__(DX2_THREADS) void msp2_dedupe_export_kernel(int k, 
     for (int u = 0; u < DX2_INFL; ++u) {
       const uint32_t r = r0 + (uint32_t)u * DX2_THREADS + tid;
       uint32_t h = r2_slot_k(recs[u], k, RX_LOG) | ((r < n1) ? 0u : R2_DONE);
-      r2_insert_loop(rtab, recs[u], h, RX - 1);
+      r2s_insert_loop(ra, rb, rz, rst, recs[u], h, RX - 1);
       if ((int32_t)h >= 0) rt_fail = 1u;
     }
   }
@@ -1565,10 +1535,9 @@ __global__ __launch_bounds__(DX2_THREADS) void msp2_dedupe_export_kernel(int k, 
   } else {
     // occupied slots -> head of the stream (eight slots per thread)
     constexpr int PER = RX / DX2_THREADS;
-    const uint32_t *words = reinterpret_cast<const uint32_t *>(rtab);
     uint32_t mine = 0;
 #pragma unroll
-    for (int i = 0; i < PER; ++i) mine += (words[8 * (PER * tid + i) + 7] != R2_EMPTY) ? 1u : 0u;
+    for (int i = 0; i < PER; ++i) mine += (rst[PER * tid + i] != R2_EMPTY) ? 1u : 0u;
     const uint32_t incl = dev_wave_scan_incl(mine);
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
@@ -1577,7 +1546,7 @@ __global__ __launch_bounds__(DX2_THREADS) void msp2_dedupe_export_kernel(int k, 
     uint32_t at = base + incl - mine;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-      const Rec2 e = rtab[PER * tid + i];
+      const Rec2 e = rt_get(PER * tid + i);
       sidx[PER * tid + i] = (uint16_t)at;
       if (e.b.w != R2_EMPTY) stream[at++] = e;
     }
@@ -1602,7 +1571,7 @@ __global__ __launch_bounds__(DX2_THREADS) void msp2_dedupe_export_kernel(int k, 
         for (int it = 0; it < 32 && __ballot((int32_t)h >= 0); ++it) {
           const bool p = (int32_t)h >= 0;
           const uint32_t hh = h & (uint32_t)(RX - 1);
-          const Rec2 e2 = rtab[hh];
+          const Rec2 e2 = rt_get(hh);
           const bool empty = e2.b.w == R2_EMPTY;
           const bool hit = p && !empty && (e2.b.w & 31u) >= nm1 && rec2_prefix_equal(e2, rec, (int)nm1 + k);
           found = hit ? hh : found;
