@@ -66,6 +66,8 @@ struct Options {
 // --timing: wall-clock seconds by phase (one file; with --batch the last file's)
 struct Timing {
   double parse = 0, add_call = 0, finish_wait = 0, export_ = 0, format = 0, write = 0, per_read = 0, total = 0;
+  double close = 0, free_batch = 0, open = 0;
+  double contexts = 0, begin = 0, wait_parse = 0;   // context creation (beside the parse), cfrk_global_begin, the main thread's wait for the parser
   float count_kernels_ms = 0;
   int64_t fasta_bytes = 0, nN = 0, nS = 0;
   uint64_t entries = 0, out_bytes = 0;
@@ -191,7 +193,9 @@ void write_global(const Options &o, const uint64_t *lo, const uint64_t *hi, cons
   g_timing.format = t1 - t0; g_timing.write = now_s() - t1; g_timing.entries = n; g_timing.out_bytes = buf.size();
 }
 
-int run_global(const Options &o, const cfrk_batch &batch, Worker &w, FILE *out) {
+// early_free: the batch is no longer needed once it has been counted -- returning 1.6 GB of pages to the kernel takes
+// ~0.17 s, which then runs beside the export, the formatting and the write instead of behind them
+int run_global(const Options &o, const cfrk_batch &batch, Worker &w, FILE *out, std::thread *early_free = nullptr, cfrk_batch *owned = nullptr) {
   int rc;
   cfrk_ctx *ctx = w.ctx;
   // The capacity hint sizes the result list and the spill table (12 B per slot at load <= 0.5).  Distinct k-mers cannot
@@ -204,14 +208,17 @@ int run_global(const Options &o, const cfrk_batch &batch, Worker &w, FILE *out) 
   uint64_t n = 0;
   double t0 = 0, t1 = 0;
   for (;;) {
+    const double tb = now_s();
     if ((rc = cfrk_global_begin(ctx, o.k, o.canonical ? CFRK_CANONICAL : 0, hint))) return die(ctx, rc, "cfrk_global_begin");
     t0 = now_s();
+    g_timing.begin = t0 - tb;
     if ((rc = cfrk_global_add(ctx, batch.data, batch.start, batch.length, batch.nN, batch.nS))) return die(ctx, rc, "cfrk_global_add");
     t1 = now_s();
     rc = cfrk_global_finish(ctx, &n);
     if (rc == CFRK_ERR_TABLE_FULL && hint < hint_max) { hint = std::min<uint64_t>(hint * 8, hint_max); continue; }
     break;
   }
+  if (early_free && owned) *early_free = std::thread([owned] { cfrk_host_free_batch(owned); });
   // (counts are 32-bit and saturate: the result is complete, the user is told)
   if (rc == CFRK_ERR_COUNT_OVERFLOW) fprintf(stderr, "cfrk: warning: %s\n", cfrk_last_error(ctx));
   else if (rc) return die(ctx, rc, "cfrk_global_finish");
@@ -360,32 +367,65 @@ int run_global_multi(const Options &o, const cfrk_batch &batch, std::vector<std:
 }
 
 // one FASTA file -> one .cfrk file on the given workers
-int run_file(const Options &o, const char *in, const char *outp, std::vector<Worker> &workers,
-             std::vector<std::vector<Worker>> *per_dev = nullptr) {
+// a FASTA file being parsed on a thread of its own while the caller creates the device contexts (single-file mode: HIP
+// start-up and two contexts are ~0.15 s, the parse of a 1.6 GB file ~0.28 s -- they need nothing from each other)
+double g_contexts_s = 0, g_wait_parse = 0;
+struct Parsed {
   cfrk_batch batch;
-  const double t0 = now_s();
-  int rc = cfrk_host_read_fasta(in, (o.native || o.global) ? 0 : CFRK_INGEST_COMPAT, &batch);
+  int rc = 0;
+  double t0 = 0, seconds = 0;
+  std::thread th;
+  void start(const Options &o, const char *in) {
+    t0 = now_s();
+    const unsigned flags = (o.native || o.global) ? 0 : CFRK_INGEST_COMPAT;
+    th = std::thread([this, in, flags] { rc = cfrk_host_read_fasta(in, flags, &batch); seconds = now_s() - t0; });
+  }
+};
+
+int run_file(const Options &o, const char *in, const char *outp, std::vector<Worker> &workers,
+             std::vector<std::vector<Worker>> *per_dev = nullptr, Parsed *pre = nullptr) {
+  cfrk_batch batch;
+  double t0 = now_s();
+  int rc;
+  if (pre) {
+    const double w0 = now_s();
+    pre->th.join();
+    g_wait_parse = now_s() - w0;
+    rc = pre->rc; batch = pre->batch; t0 = pre->t0;
+  } else {
+    rc = cfrk_host_read_fasta(in, (o.native || o.global) ? 0 : CFRK_INGEST_COMPAT, &batch);
+  }
   if (rc) { fprintf(stderr, "cfrk: cannot read %s (error %d)\n", in, rc); return 1; }
-  const double t1 = now_s();
+  const double t1 = pre ? t0 + pre->seconds : now_s();
   g_timing = Timing();
+  g_timing.contexts = g_contexts_s; g_timing.wait_parse = g_wait_parse;
   g_timing.parse = t1 - t0; g_timing.nN = batch.nN; g_timing.nS = batch.nS;
   { FILE *f = fopen(in, "rb"); if (f) { fseek(f, 0, SEEK_END); g_timing.fasta_bytes = (int64_t)ftell(f); fclose(f); } }
+  std::thread freer;                                  // (global mode: frees the batch beside the export)
+  const double to0 = now_s();
   FILE *out = fopen(outp, "wb");                      // PrintFreq opens with "w" even when empty
+  const double t_open = now_s() - to0;
   if (!out) { fprintf(stderr, "cfrk: cannot write %s\n", outp); cfrk_host_free_batch(&batch); return 1; }
   if (o.global && per_dev && per_dev->size() > 1 && o.k >= 16 && o.k <= 64 && batch.nS >= (int64_t)per_dev->size()) rc = run_global_multi(o, batch, *per_dev, out);
-  else if (o.global) rc = run_global(o, batch, workers[0], out);
+  else if (o.global) rc = run_global(o, batch, workers[0], out, &freer, &batch);
   else { const double p0 = now_s(); rc = run_per_read(o, batch, workers, out); g_timing.per_read = now_s() - p0; }
   if (!o.global) { fflush(out); g_timing.out_bytes = (uint64_t)ftell(out); }
+  const double tf0 = now_s();
   fclose(out);
-  cfrk_host_free_batch(&batch);
+  const double tf1 = now_s();
+  if (freer.joinable()) freer.join();
+  else cfrk_host_free_batch(&batch);
   g_timing.total = now_s() - t0;
+  g_timing.close = tf1 - tf0; g_timing.free_batch = now_s() - tf1; g_timing.open = t_open;
   if (o.timing)
     fprintf(stderr, "cfrk-timing {\"fasta_bytes\": %lld, \"reads\": %lld, \"code_bytes\": %lld, \"parse_s\": %.4f, \"add_call_s\": %.4f, "
             "\"finish_wait_s\": %.4f, \"count_kernels_ms\": %.3f, \"export_s\": %.4f, \"format_s\": %.4f, \"write_s\": %.4f, "
-            "\"per_read_pipeline_s\": %.4f, \"entries\": %llu, \"out_bytes\": %llu, \"wall_s\": %.4f}\n",
+            "\"per_read_pipeline_s\": %.4f, \"entries\": %llu, \"out_bytes\": %llu, \"contexts_s\": %.4f, \"wait_for_parser_s\": %.4f, "
+            "\"begin_s\": %.4f, \"open_out_s\": %.4f, \"close_out_s\": %.4f, \"free_batch_s\": %.4f, \"wall_s\": %.4f}\n",
             (long long)g_timing.fasta_bytes, (long long)g_timing.nS, (long long)g_timing.nN, g_timing.parse, g_timing.add_call,
             g_timing.finish_wait, (double)g_timing.count_kernels_ms, g_timing.export_, g_timing.format, g_timing.write,
-            g_timing.per_read, (unsigned long long)g_timing.entries, (unsigned long long)g_timing.out_bytes, g_timing.total);
+            g_timing.per_read, (unsigned long long)g_timing.entries, (unsigned long long)g_timing.out_bytes, g_timing.contexts,
+            g_timing.wait_parse, g_timing.begin, g_timing.open, g_timing.close, g_timing.free_batch, g_timing.total);
   return rc;
 }
 
@@ -423,6 +463,11 @@ int main(int argc, char **argv) {
   if (o.gpus < 1) { fprintf(stderr, "cfrk: --gpus must be positive\n"); return 1; }
   if (batch_n == 0 || batch_n < -1) { fprintf(stderr, "cfrk: --batch needs a positive file count\n"); return 1; }
 
+  // single-file mode: the parse starts now, beside the creation of the contexts
+  Parsed pre;
+  if (batch_n < 0) pre.start(o, pos[0]);
+  struct Joiner { Parsed &p; ~Joiner() { if (p.th.joinable()) { p.th.join(); if (!p.rc) cfrk_host_free_batch(&p.batch); } } } joiner{pre};   // (early returns)
+  const double tc0 = now_s();                          // (runtime start-up + the contexts)
   int ndev = 0, rc;
   if ((rc = cfrk_device_count(&ndev))) return die(nullptr, rc, "cfrk_device_count");
   if (!o.same_device && o.device + o.gpus > ndev) {
@@ -439,12 +484,13 @@ int main(int argc, char **argv) {
       per_dev[(size_t)g].push_back(w);
     }
 
+  g_contexts_s = now_s() - tc0;
   int status = 0;
   if (batch_n < 0) {
     std::vector<Worker> all;
     for (int s = 0; s < 2; ++s)                       // device-major would put both streams of a device first
       for (int g = 0; g < o.gpus; ++g) all.push_back(per_dev[(size_t)g][(size_t)s]);
-    status = run_file(o, pos[0], pos[1], all, &per_dev);
+    status = run_file(o, pos[0], pos[1], all, &per_dev, &pre);
   } else {
     // file i goes to device i % gpus (swift/cfrk.swf:15-20 starts one cfrk process per file)
     std::vector<int> st((size_t)o.gpus, 0);
