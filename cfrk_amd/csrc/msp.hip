@@ -3053,7 +3053,7 @@ extern "C" int cfrk_global_export_runs_async(cfrk_ctx *ctx, void *d_packed, uint
   cfrk_msp *ms = ctx->msp;
   if (!ctx->g_active || !ms || !ms->runs_ready)
     return cfrk_fail(ctx, CFRK_ERR_STATE, "no runs to export (begin with CFRK_RUNS_ONLY, then one add)");
-  if (ms->runs_deduped) return cfrk_fail(ctx, CFRK_ERR_STATE, "the leaf streams were deduplicated in place already (add with CFRK_RUNS_DEFER for the pipelined export; leaves shared by sub-value always are)");
+  if (ms->runs_deduped) return cfrk_fail(ctx, CFRK_ERR_STATE, "the leaf streams were deduplicated in place already (add with CFRK_RUNS_DEFER for the pipelined export)");
   if (!d_packed) return cfrk_fail(ctx, CFRK_ERR_ARG, "NULL buffer");
   if (ctx->g_two) return cfrk_msp2_export_runs_async(ctx, d_packed, seg_cap_rows, parts, ngroups);
   const MspView &v = ms->view;

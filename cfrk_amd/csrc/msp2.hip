@@ -745,10 +745,9 @@ __device__ __forceinline__ void r2s_insert_loop(uint4 *ra, uint2 *rb, uint32_t *
 constexpr uint32_t Q3_WEIGHTED = 1u;
 constexpr uint64_t Q3_HUGE_LEAF = 1ull << 25, Q3_HUGE_LEAF_SENDER = 1ull << 19;   // (msp.hip: HUGE_LEAF)
 // LISTS (round 5, the owner of the PIPELINED runs exchange, msp.hip: p3_body): the leaf's runs are the N lists its ranks
-// sent, read in place from the receive buffer -- two rows per record, a note expanded where it is read; never SHARED.
+// sent, read in place from the receive buffer -- two rows per record, a note expanded where it is read.
 template <bool CANON, bool SHARED, bool LISTS>
 __device__ __forceinline__ void q3_body(int k, uint32_t mode, const View2 &v, const TableView &t, const P3ListsT<LISTS> &lx) {
-  static_assert(!(SHARED && LISTS), "an owner's lists are counted by one workgroup per leaf");
   __shared__ ulonglong2 keys[T2];
   __shared__ uint32_t cnts[T2];
   // the record table, SPLIT (r2s_insert_loop): slot s = {ra[s], {rb[s].x, rb[s].y, rz[s], rst[s]}}
@@ -803,6 +802,7 @@ __device__ __forceinline__ void q3_body(int k, uint32_t mode, const View2 &v, co
   __shared__ uint32_t l_cpre[LISTS ? 65 : 1], l_tpre[LISTS ? 65 : 1], l_nu[LISTS ? 64 : 1];
   __shared__ const uint4 *l_base[LISTS ? 64 : 1];
   if constexpr (LISTS) {
+    if (leaf >= lx.lcount) return;                     // (shared leaves: the grid is padded to whole groups of eight)
     if (tid < 64) {
       const int r = tid;
       uint32_t nd = 0, nu = 0, na = 0;
@@ -813,7 +813,7 @@ __device__ __forceinline__ void q3_body(int k, uint32_t mode, const View2 &v, co
         bool ok = rows >= hrows;
         if (ok) { const uint4 h0 = hdr[0]; ok = h0.y == lx.lcount && h0.z == lx.ll0 && h0.w == RUNS2_MAGIC; }
         if (ok) {
-          const uint4 e = hdr[1u + blockIdx.x];
+          const uint4 e = hdr[1u + leaf];               // (LISTS: `leaf` is the local leaf of the group)
           const uint64_t tot = 2ull * ((uint64_t)e.y + e.z) + (e.w + (uint32_t)NOTES_PER_ROW - 1u) / (uint32_t)NOTES_PER_ROW;
           // (a segment that does not add up, or notes without a run they could point at, is not followed)
           if ((uint64_t)e.x + tot <= rows - hrows && (e.w == 0u || e.y != 0u)) { nd = e.y; nu = e.z; na = e.w; base = hdr + hrows + e.x; }
@@ -978,7 +978,7 @@ __device__ __forceinline__ void q3_body(int k, uint32_t mode, const View2 &v, co
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           q[u] = zrec;
-          if (r + (uint64_t)u * Q3_THREADS < ns[3]) q[u] = leaf_rec[r + (uint64_t)u * Q3_THREADS];
+          if (r + (uint64_t)u * Q3_THREADS < ns[3]) q[u] = ld_c(r + (uint64_t)u * Q3_THREADS);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -1219,27 +1219,27 @@ __device__ __forceinline__ void q3_body(int k, uint32_t mode, const View2 &v, co
         sc += n;
       };
       for (int cl = big ? 3 : 2; cl >= 0 && !(cl < 3 && (v.dbg & CFRK_ABL_P3_NO_TRUNC)); --cl) {
+        if (LISTS && (cl == 1 || cl == 2)) continue;       // (an owner's truncated runs are one class)
         if (cl == 3 && weighted) {
           // (distinct runs with multiplicities and no room to merge them: rare enough to expand them where they lie)
           for (uint64_t r = tid; r < ((ns[3] + 63) & ~63ull); r += Q3_THREADS) {
             const bool valid = r < ns[3];
             Rec2 rec = zrec;
-            if (valid) rec = leaf_rec[r];
+            if (valid) rec = ld_c(r);
             count_record2<CANON>(keys, cnts, rec, rec.b.w >> 6, valid && mine(rec), k, t, ss, ovf);
           }
           continue;
         }
-        const Rec2 *src = (cl == 3) ? leaf_rec
-                          : v.exact ? v.rec2 + v.lbase[NCLS * leaf + cl] : leaf_rec + v.cap2c + (uint64_t)cl * v.cap2t;
+        auto ld_cl = [&](uint64_t i) -> Rec2 { return (cl == 3) ? ld_c(i) : ld_t(cl, i); };
         const uint64_t done = (cl == 3) ? 0ull : (uint64_t)cov[cl];   // (the anchored ones are done)
         Rec2 nxt = zrec;
         const uint64_t r_first = done + tid;
-        if (r_first < ns[cl]) nxt = src[r_first];
+        if (r_first < ns[cl]) nxt = ld_cl(r_first);
         for (uint64_t r = r_first; r < done + ((ns[cl] - done + 63) & ~63ull); r += Q3_THREADS) {
           const Rec2 rec = nxt;
           const bool keep = r < ns[cl] && mine(rec) && (rec.b.z & hmask) == sv;
           nxt = zrec;
-          if (r + Q3_THREADS < ns[cl]) nxt = src[r + Q3_THREADS];
+          if (r + Q3_THREADS < ns[cl]) nxt = ld_cl(r + Q3_THREADS);
           sfeed(rec, keep);
         }
       }
@@ -1265,7 +1265,7 @@ __device__ __forceinline__ void q3_body(int k, uint32_t mode, const View2 &v, co
     __syncthreads();
     if (tid == 0) {
       wg_base = atomicAdd((unsigned long long *)&v.stats[ST_CURSOR], (unsigned long long)wg_total);
-      if (SHARED) {
+      if (SHARED && !LISTS) {
         // one segment per sub-value; one that took several key-subset passes has no single segment
         const uint32_t sg = (leaf << sub_bits) | (rsel << hbits) | sv;
         if (bits == 0u) { v.leaf_off[sg] = wg_base; v.leaf_n[sg] = wg_total; }
@@ -1292,9 +1292,9 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, uint32_t mod
   q3_body<CANON, SHARED, false>(k, mode, v, t, P3ListsT<false>{});
 }
 // the owner of the pipelined runs exchange: workgroup b counts local leaf lx.ll0 + b from the lists its ranks sent
-template <bool CANON>
+template <bool CANON, bool SHARED>
 __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_lists_kernel(int k, View2 v, TableView t, P3ListsT<true> lx) {
-  q3_body<CANON, false, true>(k, Q3_WEIGHTED, v, t, lx);
+  q3_body<CANON, SHARED, true>(k, Q3_WEIGHTED, v, t, lx);
 }
 
 // HUGE leaves (msp.hip: HUGE_LEAF -- 2^25 records or more, a single-key flood): not counted in LDS, where a run's
@@ -1600,14 +1600,21 @@ __global__ __launch_bounds__(DX2_THREADS) void msp2_dedupe_export_kernel(int k, 
 // round trips -- loads, a claim, a second look at the read ends -- and only other workgroups hide them) for leaves of a few
 // hundred distinct runs, 2048 slots (two per CU) beyond.  (A home-slot fast path with the leftovers compacted across the
 // wave, as in the leaf kernel, was measured SLOWER here, 2.47 against 2.10 ms: three records per thread do not pay for it.)
-constexpr int DS2_THREADS = 256, DS2_INFL = 4, DS2_TCAP = 2048;
-template <int DS2_LOG>
+// SUB: the job's leaves are shared by sub-value (configs[4]-sized hints): the records' spare word b.z (extra minimizer-hash
+// bits) is kept and travels; such leaves hold ~2000 distinct runs per rank: 4096 slots, 1024 threads, one workgroup per CU
+// (msp2_dedupe_export_kernel's shapes).
+// DS2_TCAP: read ends of a leaf that may become notes (the others travel as records: 32 bytes instead of 2) -- 2048 where
+// a rank's leaf holds a few hundred, 6144 for the shared leaves of a configs[4]-sized job (~3800)
+constexpr int DS2_INFL = 4;
+template <int DS2_LOG, int DS2_THREADS, bool SUB, int DS2_TCAP = (SUB ? 6144 : 2048)>
 __global__ __launch_bounds__(DS2_THREADS) void msp2_dedupe_send_kernel(int k, int canon, View2 v, RunsSend sg) {
   constexpr int RX = 1 << DS2_LOG;
   // SPLIT record table (r2s_insert_loop): bases 0..63, bases 64..95 and the state words are three arrays
   __shared__ uint4 ra[RX];
   __shared__ uint2 rb[RX];
   __shared__ uint32_t rst[RX];
+  __shared__ uint32_t rz_[SUB ? RX : 1];
+  uint32_t *const rz = SUB ? rz_ : nullptr;
   __shared__ uint16_t sidx[RX];                    // record-table slot -> position in the leaf's list
   __shared__ uint16_t tres[DS2_TCAP];              // truncated run g: its note, or 0xFFFF = travels as a record
   __shared__ uint32_t wsum[DS2_THREADS / 64];
@@ -1654,7 +1661,7 @@ __global__ __launch_bounds__(DS2_THREADS) void msp2_dedupe_send_kernel(int k, in
       const uint32_t r = r0 + (uint32_t)u * DS2_THREADS + tid;
       if (r0 + (uint32_t)u * DS2_THREADS >= n1) break;            // (wave-uniform)
       uint32_t h = r2_slot_k(recs[u], k, DS2_LOG) | ((r < n1) ? 0u : R2_DONE);
-      r2s_insert_loop(ra, rb, nullptr, rst, recs[u], h, RX - 1);
+      r2s_insert_loop(ra, rb, rz, rst, recs[u], h, RX - 1);
       if ((int32_t)h >= 0) rt_fail = 1u;
     }
   }
@@ -1704,7 +1711,7 @@ __global__ __launch_bounds__(DS2_THREADS) void msp2_dedupe_send_kernel(int k, in
         const bool p = (int32_t)h >= 0;
         const uint32_t hh = h & (uint32_t)(RX - 1);
         const uint2 eb2 = rb[hh];
-        const Rec2 e2 = {ra[hh], make_uint4(eb2.x, eb2.y, 0u, rst[hh])};
+        const Rec2 e2 = {ra[hh], make_uint4(eb2.x, eb2.y, 0u, rst[hh])};      // (the spare word takes no part in the comparison)
         const bool empty = e2.b.w == R2_EMPTY;
         const bool hit = p && !empty && (e2.b.w & 31u) >= nm1 && rec2_prefix_equal(e2, rec, (int)nm1 + k);
         found = hit ? hh : found;
@@ -1754,7 +1761,7 @@ __global__ __launch_bounds__(DS2_THREADS) void msp2_dedupe_send_kernel(int k, in
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const uint32_t sl = PER * tid + i, st = rst[sl];
-      if (st != R2_EMPTY) { const uint2 eb2 = rb[sl]; dst[2 * at] = ra[sl]; dst[2 * at + 1] = make_uint4(eb2.x, eb2.y, 0u, st); ++at; }
+      if (st != R2_EMPTY) { const uint2 eb2 = rb[sl]; dst[2 * at] = ra[sl]; dst[2 * at + 1] = make_uint4(eb2.x, eb2.y, SUB ? rz_[sl] : 0u, st); ++at; }
     }
   }
   uint4 *const dt = dst + 2 * (uint64_t)nd;
@@ -2035,9 +2042,11 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
   // overflow goes straight to the exact layout
   const bool runs_only = (ctx->g_flags & CFRK_RUNS_ONLY) != 0;
   if (runs_only) v.ovf_cap = v.ovf1_cap = 0;
-  // CFRK_RUNS_DEFER (msp.hip): the add ends behind Q2, unsynchronised; the pipelined export deduplicates group by group.
-  // (Leaves shared by sub-value keep the settling form: their records' extra bits have no place in the owner's list reader.)
-  const bool defer = runs_only && (ctx->g_flags & CFRK_RUNS_DEFER) && !sub && !chunked && !lean;
+  // CFRK_RUNS_DEFER (msp.hip): no deduplication here -- the pipelined export deduplicates group by group -- and, when the
+  // streams have their fixed stride (not a chunked or a count-first add, whose layouts need a read-back), the add ends behind
+  // Q2 unsynchronised
+  const bool nodedupe = runs_only && (ctx->g_flags & CFRK_RUNS_DEFER);
+  const bool defer = nodedupe && !chunked && !lean;
   v.exact = 0; v.lbase = nullptr; v.lcap = nullptr;
   v.exact1 = 0; v.rbase = nullptr; v.rcap = nullptr;
   const size_t nreg = (size_t)B1 * NXG;
@@ -2193,10 +2202,10 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
     // deduplicate the leaves where they lie (unless deferred); the streams stay for the export
     static_assert(sizeof(View2) <= sizeof(ms->view2), "cfrk_msp::view2 holds a View2");
     memcpy(ms->view2, &v, sizeof v);
-    if (!defer && (rc = msp2_dedupe_in_place(ctx, v))) return rc;
+    if (!nodedupe && (rc = msp2_dedupe_in_place(ctx, v))) return rc;
     ms->pending = false;
     ms->runs_ready = true;
-    ms->runs_deduped = !defer; ms->runs_unchecked = defer;
+    ms->runs_deduped = !nodedupe; ms->runs_unchecked = defer;
     ms->leaf_form = false;
     ms->list_n_valid = false;
     return CFRK_OK;
@@ -2404,10 +2413,12 @@ int cfrk_msp2_export_runs_async(cfrk_ctx *ctx, void *d_packed, uint64_t seg_cap_
   const int k = ctx->g_k, canon = (ctx->g_flags & CFRK_CANONICAL) ? 1 : 0;
   // (the table's size from the expected distinct runs per leaf, as in msp2_dedupe_in_place)
   const double runs_per_leaf = (double)(ctx->g_cap / NLEAF) / 2.0 * 4.0 / (double)(msp2_window(k) + 1);
-  const bool small_tab = runs_per_leaf <= 400.0 && !(ctx->dbg_flags & CFRK_DEBUG_RECORD_SUBSETS);
+  const bool small_tab = runs_per_leaf <= 400.0;
+  const bool sub = v.sub_bits != 0u;
   return runs_export_async_host(ctx, d_packed, seg_cap_rows, parts, ngroups, [&](const RunsSend &sg) {
-    if (small_tab) hipLaunchKernelGGL((msp2_dedupe_send_kernel<10>), dim3(sg.nleaf), dim3(DS2_THREADS), 0, ctx->stream, k, canon, v, sg);
-    else hipLaunchKernelGGL((msp2_dedupe_send_kernel<11>), dim3(sg.nleaf), dim3(DS2_THREADS), 0, ctx->stream, k, canon, v, sg);
+    if (sub) hipLaunchKernelGGL((msp2_dedupe_send_kernel<12, 1024, true>), dim3(sg.nleaf), dim3(1024), 0, ctx->stream, k, canon, v, sg);
+    else if (small_tab) hipLaunchKernelGGL((msp2_dedupe_send_kernel<10, 256, false>), dim3(sg.nleaf), dim3(256), 0, ctx->stream, k, canon, v, sg);
+    else hipLaunchKernelGGL((msp2_dedupe_send_kernel<11, 256, false>), dim3(sg.nleaf), dim3(256), 0, ctx->stream, k, canon, v, sg);
   });
 }
 
@@ -2425,6 +2436,14 @@ int cfrk_msp2_merge_runs_group(cfrk_ctx *ctx, const void *d_recv, const uint64_t
   if (group == 0) {
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     memset(&v, 0, sizeof v);
+    // shared leaves (cfrk_msp2_merge_runs): the owner holds 1 / parts of the leaves, each as heavy as it is in the whole job
+    const uint64_t per_leaf = ctx->g_cap / NLEAF * (uint64_t)parts;
+    uint32_t sub_bits = 0;
+    while (sub_bits < (uint32_t)SUB_BITS && (per_leaf >> sub_bits) > 2048u) ++sub_bits;
+    if (per_leaf <= 4096u) sub_bits = 0;
+    if ((ctx->dbg_flags & CFRK_DEBUG_RECORD_SUBSETS) && sub_bits < 2u) sub_bits = 2u;
+    v.sub_bits = sub_bits;
+    v.hbits = msp2_hbits(ctx, sub_bits, per_leaf);
     if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTK, (size_t)ctx->g_cap * 8, &p))) return rc;
     v.out_lo = (uint64_t *)p;
     if ((rc = cfrk_pool_get(ctx, BUF_MSP_OUTH, (size_t)ctx->g_cap * 8, &p))) return rc;
@@ -2447,8 +2466,16 @@ int cfrk_msp2_merge_runs_group(cfrk_ctx *ctx, const void *d_recv, const uint64_t
   lx.lcount = runs_ll0(lpp, group + 1, ngroups) - lx.ll0;
   TableView t = cfrk_table_view(ctx);
   if (lx.lcount) {
-    if (ctx->g_flags & CFRK_CANONICAL) hipLaunchKernelGGL((msp2_p3_lists_kernel<true>), dim3(lx.lcount), dim3(Q3_THREADS), 0, ctx->stream, ctx->g_k, v, t, lx);
-    else hipLaunchKernelGGL((msp2_p3_lists_kernel<false>), dim3(lx.lcount), dim3(Q3_THREADS), 0, ctx->stream, ctx->g_k, v, t, lx);
+    const bool canon = (ctx->g_flags & CFRK_CANONICAL) != 0;
+    if (v.sub_bits) {
+      // (one workgroup per four sub-values, eight leaves side by side on the XCDs: local leaves beyond the group's leave at once)
+      const dim3 g3(((lx.lcount + 7u) & ~7u) << (v.sub_bits - v.hbits));
+      if (canon) hipLaunchKernelGGL((msp2_p3_lists_kernel<true, true>), g3, dim3(Q3_THREADS), 0, ctx->stream, ctx->g_k, v, t, lx);
+      else hipLaunchKernelGGL((msp2_p3_lists_kernel<false, true>), g3, dim3(Q3_THREADS), 0, ctx->stream, ctx->g_k, v, t, lx);
+    } else {
+      if (canon) hipLaunchKernelGGL((msp2_p3_lists_kernel<true, false>), dim3(lx.lcount), dim3(Q3_THREADS), 0, ctx->stream, ctx->g_k, v, t, lx);
+      else hipLaunchKernelGGL((msp2_p3_lists_kernel<false, false>), dim3(lx.lcount), dim3(Q3_THREADS), 0, ctx->stream, ctx->g_k, v, t, lx);
+    }
     HIP_TRY(ctx, hipGetLastError());
   }
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
@@ -2488,7 +2515,9 @@ int cfrk_msp2_count(cfrk_ctx *ctx, const int8_t *d_data, int64_t nN) {
   {
     int cg = 0;
     const bool big = (double)(nN + 32) * msp2_density(ctx) * 1.35 * 32.0 > 6e9 || (ctx->dbg_flags & CFRK_DEBUG_SMALL_PIPELINE);
-    const bool want_defer = runs_only && (ctx->g_flags & CFRK_RUNS_DEFER);   // (a chunked add sizes its streams from a read-back)
+    // (CFRK_RUNS_DEFER: a batch that fits one pass with fixed-stride streams takes that form -- it ends unsynchronised;
+    //  a chunked add sizes its streams from a read-back)
+    const bool want_defer = runs_only && (ctx->g_flags & CFRK_RUNS_DEFER) && groups == 1;
     if (big && !want_defer && !(ctx->dbg_flags & CFRK_DEBUG_NO_PIPELINE) && !ctx->mem_budget &&
         !(rc = cfrk_msp_plan_groups(ctx, nN + 32, ntiles, (int64_t)Q1_WAVES * Q1_OWN * 32, msp2_need_chunked, (size_t)ctx->g_cap * 20, have, &cg)) &&
         cg == 1) {

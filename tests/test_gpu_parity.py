@@ -1768,7 +1768,7 @@ def test_two_word_leaves_with_more_keys_than_their_table_are_split_by_record(ctx
 
 # ------------------------------------------------------------------ pipelined runs exchange (round 5)
 
-def _pipelined_exchange(ctx, data, R, L, k, flags, world, ngroups, hint, seg_cap=1 << 18, dbg=0):
+def _pipelined_exchange(ctx, data, R, L, k, flags, world, ngroups, hint, seg_cap=1 << 18, dbg=0, owner_subvalue_bits=0):
     """`world` emulated ranks on one GPU through the PIPELINED runs exchange: CFRK_RUNS_DEFER add, export_runs_async,
     per group export_runs_wait + "all-to-all" (host copies) + merge_runs_group_device on every owner.
     -> {key: count} over all owners, or None when a rank's export refused (overflow / spill / small segment)"""
@@ -1803,7 +1803,8 @@ def _pipelined_exchange(ctx, data, R, L, k, flags, world, ngroups, hint, seg_cap
     merged = {}
     for owner in range(world):
         og = cfrk_amd.GlobalCounter(ctx, k, flags, hint)
-        og.set_debug_flags(dbg & cfrk_amd.lib.CFRK_DEBUG_NO_ANCHORS)
+        og.set_debug_flags(dbg & (cfrk_amd.lib.CFRK_DEBUG_NO_ANCHORS | cfrk_amd.lib.CFRK_DEBUG_RECORD_SUBSETS))
+        og.set_debug_param(cfrk_amd.lib.CFRK_PARAM_MSP2_SUBVALUE_BITS, owner_subvalue_bits)   # (1: one sub-value per workgroup, four workgroups per leaf)
         bufs = []
         for gi in range(ngroups):
             segs, recv = [], []
@@ -1818,6 +1819,7 @@ def _pipelined_exchange(ctx, data, R, L, k, flags, world, ngroups, hint, seg_cap
             bufs.append(d)
         lo, hi, cnt = og.export()
         og.set_debug_flags(0)
+        og.set_debug_param(cfrk_amd.lib.CFRK_PARAM_MSP2_SUBVALUE_BITS, 0)
         for d in bufs:
             ctx.free(d)
         keys = [int(x) for x in lo] if k <= 32 else [(int(h) << 64) | int(l) for l, h in zip(lo, hi)]
@@ -1835,7 +1837,11 @@ def _pipelined_exchange(ctx, data, R, L, k, flags, world, ngroups, hint, seg_cap
     # two-word keys (msp2.hip: 32-byte records travel as two rows)
     (63, True, 4, 2, 300_000, 0), (33, False, 3, 2, 300_000, 0), (47, True, 8, 3, 300_000, 0), (64, True, 2, 1, 300_000, 0),
     (63, True, 4, 2, 300_000, "rt_overflow"), (63, True, 4, 2, 300_000, "no_anchors"), (55, True, 3, 2, 300_000, "note_pos"),
-    (40, True, 5, 16, 300_000, 0)])
+    (40, True, 5, 16, 300_000, 0),
+    # ... whose leaves are shared by sub-value (configs[4]-sized hints; forced here): the spare word travels, the owner
+    # counts a leaf with several workgroups
+    (63, True, 4, 2, 300_000, "subsets"), (40, False, 3, 3, 300_000, "subsets"), (64, True, 8, 1, 300_000, "subsets"),
+    (47, True, 2, 2, 300_000, "subsets_rt_overflow"), (63, True, 4, 2, 300_000, "subsets_wg1"), (40, False, 3, 3, 300_000, "subsets_wg2")])
 def test_pipelined_runs_exchange_emulated_ranks_equal_the_oracle(ctx, k, canonical, world, ngroups, G, dbg):
     """the pipelined form of the strong-scaling exchange (cfrk_global_export_runs_async / _wait,
     cfrk_global_merge_runs_group_device): the sender deduplicates and packs one group of leaves after the
@@ -1854,8 +1860,13 @@ def test_pipelined_runs_exchange_emulated_ranks_equal_the_oracle(ctx, k, canonic
     data.reshape(R, L + 1)[:, L] = -1
     flags = cfrk_amd.CFRK_CANONICAL if canonical else 0
     bits = {0: 0, "rt_overflow": cfrk_amd.CFRK_DEBUG_FORCE_RT_OVERFLOW, "no_anchors": cfrk_amd.lib.CFRK_DEBUG_NO_ANCHORS,
-            "chunked": cfrk_amd.CFRK_DEBUG_SMALL_PIPELINE, "note_pos": cfrk_amd.lib.CFRK_DEBUG_SMALL_WAVE_CAP}[dbg]
-    merged = _pipelined_exchange(ctx, data, R, L, k, flags, world, ngroups, 2 * G, dbg=bits)
+            "chunked": cfrk_amd.CFRK_DEBUG_SMALL_PIPELINE, "note_pos": cfrk_amd.lib.CFRK_DEBUG_SMALL_WAVE_CAP,
+            "subsets": cfrk_amd.lib.CFRK_DEBUG_RECORD_SUBSETS,
+            "subsets_rt_overflow": cfrk_amd.lib.CFRK_DEBUG_RECORD_SUBSETS | cfrk_amd.CFRK_DEBUG_FORCE_RT_OVERFLOW,
+            "subsets_wg1": cfrk_amd.lib.CFRK_DEBUG_RECORD_SUBSETS, "subsets_wg2": cfrk_amd.lib.CFRK_DEBUG_RECORD_SUBSETS}[dbg]
+    # (subsets_wg1 / _wg2: the owner's workgroups take one / two sub-values each: four / two workgroups share a leaf)
+    merged = _pipelined_exchange(ctx, data, R, L, k, flags, world, ngroups, 2 * G, dbg=bits,
+                                 owner_subvalue_bits={"subsets_wg1": 1, "subsets_wg2": 2}.get(dbg, 0))
     assert merged is not None
     wlo, whi, wcnt = orc.global_count(data, k, orc.ORC_CANONICAL if canonical else 0, threads=4)
     assert len(merged) == len(wlo)

@@ -99,10 +99,16 @@ if not classic:
             if best is None or cur["group_end_ms"][-1] < best["group_end_ms"][-1]:
                 best = cur
             del g
+        # (the buffer holds the LAST run's segments: its row counts go with them -- a leaf whose record table is nearly
+        #  full deduplicates or not depending on the order its records arrive in, so runs may differ by a few rows)
+        best = dict(best, rows=rows)
         ranks.append(best)
         for gi in range(G_GROUPS):
-            segs[gi][r] = buf[gi, 0, :best["rows"][gi][0]].clone()      # what owner 0 receives from this rank
-    # owner 0
+            segs[gi][r] = buf[gi, 0, :rows[gi][0]].clone()      # what owner 0 receives from this rank
+    # owner 0 (the ranks' buffers and pools are given back first: a configs[4]-sized shard fills most of the device)
+    del buf, d
+    ctx.close()
+    torch.cuda.empty_cache()
     recvs = [torch.cat(segs[gi]) for gi in range(G_GROUPS)]
     recv_rows = [[int(s.shape[0]) for s in segs[gi]] for gi in range(G_GROUPS)]
     own = None
@@ -118,7 +124,11 @@ if not classic:
         cur = {"begin_host_ms": (t1 - t0) * 1e3, "group_ms": [cum[0]] + [cum[i] - cum[i - 1] for i in range(1, G_GROUPS)]}
         if own is None or sum(cur["group_ms"]) < sum(own["group_ms"]):
             own = cur
-    dg = og.digest()
+    try:
+        dg = og.digest()
+    except cfrk_amd.CfrkError as e:
+        print("owner digest failed:", e, og.msp_info(), "recv rows", recv_rows, file=sys.stderr, flush=True)
+        raise
 
     def schedule(me, rk):
         """step time of one rank (ms) under the overlap the code implements; returns (step, detail)"""
