@@ -68,8 +68,10 @@ extern "C" {
                                 (which must fit device memory in one pass) and stops there; its result
                                 leaves through cfrk_global_export_runs_device (multi-GPU exchange)   */
 #define CFRK_RUNS_DEFER 0x20  /* with CFRK_RUNS_ONLY (16 <= k <= 64): the add only PARTITIONS -- no
-                                deduplication kernel and no host synchronisation at its end (its overflow flags are looked
-                                at by the export).  The shard then leaves through the PIPELINED export,
+                                deduplication kernel and, when the leaf streams have their fixed stride (a batch that fits
+                                one pass that way; not a chunked or count-first add of a two-word job, which needs its
+                                read-backs), no host synchronisation at its end (its overflow flags are looked at by the
+                                export).  The shard then leaves through the PIPELINED export,
                                 cfrk_global_export_runs_async / _wait (deduplication and packing in one kernel per group of
                                 leaves), or through cfrk_global_export_runs_device, which deduplicates first.             */
 #define CFRK_FLOAT_INDEX 0x10 /* per-read dense only, matters for k = 13..15: the window index is accumulated
@@ -213,8 +215,7 @@ int cfrk_global_export_runs_device(cfrk_ctx *ctx, void *d_packed, uint64_t cap_r
                                    uint64_t *part_rows);
 int cfrk_global_merge_runs_device(cfrk_ctx *ctx, const void *d_packed, const uint64_t *recv_rows, int parts);
 
-/* PIPELINED form of the exchange by runs (round 5; both key widths, a 32-byte record of k > 32 travels as two rows; a
- * two-word job whose leaves are shared by sub-value ignores CFRK_RUNS_DEFER and is refused here with CFRK_ERR_STATE).  The owners' leaves are cut into `ngroups` ranges of
+/* PIPELINED form of the exchange by runs (round 5; both key widths, a 32-byte record of k > 32 travels as two rows).  The owners' leaves are cut into `ngroups` ranges of
  * local leaf indices (group g = local leaves [lpp * g / ngroups, lpp * (g + 1) / ngroups), lpp = cfrk_global_leaves_per_part);
  * a rank deduplicates and packs group after group straight into the send buffer and hands every finished group to the
  * wire while the next one is in the works, the owner counts every received group while the next one is on the wire:
