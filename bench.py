@@ -57,6 +57,9 @@ def parse():
                    help="gloo: rehearsal mode -- collectives staged through host memory, every "
                         "rank may sit on the same GPU (--same-gpu)")
     p.add_argument("--same-gpu", action="store_true", help="all ranks use cuda:0 (rehearsal)")
+    p.add_argument("--dist-at-one", action="store_true",
+                   help="with --gpus 1: a one-rank process group, and the step goes through the exchange (this rank owns "
+                        "every leaf) -- on a one-GPU box the only way the collectives execute over RCCL (tests)")
     p.add_argument("--scaling", default="", choices=["", "weak", "strong", "both"],
                    help="N > 1 only.  strong (BASELINE configs[3]): the reads are split over the GPUs; "
                         "weak: every GPU gets the config's reads; both (default): strong is the "
@@ -214,8 +217,18 @@ def main():
     if args.same_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # --dist-at-one: a ONE-rank process group, and the step takes the exchange all the same (this rank owns every leaf):
+    # on a one-GPU box this is the only way the collectives run over RCCL at all (tests)
+    multi = world > 1 or args.dist_at_one
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -229,10 +242,10 @@ def main():
     flags = 0 if args.no_canonical else cfrk_amd.CFRK_CANONICAL
     stream = torch.cuda.current_stream().cuda_stream
     ctx = cfrk_amd.Context(local_rank, stream)
-    owner_ctx = cfrk_amd.Context(local_rank, stream) if world > 1 else None
+    owner_ctx = cfrk_amd.Context(local_rank, stream) if multi else None
 
     def fence():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -370,7 +383,7 @@ def main():
         used = {"exchange": exch, "wire_bytes": 0}
 
         def step():
-            runs = world > 1 and exch == "runs"
+            runs = multi and exch == "runs"
             piped = runs and args.pipeline_groups > 0
             eng.deferred = piped
             eng.g = cfrk_amd.GlobalCounter(ctx, k, flags | (cfrk_amd.CFRK_RUNS_ONLY if runs else 0)
@@ -396,7 +409,7 @@ def main():
             finally:
                 if budget:
                     eng.g.set_mem_budget(0)
-            if world == 1:
+            if not multi:
                 ctx.sync()
                 return eng.g
             og = cfrk_amd.GlobalCounter(owner_ctx, k, flags, hint // world + 1024)
@@ -460,14 +473,14 @@ def main():
             kernel_ms.append(eng.g.last_add_ms())
         fence()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if multi:
             t = torch.tensor([dt], dtype=torch.float64, device="cpu" if wire else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
 
         info = eng.g.msp_info() if os.environ.get("CFRK_BENCH_INFO") else None
         digest = final.digest()
-        if world > 1:
+        if multi:
             digest = sharded.merge_digests(digest, "cpu" if wire else dev)
         del d_data, d_start, d_length, eng
         torch.cuda.empty_cache()
@@ -515,7 +528,7 @@ def main():
             "distinct": D, "sum_count_ok": ok,
             "digest": [f"{x:016x}" for x in digest],
         }
-        if world > 1:
+        if multi:
             # rank 0's view of one step: counting kernels (HIP events), everything up to the
             # return of the all-to-all (count + export + exchange), owner-side merge
             out["step_breakdown_ms"] = {"count_kernels": avg_ms,
@@ -548,7 +561,7 @@ def main():
     _PENDING["line"] = None
 
     if rank == 0:
-        if world == 1 and args.cpu_reads > 0:
+        if world == 1 and not multi and args.cpu_reads > 0:
             def gpu_digest_of_prefix(Rp):
                 nNp = Rp * (L + 1)
                 d = torch.empty(nNp + 64, dtype=torch.int8, device=dev)
@@ -566,7 +579,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     # (only a timing ablation -- bits >= 0x100, accepted by an ablation build of the library alone -- may miscount)

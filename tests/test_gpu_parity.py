@@ -499,6 +499,25 @@ def test_bench_two_ranks_exchange_runs_of_two_word_keys():
     assert classic["digest"] == one["digest"] and classic["exchange"]["exchange"] == "runs"
 
 
+@pytest.mark.parametrize("k", [31, 63, 15])
+def test_bench_one_rank_process_group_over_rccl_executes_every_exchange(k):
+    """What a one-GPU box can execute of RCCL: `bench.py --gpus 1 --dist-at-one --dist-backend nccl` -- a ONE-rank
+    process group (backend "nccl" IS RCCL) and a step that goes through the exchange all the same (the rank sends
+    everything to itself and owns every leaf): init_process_group with device_id, the size all-to-all, the payload
+    `dist.all_to_all` on segment views of the send buffer (pipelined form), the ragged `all_to_all_single` of the
+    one-shot, leaf and key forms, `all_reduce` / `all_gather` of the timing and the digests, barrier, comm-stream
+    events -- all on device tensors, none staged through the host.  The digest equals the plain one-GPU run's."""
+    common = ["--steps", "2", "--warmup", "1", "--reads", "2000000", "--k", str(k), "--cpu-reads", "0"]
+    one = _bench_line(["--gpus", "1"] + common)
+    rccl = ["--gpus", "1", "--dist-at-one", "--dist-backend", "nccl"]
+    forms = [([], "runs, pipelined in 2 groups"), (["--pipeline-groups", "0"], "runs"), (["--exchange", "leaf"], "leaf"),
+             (["--exchange", "owner"], "owner")] if k >= 16 else [([], "leaf"), (["--exchange", "owner"], "owner")]
+    for extra, name in forms:
+        got = _bench_line(rccl + extra + common)
+        assert got["sum_count_ok"] and got["digest"] == one["digest"], (name, got.get("exchange"))
+        assert got["exchange"]["exchange"] == name, got["exchange"]
+
+
 def test_bench_two_ranks_over_rccl_on_two_gpus():
     """`bench.py --gpus 2` on two REAL devices over RCCL (backend "nccl"): skipped on the one-GPU boxes the
     suite usually runs on -- the collectives of cfrk_amd/sharded.py are otherwise only exercised over gloo"""
