@@ -50,7 +50,7 @@ namespace {
 
 constexpr int P1_THREADS = 512;
 
-constexpr int P2_THREADS = 512, P2_PER = 8, P2_TILE = P2_THREADS * P2_PER;
+constexpr int P2_THREADS = 512, P2_PER = 8;   // (4096-record tiles: two 75 KB workgroups per CU; 8192 and 2560 measured slower, profiles/r05/p2_tile_size_*)
 constexpr int P2_GROUP = 4;                      // consecutive tiles per workgroup (next tile prefetched)
 
 constexpr int P3_THREADS = 1024;
