@@ -2265,11 +2265,12 @@ static void msp_params(int k, int *W, int *m) {
   // the loci of a genome -- with fewer distinct minimizers the leaves get lumpy (at k = 31: m = 11 gave a
   // 10x heavier leaf, m = 12 2.3x).  W is capped by what a 48-base record holds (49 - k k-mers),
   // which raises m to 14 / 16 for k = 31 / 32.
-  // k <= 22 (round 5): m = 12.  There the window is what is short (5 .. 10 k-mers at m = 13: one record per three k-mers
-  // at k = 17), and one more k-mer per window is 8 .. 14 % fewer records through all three kernels (10 M reads:
-  // k = 17 9.03 -> 8.30 ms, 19 7.62 -> 6.79, 22 6.30 -> 5.98; heaviest stream / mean unchanged at 3.3).  m = 11 was
-  // measured too: k = 17 7.85 ms, but the heaviest stream grows to 4.1 x the mean and outgrows its room.
-  *W = std::min(k <= 22 ? k - 11 : k - 12, 49 - k);
+  // k <= 26 (round 5): m = 12.  There the window is what is short (5 .. 14 k-mers at m = 13: one record per three k-mers
+  // at k = 17), and one more k-mer per window is 7 .. 14 % fewer records through all three kernels (10 M reads:
+  // k = 17 9.03 -> 8.30 ms, 19 7.62 -> 6.79, 22 6.30 -> 5.98, 25 5.41 -> 5.21; 100 M reads of a 10^8-base genome:
+  // k = 20 51.5 -> 48.3 ms, k = 25 35.6 -> 35.0, k = 28 no change; heaviest stream / mean unchanged at 3.3).  m = 11
+  // was measured too: k = 17 7.85 ms, but the heaviest stream grows to 4.1 x the mean and outgrows its room.
+  *W = std::min(k <= 26 ? k - 11 : k - 12, 49 - k);
   *m = k - *W + 1;
 }
 
