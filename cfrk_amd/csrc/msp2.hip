@@ -32,11 +32,8 @@ namespace {
 // positions with one to spare for the right-end flag.  Longer runs = fewer records (2 / (W + 1) per
 // position).
 constexpr int W2_LONG = 30;
-// m: 13 for even k; 14 for odd k -- 12 for odd k < 44 (round 5), where the window is what the k-mer's m-mers allow
-// (k - m - 1) and two more of them are 7 - 10 % fewer records (EXPERIMENT)
-__host__ __device__ constexpr int msp2_m(int k) { return (k & 1) ? (k < 44 ? 12 : 14) : 13; }
 __host__ __device__ constexpr int msp2_window(int k) {
-  const int nm = k - msp2_m(k) + 1;
+  const int nm = k - ((k & 1) ? 14 : 13) + 1;
   return nm - 2 > W2_LONG ? W2_LONG : nm - 2;
 }
 constexpr int Q1_THREADS = 512, Q1_WAVES = Q1_THREADS / 64;
@@ -1971,7 +1968,7 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
   int rc;
   const int k = ctx->g_k;
   const int W2 = msp2_window(k);
-  const int m = msp2_m(k);                               // k - m + 1 - W2 must be even
+  const int m = (k & 1) ? 14 : 13;                       // k - m + 1 - W2 must be even
   const int c = (k - m + 1 - W2) / 2;                    // 1 for k < 44, 1..11 (k = 44..64) with the window of 30
   const int canon = (ctx->g_flags & CFRK_CANONICAL) ? 1 : 0;
   const int64_t span = std::min(nN + 32, ntiles * (int64_t)Q1_WAVES * Q1_OWN * 32);
