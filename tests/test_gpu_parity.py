@@ -507,6 +507,16 @@ def test_bench_one_rank_process_group_over_rccl_executes_every_exchange(k):
     `dist.all_to_all` on segment views of the send buffer (pipelined form), the ragged `all_to_all_single` of the
     one-shot, leaf and key forms, `all_reduce` / `all_gather` of the timing and the digests, barrier, comm-stream
     events -- all on device tensors, none staged through the host.  The digest equals the plain one-GPU run's."""
+    import subprocess
+    import sys
+    # (RCCL itself must be able to start here -- a one-rank all_reduce in a process of its own; a box where it cannot is
+    #  no evidence about this repo's calls)
+    probe = ("import os, torch, torch.distributed as d; os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29537', RANK='0', "
+             "WORLD_SIZE='1'); torch.cuda.set_device(0); d.init_process_group('nccl', device_id=torch.device('cuda', 0)); "
+             "t = torch.ones(4, device='cuda'); d.all_reduce(t); torch.cuda.synchronize(); d.destroy_process_group(); print('ok')")
+    pr = subprocess.run([sys.executable, "-c", probe], capture_output=True, text=True, timeout=300)
+    if pr.returncode != 0 or "ok" not in pr.stdout:
+        pytest.skip("RCCL does not start on this box: " + pr.stderr[-300:])
     common = ["--steps", "2", "--warmup", "1", "--reads", "2000000", "--k", str(k), "--cpu-reads", "0"]
     one = _bench_line(["--gpus", "1"] + common)
     rccl = ["--gpus", "1", "--dist-at-one", "--dist-backend", "nccl"]
