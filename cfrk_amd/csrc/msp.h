@@ -29,9 +29,9 @@ struct TableView;
 #define CFRK_ABL_RX1_LINEAR    CFRK_ABL_BIT(0x100000u)  // radix first-level kernel: the sorted tile goes out back to back (no scatter into regions)
 // every bit cfrk_debug_set_flags accepts: the documented test switches of include/cfrk_abi.h, plus the ablations of an ablation build
 #ifdef CFRK_ABLATIONS
-#define CFRK_DEBUG_KNOWN_BITS (0x7Fu | 0x7F00u | 0x1F0000u)
+#define CFRK_DEBUG_KNOWN_BITS (0xFFu | 0x7F00u | 0x1F0000u)
 #else
-#define CFRK_DEBUG_KNOWN_BITS 0x7Fu
+#define CFRK_DEBUG_KNOWN_BITS 0xFFu
 #endif
 
 bool cfrk_msp_usable(const cfrk_ctx *ctx);                 // fast path applies to this begin()?

@@ -519,9 +519,11 @@ __global__ __launch_bounds__(Q2_THREADS) void msp2_p2_kernel(int groups_per_bin,
 }
 
 // ---------------------------------------------------------------------------------------- Q3
+// (T2L: log2 of the table's slots -- T2_LOG, or T2_LOG_SMALL in the small-leaf instantiation of the leaf kernel)
+template <int T2L = T2_LOG>
 __device__ __forceinline__ uint32_t t2_slot(uint64_t lo, uint64_t hi) {
   const uint32_t x = (uint32_t)lo ^ (uint32_t)(lo >> 32) ^ ((uint32_t)hi * 0x85EBCA77u) ^ (uint32_t)(hi >> 32);
-  return (x * 0x9E3779B1u) >> (32 - T2_LOG);
+  return (x * 0x9E3779B1u) >> (32 - T2L);
 }
 
 // One probe step for one key per lane (see msp.hip's kt_try for why it is written this way):
@@ -533,9 +535,10 @@ constexpr int T2_TRIPS_SPLIT = 24;
 // SAT: the count saturates at CFRK_COUNT_MAX (the merge of lists whose counts nothing bounds; the count word is the
 // slot state, so a wrapped value must never show: compare-and-swap).  The leaf kernel's own counts cannot overflow
 // (msp.hip: HUGE_LEAF).
-template <bool SAT = false>
+template <bool SAT = false, int T2L = T2_LOG>
 __device__ __forceinline__ void t2_step(ulonglong2 *keys, uint32_t *cnts, uint64_t lo, uint64_t hi,
                                         uint32_t add, uint32_t &h) {
+  constexpr uint32_t T2 = 1u << T2L;
   const bool p = (int32_t)h >= 0;
   const uint32_t hh = h & (T2 - 1);
   const uint32_t cst = cnts[hh];
@@ -582,7 +585,7 @@ __device__ __forceinline__ bool in_subset2(uint64_t lo, uint64_t hi, KeySubset2 
 // expand one record per lane (valid lanes), every k-mer counted `add` times; every lane of the
 // wave must call.  Only keys of subset `ss`; a key without room goes to the HBM table when
 // ovf == nullptr, else raises the LDS flag *ovf (the caller then redoes the subset in halves).
-template <bool CANON>
+template <bool CANON, int T2L = T2_LOG>
 __device__ __forceinline__ void count_record2(ulonglong2 *keys, uint32_t *cnts, const Rec2 &rec, uint32_t add,
                                               bool valid, int k, const TableView &t,
                                               KeySubset2 ss = KeySubset2{0u, 0u, 0u, 0u}, uint32_t *ovf = nullptr,
@@ -617,12 +620,12 @@ __device__ __forceinline__ void count_record2(ulonglong2 *keys, uint32_t *cnts, 
     }
     const u128 key = (CANON && roll.rc < roll.fwd) ? roll.rc : roll.fwd;
     const uint64_t lo = (uint64_t)key, hi = (uint64_t)(key >> 64);
-    uint32_t h = t2_slot(lo, hi) | ((j < nk && in_subset2(lo, hi, ss)) ? 0u : T2_DONE);
+    uint32_t h = t2_slot<T2L>(lo, hi) | ((j < nk && in_subset2(lo, hi, ss)) ? 0u : T2_DONE);
     // (a pass that may still be split gives up early: probing a nearly full table is the slow way
     //  to find out that it is full)
     // (the pass over the whole leaf or sub-value probes on: see msp.hip)
     const int trips = ovf ? (ss.mask == 0u ? T2_TRIPS : T2_TRIPS_SPLIT) : T2_TRIPS;
-    for (int it = 0; it < trips && __ballot((int32_t)h >= 0); ++it) t2_step(keys, cnts, lo, hi, addj, h);
+    for (int it = 0; it < trips && __ballot((int32_t)h >= 0); ++it) t2_step<false, T2L>(keys, cnts, lo, hi, addj, h);
     if ((int32_t)h >= 0) {
       if (ovf) {
         *ovf = 1u;
@@ -746,8 +749,14 @@ constexpr uint32_t Q3_WEIGHTED = 1u;
 constexpr uint64_t Q3_HUGE_LEAF = 1ull << 25, Q3_HUGE_LEAF_SENDER = 1ull << 19;   // (msp.hip: HUGE_LEAF)
 // LISTS (round 5, the owner of the PIPELINED runs exchange, msp.hip: p3_body): the leaf's runs are the N lists its ranks
 // sent, read in place from the receive buffer -- two rows per record, a note expanded where it is read.
-template <bool CANON, bool SHARED, bool LISTS>
+// T2L: log2 of the k-mer table's slots.  T2_LOG_SMALL = 10 (16 + 4 KB instead of 64 + 16: 62 KB of LDS in all, TWO workgroups
+// per CU at 64 VGPRs) serves jobs that announce few distinct k-mers per leaf (small genomes): there a leaf is a chain of
+// barriers and dependent round trips (~17 us) with hardly any data, and at one workgroup per CU nothing runs beside it --
+// 10 M reads of a 10^7-base genome: leaf kernel 4.3 -> 3.1 ms, k = 63 6.9 -> 5.4 ms per step.  A leaf that outgrows the small
+// table is split by key subset like any other.
+template <bool CANON, bool SHARED, bool LISTS, int T2L = T2_LOG>
 __device__ __forceinline__ void q3_body(int k, uint32_t mode, const View2 &v, const TableView &t, const P3ListsT<LISTS> &lx) {
+  constexpr int T2 = 1 << T2L;                    // (shadows the file-level constant)
   __shared__ ulonglong2 keys[T2];
   __shared__ uint32_t cnts[T2];
   // the record table, SPLIT (r2s_insert_loop): slot s = {ra[s], {rb[s].x, rb[s].y, rz[s], rst[s]}}
@@ -1163,10 +1172,10 @@ __device__ __forceinline__ void q3_body(int k, uint32_t mode, const View2 &v, co
         if (use_anchors) {
           // ... plus one for every truncated run of this locus that reaches the k-mer
           const uint32_t g0 = th[slot];
-          count_record2<CANON>(keys, cnts, rec, rec.b.w >> 6, valid, k, t, ss, ovf, (int)(i - ri * (uint32_t)parts), parts,
+          count_record2<CANON, T2L>(keys, cnts, rec, rec.b.w >> 6, valid, k, t, ss, ovf, (int)(i - ri * (uint32_t)parts), parts,
                                tbytes + g0, valid ? th[slot + 1] - g0 : 0u);
         } else {
-          count_record2<CANON>(keys, cnts, rec, rec.b.w >> 6, valid, k, t, ss, ovf, (int)(i - ri * (uint32_t)parts), parts);
+          count_record2<CANON, T2L>(keys, cnts, rec, rec.b.w >> 6, valid, k, t, ss, ovf, (int)(i - ri * (uint32_t)parts), parts);
         }
       }
       // truncated runs without a twin
@@ -1174,14 +1183,14 @@ __device__ __forceinline__ void q3_body(int k, uint32_t mode, const View2 &v, co
         const bool valid = i < nfl;
         Rec2 rec = zrec;
         if (valid) rec = trunc_at(flist[i]);
-        count_record2<CANON>(keys, cnts, rec, 1u, valid, k, t, ss, ovf);
+        count_record2<CANON, T2L>(keys, cnts, rec, 1u, valid, k, t, ss, ovf);
       }
     } else if (!SHARED) {
       for (uint64_t r = tid; r < ((ns[3] + 63) & ~63ull); r += Q3_THREADS) {
         const bool valid = r < ns[3];
         Rec2 rec = zrec;
         if (valid) rec = ld_c(r);
-        count_record2<CANON>(keys, cnts, rec, weighted ? (rec.b.w >> 6) : 1u, valid, k, t, ss, ovf);
+        count_record2<CANON, T2L>(keys, cnts, rec, weighted ? (rec.b.w >> 6) : 1u, valid, k, t, ss, ovf);
       }
     }
     if constexpr (!SHARED) {
@@ -1194,7 +1203,7 @@ __device__ __forceinline__ void q3_body(int k, uint32_t mode, const View2 &v, co
           const Rec2 rec = nxt;
           nxt = zrec;
           if (r + Q3_THREADS < ns[cl]) nxt = ld_t(cl, r + Q3_THREADS);
-          count_record2<CANON>(keys, cnts, rec, 1u, valid, k, t, ss, ovf);
+          count_record2<CANON, T2L>(keys, cnts, rec, 1u, valid, k, t, ss, ovf);
         }
       }
     } else {
@@ -1204,7 +1213,7 @@ __device__ __forceinline__ void q3_body(int k, uint32_t mode, const View2 &v, co
       Rec2 Sr = zrec;
       int sc = 0;                        // wave-uniform
       auto sflush = [&]() {
-        count_record2<CANON>(keys, cnts, Sr, 1u, lane < sc, k, t, KeySubset2{ss.mask, ss.val, 0u, 0u}, ovf);   // (sub-value: filtered when fed)
+        count_record2<CANON, T2L>(keys, cnts, Sr, 1u, lane < sc, k, t, KeySubset2{ss.mask, ss.val, 0u, 0u}, ovf);   // (sub-value: filtered when fed)
         sc = 0;
       };
       auto sfeed = [&](const Rec2 &rec, bool keep) {
@@ -1226,7 +1235,7 @@ __device__ __forceinline__ void q3_body(int k, uint32_t mode, const View2 &v, co
             const bool valid = r < ns[3];
             Rec2 rec = zrec;
             if (valid) rec = ld_c(r);
-            count_record2<CANON>(keys, cnts, rec, rec.b.w >> 6, valid && mine(rec), k, t, ss, ovf);
+            count_record2<CANON, T2L>(keys, cnts, rec, rec.b.w >> 6, valid && mine(rec), k, t, ss, ovf);
           }
           continue;
         }
@@ -1290,6 +1299,12 @@ __device__ __forceinline__ void q3_body(int k, uint32_t mode, const View2 &v, co
 template <bool CANON, bool SHARED>
 __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, uint32_t mode, View2 v, TableView t) {
   q3_body<CANON, SHARED, false>(k, mode, v, t, P3ListsT<false>{});
+}
+// ... for leaves of few distinct k-mers (q3_body: T2L): a 1024-slot k-mer table, two workgroups per CU
+constexpr int T2_LOG_SMALL = 10;
+template <bool CANON>
+__global__ __launch_bounds__(Q3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void msp2_p3_small_kernel(int k, uint32_t mode, View2 v, TableView t) {
+  q3_body<CANON, false, false, T2_LOG_SMALL>(k, mode, v, t, P3ListsT<false>{});
 }
 // the owner of the pipelined runs exchange: workgroup b counts local leaf lx.ll0 + b from the lists its ranks sent
 template <bool CANON, bool SHARED>
@@ -2213,9 +2228,14 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
   {
     // (a shared leaf: one workgroup per four sub-values)
     const dim3 g3(((unsigned)NLEAF >> sel_bits) << (v.sub_bits - v.hbits)), b3(Q3_THREADS);
+    // (the table holds 2 .. 4 x the announced distinct k-mers: 512 slots per leaf = ~300 expected keys, 0.3 of the small table)
+    const bool small_leaves = !sub && ctx->g_cap / NLEAF <= 512u && !(ctx->dbg_flags & CFRK_DEBUG_NO_SMALL_LEAVES);
     if (sub) {
       if (canon) hipLaunchKernelGGL((msp2_p3_kernel<true, true>), g3, b3, 0, ctx->stream, k, 0u, v, t);
       else hipLaunchKernelGGL((msp2_p3_kernel<false, true>), g3, b3, 0, ctx->stream, k, 0u, v, t);
+    } else if (small_leaves) {
+      if (canon) hipLaunchKernelGGL((msp2_p3_small_kernel<true>), g3, b3, 0, ctx->stream, k, 0u, v, t);
+      else hipLaunchKernelGGL((msp2_p3_small_kernel<false>), g3, b3, 0, ctx->stream, k, 0u, v, t);
     } else {
       if (canon) hipLaunchKernelGGL((msp2_p3_kernel<true, false>), g3, b3, 0, ctx->stream, k, 0u, v, t);
       else hipLaunchKernelGGL((msp2_p3_kernel<false, false>), g3, b3, 0, ctx->stream, k, 0u, v, t);

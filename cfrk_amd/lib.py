@@ -23,6 +23,7 @@ CFRK_DEBUG_RECORD_SUBSETS = 0x8
 CFRK_DEBUG_NO_PIPELINE = 0x10
 CFRK_DEBUG_SMALL_PIPELINE = 0x20
 CFRK_DEBUG_NO_RADIX16 = 0x40
+CFRK_DEBUG_NO_SMALL_LEAVES = 0x80
 CFRK_ERR_COUNT_OVERFLOW = -10        # finish / digest / export: some count was held at CFRK_COUNT_MAX
 CFRK_ERR_RUNS_REFUSED = -11          # a CFRK_RUNS_ONLY add that needs more than one pass
 CFRK_COUNT_MAX = 0xFFFFFFFE

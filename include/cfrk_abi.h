@@ -300,6 +300,10 @@ int cfrk_debug_last_add_passes(cfrk_ctx *ctx, int *out_passes);
  * the partitioned path is only four k-mers at k = 16); makes the partitioned path at k = 16 reachable with small
  * inputs (tests). */
 #define CFRK_DEBUG_NO_RADIX16 0x40
+/* Bit 7: the two-word leaf kernel keeps its 4096-slot k-mer table (one workgroup per CU) also for jobs that announce few
+ * distinct k-mers per leaf, which normally take the 1024-slot instantiation (two per CU); keeps the large instantiation
+ * reachable with small inputs (tests). */
+#define CFRK_DEBUG_NO_SMALL_LEAVES 0x80
 /* Any other bit is refused with CFRK_ERR_ARG.  (The timing ablations that skip a kernel phase and so produce WRONG
  * counts -- cfrk_amd/csrc/msp.h: CFRK_ABL_* -- are compiled into a separate ablation build only, `make -C
  * cfrk_amd/csrc abl`; the product library does not contain them.) */

@@ -147,12 +147,16 @@ def test_dense_errors(ctx):
 
 # ------------------------------------------------------------------ global counting
 
-def _cmp_global(ctx, data, k, canonical, hint=0, start=None, length=None, force_hash=False):
+def _cmp_global(ctx, data, k, canonical, hint=0, start=None, length=None, force_hash=False, dbg=0):
     import cfrk_amd
     flags = (cfrk_amd.CFRK_CANONICAL if canonical else 0) | (cfrk_amd.CFRK_FORCE_HASH if force_hash else 0)
     g = cfrk_amd.GlobalCounter(ctx, k, flags, hint)
-    g.add(data, start, length)
-    lo, hi, cnt = g.export()
+    g.set_debug_flags(dbg)
+    try:
+        g.add(data, start, length)
+        lo, hi, cnt = g.export()
+    finally:
+        g.set_debug_flags(0)
     wlo, whi, wcnt = orc.global_count(data, k, orc.ORC_CANONICAL if canonical else 0)
     assert len(lo) == len(wlo)
     assert (lo == wlo).all() and (hi == whi).all() and (cnt.astype(np.uint64) == wcnt).all()
@@ -171,6 +175,25 @@ def test_global_vs_oracle(ctx, k, canonical, force_hash):
     reads.append(np.zeros(0, np.int8))
     data, start, length = refsem.flatten(reads)
     _cmp_global(ctx, data, k, canonical, start=start, length=length, force_hash=force_hash)
+
+
+@pytest.mark.parametrize("k", [33, 34, 41, 47, 48, 55, 63, 64])
+@pytest.mark.parametrize("canonical", [False, True])
+def test_two_word_keys_with_the_large_leaf_tables_on_small_inputs(ctx, k, canonical):
+    """jobs that announce few distinct k-mers per leaf take the small-leaf instantiation of the two-word leaf kernel (a
+    1024-slot k-mer table, two workgroups per CU: round 5) -- every small test above does; CFRK_DEBUG_NO_SMALL_LEAVES keeps
+    the 4096-slot instantiation covered at these sizes (a second input: deep reads of one amplicon, both ways)."""
+    import cfrk_amd
+    rng = np.random.default_rng(900 + k)
+    reads = _random_reads(rng, 400, 1, 300)
+    reads.append(np.full(200, 0, np.int8))
+    data, start, length = refsem.flatten(reads)
+    _cmp_global(ctx, data, k, canonical, start=start, length=length, dbg=cfrk_amd.lib.CFRK_DEBUG_NO_SMALL_LEAVES)
+    amp = rng.integers(0, 4, 30_000).astype(np.int8)
+    reads = [amp[i:i + 250].copy() for i in rng.integers(0, 30_000 - 250, 3000)]
+    data, start, length = refsem.flatten(reads)
+    _cmp_global(ctx, data, k, canonical, start=start, length=length)
+    _cmp_global(ctx, data, k, canonical, start=start, length=length, dbg=cfrk_amd.lib.CFRK_DEBUG_NO_SMALL_LEAVES)
 
 
 @pytest.mark.parametrize("canonical", [False, True])

@@ -152,13 +152,13 @@ def test_homopolymer_flood_is_counted_exactly(ctx, k, L):
 
 
 def test_unknown_debug_bits_are_refused(ctx):
-    """cfrk_debug_set_flags accepts the seven documented test switches; the timing ablations (bits >= 0x100: kernels
+    """cfrk_debug_set_flags accepts the eight documented test switches; the timing ablations (bits >= 0x100: kernels
     that skip a phase and count WRONG) are compiled into an ablation build only -- the product refuses them"""
     import cfrk_amd
     g = cfrk_amd.GlobalCounter(ctx, 31, 0, 1024)
-    g.set_debug_flags(0x7F)
+    g.set_debug_flags(0xFF)
     g.set_debug_flags(0)
-    for bad in (0x100, 0x800, 0x1000, 0x2000, 0x4000, 0x10000, 0x100000, 0x80, 0x80000000):
+    for bad in (0x100, 0x800, 0x1000, 0x2000, 0x4000, 0x10000, 0x100000, 0x8000, 0x80000000):
         with pytest.raises(cfrk_amd.CfrkError) as e:
             g.set_debug_flags(bad)
         assert e.value.code == -1

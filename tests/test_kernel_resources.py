@@ -31,7 +31,9 @@ FILES = [("msp.hip", {"msp_p3_kernelILb1ELb0E": 10, "msp_p3_kernelILb0ELb0E": 10
                       # the owner of the pipelined runs exchange (the leaf kernel's body reading N lists in place): like the
                       # shared-leaf instantiations a few spills at phase boundaries at 64 VGPRs
                       "msp_p3_lists_kernel": 24}),
-         ("msp2.hip", {}),
+         # the small-leaf instantiation of the two-word leaf kernel (1024-slot k-mer table, two workgroups per CU at 64 VGPRs;
+         # jobs that announce few distinct k-mers per leaf): spills at phase boundaries, like msp_p3_kernel's
+         ("msp2.hip", {"msp2_p3_small_kernel": 32}),
          ("radix.hip", {}),
          ("dense.hip", {}),
          ("global_hash.hip", {})]
