@@ -650,6 +650,7 @@ constexpr uint32_t R2_DONE = 0x80000000u;
 constexpr int R2_TRIPS = 96;
 constexpr int TL2_PER = 4, TL2_CAP = TL2_PER * 1024;   // truncated runs that may be anchored per leaf
 constexpr int FL2_CAP = 1024;                           // ... of which so many may lack a twin
+constexpr int T2_LOG_MID = 11;                          // (q3_body: the mid-size instantiation)
 
 __device__ __forceinline__ uint32_t r2_slot(const Rec2 &r) {
   uint32_t h = (r.a.x * 0x9E3779B1u) ^ (r.a.y * 0x85EBCA77u) ^ (r.a.z * 0xC2B2AE3Du) ^ (r.a.w * 0x27D4EB2Fu) ^
@@ -746,14 +747,21 @@ __device__ __forceinline__ void r2s_insert_loop(uint4 *ra, uint2 *rb, uint32_t *
 // mode & Q3_WEIGHTED: the complete streams hold DISTINCT runs with multiplicities (header = count << 6 |
 // n-1, what msp2_dedupe_export_kernel leaves behind): an owner counting the runs its ranks sent
 constexpr uint32_t Q3_WEIGHTED = 1u;
+constexpr uint32_t Q3_SPLIT2 = 2u;     // every leaf starts with two key subsets (the mid-size instantiation on leaves of > ~1400 keys)
 constexpr uint64_t Q3_HUGE_LEAF = 1ull << 25, Q3_HUGE_LEAF_SENDER = 1ull << 19;   // (msp.hip: HUGE_LEAF)
 // LISTS (round 5, the owner of the PIPELINED runs exchange, msp.hip: p3_body): the leaf's runs are the N lists its ranks
 // sent, read in place from the receive buffer -- two rows per record, a note expanded where it is read.
-// T2L: log2 of the k-mer table's slots.  T2_LOG_SMALL = 10 (16 + 4 KB instead of 64 + 16: 62 KB of LDS in all, TWO workgroups
-// per CU at 64 VGPRs) serves jobs that announce few distinct k-mers per leaf (small genomes): there a leaf is a chain of
-// barriers and dependent round trips (~17 us) with hardly any data, and at one workgroup per CU nothing runs beside it --
-// 10 M reads of a 10^7-base genome: leaf kernel 4.3 -> 3.1 ms, k = 63 6.9 -> 5.4 ms per step.  A leaf that outgrows the small
-// table is split by key subset like any other.
+// T2L: log2 of the k-mer table's slots.  The leaf kernel at ONE 124 KB workgroup per CU spends 62 % of its wave cycles waiting
+// (barriers, dependent LDS and L2 round trips; profiles/r04/k63_pmc_sq_counters.txt) with nothing to run beside it.  Where leaves
+// are counted whole (not shared by sub-value) two smaller instantiations run TWO workgroups per CU at 64 VGPRs:
+//   T2_LOG_SMALL = 10 (62 KB of LDS) for jobs that announce <= 512 table slots per leaf (small genomes: a leaf is ~17 us of
+//     fixed work with hardly any data) -- 10 M reads of a 10^7-base genome: leaf kernel 4.3 -> 3.1 ms, k = 63 6.9 -> 5.4 ms per step;
+//   T2_LOG_MID = 11 (79 KB: a quarter of the list of twin-less read ends, no spare-word array) for everything else -- a
+//     C3-sized leaf (~3000 keys) is counted as two key subsets FROM THE START (Q3_SPLIT2: every record expanded twice,
+//     half of its k-mers inserted each time), which costs less than the second workgroup gains: k = 63 on the C3 reads
+//     leaf kernel 10.57 -> 9.41 ms, step 32.5 -> 31.1 ms.
+// A leaf that outgrows its table is split further by key subset like any other.  (The 4096-slot instantiation stays for
+// leaves shared by sub-value, for the owners' list reader, and under CFRK_DEBUG_NO_SMALL_LEAVES.)
 template <bool CANON, bool SHARED, bool LISTS, int T2L = T2_LOG>
 __device__ __forceinline__ void q3_body(int k, uint32_t mode, const View2 &v, const TableView &t, const P3ListsT<LISTS> &lx) {
   constexpr int T2 = 1 << T2L;                    // (shadows the file-level constant)
@@ -762,14 +770,15 @@ __device__ __forceinline__ void q3_body(int k, uint32_t mode, const View2 &v, co
   // the record table, SPLIT (r2s_insert_loop): slot s = {ra[s], {rb[s].x, rb[s].y, rz[s], rst[s]}}
   __shared__ uint4 ra[R2];
   __shared__ uint2 rb[R2];
-  __shared__ uint32_t rz[R2], rst[R2];
-  auto rt_get = [&](uint32_t s_) { const uint2 e = rb[s_]; return Rec2{ra[s_], make_uint4(e.x, e.y, rz[s_], rst[s_])}; };
+  __shared__ uint32_t rz[SHARED ? R2 : 1], rst[R2];   // (the spare word only matters where leaves are shared)
+  auto rt_get = [&](uint32_t s_) { const uint2 e = rb[s_]; return Rec2{ra[s_], make_uint4(e.x, e.y, SHARED ? rz[SHARED ? s_ : 0] : 0u, rst[s_])}; };
   __shared__ uint16_t occ_list[R2];
   // truncated runs anchored to their complete twin (msp.hip): per record-table slot the start of
   // the group of lengths noted with it, the lengths, and the runs without a twin
   __shared__ uint32_t th[R2 + 1];
   __shared__ uint8_t tbytes[TL2_CAP];
-  __shared__ uint16_t flist[FL2_CAP];
+  constexpr int FLC = (T2L == T2_LOG_MID) ? 256 : FL2_CAP;   // (the mid-size instantiation has 512 bytes for it)
+  __shared__ uint16_t flist[FLC];
   __shared__ uint32_t nfb, nfl;
   __shared__ uint32_t wsum2[Q3_THREADS / 64];
   constexpr int NSV = SHARED ? 4 : 1;             // sub-values a workgroup of a shared leaf counts, one after the other
@@ -852,7 +861,8 @@ __device__ __forceinline__ void q3_body(int k, uint32_t mode, const View2 &v, co
     return lo;
   };
   for (int s = tid; s < T2; s += Q3_THREADS) cnts[s] = 0;
-  rst[tid] = R2_EMPTY; rz[tid] = 0u;
+  rst[tid] = R2_EMPTY;
+  if (SHARED) rz[SHARED ? tid : 0] = 0u;
   if (tid == 0) { wg_total = 0; nocc = 0; rt_fail = 0; kovf = 0; sp = 0; leaf_total = 0; nseg = 0; nfb = 0; nfl = 0; }
   if (tid < NSV * 32 + 1) nhist[tid] = 0;
   for (int s = tid; s < R2 + 1; s += Q3_THREADS) th[s] = 0;
@@ -1008,7 +1018,7 @@ __device__ __forceinline__ void q3_body(int k, uint32_t mode, const View2 &v, co
     const uint32_t st = rst[tid];
     const bool occ = !big && st != R2_EMPTY;
     // list position: by sub-value (shared leaves), then longest first -- entry hidx of the histogram
-    const uint32_t hidx = (SHARED ? (rz[tid] & hmask) * 32u : 0u) + (31u - (st & 31u));
+    const uint32_t hidx = (SHARED ? (rz[SHARED ? tid : 0] & hmask) * 32u : 0u) + (31u - (st & 31u));
     uint32_t rank = 0;
     if (occ) rank = atomicAdd(&nhist[hidx], 1u);
     __syncthreads();
@@ -1040,6 +1050,11 @@ __device__ __forceinline__ void q3_body(int k, uint32_t mode, const View2 &v, co
           uint32_t b0 = 2u;
           while (b0 < 5u && (total >> (b0 + sub_bits)) > 6000ull) ++b0;
           for (uint32_t q = 0; q < (1u << b0); ++q) stk[d0++] = ((uint32_t)sv << 24) | (b0 << 16) | q;
+        } else if (mode & Q3_SPLIT2) {
+          // (the leaves of this job hold more keys than the table takes in one go: two key subsets from the start
+          //  instead of finding out by overflowing)
+          stk[d0++] = ((uint32_t)sv << 24) | (1u << 16) | 1u;
+          stk[d0++] = ((uint32_t)sv << 24) | (1u << 16) | 0u;
         } else stk[d0++] = (uint32_t)sv << 24;
       }
       sp = d0;
@@ -1100,7 +1115,7 @@ __device__ __forceinline__ void q3_body(int k, uint32_t mode, const View2 &v, co
       if (lane == 0 && fb) atomicAdd(&nfb, (uint32_t)__popcll(fb));
     }
     __syncthreads();
-    use_anchors = anchors_on && nfb <= (uint32_t)FL2_CAP;
+    use_anchors = anchors_on && nfb <= (uint32_t)FLC;
     if (use_anchors) {
 #pragma unroll
       for (int i = 0; i < TL2_PER; ++i) {
@@ -1302,6 +1317,11 @@ __global__ __launch_bounds__(Q3_THREADS) void msp2_p3_kernel(int k, uint32_t mod
 }
 // ... for leaves of few distinct k-mers (q3_body: T2L): a 1024-slot k-mer table, two workgroups per CU
 constexpr int T2_LOG_SMALL = 10;
+// ... and of up to a few thousand: a 2048-slot table, two workgroups per CU (q3_body: T2L)
+template <bool CANON>
+__global__ __launch_bounds__(Q3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void msp2_p3_mid_kernel(int k, uint32_t mode, View2 v, TableView t) {
+  q3_body<CANON, false, false, T2_LOG_MID>(k, mode, v, t, P3ListsT<false>{});
+}
 template <bool CANON>
 __global__ __launch_bounds__(Q3_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void msp2_p3_small_kernel(int k, uint32_t mode, View2 v, TableView t) {
   q3_body<CANON, false, false, T2_LOG_SMALL>(k, mode, v, t, P3ListsT<false>{});
@@ -2233,6 +2253,11 @@ static int msp2_count_tiles(cfrk_ctx *ctx, cfrk_msp *ms, const int8_t *d_data, i
     if (sub) {
       if (canon) hipLaunchKernelGGL((msp2_p3_kernel<true, true>), g3, b3, 0, ctx->stream, k, 0u, v, t);
       else hipLaunchKernelGGL((msp2_p3_kernel<false, true>), g3, b3, 0, ctx->stream, k, 0u, v, t);
+    } else if (!small_leaves && !(ctx->dbg_flags & CFRK_DEBUG_NO_SMALL_LEAVES)) {
+      // (2048 slots per leaf announced = ~1200 expected keys = 0.6 of the table: beyond that, two subsets from the start)
+      const uint32_t mode3 = ctx->g_cap / NLEAF > 2048u ? Q3_SPLIT2 : 0u;
+      if (canon) hipLaunchKernelGGL((msp2_p3_mid_kernel<true>), g3, b3, 0, ctx->stream, k, mode3, v, t);
+      else hipLaunchKernelGGL((msp2_p3_mid_kernel<false>), g3, b3, 0, ctx->stream, k, mode3, v, t);
     } else if (small_leaves) {
       if (canon) hipLaunchKernelGGL((msp2_p3_small_kernel<true>), g3, b3, 0, ctx->stream, k, 0u, v, t);
       else hipLaunchKernelGGL((msp2_p3_small_kernel<false>), g3, b3, 0, ctx->stream, k, 0u, v, t);

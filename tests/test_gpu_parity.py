@@ -194,6 +194,11 @@ def test_two_word_keys_with_the_large_leaf_tables_on_small_inputs(ctx, k, canoni
     data, start, length = refsem.flatten(reads)
     _cmp_global(ctx, data, k, canonical, start=start, length=length)
     _cmp_global(ctx, data, k, canonical, start=start, length=length, dbg=cfrk_amd.lib.CFRK_DEBUG_NO_SMALL_LEAVES)
+    if k in (33, 48, 63):
+        # the mid-size instantiation (2048-slot table, two workgroups per CU): what a job takes that announces more than 512
+        # table slots per leaf -- one key subset up to 2048 slots per leaf, two from the start beyond (C3's hint)
+        _cmp_global(ctx, data, k, canonical, start=start, length=length, hint=40_000_000)
+        _cmp_global(ctx, data, k, canonical, start=start, length=length, hint=100_000_000)
 
 
 @pytest.mark.parametrize("canonical", [False, True])

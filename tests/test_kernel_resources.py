@@ -33,7 +33,8 @@ FILES = [("msp.hip", {"msp_p3_kernelILb1ELb0E": 10, "msp_p3_kernelILb0ELb0E": 10
                       "msp_p3_lists_kernel": 24}),
          # the small-leaf instantiation of the two-word leaf kernel (1024-slot k-mer table, two workgroups per CU at 64 VGPRs;
          # jobs that announce few distinct k-mers per leaf): spills at phase boundaries, like msp_p3_kernel's
-         ("msp2.hip", {"msp2_p3_small_kernel": 32}),
+         # ... and the mid-size one (2048 slots, every non-shared job that is not small)
+         ("msp2.hip", {"msp2_p3_small_kernel": 32, "msp2_p3_mid_kernel": 32}),
          ("radix.hip", {}),
          ("dense.hip", {}),
          ("global_hash.hip", {})]
